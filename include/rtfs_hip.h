@@ -1,0 +1,105 @@
+/* rtfs_hip.h -- C-ABI of librtfs_hip.so: the MI355X (gfx950) kernels behind RTFS-Net's separation forward path.
+ *
+ * The reference (spkgyk/RTFS-Net) is pure Python: its "plugin interface" for this path is the nn.Module API
+ * `src.models.AVNet` (src/models/tdavnet.py:14-97); there is no FFI in it.  This header is the boundary BELOW
+ * that API: what a maintainer binds (ctypes / pybind / cffi) to replace the ATen/cuDNN/
+ * `sru` calls each reference function makes.  Every entry point
+ *   - takes raw DEVICE pointers and sizes only (no torch types), caller-allocated outputs and workspaces,
+ *   - enqueues on the given `hipStream_t` (passed as void*; NULL = default stream) and never synchronises,
+ *   - keeps no global state and is re-entrant per stream,
+ *   - returns 0 on success, RTFS_EINVAL (-1) for unsupported shapes, RTFS_ELAUNCH (-2) if the launch failed.
+ *
+ * Tensor layout below the boundary is CHANNELS-LAST fp32:
+ *     full resolution  [B][T][F=129][C]     C = 256 (encoder width) or 64 (RTFS hidden width)
+ *     compressed       [B][T2][F2=64][64]   T2 = (T-2)/2 + 1
+ * with T = 1 + L/128 STFT frames.  The kernels are specialised to the RTFS-Net family
+ * (config/{lrs2,lrs3,voxceleb2}_RTFSNet_{4,6,12}_layer.yaml): win 256, hop 128, C 256, hid 64, dw kernel 4,
+ * SRU hidden 32 x 2 directions, window 8, 4 attention heads, CAF "kernel_size" 4, lip embedding 512;
+ * B, L (hence T, T2), Tv and the number of blocks are free.
+ *
+ * gLN statistics (`stats`): double[B][2] = (sum, sum of squares) over one utterance, ACCUMULATED by producers
+ * with fp64 atomics -- the caller zeroes the slot before the producing launch.
+ */
+#ifndef RTFS_HIP_H
+#define RTFS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTFS_OK 0
+#define RTFS_EINVAL (-1)
+#define RTFS_ELAUNCH (-2)
+
+/* ---- a1: STFTEncoder.forward, src/models/TDAVNet/encoder.py:161-175 ------------------------------------- */
+/* torch.stft(n_fft 256, hop 128, hann, center, reflect, onesided) + stack(re,im): wav [B][L] -> spec [B][T][129][2] */
+int rtfs_stft_fwd(const float* wav, float* spec, int B, int L, void* stream);
+/* Conv2d(2->256,3x3,'same',no bias): Wp [18][256] (tap = ci*9+dt*3+df); also accumulates the bottleneck gLN stats of a_emb */
+int rtfs_enc_conv_fwd(const float* spec, const float* Wp, float* a_emb, double* stats, int B, int T, void* stream);
+
+/* ---- a2: audio_bottleneck ConvNormAct(pre gLN, pre ReLU, 1x1), tdavnet.py:59,89; conv_layers.py:65-129 ---- */
+int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt /*[256][256] out,in*/,
+                        const float* bias, float* a0, int B, int TF, void* stream);
+
+/* ---- a5.1-a5.2: gateway + projection, separators/tdanet.py:34-49,108-109 ------------------------------------ */
+/* y (pre-gLN) = Wp . prelu(s*gw+gb) + bias, [B][TF][64]; stats_out accumulates (sum, sumsq) of y */
+int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope, const float* Wt /*[64][256]*/, const float* bias, float* y,
+                  double* stats_out, int B, int TF, void* stream);
+
+/* ---- a5.3, a5.6: depth-wise 4x4 convolutions, tdanet.py:61-76,112-114; layers/fusion.py:25-52 ---------------- */
+/* nconv in {1,2,4} convolutions of one input; mode 0 raw, 1 gLN(in), 2 PReLU(gLN(in)); stride 1 ('same') or 2 (pad 1) */
+int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma, const float* beta, float slope, int mode, int stride, int nconv,
+                    const float* const* w /*[16][64]*/, const float* const* bias, float* const* out, double* const* stats_out, int B, int Tin,
+                    int Fin, void* stream);
+
+/* ---- a5.4: global pooling, tdanet.py:117-118 ---------------------------------------------------------------- */
+int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* d1, const double* d1_stats,
+                  const float* d1_g, const float* d1_b, float* G, int B, int T, int T2, void* stream);
+
+/* ---- a6-a7: DualPathRNN.forward, layers/rnn_layers.py:136-162; sru.SRU (external, oracle/sru_ref.py) --------- */
+/* dim 4: sequences along F (one per (b,t2)); dim 3: along T (one per (b,f2)).  S sequences of L = npos-7 windows. */
+int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, float* U0, int B, int T2, int dim,
+                            void* stream);
+int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
+                      void* stream);
+int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream);
+int rtfs_dp_convt_fwd(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, void* stream);
+
+/* ---- a8: MultiHeadSelfAttention2D.forward, layers/attention.py:149-189 ------------------------------------- */
+int rtfs_attn_qkv_fwd(const float* G, const float* Wt /*[96][64]*/, const float* bias, const float* slope, const float* gq, const float* bq,
+                      const float* gk, const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, void* stream);
+int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, int B, int T2, void* stream);
+int rtfs_attn_out_fwd(const float* O, const float* W /*[64][64] out,in*/, const float* bias, float slope, const float* gamma_fc, const float* beta_fc,
+                      float* G /*in place*/, int B, int T2, void* stream);
+
+/* ---- a5.6: TFAR, InjectionMultiSum.forward, layers/fusion.py:54-69 ------------------------------------------ */
+int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                      const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats,
+                      const float* glob_g, const float* glob_b, float* out, int B, int T, int F, int Tg, int Fg, void* stream);
+
+/* ---- a5.6-a5.7: concat_layers[0] tail + residual_conv + gateway residual, tdanet.py:127-131 ------------------ */
+int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                   const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                   const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt /*[256][64]*/,
+                   const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, int B,
+                   int T, int T2, void* stream);
+
+/* ---- a10: CAF, ATTNFusionCell.forward, layers/fusion.py:252-274 --------------------------------------------- */
+int rtfs_caf_video_fwd(const float* v /*[B][512][Tv]*/, const float* att_w, const float* att_b, const float* att_g, const float* att_be,
+                       const float* rs_w, const float* rs_b, const float* rs_g, const float* rs_be, float* att_out, float* rsz_out, int B, int Tv,
+                       void* stream);
+int rtfs_caf_fuse_fwd(const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz,
+                      const float* a0_or_null, float* out, int B, int T, int Tv, void* stream);
+
+/* ---- a11: MaskGenerator.forward + __apply_masks (RI_split), TDAVNet/mask_generator.py:67-99 ------------------ */
+int rtfs_mask_fwd(const float* x, float slope, const float* Wt /*[256][256]*/, const float* bias, const float* a_emb, float* masked, int B, int TF,
+                  void* stream);
+
+/* ---- a12: STFTDecoder.forward, TDAVNet/decoder.py:110-132 ---------------------------------------------------- */
+/* taps [B][T][129][32] = rtfs_gemm_rows_fwd(masked, Wdec' [32][256]) ; frames: workspace [B][T][256]; out [B][L] */
+int rtfs_istft_fwd(const float* taps, float* frames, float* out, int B, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTFS_HIP_H */

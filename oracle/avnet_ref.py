@@ -282,7 +282,9 @@ def tdanet_block(x, p: P, net, *, training=False, taps=None):
     pool = F.adaptive_avg_pool2d if is2d else F.adaptive_avg_pool1d
     g = sum(pool(f, output_size=size) for f in ds)
     if taps is not None:
-        taps["pooled"] = g
+        taps["gateway"], taps["proj"], taps["pooled"] = residual, x_enc, g
+        for i, d in enumerate(ds):
+            taps[f"ds{i}"] = d
     for name, layer in net.get("layers", {}).items():
         idx = list(net["layers"].keys()).index(name)
         q = p.sub(f"globalatt.{idx}")
@@ -306,6 +308,8 @@ def tdanet_block(x, p: P, net, *, training=False, taps=None):
         exp = injection_multi_sum(fused[i], exp, p.sub(f"concat_layers.{i}"), is2d=is2d, norm=norm, training=training) + ds[i]
     if taps is not None:
         taps["expanded"] = exp
+        for i, f in enumerate(fused):
+            taps[f"fused{i}"] = f
     return conv_norm_act(exp, p.sub("residual_conv"), is2d=is2d) + residual
 
 

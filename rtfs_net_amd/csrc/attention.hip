@@ -1,0 +1,319 @@
+// TF-domain multi-head self-attention of the RTFS block: MultiHeadSelfAttention2D.forward
+// (/root/reference/src/models/layers/attention.py:149-189), 4 heads, tokens = compressed time frames.
+//
+//   rtfs_attn_qkv_fwd    12 x ConvActNorm(1x1 conv -> PReLU -> LN4D over (c,F))  -> Q,K [B][4][T2][256], V [B][4][T2][1024]
+//   rtfs_attn_core_fwd   softmax(Q K^T / 16) V per (b, head, 32-query tile)       -> O [B][T2][64 ch][64 f]
+//   rtfs_attn_out_fwd    attn_concat_proj (1x1 64->64 -> PReLU -> LN4D(64,F)) + residual, in place on G
+//
+// Feature order inside a head is e = c*64 + f as in the reference (attention.py:164-168); heads are kept as
+// an explicit axis instead of being concatenated on the batch axis (attention.py:160-162).
+// QK^T and PV run on v_mfma_f32_32x32x2_f32; softmax is a wave-level reduction over the key axis.
+#include "common.h"
+
+namespace rtfs {
+
+constexpr int kHeads = 4;
+constexpr int kQkvN = 96;  // 4 heads x (4 q + 4 k + 16 v) output channels
+
+// ------------------------------------------------------------------------------------------------
+// QKV: two tokens (b,t) per workgroup: rows = 2 x 64 frequency bins, K = 64 channels, N = 96.
+// Column order n: [0,16) Q (h*4+e), [16,32) K (h*4+e), [32,96) V (h*16+c).
+// gamma/beta are host-permuted to the output order: gq,gk [4][256], gv [4][1024] (index e*64+f / c*64+f).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_qkv_kernel(const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                       const float* __restrict__ slope, const float* __restrict__ gq, const float* __restrict__ bq,
+                                                       const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
+                                                       const float* __restrict__ bv, float* __restrict__ Q, float* __restrict__ Kx,
+                                                       float* __restrict__ V, int BT, int T2) {
+    constexpr int LDA = 68, LDY = 97;
+    __shared__ __attribute__((aligned(16))) float As[128 * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[kQkvN * LDA];
+    __shared__ float Ys[128 * LDY];
+    __shared__ float st[24][2];
+
+    const int tok0 = blockIdx.x * 2;
+    const int ntok = min(2, BT - tok0);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    // stage X (2 tokens x 64 f x 64 c = 2048 float4) and W (96 x 64 = 1536 float4)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int row = idx >> 4, c4 = idx & 15;
+        float4 v = (row < ntok * 64) ? ld4(G + ((size_t)tok0 * 64 + row) * 64 + c4 * 4) : f4(0, 0, 0, 0);
+        st4(As + row * LDA + c4 * 4, v);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int row = idx >> 4, c4 = idx & 15;
+        st4(Bs + row * LDA + c4 * 4, ld4(Wt + row * 64 + c4 * 4));
+    }
+    __syncthreads();
+
+    floatx16 acc[1][3];
+    acc_zero(acc);
+    mma_block<1, 3>(acc, As + w * 32 * LDA, LDA, Bs, LDA, 64);
+
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = w * 32 + acc_row(r), col = n * 32 + (lane & 31);
+            Ys[row * LDY + col] = prelu(acc[0][n][r] + bias[col], slope[col]);
+        }
+    __syncthreads();
+
+    // LN4D statistics over (c, F) per token per module: 24 groups, 6 per wave, two-pass.
+    for (int gi = 0; gi < 6; ++gi) {
+        const int g24 = w * 6 + gi;
+        const int tok = g24 / 12, g = g24 % 12;
+        const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
+        const int ncol = g < 8 ? 4 : 16;
+        const int cnt = 64 * ncol;
+        float s = 0.f;
+        for (int i = lane; i < cnt; i += 64) s += Ys[(tok * 64 + i / ncol) * LDY + col0 + i % ncol];
+        const float mean = wave_sum(s) / cnt;
+        float q = 0.f;
+        for (int i = lane; i < cnt; i += 64) {
+            const float d = Ys[(tok * 64 + i / ncol) * LDY + col0 + i % ncol] - mean;
+            q = fmaf(d, d, q);
+        }
+        q = wave_sum(q);
+        if (lane == 0) {
+            st[g24][0] = mean;
+            st[g24][1] = 1.0f / sqrtf(q / cnt + kEps);
+        }
+    }
+    __syncthreads();
+
+    // normalise and scatter into the per-head layouts
+    for (int tok = 0; tok < ntok; ++tok) {
+        const int bt = tok0 + tok, b = bt / T2, t = bt % T2;
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) {  // Q and K: [h][e*64+f]
+            const int h = i >> 8, ef = i & 255, e = ef >> 6, f = ef & 63;
+            const size_t o = (((size_t)b * kHeads + h) * T2 + t) * 256 + ef;
+            const float yq = Ys[(tok * 64 + f) * LDY + h * 4 + e], yk = Ys[(tok * 64 + f) * LDY + 16 + h * 4 + e];
+            const float* sq = st[tok * 12 + h];
+            const float* sk = st[tok * 12 + 4 + h];
+            Q[o] = fmaf((yq - sq[0]) * sq[1], gq[i], bq[i]);
+            Kx[o] = fmaf((yk - sk[0]) * sk[1], gk[i], bk[i]);
+        }
+        for (int i = threadIdx.x; i < 4 * 1024; i += 256) {  // V: [h][c*64+f]
+            const int h = i >> 10, cf = i & 1023, c = cf >> 6, f = cf & 63;
+            const size_t o = (((size_t)b * kHeads + h) * T2 + t) * 1024 + cf;
+            const float y = Ys[(tok * 64 + f) * LDY + 32 + h * 16 + c];
+            const float* sv = st[tok * 12 + 8 + h];
+            V[o] = fmaf((y - sv[0]) * sv[1], gv[i], bv[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// core: grid (ceil(T2/32), 4, B).  T2P = key count rounded up to 32 (compile-time upper bound 256 => T2 <= 256).
+// ------------------------------------------------------------------------------------------------
+template <int MAXKT>  // max key tiles of 32
+__global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
+                                                        float* __restrict__ O, int T2) {
+    constexpr int LDQ = 260, LDK = 68, LDV = 260;
+    constexpr int LDS_S = MAXKT * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float Qs[32 * LDQ];
+    __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
+    __shared__ __attribute__((aligned(16))) float KV[128 * LDK];  // K chunk [128 keys][68] or V chunk [32 keys][260]
+    static_assert(32 * LDV <= 128 * LDK, "KV buffer must hold either chunk");
+
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = qt * 32;
+    const int NT = (T2 + 31) / 32;
+    const size_t headoff = ((size_t)b * kHeads + h) * T2;
+    const float* Qg = Q + headoff * 256;
+    const float* Kg = Kx + headoff * 256;
+    const float* Vg = V + headoff * 1024;
+
+    // Q tile: 32 rows x 256 = 2048 float4
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int row = idx >> 6, c4 = idx & 63;
+        float4 v = (q0 + row < T2) ? ld4(Qg + (size_t)(q0 + row) * 256 + c4 * 4) : f4(0, 0, 0, 0);
+        st4(Qs + row * LDQ + c4 * 4, v);
+    }
+
+    // ---- S = Q K^T / 16 ----
+    for (int kt0 = 0; kt0 < NT; kt0 += 4) {
+        floatx16 acc[1][1];
+        acc_zero(acc);
+        for (int ec = 0; ec < 4; ++ec) {  // 64-wide chunks of the 256 features
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // 128 keys x 16 float4
+                const int idx = threadIdx.x + i * 256;
+                const int key = idx >> 4, c4 = idx & 15;
+                const int kg = kt0 * 32 + key;
+                float4 v = (kg < T2) ? ld4(Kg + (size_t)kg * 256 + ec * 64 + c4 * 4) : f4(0, 0, 0, 0);
+                st4(KV + key * LDK + c4 * 4, v);
+            }
+            __syncthreads();
+            if (kt0 + w < NT) mma_block<1, 1>(acc, Qs + ec * 64, LDQ, KV + w * 32 * LDK, LDK, 64);
+        }
+        if (kt0 + w < NT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ss[acc_row(r) * LDS_S + (kt0 + w) * 32 + (lane & 31)] = acc[0][0][r] * 0.0625f;
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over keys, 8 rows per wave ----
+    for (int rr = 0; rr < 8; ++rr) {
+        float* row = Ss + (w * 8 + rr) * LDS_S;
+        float v[MAXKT / 2];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < MAXKT / 2; ++j) {
+            const int col = lane + j * 64;
+            v[j] = (col < T2) ? row[col] : -3.0e38f;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXKT / 2; ++j) {
+            const int col = lane + j * 64;
+            v[j] = (col < T2) ? __expf(v[j] - mx) : 0.f;
+            sum += v[j];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int j = 0; j < MAXKT / 2; ++j) {
+            const int col = lane + j * 64;
+            if (col < NT * 32) row[col] = v[j] * inv;
+        }
+    }
+
+    // ---- O = P V : 4 chunks of 256 output features; wave w owns features [w*64, w*64+64) of the chunk ----
+    for (int nc = 0; nc < 4; ++nc) {
+        floatx16 acc[1][2];
+        acc_zero(acc);
+        for (int kt = 0; kt < NT; ++kt) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {  // 32 keys x 64 float4
+                const int idx = threadIdx.x + i * 256;
+                const int key = idx >> 6, c4 = idx & 63;
+                const int kg = kt * 32 + key;
+                float4 v = (kg < T2) ? ld4(Vg + (size_t)kg * 1024 + nc * 256 + c4 * 4) : f4(0, 0, 0, 0);
+                st4(KV + key * LDV + c4 * 4, v);
+            }
+            __syncthreads();
+            mma_block_bn<1, 2>(acc, Ss + kt * 32, LDS_S, KV + w * 64, LDV, 32);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = q0 + acc_row(r);
+                const int e = nc * 256 + w * 64 + n * 32 + (lane & 31);
+                const int c = h * 16 + (e >> 6), f = e & 63;
+                if (t < T2) O[(((size_t)b * T2 + t) * 64 + c) * 64 + f] = acc[0][n][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out-projection + PReLU + LN4D over (64, F) + residual, one token per workgroup, in place on G.
+// Computes Y^T[co][f] = W[co][c] . X[c][f] so the O layout [c][f] is consumed without a transpose.
+// gamma/beta are host-permuted to [f][c].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__ O, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float slope, const float* __restrict__ gamma_fc, const float* __restrict__ beta_fc,
+                                                       float* __restrict__ G) {
+    constexpr int LD = 68, LDY = 65;
+    __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[64 * LD];
+    __shared__ float Ys[64 * LDY];
+    __shared__ float red[8];
+    __shared__ float bc[2];
+
+    const size_t tok = blockIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w >> 1, wn = w & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int row = idx >> 4, c4 = idx & 15;
+        st4(Ws + row * LD + c4 * 4, ld4(W + row * 64 + c4 * 4));
+        st4(Xs + row * LD + c4 * 4, ld4(O + tok * 4096 + row * 64 + c4 * 4));
+    }
+    __syncthreads();
+    floatx16 acc[1][1];
+    acc_zero(acc);
+    mma_block_bn<1, 1>(acc, Ws + wm * 32 * LD, LD, Xs + wn * 32, LD, 64);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = wm * 32 + acc_row(r), f = wn * 32 + (lane & 31);
+        const float y = prelu(acc[0][0][r] + bias[co], slope);
+        Ys[co * LDY + f] = y;
+        s += y;
+    }
+    // mean
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.f / 4096.f);
+    float q = 0.f;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const float d = Ys[(i >> 6) * LDY + (i & 63)] - mean;
+        q = fmaf(d, d, q);
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) * (1.f / 4096.f) + kEps);
+    float* g = G + tok * 4096;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const int f = i >> 6, c = i & 63;
+        const float y = (Ys[c * LDY + f] - mean) * rstd;
+        g[i] = fmaf(y, gamma_fc[i], beta_fc[i]) + g[i];
+    }
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+extern "C" {
+
+int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
+                      const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, void* stream) {
+    if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
+    const int BT = B * T2;
+    hipLaunchKernelGGL(attn_qkv_kernel, dim3((BT + 1) / 2), dim3(256), 0, (hipStream_t)stream, G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, BT,
+                       T2);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, int B, int T2, void* stream) {
+    if (B <= 0 || T2 <= 0 || T2 > 512) return RTFS_EINVAL;
+    dim3 grid((T2 + 31) / 32, kHeads, B);
+    if (T2 <= 128)
+        hipLaunchKernelGGL((attn_core_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+    else if (T2 <= 256)
+        hipLaunchKernelGGL((attn_core_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+    else
+        hipLaunchKernelGGL((attn_core_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
+                      int T2, void* stream) {
+    if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
+    hipLaunchKernelGGL(attn_out_kernel, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// Shared device helpers for the RTFS-Net hot-path kernels (gfx950 / CDNA4, wave64).
+//
+// Activation layout everywhere below the C-ABI is CHANNELS-LAST fp32:
+//   full resolution   X[b][t][f][c]   (c = 256 "C" or 64 "H")
+//   compressed        G[b][t2][f2][c] (c = 64)
+// so a "pixel" (b,t,f) owns a contiguous, 16-byte aligned channel vector and every 1x1 convolution is
+// a row-major GEMM  [pixels x Cin] x [Cin x Cout].  The reference (NCHW, /root/reference/src/models)
+// never sees this layout: only waveforms and lip embeddings cross the boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtfs {
+
+constexpr int kC = 256;   // encoder / bottleneck channels   (config yaml: enc_dec_params.out_chan)
+constexpr int kH = 64;    // RTFS block hidden channels      (audio_params.hid_chan)
+constexpr int kWin = 256; // STFT window                     (enc_dec_params.win)
+constexpr int kHop = 128; // STFT hop                        (enc_dec_params.hop_length)
+constexpr int kF = 129;   // kWin/2 + 1 frequency bins
+constexpr int kF2 = 64;   // compressed frequency bins       (layer_3.n_freqs)
+constexpr float kEps = 1e-5f;  // src/models/layers/normalizations.py:5
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- error codes returned across the C-ABI -------------------------------------------------------
+enum : int { RTFS_OK = 0, RTFS_EINVAL = -1, RTFS_ELAUNCH = -2 };
+
+#define RTFS_LAUNCH_CHECK()                         \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return RTFS_ELAUNCH;  \
+    } while (0)
+
+// ---- gLN statistics --------------------------------------------------------------------------------
+// A global layer norm (GroupNorm(1,C), normalizations.py:8-17) needs mean/var over (C,T,F) of one
+// utterance: a grid-wide reduction.  Producers add per-workgroup partial (sum, sum of squares) into a
+// double2 slot per utterance with fp64 atomics; consumers turn the slot into (mean, rstd) when they
+// load ("normalise on read").  fp64 accumulation makes the result insensitive to arrival order.
+struct Stats {
+    const double* slot;  // [B][2]
+    float inv_n;         // 1 / (C*T*F)
+};
+
+__device__ __forceinline__ void stats_finalize(const double* slot, int b, double inv_n, float& mean, float& rstd) {
+    double s = slot[2 * b], q = slot[2 * b + 1];
+    double m = s * inv_n;
+    double v = q * inv_n - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(v + (double)kEps));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide (256 threads) reduction of a (sum, sumsq) pair followed by ONE pair of fp64 atomics.
+// `red` is 8 floats of LDS.
+__device__ __forceinline__ void block_stats_commit(float s, float q, float* red, double* slot, int b) {
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[w] = s;
+        red[4 + w] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+        double Q = (double)red[4] + (double)red[5] + (double)red[6] + (double)red[7];
+        atomicAdd(slot + 2 * b, S);
+        atomicAdd(slot + 2 * b + 1, Q);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return f4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+// (x - mean) * rstd * gamma + beta  ==  x * (rstd*gamma) + (beta - mean*rstd*gamma)
+__device__ __forceinline__ float4 norm4(float4 x, float mean, float rstd, float4 g, float4 b) {
+    float4 sc = g * rstd;
+    float4 sh = f4(b.x - mean * sc.x, b.y - mean * sc.y, b.z - mean * sc.z, b.w - mean * sc.w);
+    return fma4(x, sc, sh);
+}
+__device__ __forceinline__ float4 prelu4(float4 x, float a) { return f4(prelu(x.x, a), prelu(x.y, a), prelu(x.z, a), prelu(x.w, a)); }
+__device__ __forceinline__ float4 relu4(float4 x) { return f4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f)); }
+__device__ __forceinline__ float4 sigmoid4(float4 x) {
+    return f4(sigmoidf_fast(x.x), sigmoidf_fast(x.y), sigmoidf_fast(x.z), sigmoidf_fast(x.w));
+}
+
+// nearest-neighbour source index used by F.interpolate(mode="nearest"): floor(dst * in / out)
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) { return (int)(((long long)dst * in) / out); }
+
+// ---- fp32 MFMA tile machinery --------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l supplies A[l&31][l>>5] and
+// B[l>>5][l&31]; accumulator register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+// Exact fp32 (one rounding per product) at the fp32 vector rate, 64 cycles per instruction.
+//
+// Both operands are staged in LDS "k-contiguous": As[row][k], Bs[col][k] with a row stride that is an
+// odd number of 16-byte slots (36 or 68 floats) so that a wave's ds_read_b128 is bank-conflict free.
+// Lane (i = l&31, kh = l>>5) reads the 4 consecutive k values 8q + 4kh .. +3 of its row with ONE
+// ds_read_b128 and feeds them to 4 successive MFMAs; the pairing (A k, B k) is what matters, the
+// order in which k is summed does not.
+// BT = distance in B rows (output columns) between this wave's consecutive N-tiles (32 = adjacent).
+template <int WM, int WN, int BT = 32>
+__device__ __forceinline__ void mma_block(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, kh = lane >> 5;
+    const float* ap = As + i * lda + kh * 4;
+    const float* bp = Bs + i * ldb + kh * 4;
+#pragma unroll 2
+    for (int q = 0; q < kdepth; q += 8) {
+        float4 a[WM], b[WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) a[m] = ld4(ap + m * 32 * lda + q);
+#pragma unroll
+        for (int n = 0; n < WN; ++n) b[n] = ld4(bp + n * BT * ldb + q);
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+            }
+    }
+}
+
+// Variant for a B operand stored "n-contiguous" in LDS: Bs[k][col] (row stride ldb floats).
+template <int WM, int WN>
+__device__ __forceinline__ void mma_block_bn(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, kh = lane >> 5;
+    const float* ap = As + i * lda + kh * 4;
+    const float* bp = Bs + (kh * 4) * ldb + i;
+#pragma unroll 2
+    for (int q = 0; q < kdepth; q += 8) {
+        float4 a[WM];
+        float b[WN][4];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) a[m] = ld4(ap + m * 32 * lda + q);
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[n][r] = bp[(q + r) * ldb + n * 32];
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n][0], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n][1], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n][2], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n][3], acc[m][n], 0, 0, 0);
+            }
+    }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void acc_zero(floatx16 (&acc)[WM][WN]) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+}
+
+// row of accumulator register r inside its 32x32 tile, for this lane
+__device__ __forceinline__ int acc_row(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }
+
+// Copy a [rows][BK] k-chunk of a k-contiguous global matrix W[row][ldw] into LDS Bs[row][lds].
+// All 256 threads participate; BK/4 lanes cover one row (coalesced 128/256-byte segments).
+template <int ROWS, int BK>
+struct ChunkRegs {
+    static constexpr int kPerThread = ROWS * (BK / 4) / 256;
+    float4 v[kPerThread];
+    __device__ __forceinline__ void load(const float* __restrict__ W, int ldw, int k0) {
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int row = idx / (BK / 4), c4 = idx % (BK / 4);
+            v[i] = ld4(W + (size_t)row * ldw + k0 + c4 * 4);
+        }
+    }
+    __device__ __forceinline__ void store(float* Bs, int lds) const {
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int row = idx / (BK / 4), c4 = idx % (BK / 4);
+            st4(Bs + row * lds + c4 * 4, v[i]);
+        }
+    }
+};
+
+}  // namespace rtfs

@@ -1,0 +1,219 @@
+// The dual-path SRU stage of the RTFS block: DualPathRNN.forward (/root/reference/src/models/layers/
+// rnn_layers.py:136-162) for dim=4 (sequences along F, one per (b,t)) and dim=3 (along T, one per (b,f)).
+//
+//   rtfs_dp_unfold_gemm_fwd   LN4D over C  ->  nn.Unfold((8,1))  ->  X . W0     (rnn_layers.py:146-149 + SRU layer 0)
+//   rtfs_sru_scan_fwd         the bidirectional SRU recurrence                  (sru package; oracle/sru_ref.py)
+//   rtfs_dp_convt_fwd         ConvTranspose1d(64->64,k=8) + bias + residual     (rnn_layers.py:129,153-156)
+//   (SRU layers 1-3 input projections: rtfs_gemm_rows_fwd in gemm.hip)
+//
+// Unfold is never materialised.  In channels-last layout the 8-position window starting at position l of a
+// sequence is rows l..l+7 of a [positions][64] slab, i.e. the unfolded matrix is a Toeplitz VIEW of the slab:
+//      X[l][kk*64 + c] = slab[l + kk][c]
+// (feature order (kk,c) instead of the reference's (c,kk): the host permutes W0's rows once).  The slab is
+// layer-normalised once into LDS and the MFMA A operand is read from it with a row offset per k-chunk.
+// ConvTranspose1d is the same structure on the zero-padded SRU output: y[n] = sum_k' hpad[n + k'] . W'[k'].
+#include "common.h"
+
+namespace rtfs {
+
+struct SeqMap {  // sequence s -> base element offset; positions are pos_stride apart; channels contiguous
+    int seq_div;
+    long long stride_hi, stride_lo, pos_stride;
+    int npos;  // positions per sequence (F2 or T2)
+    int L;     // npos - 8 + 1 windows
+    __device__ __forceinline__ size_t base(int s) const { return (size_t)(s / seq_div) * stride_hi + (size_t)(s % seq_div) * stride_lo; }
+};
+
+constexpr int kSlabRows = 64 + 7;
+constexpr int kSlabLd = 68;
+
+// MODE 0: slab = LN4D(G) rows m0..m0+70;  out U0[S][L][256]
+// MODE 1: slab = zero-padded h3 rows (m0-7)..(m0+63);  out G[pos] = acc + bias + G[pos]  (in place)
+template <int N, int WM, int WN, int BK, int MODE>
+__global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias, float* __restrict__ dst) {
+    constexpr int LDB = BK + 4;
+    constexpr int WGN = N / (32 * WN), WGM = 4 / WGN;
+    static_assert(WGM * WM * 32 == 64, "workgroup tile is 64 rows");
+    __shared__ __attribute__((aligned(16))) float slab[kSlabRows * kSlabLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][N * LDB];
+
+    const int s = blockIdx.y, m0 = blockIdx.x * 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w / WGN, wn = w % WGN;
+    const size_t sbase = map.base(s);
+
+    ChunkRegs<N, BK> breg;
+    breg.load(Wt, 512, 0);
+
+    // ---- slab ----
+#pragma unroll
+    for (int it = 0; it < (kSlabRows * 16 + 255) / 256; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int row = idx >> 4, c4 = idx & 15;
+        float4 v = f4(0, 0, 0, 0);
+        if (MODE == 0) {
+            const int pos = m0 + row;
+            const bool ok = row < kSlabRows && pos < map.npos;
+            if (ok) v = ld4(src + sbase + (size_t)pos * map.pos_stride + c4 * 4);
+            // LayerNormalization4D over the 64 channels of this position (normalizations.py:33-37)
+            float sum = v.x + v.y + v.z + v.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum * (1.f / 64.f);
+            float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+            float sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = 1.0f / sqrtf(sq * (1.f / 64.f) + kEps);
+            v = ok ? fma4(d * rstd, ld4(gamma + c4 * 4), ld4(beta + c4 * 4)) : f4(0, 0, 0, 0);
+        } else {
+            const int l = m0 + row - 7;
+            if (row < kSlabRows && l >= 0 && l < map.L) v = ld4(src + ((size_t)s * map.L + l) * 64 + c4 * 4);
+        }
+        if (row < kSlabRows) st4(slab + row * kSlabLd + c4 * 4, v);
+    }
+    breg.store(Bs[0], LDB);
+    __syncthreads();
+
+    floatx16 acc[WM][WN];
+    acc_zero(acc);
+    constexpr int NK = 512 / BK;
+#pragma unroll 1
+    for (int kc = 0; kc < NK; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
+        const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
+        mma_block<WM, WN>(acc, slab + (wm * WM * 32 + kk) * kSlabLd + c0, kSlabLd, Bs[cur] + wn * WN * 32 * LDB, LDB, BK);
+        if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int n = 0; n < WN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
+                const int col = (wn * WN + n) * 32 + (lane & 31);
+                if (MODE == 0) {
+                    if (row < map.L) dst[((size_t)s * map.L + row) * N + col] = acc[m][n][r];
+                } else {
+                    if (row < map.npos) {
+                        const size_t o = sbase + (size_t)row * map.pos_stride + col;
+                        dst[o] = acc[m][n][r] + bias[col] + dst[o];
+                    }
+                }
+            }
+}
+
+// Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.
+//   KM == 4 (layer 0): U[s][l][lane][4] = (u0, u1, u2, x')          -> one 16-byte load per lane per step
+//   KM == 3 (layers 1-3): U[s][l][m][lane], m = 0..2, skip input x' = X[s][l][lane] * scale_x
+// Loads do not depend on the carried state, so UNR steps are fetched ahead of the dependent chain.
+template <int KM>
+__global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__ U, const float* __restrict__ X, const float* __restrict__ wc,
+                                                       const float* __restrict__ bias, float scale_x, float* __restrict__ Hout, int S, int L) {
+    constexpr int UNR = 8;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int lane = threadIdx.x & 63;
+    const bool rev = lane >= 32;
+    const float wf = wc[lane], wr = wc[64 + lane], bf = bias[lane], br = bias[64 + lane];
+    const float* u = U + (size_t)s * L * 64 * KM + (KM == 4 ? lane * 4 : lane);
+    const float* x = X + (size_t)s * L * 64 + lane;
+    float* h = Hout + (size_t)s * L * 64 + lane;
+    float c = 0.f;
+#pragma unroll 1
+    for (int t0 = 0; t0 < L; t0 += UNR) {
+        float u0[UNR], u1[UNR], u2[UNR], xp[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const int t = t0 + i;
+            const int l = rev ? L - 1 - t : t;
+            if (t < L) {
+                if (KM == 4) {
+                    float4 v = ld4(u + (size_t)l * 256);
+                    u0[i] = v.x, u1[i] = v.y, u2[i] = v.z, xp[i] = v.w;
+                } else {
+                    const float* p = u + (size_t)l * 192;
+                    u0[i] = p[0], u1[i] = p[64], u2[i] = p[128];
+                    xp[i] = x[(size_t)l * 64] * scale_x;
+                }
+            } else {
+                u0[i] = u1[i] = u2[i] = xp[i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const int t = t0 + i;
+            if (t < L) {
+                const int l = rev ? L - 1 - t : t;
+                const float f = sigmoidf_fast(u1[i] + bf + wf * c);
+                const float r = sigmoidf_fast(u2[i] + br + wr * c);
+                c = u0[i] + (c - u0[i]) * f;
+                h[(size_t)l * 64] = xp[i] + (c - xp[i]) * r;
+            }
+        }
+    }
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+static SeqMap make_map(int dim, int B, int T2) {
+    SeqMap m;
+    if (dim == 4) {  // along F: one sequence per (b, t2), contiguous [F2][64]
+        m.seq_div = 1, m.stride_hi = (long long)kF2 * kH, m.stride_lo = 0, m.pos_stride = kH, m.npos = kF2;
+    } else {  // along T: one sequence per (b, f2)
+        m.seq_div = kF2, m.stride_hi = (long long)T2 * kF2 * kH, m.stride_lo = kH, m.pos_stride = (long long)kF2 * kH, m.npos = T2;
+    }
+    m.L = m.npos - 7;
+    return m;
+}
+
+extern "C" {
+
+// G: [B][T2][F2][64].  U0: [S][L][256] with S = B*T2 (dim 4) or B*F2 (dim 3), L = npos-7, column = (dir*32+j)*4+m.
+// Wt: [256][512], k index = kk*64 + c.
+int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim,
+                            void* stream) {
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+    SeqMap m = make_map(dim, B, T2);
+    const int S = dim == 4 ? B * T2 : B * kF2;
+    dim3 grid((m.L + 63) / 64, S);
+    hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 32, 0>), grid, dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.
+int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+    SeqMap m = make_map(dim, B, T2);
+    const int S = dim == 4 ? B * T2 : B * kF2;
+    dim3 grid((m.npos + 63) / 64, S);
+    hipLaunchKernelGGL((toeplitz_gemm_kernel<64, 1, 1, 64, 1>), grid, dim3(256), 0, (hipStream_t)stream, m, H3, nullptr, nullptr, Wt, bias, G);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// km = 4: U [S][L][64][4];  km = 3: U [S][L][3][64] and X [S][L][64].  wc, bias: [2][64] (forget | reset).  H: [S][L][64].
+int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
+                      void* stream) {
+    if (S <= 0 || L <= 0) return RTFS_EINVAL;
+    dim3 grid((S + 3) / 4);
+    if (km == 4)
+        hipLaunchKernelGGL((sru_scan_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, U, X, wc, bias, scale_x, H, S, L);
+    else if (km == 3)
+        hipLaunchKernelGGL((sru_scan_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, wc, bias, scale_x, H, S, L);
+    else
+        return RTFS_EINVAL;
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // extern "C"

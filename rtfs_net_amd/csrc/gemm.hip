@@ -1,0 +1,314 @@
+// Pixel GEMMs: every 1x1 convolution of the path as a channels-last row-major GEMM on the fp32 MFMA
+// pipe, with the surrounding norm / activation / residual work fused into the operand load
+// ("prologue") or the accumulator write-back ("epilogue").
+//
+//   rtfs_bottleneck_fwd   audio_bottleneck  = ConvNormAct(pre gLN, pre ReLU, 1x1 256->256)   tdavnet.py:59,89
+//   rtfs_proj_fwd         gateway (dw1x1+PReLU) -> projection 1x1 256->64 (+gLN partial sums) tdanet.py:34-49,108-109
+//   rtfs_resid_fwd        TFAR tail -> residual_conv 1x1 64->256 + gateway residual           tdanet.py:54-59,127-131
+//   rtfs_mask_fwd         S3: PReLU -> 1x1 256->256 -> ReLU -> complex multiply with a_emb     mask_generator.py:67-99
+//   rtfs_gemm_rows_fwd    plain  Y[M][N] = X[M][K] W^T  (SRU layers 1-3 input projections; decoder taps)
+//
+// Tiling: 256 threads = 4 waves; workgroup tile BM x N (full N), K streamed in 32-deep chunks through
+// double-buffered LDS; each wave owns WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).  Weights are
+// pre-transposed on the host to Wt[N][K] so both operands are k-contiguous in LDS (common.h).
+#include "common.h"
+
+namespace rtfs {
+
+// ------------------------------------------------------------------------------------------------
+// prologues: produce A[row][k..k+3] for row < Mb of utterance b
+// ------------------------------------------------------------------------------------------------
+struct ProPlain {
+    const float* x;
+    int K;
+    __device__ void init(int) {}
+    __device__ float4 load(int b, int Mb, int row, int k) const { return ld4(x + ((size_t)b * Mb + row) * K + k); }
+};
+
+// relu(gLN(x))  -- audio_bottleneck pre_norm / pre_act (config yaml:15-20)
+struct ProGlnRelu {
+    const float* x;
+    const double* slot;
+    double inv_n;
+    const float *gamma, *beta;
+    float mean, rstd;
+    __device__ void init(int b) { stats_finalize(slot, b, inv_n, mean, rstd); }
+    __device__ float4 load(int b, int Mb, int row, int k) const {
+        float4 v = ld4(x + ((size_t)b * Mb + row) * kC + k);
+        return relu4(norm4(v, mean, rstd, ld4(gamma + k), ld4(beta + k)));
+    }
+};
+
+// prelu(x * w_c + b_c)  -- gateway: depth-wise 1x1 conv + PReLU (tdanet.py:34-41)
+struct ProGateway {
+    const float* x;
+    const float *gw, *gb;
+    float slope;
+    __device__ void init(int) {}
+    __device__ float4 load(int b, int Mb, int row, int k) const {
+        float4 v = ld4(x + ((size_t)b * Mb + row) * kC + k);
+        return prelu4(fma4(v, ld4(gw + k), ld4(gb + k)), slope);
+    }
+};
+
+// prelu(x)  -- mask_generator.0 (mask_generator.py:47)
+struct ProPrelu {
+    const float* x;
+    float slope;
+    __device__ void init(int) {}
+    __device__ float4 load(int b, int Mb, int row, int k) const { return prelu4(ld4(x + ((size_t)b * Mb + row) * kC + k), slope); }
+};
+
+// One gLN'd tensor read "normalise on read": slot -> (mean, rstd), gamma/beta per channel.
+struct NormRef {
+    const float* x;
+    const double* slot;
+    double inv_n;
+    const float *gamma, *beta;
+};
+
+// TFAR tail (tdanet.py:127 with upsampling_depth 2; InjectionMultiSum.forward fusion.py:54-69):
+//   expanded = gLN(cl) * sigmoid(gLN(cgate))^ + gLN(cg)^ + gLN(d0)        (^ = nearest up-sampling)
+struct ProExpanded {
+    NormRef cl, d0;      // full resolution [B][T][F][64]
+    NormRef cg, cgate;   // compressed      [B][T2][F2][64]
+    int T, T2;
+    float m[4], r[4];
+    __device__ void init(int b) {
+        stats_finalize(cl.slot, b, cl.inv_n, m[0], r[0]);
+        stats_finalize(d0.slot, b, d0.inv_n, m[1], r[1]);
+        stats_finalize(cg.slot, b, cg.inv_n, m[2], r[2]);
+        stats_finalize(cgate.slot, b, cgate.inv_n, m[3], r[3]);
+    }
+    __device__ float4 load(int b, int Mb, int row, int k) const {
+        const int t = row / kF, f = row - t * kF;
+        const int t2 = nearest_src(t, T2, T), f2 = nearest_src(f, kF2, kF);
+        const size_t hi = ((size_t)b * Mb + row) * kH + k;
+        const size_t lo = (((size_t)b * T2 + t2) * kF2 + f2) * kH + k;
+        float4 a = norm4(ld4(cl.x + hi), m[0], r[0], ld4(cl.gamma + k), ld4(cl.beta + k));
+        float4 d = norm4(ld4(d0.x + hi), m[1], r[1], ld4(d0.gamma + k), ld4(d0.beta + k));
+        float4 g = norm4(ld4(cg.x + lo), m[2], r[2], ld4(cg.gamma + k), ld4(cg.beta + k));
+        float4 s = sigmoid4(norm4(ld4(cgate.x + lo), m[3], r[3], ld4(cgate.gamma + k), ld4(cgate.beta + k)));
+        return fma4(a, s, g) + d;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// epilogues
+// ------------------------------------------------------------------------------------------------
+struct EpiBias {  // y = acc + bias
+    float* y;
+    const float* bias;  // may be null
+    int N;
+    static constexpr bool kStats = false;
+    __device__ void init(int) {}
+    __device__ void store(int b, int Mb, int row, int col, float v, float&, float&) const {
+        y[((size_t)b * Mb + row) * N + col] = bias ? v + bias[col] : v;
+    }
+};
+
+struct EpiBiasStats {  // y = acc + bias, and accumulate the gLN partial sums of y
+    float* y;
+    const float* bias;
+    int N;
+    static constexpr bool kStats = true;
+    double* slot;
+    __device__ void init(int) {}
+    __device__ void store(int b, int Mb, int row, int col, float v, float& s, float& q) const {
+        v += bias[col];
+        y[((size_t)b * Mb + row) * N + col] = v;
+        s += v;
+        q = fmaf(v, v, q);
+    }
+};
+
+// out = acc + bias + gateway(s_in) [+ a0]   (tdanet.py:131; "+ a0" pre-adds the next block's input, refinement_module.py:60)
+struct EpiResidual {
+    float* y;
+    const float* bias;
+    const float* s_in;
+    const float *gw, *gb;
+    float slope;
+    const float* a0;  // may be null
+    static constexpr bool kStats = false;
+    __device__ void init(int) {}
+    __device__ void store(int b, int Mb, int row, int col, float v, float&, float&) const {
+        const size_t o = ((size_t)b * Mb + row) * kC + col;
+        v += bias[col] + prelu(fmaf(s_in[o], gw[col], gb[col]), slope);
+        if (a0) v += a0[o];
+        y[o] = v;
+    }
+};
+
+// S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
+struct EpiMask {
+    float* y;
+    const float* bias;
+    const float* emb;
+    __device__ void store2(int b, int Mb, int row, int col, float vr, float vi) const {
+        const size_t o = ((size_t)b * Mb + row) * kC + col;
+        const float mr = fmaxf(vr + bias[col], 0.f), mi = fmaxf(vi + bias[col + 128], 0.f);
+        const float er = emb[o], ei = emb[o + 128];
+        y[o] = er * mr - ei * mi;
+        y[o + 128] = fmaf(er, mi, ei * mr);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, class Pro, class Epi>
+__global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb) {
+    constexpr int BK = 32, LD = BK + 4;
+    constexpr int WGN = N / (32 * WN), WGM = 4 / WGN;
+    static_assert(WGM * WGN == 4 && BM == WGM * WM * 32, "wave tiling must cover the workgroup tile");
+    static_assert(!PAIRED || (N == 256 && WN == 2), "paired epilogue needs N=256, WN=2");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][N * LD];
+    __shared__ float red[8];
+
+    const int b = blockIdx.y, m0 = blockIdx.x * BM;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w / WGN, wn = w % WGN;
+    pro.init(b);
+
+    constexpr int A_PER = BM * (BK / 4) / 256;
+    float4 areg[A_PER];
+    ChunkRegs<N, BK> breg;
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int row = idx / (BK / 4), c4 = idx % (BK / 4);
+            areg[i] = (m0 + row < Mb) ? pro.load(b, Mb, m0 + row, k0 + c4 * 4) : f4(0, 0, 0, 0);
+        }
+    };
+    auto store_a = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int idx = threadIdx.x + i * 256;
+            int row = idx / (BK / 4), c4 = idx % (BK / 4);
+            st4(dst + row * LD + c4 * 4, areg[i]);
+        }
+    };
+
+    floatx16 acc[WM][WN];
+    acc_zero(acc);
+
+    load_a(0);
+    breg.load(Wt, K, 0);
+    store_a(As[0]);
+    breg.store(Bs[0], LD);
+    __syncthreads();
+
+    constexpr int NK = K / BK;
+    constexpr int BT = PAIRED ? 128 : 32;
+    const int bcol0 = PAIRED ? wn * 32 : wn * WN * 32;
+#pragma unroll 1
+    for (int kc = 0; kc < NK; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < NK) {
+            load_a((kc + 1) * BK);
+            breg.load(Wt, K, (kc + 1) * BK);
+        }
+        mma_block<WM, WN, BT>(acc, As[cur] + wm * WM * 32 * LD, LD, Bs[cur] + bcol0 * LD, LD, BK);
+        if (kc + 1 < NK) {
+            store_a(As[cur ^ 1]);
+            breg.store(Bs[cur ^ 1], LD);
+        }
+        __syncthreads();
+    }
+
+    if constexpr (PAIRED) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
+                if (row < Mb) epi.store2(b, Mb, row, bcol0 + (lane & 31), acc[m][0][r], acc[m][1][r]);
+            }
+    } else {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
+                    if (row < Mb) epi.store(b, Mb, row, bcol0 + n * 32 + (lane & 31), acc[m][n][r], s, q);
+                }
+        if constexpr (Epi::kStats) block_stats_commit(s, q, red, epi.slot, b);
+    }
+}
+
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, class Pro, class Epi>
+static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
+    if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
+    dim3 grid((Mb + BM - 1) / BM, B);
+    hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, Pro, Epi>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+extern "C" {
+
+// a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
+int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt,
+                        const float* bias, float* a0, int B, int TF, void* stream) {
+    ProGlnRelu pro{a_emb, stats, 1.0 / ((double)TF * kC), gamma, beta, 0.f, 0.f};
+    EpiBias epi{a0, bias, kC};
+    return launch<256, 256, 64, 2, 2, false>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+}
+
+// y = Wp . prelu(s*gw+gb) + bias (pre-gLN projection output, [B][TF][64]) and its gLN partial sums.
+int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope, const float* Wt, const float* bias, float* y,
+                  double* stats_out, int B, int TF, void* stream) {
+    ProGateway pro{s, gw, gb, gslope};
+    EpiBiasStats epi{y, bias, kH, stats_out};
+    return launch<256, 64, 128, 2, 1, false>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+}
+
+// out = Wr . expanded + bias + prelu(s*gw+gb) [+ a0]; the four tensors of `expanded` are passed pre-gLN with their stats.
+int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                   const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                   const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                   const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                   const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                   const float* a0_or_null, float* out, int B, int T, int T2, void* stream) {
+    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
+    ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
+                    {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null};
+    return launch<64, 256, 64, 2, 2, false>(pro, epi, Wt, B, T * kF, (hipStream_t)stream);
+}
+
+// masked = complex_mul(relu(Wm . prelu(x) + bias), a_emb)   all [B][TF][256]
+int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bias, const float* a_emb, float* masked, int B, int TF,
+                  void* stream) {
+    ProPrelu pro{x, slope};
+    EpiMask epi{masked, bias, a_emb};
+    return launch<256, 256, 64, 2, 2, true>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+}
+
+// Y[M][N] = X[M][K] . Wt[N][K]^T (+ bias), row-major.  Supported (K,N): (64,192), (256,32).
+int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {
+    if (K == 64 && N == 192) {
+        ProPlain pro{X, 64};
+        EpiBias epi{Y, bias_or_null, 192};
+        return launch<64, 192, 64, 1, 3, false>(pro, epi, Wt, 1, M, (hipStream_t)stream);
+    }
+    if (K == 256 && N == 32) {
+        ProPlain pro{X, 256};
+        EpiBias epi{Y, bias_or_null, 32};
+        return launch<256, 32, 128, 1, 1, false>(pro, epi, Wt, 1, M, (hipStream_t)stream);
+    }
+    return RTFS_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// Bandwidth-bound stages of the RTFS block and the CAF fusion, channels-last, 16-byte vector access.
+//
+//   rtfs_dwconv_fwd     depth-wise 4x4 convolutions (+bias) with gLN partial sums; input normalised on read
+//                       downsample_layers (tdanet.py:61-76,112-114), InjectionMultiSum embeddings (fusion.py:25-52)
+//   rtfs_pool_fwd       adaptive_avg_pool2d(D0) + D1 (tdanet.py:117-118)
+//   rtfs_tfar_mix_fwd   local * sigmoid(gate)^ + global^   (fusion.py:67)  (^ = nearest up-sampling, fusion.py:59-61)
+//   rtfs_caf_video_fwd  video side of ATTNFusionCell (fusion.py:255,262-265): grouped 1x1 convs + gLN, head mean, softmax over Tv
+//   rtfs_caf_fuse_fwd   audio side: key/value depth-wise 1x1 + BatchNorm(eval) folded, k1 + k2 (fusion.py:259-272) [+ a0]
+//
+// Thread mapping for all H=64 tensors: 16 consecutive lanes own the 64 channels of one pixel (float4 each).
+#include "common.h"
+
+namespace rtfs {
+
+constexpr int kMaxConv = 4;
+
+struct DwArgs {
+    const float* in;      // [B][Tin][Fin][64]
+    const double* slot;   // gLN stats of `in` (mode >= 1)
+    double inv_n;
+    const float *gamma, *beta;
+    float slope;          // PReLU slope (mode 2)
+    int Tin, Fin, Tout, Fout;
+    int nconv;
+    const float* w[kMaxConv];     // [16 taps][64], tap = dt*4 + df
+    const float* bias[kMaxConv];  // [64] or null
+    float* out[kMaxConv];         // [B][Tout][Fout][64]
+    double* stats[kMaxConv];      // [B][2]
+};
+
+// MODE 0: raw input; 1: gLN(input); 2: PReLU(gLN(input)).  STRIDE 1: 'same' padding (1 before, 2 after); 2: padding 1.
+// Zero padding applies to the transformed input (conv_layers.py:104-113), so out-of-range taps are skipped.
+template <int STRIDE, int NCONV, int MODE>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NCONV * 256; i += 256) {
+        const int j = i >> 8, o = (i & 255) * 4;
+        st4(&ws[j][o], ld4(a.w[j] + o));
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (MODE >= 1) stats_finalize(a.slot, b, a.inv_n, mean, rstd);
+    const int c4 = (threadIdx.x & 15) * 4;
+    float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
+    if (MODE >= 1) {
+        const float4 g = ld4(a.gamma + c4), be = ld4(a.beta + c4);
+        sc = g * rstd;
+        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+    }
+    __syncthreads();
+
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int npix = a.Tout * a.Fout;
+    const bool valid = p < npix;
+    const int to = valid ? p / a.Fout : 0, fo = valid ? p - to * a.Fout : 0;
+    float4 acc[NCONV];
+#pragma unroll
+    for (int j = 0; j < NCONV; ++j) acc[j] = a.bias[j] ? ld4(a.bias[j] + c4) : f4(0, 0, 0, 0);
+    const float* inb = a.in + (size_t)b * a.Tin * a.Fin * kH;
+    if (valid) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int ti = to * STRIDE - 1 + dt;
+            if (ti < 0 || ti >= a.Tin) continue;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const int fi = fo * STRIDE - 1 + df;
+                if (fi < 0 || fi >= a.Fin) continue;
+                float4 x = ld4(inb + ((size_t)ti * a.Fin + fi) * kH + c4);
+                if (MODE >= 1) x = fma4(x, sc, sh);
+                if (MODE == 2) x = prelu4(x, a.slope);
+#pragma unroll
+                for (int j = 0; j < NCONV; ++j) acc[j] = fma4(ld4(&ws[j][(dt * 4 + df) * 64 + c4]), x, acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCONV; ++j) {
+        float s = 0.f, q = 0.f;
+        if (valid) {
+            st4(a.out[j] + ((size_t)b * npix + p) * kH + c4, acc[j]);
+            s = acc[j].x + acc[j].y + acc[j].z + acc[j].w;
+            q = acc[j].x * acc[j].x + acc[j].y * acc[j].y + acc[j].z * acc[j].z + acc[j].w * acc[j].w;
+        }
+        if (j) __syncthreads();
+        block_stats_commit(s, q, red, a.stats[j], b);
+    }
+}
+
+struct NormRefLite {
+    const float* x;
+    const double* slot;
+    double inv_n;
+    const float *gamma, *beta;
+};
+
+__device__ __forceinline__ void norm_coef(const NormRefLite& r, int b, int c4, float4& sc, float4& sh) {
+    float mean, rstd;
+    stats_finalize(r.slot, b, r.inv_n, mean, rstd);
+    const float4 g = ld4(r.gamma + c4), be = ld4(r.beta + c4);
+    sc = g * rstd;
+    sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+}
+
+// G = adaptive_avg_pool2d(gLN(D0p) -> (T2,F2)) + gLN(D1p); window [floor(i*in/out), ceil((i+1)*in/out)).
+__global__ __launch_bounds__(256) void pool_kernel(NormRefLite d0, NormRefLite d1, float* __restrict__ G, int T, int T2) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T2 * kF2) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t2 = p / kF2, f2 = p - t2 * kF2;
+    float4 sc0, sh0, sc1, sh1;
+    norm_coef(d0, b, c4, sc0, sh0);
+    norm_coef(d1, b, c4, sc1, sh1);
+    const int ts = (t2 * T) / T2, te = ((t2 + 1) * T + T2 - 1) / T2;
+    const int fs = (f2 * kF) / kF2, fe = ((f2 + 1) * kF + kF2 - 1) / kF2;
+    float4 s = f4(0, 0, 0, 0);
+    for (int t = ts; t < te; ++t)
+        for (int f = fs; f < fe; ++f) s = s + ld4(d0.x + (((size_t)b * T + t) * kF + f) * kH + c4);
+    const float inv = 1.0f / (float)((te - ts) * (fe - fs));
+    const size_t o = ((size_t)b * T2 * kF2 + p) * kH + c4;
+    st4(G + o, fma4(s * inv, sc0, sh0) + fma4(ld4(d1.x + o), sc1, sh1));
+}
+
+// out[p] = gLN(loc)[p] * sigmoid(gLN(gate)[up(p)]) + gLN(glob)[up(p)]; loc at (T,F), gate/glob at (Tg,Fg).
+__global__ __launch_bounds__(256) void tfar_mix_kernel(NormRefLite loc, NormRefLite gate, NormRefLite glob, float* __restrict__ out, int T, int F,
+                                                       int Tg, int Fg) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T * F) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = p / F, f = p - t * F;
+    const int tg = nearest_src(t, Tg, T), fg = nearest_src(f, Fg, F);
+    float4 scl, shl, scg, shg, sce, she;
+    norm_coef(loc, b, c4, scl, shl);
+    norm_coef(gate, b, c4, scg, shg);
+    norm_coef(glob, b, c4, sce, she);
+    const size_t o = ((size_t)b * T * F + p) * kH + c4;
+    const size_t og = (((size_t)b * Tg + tg) * Fg + fg) * kH + c4;
+    const float4 l = fma4(ld4(loc.x + o), scl, shl);
+    const float4 g = sigmoid4(fma4(ld4(gate.x + og), scg, shg));
+    const float4 e = fma4(ld4(glob.x + og), sce, she);
+    st4(out + o, fma4(l, g, e));
+}
+
+// Video side of the CAF cell, one workgroup per utterance, thread = audio channel c (256).
+//   v: [B][512][Tv] (NCW, as produced by the VP block).  att_w [1024][2], att_b/att_g/att_be [1024]; rs_w [256][2], rs_b/rs_g/rs_be [256].
+//   att_out, rsz_out: [B][Tv][256]
+__global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict__ v, const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                        const float* __restrict__ att_g, const float* __restrict__ att_be,
+                                                        const float* __restrict__ rs_w, const float* __restrict__ rs_b, const float* __restrict__ rs_g,
+                                                        const float* __restrict__ rs_be, float* __restrict__ att_out, float* __restrict__ rsz_out,
+                                                        int Tv) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
+    const float* v0 = v + ((size_t)b * 512 + 2 * c) * Tv;
+    const float* v1 = v0 + Tv;
+    float aw0[4], aw1[4], ab[4], ag[4], abe[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int o = c * 4 + h;
+        aw0[h] = att_w[2 * o], aw1[h] = att_w[2 * o + 1], ab[h] = att_b[o], ag[h] = att_g[o], abe[h] = att_be[o];
+    }
+    const float rw0 = rs_w[2 * c], rw1 = rs_w[2 * c + 1], rb = rs_b[c], rg = rs_g[c], rbe = rs_be[c];
+
+    // pass 1: gLN statistics of both pre-norm tensors (two-pass: mean first, then centred squares)
+    float s_att = 0.f, s_rs = 0.f;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) s_att += fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h]));
+        s_rs += fmaf(rw0, x0, fmaf(rw1, x1, rb));
+    }
+    s_att = wave_sum(s_att), s_rs = wave_sum(s_rs);
+    if (lane == 0) red[w] = s_att, red[4 + w] = s_rs;
+    __syncthreads();
+    const float m_att = (red[0] + red[1] + red[2] + red[3]) / (1024.f * Tv);
+    const float m_rs = (red[4] + red[5] + red[6] + red[7]) / (256.f * Tv);
+    float q_att = 0.f, q_rs = 0.f;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float d = fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att;
+            q_att = fmaf(d, d, q_att);
+        }
+        const float d = fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs;
+        q_rs = fmaf(d, d, q_rs);
+    }
+    q_att = wave_sum(q_att), q_rs = wave_sum(q_rs);
+    if (lane == 0) red[8 + w] = q_att, red[12 + w] = q_rs;
+    __syncthreads();
+    const float r_att = 1.0f / sqrtf((red[8] + red[9] + red[10] + red[11]) / (1024.f * Tv) + kEps);
+    const float r_rs = 1.0f / sqrtf((red[12] + red[13] + red[14] + red[15]) / (256.f * Tv) + kEps);
+
+    // pass 2: head mean -> softmax over Tv (max, sum, write); resize branch written directly
+    auto att_at = [&](int t) {
+        const float x0 = v0[t], x1 = v1[t];
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) m += fmaf((fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att, ag[h], abe[h]);
+        return m * 0.25f;
+    };
+    float mx = -3.0e38f;
+    for (int t = 0; t < Tv; ++t) mx = fmaxf(mx, att_at(t));
+    float sum = 0.f;
+    for (int t = 0; t < Tv; ++t) sum += __expf(att_at(t) - mx);
+    const float inv = 1.0f / sum;
+    for (int t = 0; t < Tv; ++t) {
+        const size_t o = ((size_t)b * Tv + t) * 256 + c;
+        att_out[o] = __expf(att_at(t) - mx) * inv;
+        rsz_out[o] = fmaf((fmaf(rw0, v0[t], fmaf(rw1, v1[t], rb)) - m_rs) * r_rs, rg, rbe);
+    }
+}
+
+// out = relu(x*ks+kb) * rsz[b][tv(t)] + att[b][tv(t)] * (x*vs+vb) [+ a0];  x,out,a0: [B][T][F][256]; tv(t) = floor(t*Tv/T)
+__global__ __launch_bounds__(256) void caf_fuse_kernel(const float* __restrict__ x, const float* __restrict__ ks, const float* __restrict__ kb,
+                                                       const float* __restrict__ vs, const float* __restrict__ vb, const float* __restrict__ att,
+                                                       const float* __restrict__ rsz, const float* __restrict__ a0, float* __restrict__ out, int T,
+                                                       int Tv) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= T * kF) return;
+    const int c4 = (threadIdx.x & 63) * 4;
+    const int t = p / kF;
+    const int tv = nearest_src(t, Tv, T);
+    const size_t o = ((size_t)b * T * kF + p) * kC + c4;
+    const size_t ov = ((size_t)b * Tv + tv) * kC + c4;
+    const float4 xv = ld4(x + o);
+    const float4 k1 = relu4(fma4(xv, ld4(ks + c4), ld4(kb + c4))) * ld4(rsz + ov);
+    const float4 vv = fma4(xv, ld4(vs + c4), ld4(vb + c4));
+    float4 r = fma4(ld4(att + ov), vv, k1);
+    if (a0) r = r + ld4(a0 + o);
+    st4(out + o, r);
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+template <int STRIDE, int MODE>
+static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
+    dim3 grid((a.Tout * a.Fout + 15) / 16, B);
+    switch (a.nconv) {
+        case 1: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 1, MODE>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 2, MODE>), grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 4, MODE>), grid, dim3(256), 0, st, a); break;
+        default: return RTFS_EINVAL;
+    }
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+extern "C" {
+
+// nconv in {1,2,4} depth-wise 4x4 convolutions of the same (optionally normalised) input.
+// mode 0: raw input, 1: gLN(in), 2: PReLU(gLN(in)).  stride 1 -> output (Tin,Fin); stride 2 -> ((Tin-2)/2+1, (Fin-2)/2+1).
+// w[j]: [16][64] (tap-major), bias[j]: [64] or NULL, out[j]: [B][Tout][Fout][64], stats_out[j]: [B][2] (accumulated into).
+int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma, const float* beta, float slope, int mode, int stride, int nconv,
+                    const float* const* w, const float* const* bias, float* const* out, double* const* stats_out, int B, int Tin, int Fin,
+                    void* stream) {
+    if (B <= 0 || nconv < 1 || nconv > kMaxConv || (stride != 1 && stride != 2) || mode < 0 || mode > 2) return RTFS_EINVAL;
+    DwArgs a;
+    a.in = in, a.slot = stats_in, a.inv_n = 1.0 / ((double)Tin * Fin * kH), a.gamma = gamma, a.beta = beta, a.slope = slope;
+    a.Tin = Tin, a.Fin = Fin;
+    a.Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1;
+    a.Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
+    a.nconv = nconv;
+    for (int j = 0; j < kMaxConv; ++j) {
+        a.w[j] = j < nconv ? w[j] : nullptr;
+        a.bias[j] = j < nconv ? bias[j] : nullptr;
+        a.out[j] = j < nconv ? out[j] : nullptr;
+        a.stats[j] = j < nconv ? stats_out[j] : nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) {
+        if (mode == 0) return launch_dw<1, 0>(a, B, st);
+        if (mode == 1) return launch_dw<1, 1>(a, B, st);
+        return launch_dw<1, 2>(a, B, st);
+    }
+    if (mode == 0) return launch_dw<2, 0>(a, B, st);
+    if (mode == 1) return launch_dw<2, 1>(a, B, st);
+    return launch_dw<2, 2>(a, B, st);
+}
+
+int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* d1, const double* d1_stats,
+                  const float* d1_g, const float* d1_b, float* G, int B, int T, int T2, void* stream) {
+    if (B <= 0 || T <= 0 || T2 <= 0) return RTFS_EINVAL;
+    NormRefLite r0{d0, d0_stats, 1.0 / ((double)T * kF * kH), d0_g, d0_b};
+    NormRefLite r1{d1, d1_stats, 1.0 / ((double)T2 * kF2 * kH), d1_g, d1_b};
+    hipLaunchKernelGGL(pool_kernel, dim3((T2 * kF2 + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, r0, r1, G, T, T2);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                      const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats,
+                      const float* glob_g, const float* glob_b, float* out, int B, int T, int F, int Tg, int Fg, void* stream) {
+    if (B <= 0 || T <= 0 || F <= 0 || Tg <= 0 || Fg <= 0) return RTFS_EINVAL;
+    const double nl = 1.0 / ((double)T * F * kH), ng = 1.0 / ((double)Tg * Fg * kH);
+    NormRefLite l{loc, loc_stats, nl, loc_g, loc_b}, ga{gate, gate_stats, ng, gate_g, gate_b}, gl{glob, glob_stats, ng, glob_g, glob_b};
+    hipLaunchKernelGGL(tfar_mix_kernel, dim3((T * F + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, l, ga, gl, out, T, F, Tg, Fg);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_caf_video_fwd(const float* v, const float* att_w, const float* att_b, const float* att_g, const float* att_be, const float* rs_w,
+                       const float* rs_b, const float* rs_g, const float* rs_be, float* att_out, float* rsz_out, int B, int Tv, void* stream) {
+    if (B <= 0 || Tv <= 0) return RTFS_EINVAL;
+    hipLaunchKernelGGL(caf_video_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, att_out,
+                       rsz_out, Tv);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_caf_fuse_fwd(const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz,
+                      const float* a0_or_null, float* out, int B, int T, int Tv, void* stream) {
+    if (B <= 0 || T <= 0 || Tv <= 0) return RTFS_EINVAL;
+    hipLaunchKernelGGL(caf_fuse_kernel, dim3((T * kF + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, ks, kb, vs, vb, att, rsz, a0_or_null, out, T, Tv);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""ctypes binding of include/rtfs_hip.h (librtfs_hip.so).
+
+The product path has NO fallback: if the library is missing or a launch fails this module raises.
+Tensors are handed over as raw device pointers; kernels are enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "librtfs_hip.so"
+
+P = c_void_p
+I = c_int
+F = c_float
+
+# name -> argtypes, in the order of include/rtfs_hip.h
+SIGNATURES = {
+    "rtfs_stft_fwd": [P, P, I, I, P],
+    "rtfs_enc_conv_fwd": [P, P, P, P, I, I, P],
+    "rtfs_bottleneck_fwd": [P, P, P, P, P, P, P, I, I, P],
+    "rtfs_proj_fwd": [P, P, P, F, P, P, P, P, I, I, P],
+    "rtfs_dwconv_fwd": [P, P, P, P, F, I, I, I, P, P, P, P, I, I, I, P],
+    "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
+    "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
+    "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
+    "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
+    "rtfs_attn_qkv_fwd": [P] * 13 + [I, I, P],
+    "rtfs_attn_core_fwd": [P, P, P, P, I, I, P],
+    "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, I, I, P],
+    "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
+    "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
+    "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
+    "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
+    "rtfs_mask_fwd": [P, F, P, P, P, P, I, I, P],
+    "rtfs_istft_fwd": [P, P, P, I, I, P],
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    """librtfs_hip.so next to this file, or $RTFS_HIP_LIB (lets a relocated copy of `models` find it)."""
+    return os.environ.get("RTFS_HIP_LIB", os.path.join(_HERE, LIB_NAME))
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension is not built. Run `python -m rtfs_net_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the product path."
+            )
+        lib = ctypes.CDLL(path)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.argtypes = args
+            fn.restype = c_int
+        _lib = lib
+    return _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("rtfs HIP kernels need contiguous device tensors")
+    return t.data_ptr()
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+    return arr
+
+
+def call(name: str, *args):
+    """Invoke an entry point; tensors are converted to pointers, the current stream is appended."""
+    conv = []
+    keep = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            conv.append(ptr(a))
+        elif isinstance(a, (list, tuple)):
+            arr = ptr_array(a)
+            keep.append(arr)
+            conv.append(ctypes.cast(arr, c_void_p))
+        else:
+            conv.append(a)
+    rc = getattr(load(), name)(*conv, _stream())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")

@@ -1,0 +1,208 @@
+"""AVNet: drop-in for `src.models.AVNet` (/root/reference/src/models/tdavnet.py:14-108 and
+TDAVNet/base_av_model.py:9-118) whose forward runs on hand-written HIP kernels.
+
+Constructor, forward signature, state-dict keys, serialize()/from_pretrain()/get_config()/get_MACs()
+follow the reference so `train.py:79` / `test.py:39,55` work unchanged.  Supported configuration
+family: config/*_RTFSNet_*_layer.yaml (anything else raises ValueError, like the reference's
+string->class factories do for unknown names).
+"""
+from __future__ import annotations
+
+import copy
+import sys
+
+import torch
+import torch.nn as nn
+
+from . import modules as M
+from .hip_path import HipForward
+
+__version__ = "0.1.0"
+
+
+class STFTEncoder(nn.Module):
+    def __init__(self, win, hop_length, out_chan, kernel_size, stride=1, act_type=None, norm_type=None, bias=False, **kw):
+        super().__init__()
+        self.win, self.hop_length, self.out_chan, self.kernel_size = win, hop_length, out_chan, kernel_size
+        self.conv = M.ConvNormAct(2, out_chan, kernel_size, is2d=True, stride=stride, act_type=act_type, norm_type=norm_type, bias=bias,
+                                  xavier_init=True)
+        self.register_buffer("window", torch.hann_window(win), False)
+
+    def get_out_chan(self):
+        return self.out_chan
+
+    def get_config(self):
+        return dict(win=self.win, hop_length=self.hop_length, out_chan=self.out_chan, kernel_size=self.kernel_size)
+
+    forward = M._holder_forward
+
+
+class STFTDecoder(nn.Module):
+    def __init__(self, win, hop_length, in_chan, n_src, kernel_size, stride=1, bias=False, **kw):
+        super().__init__()
+        self.win, self.hop_length, self.in_chan, self.n_src, self.kernel_size = win, hop_length, in_chan, n_src, kernel_size
+        self.decoder = nn.ConvTranspose2d(in_chan, 2, kernel_size, stride=stride, padding=(kernel_size - 1) // 2, bias=bias)
+        nn.init.xavier_uniform_(self.decoder.weight)
+        self.register_buffer("window", torch.hann_window(win), False)
+
+    def get_config(self):
+        return dict(win=self.win, hop_length=self.hop_length, in_chan=self.in_chan, n_src=self.n_src, kernel_size=self.kernel_size)
+
+    forward = M._holder_forward
+
+
+class MaskGenerator(nn.Module):
+    def __init__(self, n_src, audio_emb_dim, bottleneck_chan, kernel_size=1, mask_act="ReLU", RI_split=False, is2d=False, **kw):
+        super().__init__()
+        self.n_src, self.in_chan, self.bottleneck_chan, self.mask_act, self.RI_split = n_src, audio_emb_dim, bottleneck_chan, mask_act, RI_split
+        self.mask_generator = nn.Sequential(nn.PReLU(), M.ConvNormAct(bottleneck_chan, n_src * audio_emb_dim, kernel_size, act_type=mask_act, is2d=is2d))
+
+    def get_config(self):
+        return dict(n_src=self.n_src, in_chan=self.in_chan, bottleneck_chan=self.bottleneck_chan, mask_act=self.mask_act, RI_split=self.RI_split)
+
+    forward = M._holder_forward
+
+
+class RefinementModule(nn.Module):
+    def __init__(self, audio_params, video_params, audio_bn_chan, video_bn_chan, fusion_params):
+        super().__init__()
+        self.audio_params, self.video_params, self.fusion_params = audio_params, video_params, fusion_params
+        self.audio_bn_chan, self.video_bn_chan = audio_bn_chan, video_bn_chan
+        self.fusion_repeats = video_params.get("repeats", 0)
+        self.audio_repeats = audio_params["repeats"] - self.fusion_repeats
+        for name, key in (("audio_net", audio_params.get("audio_net")), ("video_net", video_params.get("video_net"))):
+            if key != "TDANet":
+                raise ValueError(f"Could not interpret separator identifier: {key} (the HIP path implements TDANet)")
+        self.audio_net = M.TDANet(**audio_params, in_chan=audio_bn_chan)
+        self.video_net = M.TDANet(**video_params, in_chan=video_bn_chan)
+        self.crossmodal_fusion = M.MultiModalFusion(**fusion_params, audio_bn_chan=audio_bn_chan, video_bn_chan=video_bn_chan,
+                                                    fusion_repeats=self.fusion_repeats)
+
+    def get_config(self):
+        return dict(audio_params=self.audio_params, video_params=self.video_params, fusion_params=self.fusion_params,
+                    audio_bn_chan=self.audio_bn_chan, video_bn_chan=self.video_bn_chan)
+
+    forward = M._holder_forward
+
+
+class AVNet(nn.Module):
+    def __init__(self, n_src: int, enc_dec_params: dict, audio_bn_params: dict, audio_params: dict, mask_generation_params: dict,
+                 pretrained_vout_chan: int = -1, video_bn_params: dict = dict(), video_params: dict = dict(), fusion_params: dict = dict(),
+                 print_macs: bool = True, *args, **kwargs):
+        super().__init__()
+        self.n_src = n_src
+        self.pretrained_vout_chan = pretrained_vout_chan
+        self.audio_bn_params, self.video_bn_params = audio_bn_params, video_bn_params
+        self.enc_dec_params, self.audio_params, self.video_params = enc_dec_params, audio_params, video_params
+        self.fusion_params, self.mask_generation_params = fusion_params, mask_generation_params
+        self.print_macs = print_macs
+        self._check_family()
+
+        self.encoder = STFTEncoder(**enc_dec_params)
+        self.enc_out_chan = self.encoder.get_out_chan()
+        # same dict mutations as tdavnet.py:54-56
+        self.mask_generation_params["mask_generator_type"] = self.mask_generation_params.get("mask_generator_type", "MaskGenerator")
+        self.audio_bn_chan = self.audio_bn_params.get("out_chan", self.enc_out_chan)
+        self.audio_bn_params["out_chan"] = self.audio_bn_chan
+        self.video_bn_chan = self.video_bn_params.get("out_chan", self.pretrained_vout_chan)
+
+        bn = {k: v for k, v in self.audio_bn_params.items() if k in ("pre_norm_type", "pre_act_type", "norm_type", "act_type", "out_chan", "kernel_size", "is2d")}
+        self.audio_bottleneck = M.ConvNormAct(in_chan=self.enc_out_chan, **{"is2d": False, **bn})
+        self.video_bottleneck = M.ConvNormAct(self.pretrained_vout_chan, self.video_bn_chan, self.video_bn_params.get("kernel_size", -1),
+                                              is2d=self.video_bn_params.get("is2d", False))
+        self.refinement_module = RefinementModule(self.audio_params, self.video_params, self.audio_bn_chan, self.video_bn_chan, self.fusion_params)
+        self.mask_generator = MaskGenerator(**{k: v for k, v in self.mask_generation_params.items() if k != "n_src"}, n_src=n_src,
+                                            audio_emb_dim=self.enc_out_chan, bottleneck_chan=self.audio_bn_chan)
+        self.decoder = STFTDecoder(**{k: v for k, v in enc_dec_params.items() if k not in ("in_chan", "n_src")},
+                                   in_chan=self.enc_out_chan * n_src, n_src=n_src)
+        self._hip = HipForward(self)
+        if self.print_macs:
+            self.get_MACs()
+
+    # ---- configuration family check ------------------------------------------------------------
+    def _check_family(self):
+        ed, ap, vp, mg = self.enc_dec_params, self.audio_params, self.video_params, self.mask_generation_params
+        def need(cond, msg):
+            if not cond:
+                raise ValueError("rtfs_net_amd implements the RTFS-Net family (config/*_RTFSNet_*_layer.yaml): " + msg)
+        need(ed.get("encoder_type") == "STFTEncoder" and ed.get("decoder_type") == "STFTDecoder", "encoder/decoder must be STFTEncoder/STFTDecoder")
+        need(ed.get("win") == 256 and ed.get("hop_length") == 128 and ed.get("out_chan") == 256 and ed.get("kernel_size") == 3, "win 256, hop 128, out_chan 256, kernel 3")
+        need(not ed.get("bias", False) and ed.get("act_type") is None and ed.get("norm_type") is None and ed.get("stride", 1) == 1, "encoder conv without bias/norm/act")
+        need(self.n_src == 1, "n_src == 1")
+        need(self.audio_bn_params.get("pre_norm_type") == "gLN" and self.audio_bn_params.get("pre_act_type") == "ReLU"
+             and self.audio_bn_params.get("kernel_size") == 1 and self.audio_bn_params.get("out_chan", 256) == 256, "audio bottleneck gLN->ReLU->1x1(256)")
+        need(self.video_bn_params.get("kernel_size", -1) == -1, "identity video bottleneck")
+        need(ap.get("hid_chan") == 64 and ap.get("kernel_size") == 4 and ap.get("stride") == 2 and ap.get("upsampling_depth") == 2
+             and ap.get("norm_type") == "gLN" and ap.get("act_type") == "PReLU" and ap.get("is2d"), "audio TDANet hid 64, k 4, stride 2, depth 2, gLN, PReLU, 2-D")
+        lay = list(ap.get("layers", {}).values())
+        need(len(lay) == 3 and [l.get("layer_type") for l in lay] == ["DualPathRNN", "DualPathRNN", "MultiHeadSelfAttention2D"], "layers = DualPathRNN, DualPathRNN, MultiHeadSelfAttention2D")
+        need(lay[0].get("dim") == 4 and lay[1].get("dim") == 3 and all(l.get("hid_chan") == 32 and l.get("kernel_size", 8) == 8 and l.get("num_layers") == 4
+             and l.get("rnn_type") == "SRU" for l in lay[:2]), "dual-path SRU hid 32, window 8, 4 layers, dims (4,3)")
+        need(lay[2].get("n_head", 4) == 4 and lay[2].get("hid_chan", 4) == 4 and lay[2].get("n_freqs") == 64, "attention 4 heads, hid 4, n_freqs 64")
+        need(vp.get("repeats") == 1 and not vp.get("is2d", False), "one 1-D video block")
+        need(self.pretrained_vout_chan == 512, "512-d lip embeddings")
+        need(self.fusion_params.get("fusion_type") == "ATTNFusion" and self.fusion_params.get("kernel_size") == 4, "ATTNFusion with kernel_size 4")
+        need(mg.get("mask_generator_type", "MaskGenerator") == "MaskGenerator" and mg.get("RI_split") and mg.get("mask_act", "ReLU") == "ReLU"
+             and mg.get("kernel_size", 1) == 1 and not mg.get("output_gate", False) and not mg.get("direct", False), "MaskGenerator(RI_split, ReLU)")
+
+    # ---- forward (tdavnet.py:86-97) ------------------------------------------------------------
+    def forward(self, audio_mixture: torch.Tensor, mouth_embedding: torch.Tensor = None):
+        x = audio_mixture
+        if x.ndim == 1:  # encoder.py:18-25
+            x = x.reshape(1, -1)
+        elif x.ndim == 3:
+            assert x.shape[1] == 1
+            x = x.reshape(x.shape[0], -1)
+        if mouth_embedding is None:
+            raise ValueError("RTFS-Net needs the lip embedding tensor [B, 512, Tv]")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()) and self.training):
+            raise NotImplementedError("backward through the HIP path is not built yet: call under torch.no_grad() with model.eval()")
+        return self._hip(x, mouth_embedding)
+
+    # ---- BaseAVModel API (TDAVNet/base_av_model.py) ---------------------------------------------
+    @staticmethod
+    def load_state_dict_in(model, pretrained_dict):
+        model_dict = model.state_dict()
+        update = {k[12:]: v for k, v in pretrained_dict.items() if "audio_model" in k}
+        model_dict.update(update)
+        model.load_state_dict(model_dict)
+        return model
+
+    @staticmethod
+    def from_pretrain(pretrained_model_conf_or_path, *args, **kwargs):
+        from . import get
+
+        conf = torch.load(pretrained_model_conf_or_path, map_location="cpu")
+        model_class = get(conf["model_name"])
+        model = model_class(print_macs=False, *args, **kwargs)
+        model.load_state_dict(conf["state_dict"])
+        return model
+
+    def serialize(self):
+        infos = {"software_versions": dict(torch_version=torch.__version__, pytorch_lightning_version=_ptl_version(),
+                                           python_version=sys.version, rtfs_net_amd_version=__version__)}
+        return dict(model_name=self.__class__.__name__, state_dict=self.get_state_dict(), model_args=self.get_config(), infos=infos)
+
+    def get_state_dict(self):
+        return self.state_dict()
+
+    def get_config(self):
+        return dict(encoder=self.encoder.get_config(), audio_bottleneck=self.audio_bottleneck.get_config(),
+                    video_bottleneck=self.video_bottleneck.get_config(), refinement_module=self.refinement_module.get_config(),
+                    mask_generator=self.mask_generator.get_config(), decoder=self.decoder.get_config())
+
+    def get_MACs(self):
+        """Analytic MAC / parameter report in the reference's format (base_av_model.py:61-118); thop is not needed."""
+        from .macs import macs_report
+
+        self.macs_parms = macs_report(self)
+        print(self.macs_parms)
+
+
+def _ptl_version():
+    try:
+        import pytorch_lightning as ptl
+
+        return ptl.__version__
+    except Exception:
+        return None

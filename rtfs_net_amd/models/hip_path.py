@@ -1,0 +1,288 @@
+"""Host-side driver of the HIP separation path: weight preparation + kernel sequencing.
+
+`HipForward(model)` mirrors `AVNet.forward` (/root/reference/src/models/tdavnet.py:86-97) and
+`RefinementModule.forward` (TDAVNet/refinement_module.py:45-62) stage by stage, but every stage is an
+entry point of include/rtfs_hip.h working on channels-last device buffers.  PyTorch only provides
+device memory (caching allocator), the current stream and the tiny video (VP) block.
+
+Inference only for now (eval-mode BatchNorm, no autograd); training mode raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import lib
+
+F_BINS = 129
+F2 = 64
+H = 64
+C = 256
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class PreparedWeights:
+    """Kernel-layout copies of the parameters (transposes / permutations done once, re-done when parameters change)."""
+
+    def __init__(self, model):
+        self.version = self.fingerprint(model)
+        dev = next(model.parameters()).device
+        self.device = dev
+        w = {}
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+
+        def g(name):
+            return _f32(sd[name])
+
+        # a1 encoder conv [256,2,3,3] -> [18][256]
+        w["enc"] = _f32(sd["encoder.conv.full_layer.2.weight"].reshape(C, 18).t())
+        # a2 bottleneck
+        w["bn_g"], w["bn_b"] = g("audio_bottleneck.full_layer.0.norm.weight"), g("audio_bottleneck.full_layer.0.norm.bias")
+        w["bn_w"] = _f32(sd["audio_bottleneck.full_layer.2.weight"].reshape(C, C))
+        w["bn_bias"] = g("audio_bottleneck.full_layer.2.bias")
+
+        blk = "refinement_module.audio_net.blocks."
+        self.blocks = []
+        shared = model.refinement_module.audio_net.shared
+        n_blocks = 1 if shared else model.refinement_module.audio_net.repeats
+        for i in range(n_blocks):
+            self.blocks.append(self._prep_block(sd, blk if shared else f"{blk}{i}."))
+
+        # a10 CAF (BatchNorm folded with running statistics: eval mode)
+        caf = "refinement_module.crossmodal_fusion.fusion_module." + ("" if model.refinement_module.crossmodal_fusion.fusion_shared else "0.") + "audio_lstm."
+        for tag in ("key", "value"):
+            p = f"{caf}{tag}_embed.full_layer."
+            dw = sd[p + "2.weight"].reshape(C).float()
+            scale = sd[p + "3.weight"].float() / torch.sqrt(sd[p + "3.running_var"].float() + 1e-5)
+            w[f"caf_{tag}_s"] = _f32(dw * scale)
+            w[f"caf_{tag}_b"] = _f32(sd[p + "3.bias"].float() - sd[p + "3.running_mean"].float() * scale)
+        p = caf + "attention_embed.full_layer."
+        w["caf_att_w"], w["caf_att_b"] = _f32(sd[p + "2.weight"].reshape(-1, 2)), g(p + "2.bias")
+        w["caf_att_g"], w["caf_att_be"] = g(p + "3.norm.weight"), g(p + "3.norm.bias")
+        p = caf + "resize.full_layer."
+        w["caf_rs_w"], w["caf_rs_b"] = _f32(sd[p + "2.weight"].reshape(-1, 2)), g(p + "2.bias")
+        w["caf_rs_g"], w["caf_rs_be"] = g(p + "3.norm.weight"), g(p + "3.norm.bias")
+
+        # a11 mask
+        w["mask_slope"] = float(sd["mask_generator.mask_generator.0.weight"].item())
+        w["mask_w"] = _f32(sd["mask_generator.mask_generator.1.full_layer.2.weight"].reshape(C, C))
+        w["mask_b"] = g("mask_generator.mask_generator.1.full_layer.2.bias")
+        # a12 decoder ConvTranspose2d weight [256 c][2 o][3][3] -> taps [32][256] (rows o*9+kt*3+kf, zero padded)
+        wd = torch.zeros(32, C, device=dev)
+        wd[:18] = sd["decoder.decoder.weight"].reshape(C, 18).t()
+        w["dec_w"] = _f32(wd)
+        self.w = w
+
+    @staticmethod
+    def fingerprint(model):
+        return tuple((p.data_ptr(), p._version) for p in list(model.parameters()) + list(model.buffers()))
+
+    @staticmethod
+    def _dw(sd, prefix):
+        """depth-wise ConvNormAct -> (taps [16][64], bias or None, gamma, beta)"""
+        wt = _f32(sd[prefix + "full_layer.2.weight"].reshape(H, 16).t())
+        b = _f32(sd[prefix + "full_layer.2.bias"]) if (prefix + "full_layer.2.bias") in sd else None
+        return wt, b, _f32(sd[prefix + "full_layer.3.norm.weight"]), _f32(sd[prefix + "full_layer.3.norm.bias"])
+
+    def _prep_block(self, sd, p):
+        b = {}
+        b["gw"], b["gb"] = _f32(sd[p + "gateway.full_layer.2.weight"].reshape(C)), _f32(sd[p + "gateway.full_layer.2.bias"])
+        b["gslope"] = float(sd[p + "gateway.full_layer.4.weight"].item())
+        b["pw"] = _f32(sd[p + "projection.full_layer.2.weight"].reshape(H, C))
+        b["pb"] = _f32(sd[p + "projection.full_layer.2.bias"])
+        b["pg"], b["pbe"] = _f32(sd[p + "projection.full_layer.3.norm.weight"]), _f32(sd[p + "projection.full_layer.3.norm.bias"])
+        b["pslope"] = float(sd[p + "projection.full_layer.4.weight"].item())
+        b["d0"] = self._dw(sd, p + "downsample_layers.0.")
+        b["d1"] = self._dw(sd, p + "downsample_layers.1.")
+        for i in (0, 1):  # dual-path: globalatt.0 (dim 4, along F), globalatt.1 (dim 3, along T)
+            q = f"{p}globalatt.{i}."
+            d = {"g": _f32(sd[q + "norm.gamma"].reshape(H)), "b": _f32(sd[q + "norm.beta"].reshape(H))}
+            w0 = sd[q + "rnn.rnn_lst.0.weight"].float()  # [c*8+kk][n] -> [n][kk*64+c]
+            d["w0"] = _f32(w0.reshape(H, 8, 256).permute(2, 1, 0).reshape(256, 512))
+            d["layers"] = []
+            for l in range(4):
+                lw = {"wc": _f32(sd[q + f"rnn.rnn_lst.{l}.weight_c"]), "bias": _f32(sd[q + f"rnn.rnn_lst.{l}.bias"]),
+                      "scale_x": float(sd[q + f"rnn.rnn_lst.{l}.scale_x"].item())}
+                if l > 0:  # [k][lane*3+m] -> [m*64+lane][k]
+                    lw["w"] = _f32(sd[q + f"rnn.rnn_lst.{l}.weight"].float().reshape(H, 64, 3).permute(2, 1, 0).reshape(192, H))
+                d["layers"].append(lw)
+            # ConvTranspose1d weight [j][c][k] -> [c][k'*64+j], k' = 7-k
+            d["ct_w"] = _f32(sd[q + "linear.weight"].float().flip(2).permute(1, 2, 0).reshape(H, 512))
+            d["ct_b"] = _f32(sd[q + "linear.bias"])
+            b[f"dp{i}"] = d
+        q = p + "globalatt.2."
+        mods = [f"{q}{n}.{h}." for n in ("Queries", "Keys", "Values") for h in range(4)]
+        a = {}
+        a["w"] = _f32(torch.cat([sd[m + "conv.weight"].reshape(-1, H) for m in mods], 0))  # [96][64]
+        a["bias"] = _f32(torch.cat([sd[m + "conv.bias"] for m in mods], 0))
+        a["slope"] = _f32(torch.cat([sd[m + "act.weight"].expand(sd[m + "conv.bias"].numel()) for m in mods], 0))
+        for tag, name in (("q", "Queries"), ("k", "Keys"), ("v", "Values")):
+            a["g" + tag] = _f32(torch.stack([sd[f"{q}{name}.{h}.norm.gamma"].reshape(-1) for h in range(4)], 0))
+            a["b" + tag] = _f32(torch.stack([sd[f"{q}{name}.{h}.norm.beta"].reshape(-1) for h in range(4)], 0))
+        m = q + "attn_concat_proj."
+        a["ow"] = _f32(sd[m + "conv.weight"].reshape(H, H))
+        a["ob"] = _f32(sd[m + "conv.bias"])
+        a["oslope"] = float(sd[m + "act.weight"].item())
+        a["og"] = _f32(sd[m + "norm.gamma"].reshape(H, F2).t())  # [c][f] -> [f][c]
+        a["obe"] = _f32(sd[m + "norm.beta"].reshape(H, F2).t())
+        b["attn"] = a
+        for name in ("fusion_layers.0", "fusion_layers.1", "concat_layers.0"):
+            for emb in ("local_embedding", "global_embedding", "global_gate"):
+                b[f"{name}.{emb}"] = self._dw(sd, f"{p}{name}.{emb}.")
+        b["rw"] = _f32(sd[p + "residual_conv.full_layer.2.weight"].reshape(C, H))
+        b["rb"] = _f32(sd[p + "residual_conv.full_layer.2.bias"])
+        return b
+
+
+class HipForward:
+    def __init__(self, model):
+        self.model = model
+        self._prep = None
+        self.taps = None  # set to a dict to capture stage outputs (tests)
+
+    def weights(self) -> PreparedWeights:
+        fp = PreparedWeights.fingerprint(self.model)
+        if self._prep is None or self._prep.version != fp:
+            self._prep = PreparedWeights(self.model)
+        return self._prep
+
+    # ---- dual path (a6-a7) ----
+    def _dual_path(self, G, d, B, T2, dim):
+        S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
+        L = npos - 7
+        dev = G.device
+        U = torch.empty(S * L * 256, device=dev)
+        lib.call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U, B, T2, dim)
+        h = torch.empty(S * L * 64, device=dev)
+        l0 = d["layers"][0]
+        lib.call("rtfs_sru_scan_fwd", U, None, l0["wc"], l0["bias"], l0["scale_x"], h, S, L, 4)
+        for lw in d["layers"][1:]:
+            lib.call("rtfs_gemm_rows_fwd", h, lw["w"], None, U, S * L, 64, 192)
+            h2 = torch.empty_like(h)
+            lib.call("rtfs_sru_scan_fwd", U, h, lw["wc"], lw["bias"], lw["scale_x"], h2, S, L, 3)
+            h = h2
+        lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
+
+    # ---- one RTFS block (a5) ----
+    def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None):
+        dev = s_in.device
+        TF = T * F_BINS
+        full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
+        low = lambda: torch.empty(B * T2 * F2 * H, device=dev)  # noqa: E731
+        y0 = full()
+        lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], y0, st[0], B, TF)
+        d0w, d0b, d0g, d0be = bw["d0"]
+        d1w, d1b, d1g, d1be = bw["d1"]
+        D0 = full()
+        lib.call("rtfs_dwconv_fwd", y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [D0], [st[1]], B, T, F_BINS)
+        D1 = low()
+        lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [D1], [st[2]], B, T, F_BINS)
+        G = low()
+        lib.call("rtfs_pool_fwd", D0, st[1], d0g, d0be, D1, st[2], d1g, d1be, G, B, T, T2)
+        if tap is not None:
+            tap["y0"], tap["D0"], tap["D1"], tap["pooled"] = y0, D0, D1, G.clone()
+        self._dual_path(G, bw["dp0"], B, T2, 4)
+        if tap is not None:
+            tap["dp_freq"] = G.clone()
+        self._dual_path(G, bw["dp1"], B, T2, 3)
+        if tap is not None:
+            tap["dp_time"] = G.clone()
+        a = bw["attn"]
+        Q = torch.empty(B * 4 * T2 * 256, device=dev)
+        K = torch.empty_like(Q)
+        V = torch.empty(B * 4 * T2 * 1024, device=dev)
+        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, B, T2)
+        O = torch.empty(B * T2 * 4096, device=dev)
+        lib.call("rtfs_attn_core_fwd", Q, K, V, O, B, T2)
+        lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, B, T2)
+        if tap is not None:
+            tap["attn"] = G.clone()
+        # TFAR (a5.6)
+        f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
+        f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
+        cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
+        l0, l1 = full(), low()
+        lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [l0], [st[3]], B, T, F_BINS)
+        lib.call("rtfs_dwconv_fwd", D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [l1], [st[4]], B, T2, F2)
+        g0, gg0, g1, gg1 = low(), low(), low(), low()
+        lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [g0, gg0, g1, gg1],
+                 [st[5], st[6], st[7], st[8]], B, T2, F2)
+        F0, F1 = full(), low()
+        lib.call("rtfs_tfar_mix_fwd", l0, st[3], f0l[2], f0l[3], gg0, st[6], f0gate[2], f0gate[3], g0, st[5], f0g[2], f0g[3], F0, B, T, F_BINS, T2, F2)
+        lib.call("rtfs_tfar_mix_fwd", l1, st[4], f1l[2], f1l[3], gg1, st[8], f1gate[2], f1gate[3], g1, st[7], f1g[2], f1g[3], F1, B, T2, F2, T2, F2)
+        if tap is not None:
+            tap["tfar0"], tap["tfar1"] = F0, F1
+        cl, cg, cgate = full(), low(), low()
+        lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
+        lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
+        lib.call("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
+                 cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+
+    @torch.no_grad()
+    def __call__(self, wav: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        if m.training:
+            raise NotImplementedError("the HIP path implements inference (model.eval()); training-mode BatchNorm/backward are not built yet")
+        if not wav.is_cuda:
+            raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
+        pw = self.weights()
+        w = pw.w
+        wav = wav.to(torch.float32).contiguous()
+        B, L = wav.shape
+        T = 1 + L // 128
+        T2 = (T - 2) // 2 + 1
+        if T2 < 8:
+            raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
+        TF = T * F_BINS
+        dev = wav.device
+        R = m.refinement_module.audio_net.repeats
+        stats = torch.zeros(1 + 12 * R, B, 2, dtype=torch.float64, device=dev)
+        taps = self.taps
+
+        # a1: STFT + encoder conv
+        spec = torch.empty(B * TF * 2, device=dev)
+        lib.call("rtfs_stft_fwd", wav, spec, B, L)
+        a_emb = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_enc_conv_fwd", spec, w["enc"], a_emb, stats[0], B, T)
+        # a2: bottleneck
+        a0 = torch.empty_like(a_emb)
+        lib.call("rtfs_bottleneck_fwd", a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], a0, B, TF)
+        if taps is not None:
+            taps["spec"], taps["a_emb"], taps["a0"] = spec, a_emb, a0
+
+        # a9: VP block (PyTorch-ROCm glue) -- independent of the audio branch
+        v1 = m.refinement_module.video_net.get_block(0)(m.video_bottleneck(emb.to(torch.float32))).contiguous()
+        Tv = v1.shape[-1]
+
+        blocks = pw.blocks
+        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
+        x = torch.empty_like(a_emb)
+        self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
+        att = torch.empty(B * Tv * C, device=dev)
+        rsz = torch.empty_like(att)
+        lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
+                 w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
+        s = torch.empty_like(a_emb)
+        last = R == 1
+        lib.call("rtfs_caf_fuse_fwd", x, w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, None if last else a0, s, B, T, Tv)
+        if taps is not None:
+            taps["block0"], taps["vp"] = x.clone(), v1
+            taps["caf_plus_a0" if not last else "caf"] = s.clone()
+        for i in range(1, R):
+            last = i == R - 1
+            self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2)
+            s, x = x, s
+        # a11: S3 mask; a12: decoder taps + iSTFT
+        masked = x
+        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], a_emb, masked, B, TF)
+        tapbuf = torch.empty(B * TF * 32, device=dev)
+        lib.call("rtfs_gemm_rows_fwd", masked, w["dec_w"], None, tapbuf, B * TF, 256, 32)
+        frames = torch.empty(B * T * 256, device=dev)
+        out = torch.empty(B, L, device=dev)
+        lib.call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
+        if taps is not None:
+            taps["refined"], taps["masked"] = s, masked
+        return out.view(B, 1, L)
