@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- separated STFT frames/s of the HIP RTFS-Net path (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W] [--layers 6 --batch 32 --seconds 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (AVNet.forward: STFT -> RTFS blocks -> CAF -> S3 mask -> iSTFT) over one
+batch of synthetic 16 kHz mixtures + lip embeddings already resident in HBM.  Utterances are independent, so N
+GPUs = N shards of the global batch with NO data-path collective ("scaling": "weak"); the only collectives are the
+timing barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     -- the dominant kernel, timed live with HIP events on the launch stream during the timed steps
+  cpu_baseline -- the oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+F_BINS, F2, C, H = 129, 64, 256, 64
+
+
+def kernel_models(B, T, T2, Tv):
+    """Algorithmic work per launch of each C-ABI entry point: (bound, amount, unit).
+    bytes = stage-boundary tensors read once + written once (fp32); flops = 2 * MACs."""
+    TF, lo = T * F_BINS, T2 * F2
+    full_c, full_h, low_h = 4.0 * B * TF * C, 4.0 * B * TF * H, 4.0 * B * lo * H
+    m = {
+        "rtfs_bottleneck_fwd": ("mfma", 2.0 * B * TF * C * C),
+        "rtfs_mask_fwd": ("mfma", 2.0 * B * TF * C * C),
+        "rtfs_proj_fwd": ("hbm", full_c + full_h),
+        "rtfs_resid_fwd": ("hbm", 2 * full_h + 2 * low_h + 3 * full_c),  # cl, d0, cg, cgate, s_in, a0 -> out
+        "rtfs_caf_fuse_fwd": ("hbm", 3 * full_c),
+        "rtfs_enc_conv_fwd": ("hbm", full_c + 4.0 * B * TF * 2),
+    }
+    return m
+
+
+def dp_gemm_flops(B, T2):
+    """per-launch flops of rtfs_dp_unfold_gemm_fwd: freq (dim 4) and time (dim 3) launches differ"""
+    return {4: 2.0 * B * T2 * (F2 - 7) * 512 * 256, 3: 2.0 * B * F2 * (T2 - 7) * 512 * 256}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=6, help="RTFS-Net-R (audio_params.repeats)")
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--roofline-kernel", default="rtfs_dp_unfold_gemm_fwd")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from oracle import synth  # synthetic inputs only (shared with the tests); the oracle itself is used for cpu_baseline below
+    from rtfs_net_amd import AVNet, lib
+
+    L = int(args.seconds * 16000)
+    T = 1 + L // 128
+    T2 = (T - 2) // 2 + 1
+    Tv = int(25 * args.seconds)
+    cfg = synth.rtfs_audionet(args.layers)
+    torch.manual_seed(1234)
+    model = AVNet(print_macs=False, **copy.deepcopy(cfg)).eval()
+    sd = synth.synth_state_dict(model.state_dict())  # random-init weights of the architecture ("data": synthetic)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    # each rank gets its own shard of the global batch (different seed -> different utterances)
+    mix, _, emb = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)
+    mix, emb = mix.to(dev), emb.to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(mix, emb)
+        barrier()
+        lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(mix, emb)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = lib.profile_end()
+    assert torch.isfinite(out).all()
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        frames = world * args.batch * T * args.steps
+        res = {
+            "metric": "separated STFT frames/sec",
+            "value": frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), {args.seconds:g} s @16 kHz, "
+                            f"batch {args.batch} per GPU, fp32, random-init weights",
+                "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
+                "parallelism": f"utterance-sharded x{world}, no data-path collective",
+            },
+        }
+        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
+        roof = None
+        if prof:
+            name = args.roofline_kernel
+            if name == "rtfs_dp_unfold_gemm_fwd":
+                fl = dp_gemm_flops(args.batch, T2)
+                durs = prof  # launches alternate dim 4 (freq), dim 3 (time)
+                tot_ms = sum(durs)
+                tot_fl = (fl[4] + fl[3]) * (len(durs) // 2)
+                roof = {"kernel": "toeplitz_gemm_kernel<256,2,2,32,0> (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM)",
+                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "launches": len(durs), "avg_launch_ms": tot_ms / len(durs), "traffic": None}
+            else:
+                km = kernel_models(args.batch, T, T2, Tv).get(name)
+                if km is not None:
+                    bound, amount = km
+                    avg_ms = sum(prof) / len(prof)
+                    if bound == "hbm":
+                        roof = {"kernel": name, "bound": "hbm", "achieved": amount / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+                    else:
+                        roof = {"kernel": name, "bound": "mfma", "achieved": amount / (avg_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
+                    roof.update(launches=len(prof), avg_launch_ms=avg_ms, traffic=None)
+            if roof:
+                roof["frac"] = roof["achieved"] / roof["peak"]
+        res["roofline"] = roof
+        # ---- CPU baseline: the oracle on the host cores, bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.avnet_ref import avnet_forward
+
+            cmix, _, cemb = synth.synth_inputs(1, L, Tv)
+            n = torch.get_num_threads()
+            with torch.no_grad():
+                avnet_forward(sd, cfg, cmix, cemb)  # warm-up
+                runs, t0 = 0, time.perf_counter()
+                while runs < 10 and (time.perf_counter() - t0) < args.cpu_budget_s:
+                    avnet_forward(sd, cfg, cmix, cemb)
+                    runs += 1
+                dt = (time.perf_counter() - t0) / runs
+            res["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": n, "kind": "port",
+                                   "sample": f"oracle/avnet_ref.py, RTFS-Net-{args.layers}, batch 1 x {args.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

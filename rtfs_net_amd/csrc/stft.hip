@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
             env = fmaf(wv, wv, env);
         }
     }
-    // torch.istft produces (T-1)*hop samples and zero-pads up to `length`
-    out[(size_t)b * L + n] = (n < (T - 1) * kHop && env > 1e-11f) ? acc / env : 0.f;
+    // samples past (T-1)*hop are still covered by the second half of the last frame (torch.istft keeps them)
+    out[(size_t)b * L + n] = env > 1e-11f ? acc / env : 0.f;
 }
 
 }  // namespace rtfs

@@ -85,6 +85,24 @@ def ptr_array(tensors):
     return arr
 
 
+_prof_name = None
+_prof_events = []
+
+
+def profile_begin(name: str):
+    """Time every launch of ONE entry point with HIP events recorded on the launch stream (bench.py roofline)."""
+    global _prof_name, _prof_events
+    _prof_name, _prof_events = name, []
+
+
+def profile_end():
+    """-> list of per-launch durations in ms (synchronises)."""
+    global _prof_name
+    _prof_name = None
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in _prof_events]
+
+
 def call(name: str, *args):
     """Invoke an entry point; tensors are converted to pointers, the current stream is appended."""
     conv = []
@@ -98,6 +116,13 @@ def call(name: str, *args):
             conv.append(ctypes.cast(arr, c_void_p))
         else:
             conv.append(a)
-    rc = getattr(load(), name)(*conv, _stream())
+    if name == _prof_name:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # torch's current stream == the stream handed to the kernel
+        rc = getattr(load(), name)(*conv, _stream())
+        e1.record()
+        _prof_events.append((e0, e1))
+    else:
+        rc = getattr(load(), name)(*conv, _stream())
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")

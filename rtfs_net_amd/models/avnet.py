@@ -172,14 +172,15 @@ class AVNet(nn.Module):
     def from_pretrain(pretrained_model_conf_or_path, *args, **kwargs):
         from . import get
 
-        conf = torch.load(pretrained_model_conf_or_path, map_location="cpu")
+        # reference checkpoints (train.py:156-160) carry a torch TorchVersion object in "infos": load like torch 2.1 did
+        conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=False)
         model_class = get(conf["model_name"])
         model = model_class(print_macs=False, *args, **kwargs)
         model.load_state_dict(conf["state_dict"])
         return model
 
     def serialize(self):
-        infos = {"software_versions": dict(torch_version=torch.__version__, pytorch_lightning_version=_ptl_version(),
+        infos = {"software_versions": dict(torch_version=str(torch.__version__), pytorch_lightning_version=_ptl_version(),
                                            python_version=sys.version, rtfs_net_amd_version=__version__)}
         return dict(model_name=self.__class__.__name__, state_dict=self.get_state_dict(), model_args=self.get_config(), infos=infos)
 

@@ -1,0 +1,77 @@
+"""GPU parity of the whole separation path through the module API.
+
+* against the REFERENCE's own outputs (tests/golden/rtfs*.npz, produced by oracle/gen_golden.py from /root/reference)
+  -- RTFS-Net-4 (B=1), RTFS-Net-6 (B=2), RTFS-Net-12 on 4 s (B=1): relative L2 <= 1e-3 on the waveform (BASELINE.json)
+* size-independent properties at the bench size (B=16): batch invariance, finite output, SI-SDR parity vs the oracle
+  on the utterances the oracle can afford (<= 0.01 dB)
+* edge cases of the boundary: 1-D / 3-D inputs, odd lengths, ragged Tv, too-short input
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import load_npz, make_model, rel, synth
+
+pytestmark = pytest.mark.gpu
+WAVE_TOL = 1e-3
+
+
+@pytest.mark.parametrize("name,R,B,L", [("rtfs4_b1.npz", 4, 1, 32000), ("rtfs6_b2.npz", 6, 2, 32000), ("rtfs12_4s_b1.npz", 12, 1, 64000)])
+def test_against_reference_golden(name, R, B, L):
+    z = load_npz(name)
+    model, _, _ = make_model(R, "cuda")
+    mix, _, emb = synth.synth_inputs(B, L, 25 * L // 16000)
+    assert np.array_equal(mix[:, :256].numpy(), z["mix_head"])
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+    assert rel(out, torch.from_numpy(z["out"])) < WAVE_TOL
+
+
+def test_batch_invariance_and_sisdr_parity():
+    from oracle.avnet_ref import avnet_forward, si_sdr
+
+    B, L, Tv = 16, 32000, 50
+    model, sd, cfg = make_model(6, "cuda")
+    mix, s1, emb = synth.synth_inputs(B, L, Tv)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+        assert torch.isfinite(out).all()
+        # utterances are independent: item 5 alone gives the same waveform as inside the batch
+        solo = model(mix[5:6].cuda(), emb[5:6].cuda())
+        assert rel(solo[0], out[5]) < 1e-5
+        ref = avnet_forward(sd, cfg, mix[5:6], emb[5:6])
+    assert rel(out[5:6], ref) < WAVE_TOL
+    d = si_sdr(out[5, 0].cpu(), s1[5]) - si_sdr(ref[0, 0], s1[5])
+    assert abs(float(d)) < 0.01  # dB
+
+
+def test_input_shapes_and_edges():
+    model, _, _ = make_model(4, "cuda")
+    mix, _, emb = synth.synth_inputs(2, 8000 + 37, 11)  # L not a multiple of the hop, ragged Tv
+    with torch.no_grad():
+        a = model(mix.cuda(), emb.cuda())
+        b = model(mix.cuda().unsqueeze(1), emb.cuda())        # [B,1,L]
+        c = model(mix[0].cuda(), emb[:1].cuda())               # [L]
+        assert a.shape == (2, 1, 8037) and torch.equal(a, b) and rel(c[0], a[0]) < 1e-5
+        with pytest.raises(ValueError):
+            model(mix[:, :1000].cuda(), emb.cuda())
+
+
+def test_edge_lengths_against_oracle():
+    from oracle.avnet_ref import avnet_forward
+
+    model, sd, cfg = make_model(4, "cuda")
+    for L, Tv in ((1920 + 128 * 1, 3), (8037, 11)):
+        mix, _, emb = synth.synth_inputs(1, L, Tv)
+        with torch.no_grad():
+            out = model(mix.cuda(), emb.cuda())
+            ref = avnet_forward(sd, cfg, mix, emb)
+        assert rel(out, ref) < WAVE_TOL, (L, Tv)
+
+
+def test_train_mode_is_refused_loudly():
+    model, _, _ = make_model(4, "cuda")
+    model.train()
+    mix, _, emb = synth.synth_inputs(1, 8000, 12)
+    with pytest.raises(NotImplementedError):
+        model(mix.cuda(), emb.cuda())
