@@ -106,7 +106,8 @@ __device__ __forceinline__ float4 sigmoid4(float4 x) {
 }
 
 // nearest-neighbour source index used by F.interpolate(mode="nearest"): floor(dst * in / out)
-__device__ __forceinline__ int nearest_src(int dst, int in, int out) { return (int)(((long long)dst * in) / out); }
+// (32-bit: dst * in < 2^31 for every shape on this path; a 64-bit divide would cost ~100 instructions per pixel)
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) { return (int)(((unsigned)dst * (unsigned)in) / (unsigned)out); }
 
 // ---- fp32 MFMA tile machinery --------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l supplies A[l&31][l>>5] and

@@ -109,6 +109,82 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
             }
 }
 
+
+// Layer-0 kernel, second generation: workgroup tile 128 rows x 256 columns = TWO 64-row slabs (two frequency
+// sequences, or the two halves of one time sequence), 4 waves as 2 (slab) x 2 (column half), each wave 64 x 128
+// (2 x 4 accumulator tiles = 128 AGPRs).  Against the 64 x 256 tile this halves the weight bytes staged per
+// flop and the barriers per flop; BK = 16 keeps LDS at 79.6 KB so two workgroups share a CU.
+__global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
+                                                                int tiles_per_seq, int total_tiles) {
+    constexpr int BK = 16, LDB = BK + 4, N = 256;
+    __shared__ __attribute__((aligned(16))) float slab[2][kSlabRows * kSlabLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][N * LDB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w >> 1, wn = w & 1;
+
+    ChunkRegs<N, BK> breg;
+    breg.load(Wt, 512, 0);
+
+    int seq[2], m0[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        const int gt = min(blockIdx.x * 2 + st, total_tiles - 1);
+        seq[st] = gt / tiles_per_seq;
+        m0[st] = (gt - seq[st] * tiles_per_seq) * 64;
+    }
+    // ---- two LN4D-normalised slabs ----
+#pragma unroll
+    for (int it = 0; it < (2 * kSlabRows * 16 + 255) / 256; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int st = idx >= kSlabRows * 16 ? 1 : 0;
+        const int loc = idx - st * kSlabRows * 16;
+        const int row = loc >> 4, c4 = loc & 15;
+        const bool inr = idx < 2 * kSlabRows * 16;
+        const int pos = m0[st] + row;
+        const bool ok = inr && pos < map.npos;
+        float4 v = f4(0, 0, 0, 0);
+        if (ok) v = ld4(src + map.base(seq[st]) + (size_t)pos * map.pos_stride + c4 * 4);
+        float sum = v.x + v.y + v.z + v.w;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum * (1.f / 64.f);
+        const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        float sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.f / 64.f) + kEps);
+        v = ok ? fma4(d * rstd, ld4(gamma + c4 * 4), ld4(beta + c4 * 4)) : f4(0, 0, 0, 0);
+        if (inr) st4(slab[st] + row * kSlabLd + c4 * 4, v);
+    }
+    breg.store(Bs[0], LDB);
+    __syncthreads();
+
+    floatx16 acc[2][4];
+    acc_zero(acc);
+    constexpr int NK = 512 / BK;
+#pragma unroll 1
+    for (int kc = 0; kc < NK; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
+        const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
+        mma_block<2, 4>(acc, slab[wm] + kk * kSlabLd + c0, kSlabLd, Bs[cur] + wn * 128 * LDB, LDB, BK);
+        if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
+        __syncthreads();
+    }
+    if (blockIdx.x * 2 + wm >= total_tiles) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0[wm] + m * 32 + acc_row(r);
+                const int col = wn * 128 + n * 32 + (lane & 31);
+                if (row < map.L) dst[((size_t)seq[wm] * map.L + row) * N + col] = acc[m][n][r];
+            }
+}
+
 // Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.
 //   KM == 4 (layer 0): U[s][l][lane][4] = (u0, u1, u2, x')          -> one 16-byte load per lane per step
 //   KM == 3 (layers 1-3): U[s][l][m][lane], m = 0..2, skip input x' = X[s][l][lane] * scale_x
@@ -184,8 +260,8 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
-    dim3 grid((m.L + 63) / 64, S);
-    hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 32, 0>), grid, dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+    const int tps = (m.L + 63) / 64, total = S * tps;
+    hipLaunchKernelGGL(unfold_gemm128_kernel, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

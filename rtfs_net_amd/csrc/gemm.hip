@@ -157,9 +157,9 @@ struct EpiMask {
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int K, int N, int BM, int WM, int WN, bool PAIRED, class Pro, class Epi>
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK, class Pro, class Epi>
 __global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb) {
-    constexpr int BK = 32, LD = BK + 4;
+    constexpr int LD = BK + 4;
     constexpr int WGN = N / (32 * WN), WGM = 4 / WGN;
     static_assert(WGM * WGN == 4 && BM == WGM * WM * 32, "wave tiling must cover the workgroup tile");
     static_assert(!PAIRED || (N == 256 && WN == 2), "paired epilogue needs N=256, WN=2");
@@ -243,11 +243,196 @@ __global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const
     }
 }
 
-template <int K, int N, int BM, int WM, int WN, bool PAIRED, class Pro, class Epi>
+
+// ------------------------------------------------------------------------------------------------
+// residual_conv (K = 64 -> N = 256) with the operands SWAPPED: out^T[n][p] = W[n][k] . E^T[k][p].
+//  * the weight is the MFMA A operand and lives in registers for the whole workgroup (64 VGPRs per
+//    wave: wave w owns output channels [64w, 64w+64)), so nothing but the 64-pixel E tile goes through LDS;
+//  * in the accumulator layout a lane owns pixel p = lane&31 and, per 4-register group, 4 CONSECUTIVE
+//    output channels -> the epilogue (gateway residual, +a0, store) is all 16-byte vector access;
+//  * 17 KB of LDS and ~170 VGPRs -> several workgroups per CU hide the HBM latency of the epilogue.
+// Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_A0>
+__global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+    constexpr int LDE = 68;
+    __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
+    __shared__ __attribute__((aligned(16))) float Cs[3][kC];  // bias | gateway weight | gateway bias
+    const int b = blockIdx.y;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    pro.init(b);
+    Cs[0][threadIdx.x] = epi.bias[threadIdx.x];
+    Cs[1][threadIdx.x] = epi.gw[threadIdx.x];
+    Cs[2][threadIdx.x] = epi.gb[threadIdx.x];
+    // fold (mean, rstd, gamma, beta) of the four gLNs into scale/shift tables once: Ns[tensor][scale|shift][channel]
+    __shared__ __attribute__((aligned(16))) float Ns[4][2][kH];
+    const int c4 = (threadIdx.x & 15) * 4;
+    {
+        const NormRef* refs[4] = {&pro.cl, &pro.d0, &pro.cg, &pro.cgate};
+        const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const float sc = refs[j]->gamma[c] * pro.r[j];
+        Ns[j][0][c] = sc;
+        Ns[j][1][c] = refs[j]->beta[c] - pro.m[j] * sc;
+    }
+
+    float4 wf[2][8];  // W fragments: rows n = 64w + 32nt + i, k = 8q + 4kh .. +3
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
+    __syncthreads();  // Cs / Ns tables
+
+    const int tile0 = blockIdx.x * tiles_per_wg;
+#pragma unroll 1
+    for (int tl = 0; tl < tiles_per_wg; ++tl) {
+        const int m0 = (tile0 + tl) * 64;
+        if (m0 >= Mb) break;
+        // E tile: 64 pixels x 64 channels, 4 float4 per thread (rows past the end are clamped: their columns are never stored)
+        {
+            float4 xa[4], xd[4], xg[4], xs[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {  // all 16 loads first
+                const int row = min(m0 + (threadIdx.x >> 4) + it * 16, Mb - 1);
+                const int t = row / kF, f = row - t * kF;
+                const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
+                const size_t hi = ((size_t)b * Mb + row) * kH + c4;
+                const size_t lo = (((size_t)b * pro.T2 + t2) * kF2 + f2) * kH + c4;
+                xa[it] = ld4(pro.cl.x + hi), xd[it] = ld4(pro.d0.x + hi), xg[it] = ld4(pro.cg.x + lo), xs[it] = ld4(pro.cgate.x + lo);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float4 a = fma4(xa[it], ld4(&Ns[0][0][c4]), ld4(&Ns[0][1][c4])), d = fma4(xd[it], ld4(&Ns[1][0][c4]), ld4(&Ns[1][1][c4]));
+                const float4 g = fma4(xg[it], ld4(&Ns[2][0][c4]), ld4(&Ns[2][1][c4])), sg = sigmoid4(fma4(xs[it], ld4(&Ns[3][0][c4]), ld4(&Ns[3][1][c4])));
+                st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, fma4(a, sg, g) + d);
+            }
+        }
+        __syncthreads();
+        floatx16 acc[2][2];
+        acc_zero(acc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 e0 = ld4(Es + i * LDE + 8 * q + 4 * kh);
+            const float4 e1 = ld4(Es + (32 + i) * LDE + 8 * q + 4 * kh);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e0.x, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e1.x, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e0.y, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e1.y, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e0.z, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e1.z, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e0.w, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e1.w, acc[nt][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // Es may be overwritten by the next tile while this wave is still in its epilogue
+        // epilogue: rows of the accumulator are output channels; register group g holds channels n0 + 8g + 4kh .. +3.
+        // All loads of one pixel sub-tile are issued before the first use (no data-dependent branch in between).
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int p = m0 + pt * 32 + i;
+            const size_t base = ((size_t)b * Mb + min(p, Mb - 1)) * kC + 64 * w + 4 * kh;
+            float4 sv[8], av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = ld4(epi.s_in + base + 32 * (j >> 2) + 8 * (j & 3));
+            if (HAS_A0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = ld4(epi.a0 + base + 32 * (j >> 2) + 8 * (j & 3));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nt = j >> 2, g = j & 3;
+                const int n = 64 * w + 32 * nt + 8 * g + 4 * kh;
+                float4 v = f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]);
+                v = v + ld4(&Cs[0][n]) + prelu4(fma4(sv[j], ld4(&Cs[1][n]), ld4(&Cs[2][n])), epi.slope);
+                if (HAS_A0) v = v + av[j];
+                if (p < Mb) st4(epi.y + base + 32 * nt + 8 * g, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gateway + projection (K = 256 -> N = 64), operands swapped like resid_kernel: y^T[n][p] = Wp[n][k] . A^T[k][p].
+// Wave w = (nt = w&1: 32 output channels, kq = w>>1: one half of K); its weight fragments (64 VGPRs) stay in
+// registers; the 32-pixel A tile (gateway applied on load) is the only thing in LDS (33 KB -> 3-4 workgroups
+// per CU keep ~100 KB of loads in flight per CU).  The two K halves are summed through LDS; the epilogue
+// (bias, 16-byte stores, gLN partial sums) runs on the kq = 0 waves.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void proj_kernel(ProGateway pro, EpiBiasStats epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+    constexpr int LDA = 260, LDR = 33;
+    __shared__ __attribute__((aligned(16))) float As[32 * LDA];
+    __shared__ float Rs[2][32 * LDR * 1];  // partial sums of the kq = 1 waves: [nt][n][p]
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int nt = w & 1, kq = w >> 1;
+
+    float4 wf[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wf[q] = ld4(Wt + (size_t)(32 * nt + i) * 256 + 128 * kq + 8 * q + 4 * kh);
+    const int c4 = (threadIdx.x & 63) * 4;  // this thread's channel quad of the A tile (constant across rows)
+    const float4 gw4 = ld4(pro.gw + c4), gb4 = ld4(pro.gb + c4);
+
+    float s = 0.f, qq = 0.f;
+    const int tile0 = blockIdx.x * tiles_per_wg;
+#pragma unroll 1
+    for (int tl = 0; tl < tiles_per_wg; ++tl) {
+        const int m0 = (tile0 + tl) * 32;
+        if (m0 >= Mb) break;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (threadIdx.x >> 6) + it * 4;
+            float4 v = f4(0, 0, 0, 0);
+            if (m0 + row < Mb) v = prelu4(fma4(ld4(pro.x + ((size_t)b * Mb + m0 + row) * kC + c4), gw4, gb4), pro.slope);
+            st4(As + row * LDA + c4, v);
+        }
+        __syncthreads();
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 e = ld4(As + i * LDA + 128 * kq + 8 * q + 4 * kh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e.w, acc, 0, 0, 0);
+        }
+        if (kq == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Rs[nt][acc_row(r) * LDR + i] = acc[r];
+        }
+        __syncthreads();  // As consumed by every wave; Rs published
+        if (kq == 0) {
+            const int p = m0 + i;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * nt + 8 * g + 4 * kh;
+                float4 v;
+                v.x = acc[4 * g] + Rs[nt][(8 * g + 4 * kh) * LDR + i];
+                v.y = acc[4 * g + 1] + Rs[nt][(8 * g + 4 * kh + 1) * LDR + i];
+                v.z = acc[4 * g + 2] + Rs[nt][(8 * g + 4 * kh + 2) * LDR + i];
+                v.w = acc[4 * g + 3] + Rs[nt][(8 * g + 4 * kh + 3) * LDR + i];
+                v = v + ld4(epi.bias + n);
+                if (p < Mb) {
+                    st4(epi.y + ((size_t)b * Mb + p) * kH + n, v);
+                    s += v.x + v.y + v.z + v.w;
+                    qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            }
+        }
+        // the next tile's As stores are ordered after this tile's Rs reads by the barrier that follows them
+    }
+    __syncthreads();
+    block_stats_commit(s, qq, red, epi.slot, b);
+}
+
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK = 32, class Pro, class Epi>
 static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
     if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
     dim3 grid((Mb + BM - 1) / BM, B);
-    hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, Pro, Epi>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
+    hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, BK, Pro, Epi>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -263,7 +448,7 @@ int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* ga
                         const float* bias, float* a0, int B, int TF, void* stream) {
     ProGlnRelu pro{a_emb, stats, 1.0 / ((double)TF * kC), gamma, beta, 0.f, 0.f};
     EpiBias epi{a0, bias, kC};
-    return launch<256, 256, 64, 2, 2, false>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+    return launch<256, 256, 64, 2, 2, false, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
 }
 
 // y = Wp . prelu(s*gw+gb) + bias (pre-gLN projection output, [B][TF][64]) and its gLN partial sums.
@@ -271,7 +456,11 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
                   double* stats_out, int B, int TF, void* stream) {
     ProGateway pro{s, gw, gb, gslope};
     EpiBiasStats epi{y, bias, kH, stats_out};
-    return launch<256, 64, 128, 2, 1, false>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+    if (B <= 0 || TF <= 0) return RTFS_EINVAL;
+    const int tiles = (TF + 31) / 32, per = 16;
+    hipLaunchKernelGGL(proj_kernel, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, TF, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
 }
 
 // out = Wr . expanded + bias + prelu(s*gw+gb) [+ a0]; the four tensors of `expanded` are passed pre-gLN with their stats.
@@ -285,7 +474,14 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
     ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
     EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null};
-    return launch<64, 256, 64, 2, 2, false>(pro, epi, Wt, B, T * kF, (hipStream_t)stream);
+    if (B <= 0 || T <= 0) return RTFS_EINVAL;
+    const int Mb = T * kF, tiles = (Mb + 63) / 64, per = 8;
+    if (a0_or_null)
+        hipLaunchKernelGGL(resid_kernel<true>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
+    else
+        hipLaunchKernelGGL(resid_kernel<false>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
 }
 
 // masked = complex_mul(relu(Wm . prelu(x) + bias), a_emb)   all [B][TF][256]
@@ -293,7 +489,7 @@ int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bia
                   void* stream) {
     ProPrelu pro{x, slope};
     EpiMask epi{masked, bias, a_emb};
-    return launch<256, 256, 64, 2, 2, true>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+    return launch<256, 256, 64, 2, 2, true, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
 }
 
 // Y[M][N] = X[M][K] . Wt[N][K]^T (+ bias), row-major.  Supported (K,N): (64,192), (256,32).

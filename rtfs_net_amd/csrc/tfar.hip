@@ -88,6 +88,80 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     }
 }
 
+
+// Full-resolution variant (stride 1, one convolution): each thread owns 4 channels of one time row and slides a
+// 4x4 register window along the frequency axis, so an input element is loaded 4 times (once per overlapping
+// time row, L1 hits) instead of 16, the 16 tap weights stay in registers, and a workgroup (16 rows x 16 channel
+// quads) commits its gLN partial sums once per frequency segment instead of once per 16 pixels.
+// grid: (ceil(T/16), B, nseg); fseg = frequency bins per segment (multiple of 4).
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv_row_kernel(DwArgs a, int fseg) {
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int T = a.Tin, F = a.Fin;
+    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    float mean = 0.f, rstd = 1.f;
+    if (MODE >= 1) stats_finalize(a.slot, b, a.inv_n, mean, rstd);
+    float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
+    if (MODE >= 1) {
+        const float4 g = ld4(a.gamma + c4), be = ld4(a.beta + c4);
+        sc = g * rstd;
+        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+    }
+    float4 wv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wv[i] = ld4(a.w[0] + i * 64 + c4);
+    const float4 bias = a.bias[0] ? ld4(a.bias[0] + c4) : f4(0, 0, 0, 0);
+    const bool tvalid = t < T;
+    const float* rowp[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ti = t - 1 + r;
+        rok[r] = tvalid && ti >= 0 && ti < T;
+        rowp[r] = a.in + (((size_t)b * T + (rok[r] ? ti : 0)) * F) * kH + c4;
+    }
+    auto load_col = [&](int f, float4(&col)[4]) {
+        const bool fok = f >= 0 && f < F;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 x = f4(0, 0, 0, 0);
+            if (rok[r] && fok) {
+                x = ld4(rowp[r] + (size_t)f * kH);
+                if (MODE >= 1) x = fma4(x, sc, sh);
+                if (MODE == 2) x = prelu4(x, a.slope);
+            }
+            col[r] = x;
+        }
+    };
+    float4 win[4][4];  // [column slot][time row]
+    load_col(f0 - 1, win[0]);
+    load_col(f0, win[1]);
+    load_col(f0 + 1, win[2]);
+    float s = 0.f, q = 0.f;
+    float* outp = a.out[0] + (((size_t)b * T + (tvalid ? t : 0)) * F) * kH + c4;
+#pragma unroll 1
+    for (int f = f0; f < f1; f += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            load_col(f + j + 2, win[(j + 3) & 3]);
+            float4 acc = bias;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int df = 0; df < 4; ++df) acc = fma4(wv[dt * 4 + df], win[(j + df) & 3][dt], acc);
+            if (tvalid && f + j < f1) {
+                st4(outp + (size_t)(f + j) * kH, acc);
+                s += acc.x + acc.y + acc.z + acc.w;
+                q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+            }
+        }
+    }
+    block_stats_commit(s, q, red, a.stats[0], b);
+}
+
 struct NormRefLite {
     const float* x;
     const double* slot;
@@ -274,6 +348,15 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
         a.stats[j] = j < nconv ? stats_out[j] : nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (stride == 1 && nconv == 1 && Fin >= 64) {  // full-resolution path: sliding register window along F
+        const int nseg = 4, fseg = (((Fin + nseg - 1) / nseg) + 3) / 4 * 4;
+        dim3 grid((Tin + 15) / 16, B, (Fin + fseg - 1) / fseg);
+        if (mode == 0) hipLaunchKernelGGL((dwconv_row_kernel<0>), grid, dim3(256), 0, st, a, fseg);
+        else if (mode == 1) hipLaunchKernelGGL((dwconv_row_kernel<1>), grid, dim3(256), 0, st, a, fseg);
+        else hipLaunchKernelGGL((dwconv_row_kernel<2>), grid, dim3(256), 0, st, a, fseg);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     if (stride == 1) {
         if (mode == 0) return launch_dw<1, 0>(a, B, st);
         if (mode == 1) return launch_dw<1, 1>(a, B, st);
