@@ -28,10 +28,17 @@ struct DwArgs {
     double* stats[kMaxConv];      // [B][2]
 };
 
-// MODE 0: raw input; 1: gLN(input); 2: PReLU(gLN(input)).  STRIDE 1: 'same' padding (1 before, 2 after); 2: padding 1.
-// Zero padding applies to the transformed input (conv_layers.py:104-113), so out-of-range taps are skipped.
+// Depth-wise 4x4 convolution, sliding-window form.
+//   MODE 0: raw input; 1: gLN(input); 2: PReLU(gLN(input)).  STRIDE 1: 'same' padding (1 before, 2 after); 2: padding 1.
+//   Zero padding applies to the transformed input (conv_layers.py:104-113): out-of-range taps are masked to 0.
+// Thread = (output time row, channel quad); it walks a frequency segment keeping a 4-column x 4-row register
+// window of the (normalised) input, so every input element is loaded once per overlapping time row (4x for
+// stride 1, 2x for stride 2; L1 hits) instead of 16x.  Loads use clamped addresses + a select instead of
+// branches so the compiler issues a whole step's loads before the first use.  Tap weights sit in LDS
+// ([conv][tap][64]); a workgroup (16 rows x 16 channel quads) commits its gLN partial sums once.
+// Column c of the input lives in window slot (c+1)&3.   grid: (ceil(Tout/16), B, nseg); fseg % 4 == 0.
 template <int STRIDE, int NCONV, int MODE>
-__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
+__global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
     __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
     __shared__ float red[8];
     const int b = blockIdx.y;
@@ -39,69 +46,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
         const int j = i >> 8, o = (i & 255) * 4;
         st4(&ws[j][o], ld4(a.w[j] + o));
     }
-    float mean = 0.f, rstd = 1.f;
-    if (MODE >= 1) stats_finalize(a.slot, b, a.inv_n, mean, rstd);
     const int c4 = (threadIdx.x & 15) * 4;
-    float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
-    if (MODE >= 1) {
-        const float4 g = ld4(a.gamma + c4), be = ld4(a.beta + c4);
-        sc = g * rstd;
-        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
-    }
-    __syncthreads();
-
-    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int npix = a.Tout * a.Fout;
-    const bool valid = p < npix;
-    const int to = valid ? p / a.Fout : 0, fo = valid ? p - to * a.Fout : 0;
-    float4 acc[NCONV];
-#pragma unroll
-    for (int j = 0; j < NCONV; ++j) acc[j] = a.bias[j] ? ld4(a.bias[j] + c4) : f4(0, 0, 0, 0);
-    const float* inb = a.in + (size_t)b * a.Tin * a.Fin * kH;
-    if (valid) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int ti = to * STRIDE - 1 + dt;
-            if (ti < 0 || ti >= a.Tin) continue;
-#pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const int fi = fo * STRIDE - 1 + df;
-                if (fi < 0 || fi >= a.Fin) continue;
-                float4 x = ld4(inb + ((size_t)ti * a.Fin + fi) * kH + c4);
-                if (MODE >= 1) x = fma4(x, sc, sh);
-                if (MODE == 2) x = prelu4(x, a.slope);
-#pragma unroll
-                for (int j = 0; j < NCONV; ++j) acc[j] = fma4(ld4(&ws[j][(dt * 4 + df) * 64 + c4]), x, acc[j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NCONV; ++j) {
-        float s = 0.f, q = 0.f;
-        if (valid) {
-            st4(a.out[j] + ((size_t)b * npix + p) * kH + c4, acc[j]);
-            s = acc[j].x + acc[j].y + acc[j].z + acc[j].w;
-            q = acc[j].x * acc[j].x + acc[j].y * acc[j].y + acc[j].z * acc[j].z + acc[j].w * acc[j].w;
-        }
-        if (j) __syncthreads();
-        block_stats_commit(s, q, red, a.stats[j], b);
-    }
-}
-
-
-// Full-resolution variant (stride 1, one convolution): each thread owns 4 channels of one time row and slides a
-// 4x4 register window along the frequency axis, so an input element is loaded 4 times (once per overlapping
-// time row, L1 hits) instead of 16, the 16 tap weights stay in registers, and a workgroup (16 rows x 16 channel
-// quads) commits its gLN partial sums once per frequency segment instead of once per 16 pixels.
-// grid: (ceil(T/16), B, nseg); fseg = frequency bins per segment (multiple of 4).
-template <int MODE>
-__global__ __launch_bounds__(256) void dwconv_row_kernel(DwArgs a, int fseg) {
-    __shared__ float red[8];
-    const int b = blockIdx.y;
-    const int c4 = (threadIdx.x & 15) * 4;
-    const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int T = a.Tin, F = a.Fin;
-    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    const int to = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int Tin = a.Tin, Fin = a.Fin, Tout = a.Tout, Fout = a.Fout;
+    const int f0 = blockIdx.z * fseg, f1 = min(Fout, f0 + fseg);
     float mean = 0.f, rstd = 1.f;
     if (MODE >= 1) stats_finalize(a.slot, b, a.inv_n, mean, rstd);
     float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
@@ -110,56 +58,85 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(DwArgs a, int fseg) {
         sc = g * rstd;
         sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
     }
-    float4 wv[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wv[i] = ld4(a.w[0] + i * 64 + c4);
-    const float4 bias = a.bias[0] ? ld4(a.bias[0] + c4) : f4(0, 0, 0, 0);
-    const bool tvalid = t < T;
+    const bool tvalid = to < Tout;
     const float* rowp[4];
-    bool rok[4];
+    float rmask[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int ti = t - 1 + r;
-        rok[r] = tvalid && ti >= 0 && ti < T;
-        rowp[r] = a.in + (((size_t)b * T + (rok[r] ? ti : 0)) * F) * kH + c4;
+        const int ti = to * STRIDE - 1 + r;
+        const bool ok = tvalid && ti >= 0 && ti < Tin;
+        rmask[r] = ok ? 1.f : 0.f;
+        rowp[r] = a.in + (((size_t)b * Tin + min(max(ti, 0), Tin - 1)) * Fin) * kH + c4;
     }
-    auto load_col = [&](int f, float4(&col)[4]) {
-        const bool fok = f >= 0 && f < F;
+    auto load_col = [&](int c, float4(&col)[4]) {
+        const float cm = (c >= 0 && c < Fin) ? 1.f : 0.f;
+        const size_t off = (size_t)min(max(c, 0), Fin - 1) * kH;
+        float4 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ld4(rowp[r] + off);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float4 x = f4(0, 0, 0, 0);
-            if (rok[r] && fok) {
-                x = ld4(rowp[r] + (size_t)f * kH);
-                if (MODE >= 1) x = fma4(x, sc, sh);
-                if (MODE == 2) x = prelu4(x, a.slope);
-            }
-            col[r] = x;
+            float4 v = x[r];
+            if (MODE >= 1) v = fma4(v, sc, sh);
+            if (MODE == 2) v = prelu4(v, a.slope);
+            col[r] = v * (cm * rmask[r]);
         }
     };
+    __syncthreads();
     float4 win[4][4];  // [column slot][time row]
-    load_col(f0 - 1, win[0]);
-    load_col(f0, win[1]);
-    load_col(f0 + 1, win[2]);
-    float s = 0.f, q = 0.f;
-    float* outp = a.out[0] + (((size_t)b * T + (tvalid ? t : 0)) * F) * kH + c4;
-#pragma unroll 1
-    for (int f = f0; f < f1; f += 4) {
+    if (STRIDE == 1) {
+        load_col(f0 - 1, win[0]);
+        load_col(f0, win[1]);
+        load_col(f0 + 1, win[2]);
+    } else {
+        load_col(2 * f0 - 1, win[0]);
+        load_col(2 * f0, win[1]);
+    }
+    float s[NCONV], q[NCONV];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            load_col(f + j + 2, win[(j + 3) & 3]);
-            float4 acc = bias;
+    for (int j = 0; j < NCONV; ++j) s[j] = q[j] = 0.f;
+    const size_t orow = (((size_t)b * Tout + (tvalid ? to : 0)) * Fout) * kH + c4;
+    constexpr int STEPS = 4 / STRIDE;
+#pragma unroll 1
+    for (int f = f0; f < f1; f += STEPS) {
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+            const int fo = f + j;
+            int base;  // window slot of tap column df = 0
+            if (STRIDE == 1) {
+                load_col(fo + 2, win[(j + 3) & 3]);
+                base = j;
+            } else {
+                load_col(2 * fo + 1, win[(2 * j + 2) & 3]);
+                load_col(2 * fo + 2, win[(2 * j + 3) & 3]);
+                base = 2 * j;
+            }
+            float4 acc[NCONV];
+#pragma unroll
+            for (int k = 0; k < NCONV; ++k) acc[k] = a.bias[k] ? ld4(a.bias[k] + c4) : f4(0, 0, 0, 0);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int df = 0; df < 4; ++df) acc = fma4(wv[dt * 4 + df], win[(j + df) & 3][dt], acc);
-            if (tvalid && f + j < f1) {
-                st4(outp + (size_t)(f + j) * kH, acc);
-                s += acc.x + acc.y + acc.z + acc.w;
-                q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                for (int df = 0; df < 4; ++df) {
+                    const float4 x = win[(base + df) & 3][dt];
+#pragma unroll
+                    for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + c4]), x, acc[k]);
+                }
+            if (tvalid && fo < f1) {
+#pragma unroll
+                for (int k = 0; k < NCONV; ++k) {
+                    st4(a.out[k] + orow + (size_t)fo * kH, acc[k]);
+                    s[k] += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
+                    q[k] += acc[k].x * acc[k].x + acc[k].y * acc[k].y + acc[k].z * acc[k].z + acc[k].w * acc[k].w;
+                }
             }
         }
     }
-    block_stats_commit(s, q, red, a.stats[0], b);
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        if (k) __syncthreads();
+        block_stats_commit(s[k], q[k], red, a.stats[k], b);
+    }
 }
 
 struct NormRefLite {
@@ -315,11 +292,13 @@ using namespace rtfs;
 
 template <int STRIDE, int MODE>
 static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
-    dim3 grid((a.Tout * a.Fout + 15) / 16, B);
+    const int nseg = a.Fout >= 96 ? 4 : 2;
+    const int fseg = (((a.Fout + nseg - 1) / nseg) + 3) / 4 * 4;
+    dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
     switch (a.nconv) {
-        case 1: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 1, MODE>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 2, MODE>), grid, dim3(256), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 4, MODE>), grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 1, MODE>), grid, dim3(256), 0, st, a, fseg); break;
+        case 2: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 2, MODE>), grid, dim3(256), 0, st, a, fseg); break;
+        case 4: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 4, MODE>), grid, dim3(256), 0, st, a, fseg); break;
         default: return RTFS_EINVAL;
     }
     RTFS_LAUNCH_CHECK();
@@ -348,15 +327,6 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
         a.stats[j] = j < nconv ? stats_out[j] : nullptr;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1 && nconv == 1 && Fin >= 64) {  // full-resolution path: sliding register window along F
-        const int nseg = 4, fseg = (((Fin + nseg - 1) / nseg) + 3) / 4 * 4;
-        dim3 grid((Tin + 15) / 16, B, (Fin + fseg - 1) / fseg);
-        if (mode == 0) hipLaunchKernelGGL((dwconv_row_kernel<0>), grid, dim3(256), 0, st, a, fseg);
-        else if (mode == 1) hipLaunchKernelGGL((dwconv_row_kernel<1>), grid, dim3(256), 0, st, a, fseg);
-        else hipLaunchKernelGGL((dwconv_row_kernel<2>), grid, dim3(256), 0, st, a, fseg);
-        RTFS_LAUNCH_CHECK();
-        return RTFS_OK;
-    }
     if (stride == 1) {
         if (mode == 0) return launch_dw<1, 0>(a, B, st);
         if (mode == 1) return launch_dw<1, 1>(a, B, st);
