@@ -119,8 +119,18 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) { return (i
 // Lane (i = l&31, kh = l>>5) reads the 4 consecutive k values 8q + 4kh .. +3 of its row with ONE
 // ds_read_b128 and feeds them to 4 successive MFMAs; the pairing (A k, B k) is what matters, the
 // order in which k is summed does not.
-// BT = distance in B rows (output columns) between this wave's consecutive N-tiles (32 = adjacent).
-template <int WM, int WN, int BT = 32>
+// BT = distance in B rows (output columns) between this wave's consecutive N-tiles (32 = adjacent);
+// BT == -4 selects the "paired" map for 4 tiles: tiles 0,1 are adjacent, tiles 2,3 sit 128 columns further.
+template <int BT>
+__device__ __forceinline__ constexpr int btile_row(int n) { return BT == -4 ? ((n >> 1) * 128 + (n & 1) * 32) : n * BT; }
+
+//
+// Orientation: the FIRST operand's rows become accumulator rows (spread over the 16 registers of a lane: each
+// group of 4 registers = 4 consecutive rows), the SECOND operand's rows become accumulator columns (= lanes).
+// Passing the WEIGHTS first and the PIXELS second therefore leaves every lane with 4 consecutive output
+// channels of one pixel per register group -> channels-last write-back in 16-byte vectors.  AT is the tile map
+// of the first operand, BT of the second.
+template <int WM, int WN, int BT = 32, int AT = 32>
 __device__ __forceinline__ void mma_block(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, kh = lane >> 5;
@@ -130,9 +140,9 @@ __device__ __forceinline__ void mma_block(floatx16 (&acc)[WM][WN], const float* 
     for (int q = 0; q < kdepth; q += 8) {
         float4 a[WM], b[WN];
 #pragma unroll
-        for (int m = 0; m < WM; ++m) a[m] = ld4(ap + m * 32 * lda + q);
+        for (int m = 0; m < WM; ++m) a[m] = ld4(ap + btile_row<AT>(m) * lda + q);
 #pragma unroll
-        for (int n = 0; n < WN; ++n) b[n] = ld4(bp + n * BT * ldb + q);
+        for (int n = 0; n < WN; ++n) b[n] = ld4(bp + btile_row<BT>(n) * ldb + q);
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -183,6 +193,9 @@ __device__ __forceinline__ void acc_zero(floatx16 (&acc)[WM][WN]) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 }
+
+// register group g (0..3) of a 32x32 accumulator tile: rows 8g + 4*(lane>>5) .. +3 of column lane&31
+__device__ __forceinline__ float4 acc_group(const floatx16& a, int g) { return f4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]); }
 
 // row of accumulator register r inside its 32x32 tile, for this lane
 __device__ __forceinline__ int acc_row(int r) { return (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x & 63) >> 5); }

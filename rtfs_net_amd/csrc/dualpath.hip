@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
     breg.store(Bs[0], LDB);
     __syncthreads();
 
-    floatx16 acc[WM][WN];
+    floatx16 acc[WN][WM];  // [weight tile][row tile]: lanes = sequence positions, registers = output channels
     acc_zero(acc);
     constexpr int NK = 512 / BK;
 #pragma unroll 1
@@ -85,28 +85,30 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
         const int cur = kc & 1;
         if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
         const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-        mma_block<WM, WN>(acc, slab + (wm * WM * 32 + kk) * kSlabLd + c0, kSlabLd, Bs[cur] + wn * WN * 32 * LDB, LDB, BK);
+        mma_block<WN, WM>(acc, Bs[cur] + wn * WN * 32 * LDB, LDB, slab + (wm * WM * 32 + kk) * kSlabLd + c0, kSlabLd, BK);
         if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
         __syncthreads();
     }
 
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
+    for (int m = 0; m < WM; ++m) {
+        const int row = m0 + (wm * WM + m) * 32 + (lane & 31);
 #pragma unroll
         for (int n = 0; n < WN; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
-                const int col = (wn * WN + n) * 32 + (lane & 31);
+            for (int g = 0; g < 4; ++g) {
+                const int col = (wn * WN + n) * 32 + 8 * g + 4 * (lane >> 5);
+                const float4 v = acc_group(acc[n][m], g);
                 if (MODE == 0) {
-                    if (row < map.L) dst[((size_t)s * map.L + row) * N + col] = acc[m][n][r];
+                    if (row < map.L) st4(dst + ((size_t)s * map.L + row) * N + col, v);
                 } else {
                     if (row < map.npos) {
-                        const size_t o = sbase + (size_t)row * map.pos_stride + col;
-                        dst[o] = acc[m][n][r] + bias[col] + dst[o];
+                        float* o = dst + sbase + (size_t)row * map.pos_stride + col;
+                        st4(o, v + ld4(bias + col) + ld4(o));
                     }
                 }
             }
+    }
 }
 
 
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, cons
     breg.store(Bs[0], LDB);
     __syncthreads();
 
-    floatx16 acc[2][4];
+    floatx16 acc[4][2];  // [weight tile][row tile]
     acc_zero(acc);
     constexpr int NK = 512 / BK;
 #pragma unroll 1
@@ -168,21 +170,22 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, cons
         const int cur = kc & 1;
         if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
         const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-        mma_block<2, 4>(acc, slab[wm] + kk * kSlabLd + c0, kSlabLd, Bs[cur] + wn * 128 * LDB, LDB, BK);
+        mma_block<4, 2>(acc, Bs[cur] + wn * 128 * LDB, LDB, slab[wm] + kk * kSlabLd + c0, kSlabLd, BK);
         if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
         __syncthreads();
     }
     if (blockIdx.x * 2 + wm >= total_tiles) return;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+        const int row = m0[wm] + m * 32 + (lane & 31);
+        if (row < map.L) {
+            float* o = dst + ((size_t)seq[wm] * map.L + row) * N + wn * 128 + 4 * (lane >> 5);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0[wm] + m * 32 + acc_row(r);
-                const int col = wn * 128 + n * 32 + (lane & 31);
-                if (row < map.L) dst[((size_t)seq[wm] * map.L + row) * N + col] = acc[m][n][r];
-            }
+                for (int g = 0; g < 4; ++g) st4(o + n * 32 + 8 * g, acc_group(acc[n][m], g));
+        }
+    }
 }
 
 // Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.

@@ -18,45 +18,48 @@ namespace rtfs {
 // ------------------------------------------------------------------------------------------------
 // prologues: produce A[row][k..k+3] for row < Mb of utterance b
 // ------------------------------------------------------------------------------------------------
+// A prologue supplies   raw(b, Mb, row, k)  -- the global load of A[row][k..k+3], no arithmetic, so it can be issued
+// a whole k-chunk ahead of its use;   init(b, tab) -- fills a 512-float LDS table with per-channel constants once;
+// xform(raw, k, tab) -- the arithmetic, run when the chunk is written to LDS (after the MFMA block it overlaps).
 struct ProPlain {
-    const float* x;
+    const float* __restrict__ x;
     int K;
-    __device__ void init(int) {}
-    __device__ float4 load(int b, int Mb, int row, int k) const { return ld4(x + ((size_t)b * Mb + row) * K + k); }
+    __device__ void init(int, float*) {}
+    __device__ float4 raw(int b, int Mb, int row, int k) const { return ld4(x + ((size_t)b * Mb + row) * K + k); }
+    __device__ float4 xform(float4 v, int, const float*) const { return v; }
 };
 
-// relu(gLN(x))  -- audio_bottleneck pre_norm / pre_act (config yaml:15-20)
+// relu(gLN(x))  -- audio_bottleneck pre_norm / pre_act (config yaml:15-20); tab = [scale(256) | shift(256)]
 struct ProGlnRelu {
-    const float* x;
+    const float* __restrict__ x;
     const double* slot;
     double inv_n;
-    const float *gamma, *beta;
-    float mean, rstd;
-    __device__ void init(int b) { stats_finalize(slot, b, inv_n, mean, rstd); }
-    __device__ float4 load(int b, int Mb, int row, int k) const {
-        float4 v = ld4(x + ((size_t)b * Mb + row) * kC + k);
-        return relu4(norm4(v, mean, rstd, ld4(gamma + k), ld4(beta + k)));
+    const float *__restrict__ gamma, *__restrict__ beta;
+    __device__ void init(int b, float* tab) const {
+        float mean, rstd;
+        stats_finalize(slot, b, inv_n, mean, rstd);
+        const float sc = gamma[threadIdx.x] * rstd;
+        tab[threadIdx.x] = sc;
+        tab[kC + threadIdx.x] = beta[threadIdx.x] - mean * sc;
     }
+    __device__ float4 raw(int b, int Mb, int row, int k) const { return ld4(x + ((size_t)b * Mb + row) * kC + k); }
+    __device__ float4 xform(float4 v, int k, const float* tab) const { return relu4(fma4(v, ld4(tab + k), ld4(tab + kC + k))); }
 };
 
-// prelu(x * w_c + b_c)  -- gateway: depth-wise 1x1 conv + PReLU (tdanet.py:34-41)
+// gateway parameters of the RTFS block (argument pack of proj_kernel)
 struct ProGateway {
-    const float* x;
-    const float *gw, *gb;
+    const float* __restrict__ x;
+    const float *__restrict__ gw, *__restrict__ gb;
     float slope;
-    __device__ void init(int) {}
-    __device__ float4 load(int b, int Mb, int row, int k) const {
-        float4 v = ld4(x + ((size_t)b * Mb + row) * kC + k);
-        return prelu4(fma4(v, ld4(gw + k), ld4(gb + k)), slope);
-    }
 };
 
 // prelu(x)  -- mask_generator.0 (mask_generator.py:47)
 struct ProPrelu {
-    const float* x;
+    const float* __restrict__ x;
     float slope;
-    __device__ void init(int) {}
-    __device__ float4 load(int b, int Mb, int row, int k) const { return prelu4(ld4(x + ((size_t)b * Mb + row) * kC + k), slope); }
+    __device__ void init(int, float*) {}
+    __device__ float4 raw(int b, int Mb, int row, int k) const { return ld4(x + ((size_t)b * Mb + row) * kC + k); }
+    __device__ float4 xform(float4 v, int, const float*) const { return prelu4(v, slope); }
 };
 
 // One gLN'd tensor read "normalise on read": slot -> (mean, rstd), gamma/beta per channel.
@@ -80,77 +83,51 @@ struct ProExpanded {
         stats_finalize(cg.slot, b, cg.inv_n, m[2], r[2]);
         stats_finalize(cgate.slot, b, cgate.inv_n, m[3], r[3]);
     }
-    __device__ float4 load(int b, int Mb, int row, int k) const {
-        const int t = row / kF, f = row - t * kF;
-        const int t2 = nearest_src(t, T2, T), f2 = nearest_src(f, kF2, kF);
-        const size_t hi = ((size_t)b * Mb + row) * kH + k;
-        const size_t lo = (((size_t)b * T2 + t2) * kF2 + f2) * kH + k;
-        float4 a = norm4(ld4(cl.x + hi), m[0], r[0], ld4(cl.gamma + k), ld4(cl.beta + k));
-        float4 d = norm4(ld4(d0.x + hi), m[1], r[1], ld4(d0.gamma + k), ld4(d0.beta + k));
-        float4 g = norm4(ld4(cg.x + lo), m[2], r[2], ld4(cg.gamma + k), ld4(cg.beta + k));
-        float4 s = sigmoid4(norm4(ld4(cgate.x + lo), m[3], r[3], ld4(cgate.gamma + k), ld4(cgate.beta + k)));
-        return fma4(a, s, g) + d;
-    }
 };
 
 // ------------------------------------------------------------------------------------------------
 // epilogues
 // ------------------------------------------------------------------------------------------------
-struct EpiBias {  // y = acc + bias
-    float* y;
-    const float* bias;  // may be null
+// Epilogues work on 16-byte vectors: the kernel multiplies WEIGHTS x PIXELS (see mma_block), so a lane owns one
+// pixel row and, per accumulator register group, 4 consecutive output channels `col..col+3`.
+template <bool HAS_BIAS>
+struct EpiBias {  // y = acc (+ bias)
+    float* __restrict__ y;
+    const float* __restrict__ bias;
     int N;
-    static constexpr bool kStats = false;
-    __device__ void init(int) {}
-    __device__ void store(int b, int Mb, int row, int col, float v, float&, float&) const {
-        y[((size_t)b * Mb + row) * N + col] = bias ? v + bias[col] : v;
-    }
+    __device__ float4 colconst(int col) const { return HAS_BIAS ? ld4(bias + col) : f4(0, 0, 0, 0); }
+    __device__ void store(int b, int Mb, int row, int col, float4 v, float4 cc) const { st4(y + ((size_t)b * Mb + row) * N + col, v + cc); }
 };
 
-struct EpiBiasStats {  // y = acc + bias, and accumulate the gLN partial sums of y
-    float* y;
-    const float* bias;
+// argument pack of proj_kernel: y = acc + bias, plus the gLN partial sums of y
+struct EpiBiasStats {
+    float* __restrict__ y;
+    const float* __restrict__ bias;
     int N;
-    static constexpr bool kStats = true;
     double* slot;
-    __device__ void init(int) {}
-    __device__ void store(int b, int Mb, int row, int col, float v, float& s, float& q) const {
-        v += bias[col];
-        y[((size_t)b * Mb + row) * N + col] = v;
-        s += v;
-        q = fmaf(v, v, q);
-    }
 };
 
-// out = acc + bias + gateway(s_in) [+ a0]   (tdanet.py:131; "+ a0" pre-adds the next block's input, refinement_module.py:60)
+// argument pack of resid_kernel: out = acc + bias + gateway(s_in) [+ a0]   (tdanet.py:131; refinement_module.py:60)
 struct EpiResidual {
-    float* y;
-    const float* bias;
-    const float* s_in;
-    const float *gw, *gb;
+    float* __restrict__ y;
+    const float* __restrict__ bias;
+    const float* __restrict__ s_in;
+    const float *__restrict__ gw, *__restrict__ gb;
     float slope;
-    const float* a0;  // may be null
-    static constexpr bool kStats = false;
-    __device__ void init(int) {}
-    __device__ void store(int b, int Mb, int row, int col, float v, float&, float&) const {
-        const size_t o = ((size_t)b * Mb + row) * kC + col;
-        v += bias[col] + prelu(fmaf(s_in[o], gw[col], gb[col]), slope);
-        if (a0) v += a0[o];
-        y[o] = v;
-    }
+    const float* __restrict__ a0;  // may be null
 };
 
 // S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
 struct EpiMask {
-    float* y;
-    const float* bias;
-    const float* emb;
-    __device__ void store2(int b, int Mb, int row, int col, float vr, float vi) const {
+    float* __restrict__ y;
+    const float* __restrict__ bias;
+    const float* __restrict__ emb;
+    __device__ void store2(int b, int Mb, int row, int col, float4 vr, float4 vi) const {
         const size_t o = ((size_t)b * Mb + row) * kC + col;
-        const float mr = fmaxf(vr + bias[col], 0.f), mi = fmaxf(vi + bias[col + 128], 0.f);
-        const float er = emb[o], ei = emb[o + 128];
-        y[o] = er * mr - ei * mi;
-        y[o + 128] = fmaf(er, mi, ei * mr);
+        const float4 er = ld4(emb + o), ei = ld4(emb + o + 128);
+        const float4 mr = relu4(vr + ld4(bias + col)), mi = relu4(vi + ld4(bias + col + 128));
+        st4(y + o, f4(er.x * mr.x - ei.x * mi.x, er.y * mr.y - ei.y * mi.y, er.z * mr.z - ei.z * mi.z, er.w * mr.w - ei.w * mi.w));
+        st4(y + o + 128, f4(fmaf(er.x, mi.x, ei.x * mr.x), fmaf(er.y, mi.y, ei.y * mr.y), fmaf(er.z, mi.z, ei.z * mr.z), fmaf(er.w, mi.w, ei.w * mr.w)));
     }
 };
 
@@ -158,42 +135,40 @@ struct EpiMask {
 // the kernel
 // ------------------------------------------------------------------------------------------------
 template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK, class Pro, class Epi>
-__global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb) {
+__global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb) {
     constexpr int LD = BK + 4;
     constexpr int WGN = N / (32 * WN), WGM = 4 / WGN;
     static_assert(WGM * WGN == 4 && BM == WGM * WM * 32, "wave tiling must cover the workgroup tile");
-    static_assert(!PAIRED || (N == 256 && WN == 2), "paired epilogue needs N=256, WN=2");
+    static_assert(!PAIRED || (N == 256 && (WN == 2 || WN == 4)), "paired epilogue needs N=256, WN in {2,4}");
     __shared__ __attribute__((aligned(16))) float As[2][BM * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][N * LD];
-    __shared__ float red[8];
-
     const int b = blockIdx.y, m0 = blockIdx.x * BM;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = w / WGN, wn = w % WGN;
-    pro.init(b);
+    __shared__ __attribute__((aligned(16))) float ptab[2 * kC];
+    pro.init(b, ptab);
+    __syncthreads();
 
     constexpr int A_PER = BM * (BK / 4) / 256;
+    static_assert(256 % (BK / 4) == 0, "a thread keeps the same channel quad for all its rows");
     float4 areg[A_PER];
+    int ak0 = 0;
     ChunkRegs<N, BK> breg;
+    const int ac4 = (threadIdx.x % (BK / 4)) * 4, arow0 = threadIdx.x / (BK / 4);
 
+    // rows past the end of the utterance are clamped (their accumulator rows are never stored): no branch, so the
+    // loads of chunk kc+1 are issued before the MFMA block of chunk kc and first touched after it
     auto load_a = [&](int k0) {
+        ak0 = k0;
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            int idx = threadIdx.x + i * 256;
-            int row = idx / (BK / 4), c4 = idx % (BK / 4);
-            areg[i] = (m0 + row < Mb) ? pro.load(b, Mb, m0 + row, k0 + c4 * 4) : f4(0, 0, 0, 0);
-        }
+        for (int i = 0; i < A_PER; ++i) areg[i] = pro.raw(b, Mb, min(m0 + arow0 + i * (1024 / BK), Mb - 1), k0 + ac4);
     };
     auto store_a = [&](float* dst) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            int idx = threadIdx.x + i * 256;
-            int row = idx / (BK / 4), c4 = idx % (BK / 4);
-            st4(dst + row * LD + c4 * 4, areg[i]);
-        }
+        for (int i = 0; i < A_PER; ++i) st4(dst + (arow0 + i * (1024 / BK)) * LD + ac4, pro.xform(areg[i], ak0 + ac4, ptab));
     };
 
-    floatx16 acc[WM][WN];
+    floatx16 acc[WN][WM];  // [weight tile][pixel tile]: rows = output channels, lanes = pixels
     acc_zero(acc);
 
     load_a(0);
@@ -203,8 +178,8 @@ __global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const
     __syncthreads();
 
     constexpr int NK = K / BK;
-    constexpr int BT = PAIRED ? 128 : 32;
-    const int bcol0 = PAIRED ? wn * 32 : wn * WN * 32;
+    constexpr int BT = PAIRED ? (WN == 4 ? -4 : 128) : 32;
+    const int bcol0 = PAIRED ? wn * (WN * 16) : wn * WN * 32;  // paired: this wave owns WN/2 real tiles and their imaginary partners
 #pragma unroll 1
     for (int kc = 0; kc < NK; ++kc) {
         const int cur = kc & 1;
@@ -212,7 +187,7 @@ __global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const
             load_a((kc + 1) * BK);
             breg.load(Wt, K, (kc + 1) * BK);
         }
-        mma_block<WM, WN, BT>(acc, As[cur] + wm * WM * 32 * LD, LD, Bs[cur] + bcol0 * LD, LD, BK);
+        mma_block<WN, WM, 32, BT>(acc, Bs[cur] + bcol0 * LD, LD, As[cur] + wm * WM * 32 * LD, LD, BK);
         if (kc + 1 < NK) {
             store_a(As[cur ^ 1]);
             breg.store(Bs[cur ^ 1], LD);
@@ -220,26 +195,27 @@ __global__ __launch_bounds__(256) void pixel_gemm_kernel(Pro pro, Epi epi, const
         __syncthreads();
     }
 
-    if constexpr (PAIRED) {
+    const int i = lane & 31, kh = lane >> 5;
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+    for (int m = 0; m < WM; ++m) {
+        const int row = m0 + (wm * WM + m) * 32 + i;
+        if (row < Mb) {
+            if constexpr (PAIRED) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
-                if (row < Mb) epi.store2(b, Mb, row, bcol0 + (lane & 31), acc[m][0][r], acc[m][1][r]);
+                for (int n = 0; n < WN / 2; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        epi.store2(b, Mb, row, bcol0 + n * 32 + 8 * g + 4 * kh, acc_group(acc[n][m], g), acc_group(acc[n + WN / 2][m], g));
+            } else {
+#pragma unroll
+                for (int n = 0; n < WN; ++n)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = bcol0 + n * 32 + 8 * g + 4 * kh;
+                        epi.store(b, Mb, row, col, acc_group(acc[n][m], g), epi.colconst(col));
+                    }
             }
-    } else {
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int n = 0; n < WN; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + (wm * WM + m) * 32 + acc_row(r);
-                    if (row < Mb) epi.store(b, Mb, row, bcol0 + n * 32 + (lane & 31), acc[m][n][r], s, q);
-                }
-        if constexpr (Epi::kStats) block_stats_commit(s, q, red, epi.slot, b);
+        }
     }
 }
 
@@ -446,8 +422,8 @@ extern "C" {
 // a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
 int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt,
                         const float* bias, float* a0, int B, int TF, void* stream) {
-    ProGlnRelu pro{a_emb, stats, 1.0 / ((double)TF * kC), gamma, beta, 0.f, 0.f};
-    EpiBias epi{a0, bias, kC};
+    ProGlnRelu pro{a_emb, stats, 1.0 / ((double)TF * kC), gamma, beta};
+    EpiBias<true> epi{a0, bias, kC};
     return launch<256, 256, 64, 2, 2, false, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
 }
 
@@ -496,13 +472,13 @@ int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bia
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {
     if (K == 64 && N == 192) {
         ProPlain pro{X, 64};
-        EpiBias epi{Y, bias_or_null, 192};
-        return launch<64, 192, 64, 1, 3, false>(pro, epi, Wt, 1, M, (hipStream_t)stream);
+        if (bias_or_null) return launch<64, 192, 64, 1, 3, false>(pro, EpiBias<true>{Y, bias_or_null, 192}, Wt, 1, M, (hipStream_t)stream);
+        return launch<64, 192, 64, 1, 3, false>(pro, EpiBias<false>{Y, nullptr, 192}, Wt, 1, M, (hipStream_t)stream);
     }
     if (K == 256 && N == 32) {
         ProPlain pro{X, 256};
-        EpiBias epi{Y, bias_or_null, 32};
-        return launch<256, 32, 128, 1, 1, false>(pro, epi, Wt, 1, M, (hipStream_t)stream);
+        if (bias_or_null) return launch<256, 32, 128, 1, 1, false>(pro, EpiBias<true>{Y, bias_or_null, 32}, Wt, 1, M, (hipStream_t)stream);
+        return launch<256, 32, 128, 1, 1, false>(pro, EpiBias<false>{Y, nullptr, 32}, Wt, 1, M, (hipStream_t)stream);
     }
     return RTFS_EINVAL;
 }
