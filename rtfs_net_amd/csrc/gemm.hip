@@ -349,20 +349,26 @@ __global__ __launch_bounds__(256, 3) void proj_kernel(ProGateway pro, EpiBiasSta
     for (int q = 0; q < 16; ++q) wf[q] = ld4(Wt + (size_t)(32 * nt + i) * 256 + 128 * kq + 8 * q + 4 * kh);
     const int c4 = (threadIdx.x & 63) * 4;  // this thread's channel quad of the A tile (constant across rows)
     const float4 gw4 = ld4(pro.gw + c4), gb4 = ld4(pro.gb + c4);
+    float4 bias4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias4[g] = ld4(epi.bias + 32 * nt + 8 * g + 4 * kh);
 
     float s = 0.f, qq = 0.f;
     const int tile0 = blockIdx.x * tiles_per_wg;
+    // raw A rows of the NEXT tile are fetched while the current tile is in its MFMA / epilogue phase
+    float4 araw[8];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) araw[it] = ld4(pro.x + ((size_t)b * Mb + min(m0 + (int)(threadIdx.x >> 6) + it * 4, Mb - 1)) * kC + c4);
+    };
+    fetch(tile0 * 32);
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
         const int m0 = (tile0 + tl) * 32;
         if (m0 >= Mb) break;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = (threadIdx.x >> 6) + it * 4;
-            float4 v = f4(0, 0, 0, 0);
-            if (m0 + row < Mb) v = prelu4(fma4(ld4(pro.x + ((size_t)b * Mb + m0 + row) * kC + c4), gw4, gb4), pro.slope);
-            st4(As + row * LDA + c4, v);
-        }
+        for (int it = 0; it < 8; ++it) st4(As + ((threadIdx.x >> 6) + it * 4) * LDA + c4, prelu4(fma4(araw[it], gw4, gb4), pro.slope));
+        if (tl + 1 < tiles_per_wg) fetch(min(m0 + 32, Mb - 1));
         __syncthreads();
         floatx16 acc;
 #pragma unroll
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256, 3) void proj_kernel(ProGateway pro, EpiBiasSta
                 v.y = acc[4 * g + 1] + Rs[nt][(8 * g + 4 * kh + 1) * LDR + i];
                 v.z = acc[4 * g + 2] + Rs[nt][(8 * g + 4 * kh + 2) * LDR + i];
                 v.w = acc[4 * g + 3] + Rs[nt][(8 * g + 4 * kh + 3) * LDR + i];
-                v = v + ld4(epi.bias + n);
+                v = v + bias4[g];
                 if (p < Mb) {
                     st4(epi.y + ((size_t)b * Mb + p) * kH + n, v);
                     s += v.x + v.y + v.z + v.w;
