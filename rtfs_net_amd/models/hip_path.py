@@ -141,6 +141,7 @@ class HipForward:
         self.model = model
         self._prep = None
         self.taps = None  # set to a dict to capture stage outputs (tests)
+        self._vp_stream = None
 
     def weights(self) -> PreparedWeights:
         fp = PreparedWeights.fingerprint(self.model)
@@ -252,8 +253,14 @@ class HipForward:
         if taps is not None:
             taps["spec"], taps["a_emb"], taps["a0"] = spec, a_emb, a0
 
-        # a9: VP block (PyTorch-ROCm glue) -- independent of the audio branch
-        v1 = m.refinement_module.video_net.get_block(0)(m.video_bottleneck(emb.to(torch.float32))).contiguous()
+        # a9: VP block (PyTorch-ROCm glue) -- independent of the audio branch until the CAF cell, so its ~100 tiny
+        # launches run on a side stream underneath the encoder / bottleneck / first RTFS block
+        if self._vp_stream is None or self._vp_stream.device != dev:
+            self._vp_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        self._vp_stream.wait_stream(cur)
+        with torch.cuda.stream(self._vp_stream):
+            v1 = m.refinement_module.video_net.get_block(0)(m.video_bottleneck(emb.to(torch.float32))).contiguous()
         Tv = v1.shape[-1]
 
         blocks = pw.blocks
@@ -263,6 +270,8 @@ class HipForward:
         self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
         att = torch.empty(B * Tv * C, device=dev)
         rsz = torch.empty_like(att)
+        cur.wait_stream(self._vp_stream)
+        v1.record_stream(cur)
         lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
                  w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
         s = torch.empty_like(a_emb)
