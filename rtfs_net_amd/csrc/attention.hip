@@ -20,15 +20,18 @@ constexpr int kQkvN = 96;  // 4 heads x (4 q + 4 k + 16 v) output channels
 // Column order n: [0,16) Q (h*4+e), [16,32) K (h*4+e), [32,96) V (h*16+c).
 // gamma/beta are host-permuted to the output order: gq,gk [4][256], gv [4][1024] (index e*64+f / c*64+f).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_qkv_kernel(const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        const float* __restrict__ slope, const float* __restrict__ gq, const float* __restrict__ bq,
                                                        const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
                                                        const float* __restrict__ bv, float* __restrict__ Q, float* __restrict__ Kx,
                                                        float* __restrict__ V, int BT, int T2) {
     constexpr int LDA = 68, LDY = 97;
-    __shared__ __attribute__((aligned(16))) float As[128 * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[kQkvN * LDA];
-    __shared__ float Ys[128 * LDY];
+    // one LDS arena: [X tile | W] during the GEMM, then re-used as the post-PReLU tile Ys (61 KB -> two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float arena[(128 + kQkvN) * LDA];
+    static_assert(128 * LDY <= (128 + kQkvN) * LDA, "Ys must fit in the arena");
+    float* As = arena;
+    float* Bs = arena + 128 * LDA;
+    float* Ys = arena;
     __shared__ float st[24][2];
 
     const int tok0 = blockIdx.x * 2;
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const float* __restrict__
     floatx16 acc[1][3];
     acc_zero(acc);
     mma_block<1, 3>(acc, As + w * 32 * LDA, LDA, Bs, LDA, 64);
+    __syncthreads();  // every wave is done reading As / Bs before Ys overwrites them
 
 #pragma unroll
     for (int n = 0; n < 3; ++n)
@@ -110,20 +114,22 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// core: grid (ceil(T2/32), 4, B).  T2P = key count rounded up to 32 (compile-time upper bound 256 => T2 <= 256).
+// core: grid (ceil(T2/32), 4, B): one 32-query tile of one head.  MAXKT = compile-time bound on key tiles of 32.
+//  * S = Q K^T / 16: wave w owns key tiles w, w+4, ...; BOTH operands are read straight from global memory in
+//    MFMA fragment shape (each lane streams 16-byte pieces of its own Q / K row; rows are 1 KB and fully consumed
+//    by the wave, so L1 absorbs the partial-line accesses).  No LDS, no barrier.
+//  * softmax over the key axis through a [32][keys] LDS tile (the only LDS use; two barriers).
+//  * O = P V: wave w owns output features [256w, 256w+256); P fragments come from the LDS tile, V fragments are
+//    coalesced 128-byte row segments read directly from global memory -- every V element is fetched once per
+//    workgroup and there is no barrier in this phase either.
 // ------------------------------------------------------------------------------------------------
-template <int MAXKT>  // max key tiles of 32
-__global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
-                                                        float* __restrict__ O, int T2) {
-    constexpr int LDQ = 260, LDK = 68, LDV = 260;
+template <int MAXKT>
+__global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
+                                                           float* __restrict__ O, int T2) {
     constexpr int LDS_S = MAXKT * 32 + 4;
-    __shared__ __attribute__((aligned(16))) float Qs[32 * LDQ];
     __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
-    __shared__ __attribute__((aligned(16))) float KV[128 * LDK];  // K chunk [128 keys][68] or V chunk [32 keys][260]
-    static_assert(32 * LDV <= 128 * LDK, "KV buffer must hold either chunk");
-
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int q0 = qt * 32;
     const int NT = (T2 + 31) / 32;
     const size_t headoff = ((size_t)b * kHeads + h) * T2;
@@ -131,36 +137,23 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
     const float* Kg = Kx + headoff * 256;
     const float* Vg = V + headoff * 1024;
 
-    // Q tile: 32 rows x 256 = 2048 float4
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = threadIdx.x + i * 256;
-        const int row = idx >> 6, c4 = idx & 63;
-        float4 v = (q0 + row < T2) ? ld4(Qg + (size_t)(q0 + row) * 256 + c4 * 4) : f4(0, 0, 0, 0);
-        st4(Qs + row * LDQ + c4 * 4, v);
-    }
-
     // ---- S = Q K^T / 16 ----
-    for (int kt0 = 0; kt0 < NT; kt0 += 4) {
-        floatx16 acc[1][1];
-        acc_zero(acc);
-        for (int ec = 0; ec < 4; ++ec) {  // 64-wide chunks of the 256 features
-            __syncthreads();
+    const float* qrow = Qg + (size_t)min(q0 + i, T2 - 1) * 256 + 4 * kh;  // clamped rows are never stored
+    for (int kt = w; kt < NT; kt += 4) {
+        const float* krow = Kg + (size_t)min(kt * 32 + i, T2 - 1) * 256 + 4 * kh;
+        floatx16 acc;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {  // 128 keys x 16 float4
-                const int idx = threadIdx.x + i * 256;
-                const int key = idx >> 4, c4 = idx & 15;
-                const int kg = kt0 * 32 + key;
-                float4 v = (kg < T2) ? ld4(Kg + (size_t)kg * 256 + ec * 64 + c4 * 4) : f4(0, 0, 0, 0);
-                st4(KV + key * LDK + c4 * 4, v);
-            }
-            __syncthreads();
-            if (kt0 + w < NT) mma_block<1, 1>(acc, Qs + ec * 64, LDQ, KV + w * 32 * LDK, LDK, 64);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            const float4 a = ld4(qrow + 8 * q), kb = ld4(krow + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kb.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kb.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kb.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kb.w, acc, 0, 0, 0);
         }
-        if (kt0 + w < NT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Ss[acc_row(r) * LDS_S + (kt0 + w) * 32 + (lane & 31)] = acc[0][0][r] * 0.0625f;
-        }
+        for (int r = 0; r < 16; ++r) Ss[acc_row(r) * LDS_S + kt * 32 + i] = acc[r] * 0.0625f;
     }
     __syncthreads();
 
@@ -187,35 +180,47 @@ __global__ __launch_bounds__(256) void attn_core_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < MAXKT / 2; ++j) {
             const int col = lane + j * 64;
-            if (col < NT * 32) row[col] = v[j] * inv;
+            if (col < NT * 32) row[col] = v[j] * inv;  // zero weight for the padded keys
         }
     }
+    __syncthreads();
 
-    // ---- O = P V : 4 chunks of 256 output features; wave w owns features [w*64, w*64+64) of the chunk ----
-    for (int nc = 0; nc < 4; ++nc) {
-        floatx16 acc[1][2];
-        acc_zero(acc);
-        for (int kt = 0; kt < NT; ++kt) {
-            __syncthreads();
+    // ---- O = P V: two passes of 4 feature tiles (128 features) per wave ----
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int n0 = w * 256 + pass * 128;
+        floatx16 acc[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {  // 32 keys x 64 float4
-                const int idx = threadIdx.x + i * 256;
-                const int key = idx >> 6, c4 = idx & 63;
-                const int kg = kt * 32 + key;
-                float4 v = (kg < T2) ? ld4(Vg + (size_t)kg * 1024 + nc * 256 + c4 * 4) : f4(0, 0, 0, 0);
-                st4(KV + key * LDV + c4 * 4, v);
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        const float* pa = Ss + i * LDS_S + 4 * kh;
+        for (int kq = 0; kq < NT * 4; ++kq) {  // 8 keys per step: this lane's keys are 8kq + 4kh .. +3
+            const float4 p = ld4(pa + 8 * kq);
+            const int key = 8 * kq + 4 * kh;
+            float vb[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* vr = Vg + (size_t)min(key + r, T2 - 1) * 1024 + n0 + i;  // padded keys carry zero weight
+#pragma unroll
+                for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
             }
-            __syncthreads();
-            mma_block_bn<1, 2>(acc, Ss + kt * 32, LDS_S, KV + w * 64, LDV, 32);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, vb[n][0], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, vb[n][1], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, vb[n][2], acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, vb[n][3], acc[n], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int t = q0 + acc_row(r);
-                const int e = nc * 256 + w * 64 + n * 32 + (lane & 31);
+                const int e = n0 + n * 32 + i;
                 const int c = h * 16 + (e >> 6), f = e & 63;
-                if (t < T2) O[(((size_t)b * T2 + t) * 64 + c) * 64 + f] = acc[0][n][r];
+                if (t < T2) O[(((size_t)b * T2 + t) * 64 + c) * 64 + f] = acc[n][r];
             }
     }
 }
