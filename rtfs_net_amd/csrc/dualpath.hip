@@ -114,77 +114,121 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
 
 // Layer-0 kernel, second generation: workgroup tile 128 rows x 256 columns = TWO 64-row slabs (two frequency
 // sequences, or the two halves of one time sequence), 4 waves as 2 (slab) x 2 (column half), each wave 64 x 128
-// (2 x 4 accumulator tiles = 128 AGPRs).  Against the 64 x 256 tile this halves the weight bytes staged per
+// (4 x 2 accumulator tiles = 128 registers).  Against a 64 x 256 tile this halves the weight bytes staged per
 // flop and the barriers per flop; BK = 16 keeps LDS at 79.6 KB so two workgroups share a CU.
+// PERSISTENT: a workgroup walks tile pairs blockIdx.x, blockIdx.x + gridDim.x, ...; the raw slab rows of the
+// next pair are fetched into registers before the current pair's 32 k-chunks and layer-normalised into LDS after
+// its write-back, so slab latency and most of the prologue disappear from the MFMA timeline.
 __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
                                                                 int tiles_per_seq, int total_tiles) {
     constexpr int BK = 16, LDB = BK + 4, N = 256;
+    constexpr int NIT = (2 * kSlabRows * 16 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float slab[2][kSlabRows * kSlabLd];
     __shared__ __attribute__((aligned(16))) float Bs[2][N * LDB];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = w >> 1, wn = w & 1;
+    const float4 g4 = ld4(gamma + (threadIdx.x & 15) * 4), b4 = ld4(beta + (threadIdx.x & 15) * 4);
 
     ChunkRegs<N, BK> breg;
-    breg.load(Wt, 512, 0);
-
+    float4 sraw[NIT];
     int seq[2], m0[2];
+    auto locate = [&](int pair) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const int gt = min(blockIdx.x * 2 + st, total_tiles - 1);
-        seq[st] = gt / tiles_per_seq;
-        m0[st] = (gt - seq[st] * tiles_per_seq) * 64;
-    }
-    // ---- two LN4D-normalised slabs ----
+        for (int st = 0; st < 2; ++st) {
+            const int gt = min(pair * 2 + st, total_tiles - 1);
+            seq[st] = gt / tiles_per_seq;
+            m0[st] = (gt - seq[st] * tiles_per_seq) * 64;
+        }
+    };
+    // raw rows of both slabs of `pair` -> registers (rows past the sequence end are clamped and zeroed at store time)
+    auto fetch_slabs = [&](int pair) {
+        int sq[2], mm[2];
 #pragma unroll
-    for (int it = 0; it < (2 * kSlabRows * 16 + 255) / 256; ++it) {
-        const int idx = threadIdx.x + it * 256;
-        const int st = idx >= kSlabRows * 16 ? 1 : 0;
-        const int loc = idx - st * kSlabRows * 16;
-        const int row = loc >> 4, c4 = loc & 15;
-        const bool inr = idx < 2 * kSlabRows * 16;
-        const int pos = m0[st] + row;
-        const bool ok = inr && pos < map.npos;
-        float4 v = f4(0, 0, 0, 0);
-        if (ok) v = ld4(src + map.base(seq[st]) + (size_t)pos * map.pos_stride + c4 * 4);
-        float sum = v.x + v.y + v.z + v.w;
+        for (int st = 0; st < 2; ++st) {
+            const int gt = min(pair * 2 + st, total_tiles - 1);
+            sq[st] = gt / tiles_per_seq;
+            mm[st] = (gt - sq[st] * tiles_per_seq) * 64;
+        }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mean = sum * (1.f / 64.f);
-        const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-        float sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int st = idx >= kSlabRows * 16 ? 1 : 0;
+            const int row = (idx - st * kSlabRows * 16) >> 4;
+            const int pos = min(mm[st] + row, map.npos - 1);
+            sraw[it] = ld4(src + map.base(sq[st]) + (size_t)pos * map.pos_stride + (threadIdx.x & 15) * 4);
+        }
+    };
+    // LayerNormalization4D over the 64 channels of each position (normalizations.py:33-37) -> LDS slabs
+    auto store_slabs = [&]() {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-        const float rstd = 1.0f / sqrtf(sq * (1.f / 64.f) + kEps);
-        v = ok ? fma4(d * rstd, ld4(gamma + c4 * 4), ld4(beta + c4 * 4)) : f4(0, 0, 0, 0);
-        if (inr) st4(slab[st] + row * kSlabLd + c4 * 4, v);
-    }
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int st = idx >= kSlabRows * 16 ? 1 : 0;
+            const int row = (idx - st * kSlabRows * 16) >> 4;
+            const bool inr = idx < 2 * kSlabRows * 16;
+            const bool ok = inr && (m0[st] + row < map.npos);
+            const float4 v = sraw[it];
+            float sum = v.x + v.y + v.z + v.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum * (1.f / 64.f);
+            const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+            float sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+            const float rstd = 1.0f / sqrtf(sq * (1.f / 64.f) + kEps);
+            const float4 y = ok ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
+            if (inr) st4(slab[st] + row * kSlabLd + (threadIdx.x & 15) * 4, y);
+        }
+    };
+
+    int pair = blockIdx.x;
+    const int npairs = (total_tiles + 1) / 2;
+    breg.load(Wt, 512, 0);
+    fetch_slabs(pair);
+    locate(pair);
+    store_slabs();
     breg.store(Bs[0], LDB);
     __syncthreads();
 
-    floatx16 acc[4][2];  // [weight tile][row tile]
-    acc_zero(acc);
     constexpr int NK = 512 / BK;
 #pragma unroll 1
-    for (int kc = 0; kc < NK; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
-        const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-        mma_block<4, 2>(acc, Bs[cur] + wn * 128 * LDB, LDB, slab[wm] + kk * kSlabLd + c0, kSlabLd, BK);
-        if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
-        __syncthreads();
-    }
-    if (blockIdx.x * 2 + wm >= total_tiles) return;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = m0[wm] + m * 32 + (lane & 31);
-        if (row < map.L) {
-            float* o = dst + ((size_t)seq[wm] * map.L + row) * N + wn * 128 + 4 * (lane >> 5);
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) st4(o + n * 32 + 8 * g, acc_group(acc[n][m], g));
+    while (true) {
+        const int next = pair + gridDim.x;
+        const bool has_next = next < npairs;
+        if (has_next) fetch_slabs(next);
+        floatx16 acc[4][2];  // [weight tile][row tile]
+        acc_zero(acc);
+#pragma unroll 1
+        for (int kc = 0; kc < NK; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
+            const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
+            mma_block<4, 2>(acc, Bs[cur] + wn * 128 * LDB, LDB, slab[wm] + kk * kSlabLd + c0, kSlabLd, BK);
+            if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
+            __syncthreads();
         }
+        if (has_next) breg.load(Wt, 512, 0);
+        if (pair * 2 + wm < total_tiles) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int row = m0[wm] + m * 32 + (lane & 31);
+                if (row < map.L) {
+                    float* o = dst + ((size_t)seq[wm] * map.L + row) * N + wn * 128 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) st4(o + n * 32 + 8 * g, acc_group(acc[n][m], g));
+                }
+            }
+        }
+        if (!has_next) break;
+        pair = next;
+        locate(pair);
+        store_slabs();  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
+        breg.store(Bs[0], LDB);
+        __syncthreads();
     }
 }
 
@@ -264,7 +308,9 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
-    hipLaunchKernelGGL(unfold_gemm128_kernel, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, tps, total);
+    const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
+    hipLaunchKernelGGL(unfold_gemm128_kernel, dim3(npairs < resident ? npairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0,
+                       tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -95,6 +95,12 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
     float s[NCONV], q[NCONV];
 #pragma unroll
     for (int j = 0; j < NCONV; ++j) s[j] = q[j] = 0.f;
+    // a single convolution keeps its 16 tap vectors in registers; several share the LDS copy
+    float4 wreg[NCONV == 1 ? 16 : 1];
+    if (NCONV == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wreg[i] = ld4(&ws[0][i * 64 + c4]);
+    }
     const size_t orow = (((size_t)b * Tout + (tvalid ? to : 0)) * Fout) * kH + c4;
     constexpr int STEPS = 4 / STRIDE;
 #pragma unroll 1
@@ -119,8 +125,12 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
 #pragma unroll
                 for (int df = 0; df < 4; ++df) {
                     const float4 x = win[(base + df) & 3][dt];
+                    if (NCONV == 1) {
+                        acc[0] = fma4(wreg[dt * 4 + df], x, acc[0]);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + c4]), x, acc[k]);
+                        for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + c4]), x, acc[k]);
+                    }
                 }
             if (tvalid && fo < f1) {
 #pragma unroll
