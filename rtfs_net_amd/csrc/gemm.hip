@@ -439,7 +439,7 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
     ProGateway pro{s, gw, gb, gslope};
     EpiBiasStats epi{y, bias, kH, stats_out};
     if (B <= 0 || TF <= 0) return RTFS_EINVAL;
-    const int tiles = (TF + 31) / 32, per = 16;
+    const int tiles = (TF + 31) / 32, per = 16;  // swept 4..64: flat between 8 and 64
     hipLaunchKernelGGL(proj_kernel, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, TF, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
@@ -457,7 +457,7 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
     EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null};
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
-    const int Mb = T * kF, tiles = (Mb + 63) / 64, per = 8;
+    const int Mb = T * kF, tiles = (Mb + 63) / 64, per = 16;  // swept 2..32 on MI355X: 16 is the minimum (0.84 ms at B=32)
     if (a0_or_null)
         hipLaunchKernelGGL(resid_kernel<true>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
     else
