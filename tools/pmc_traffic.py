@@ -34,6 +34,12 @@ def main(fetch_csv, write_csv, out=None):
         lines.append(f"{k[:100]:100s} {c:8d} {rd / 1e6:10.1f} {wr / 1e6:10.1f} {tot / 1e6:10.1f}")
     text = "\n".join(lines) + "\n"
     (open(out, "w") if out else sys.stdout).write(text)
+    if out:
+        import json
+        import os
+
+        js = {k: {"bytes_per_launch": tot, "read_bytes": rd, "write_bytes": wr, "launches": c} for tot, k, c, rd, wr in rows}
+        json.dump(js, open(os.path.join(os.path.dirname(out), "pmc_traffic.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":
