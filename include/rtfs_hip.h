@@ -63,14 +63,17 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
                       void* stream);
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream);
+/* generic row GEMM Y (= or +=) X . Wt^T (+bias): also every input-gradient GEMM of the backward pass (Wt = transposed weight) */
+int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream);
 int rtfs_dp_convt_fwd(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, void* stream);
 
 /* ---- a8: MultiHeadSelfAttention2D.forward, layers/attention.py:149-189 ------------------------------------- */
 int rtfs_attn_qkv_fwd(const float* G, const float* Wt /*[96][64]*/, const float* bias, const float* slope, const float* gq, const float* bq,
-                      const float* gk, const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, void* stream);
-int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, int B, int T2, void* stream);
+                      const float* gk, const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null /*[B*T2*64][96], training*/,
+                      int B, int T2, void* stream);
+int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null /*[B][4][T2], training*/, int B, int T2, void* stream);
 int rtfs_attn_out_fwd(const float* O, const float* W /*[64][64] out,in*/, const float* bias, float slope, const float* gamma_fc, const float* beta_fc,
-                      float* G /*in place*/, int B, int T2, void* stream);
+                      float* G /*in place*/, float* Ypre_or_null /*[B*T2][64 f][64 co], training*/, int B, int T2, void* stream);
 
 /* ---- a5.6: TFAR, InjectionMultiSum.forward, layers/fusion.py:54-69 ------------------------------------------ */
 int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
@@ -92,12 +95,73 @@ int rtfs_caf_fuse_fwd(const float* x, const float* ks, const float* kb, const fl
                       const float* a0_or_null, float* out, int B, int T, int Tv, void* stream);
 
 /* ---- a11: MaskGenerator.forward + __apply_masks (RI_split), TDAVNet/mask_generator.py:67-99 ------------------ */
-int rtfs_mask_fwd(const float* x, float slope, const float* Wt /*[256][256]*/, const float* bias, const float* a_emb, float* masked, int B, int TF,
-                  void* stream);
+int rtfs_mask_fwd(const float* x, float slope, const float* Wt /*[256][256]*/, const float* bias, const float* a_emb, float* masked,
+                  float* m_or_null /*post-ReLU mask, training*/, int B, int TF, void* stream);
 
 /* ---- a12: STFTDecoder.forward, TDAVNet/decoder.py:110-132 ---------------------------------------------------- */
 /* taps [B][T][129][32] = rtfs_gemm_rows_fwd(masked, Wdec' [32][256]) ; frames: workspace [B][T][256]; out [B][L] */
 int rtfs_istft_fwd(const float* taps, float* frames, float* out, int B, int L, void* stream);
+
+
+/* ======================================================================================================================
+ * Backward (training step, BASELINE configs 3-5).  The reference has no backward code -- it is torch autograd over the
+ * forward modules (train.py:148 via Lightning) plus sru's CUDA backward kernel; every entry point below is the adjoint of
+ * the forward entry point it names, checked against autograd of the oracle (tests/test_hip_backward.py).
+ * Parameter gradients are ACCUMULATED (+=) into caller-zeroed buffers (the RTFS block's weights are shared by all blocks).
+ * ====================================================================================================================== */
+int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream);
+int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream);
+/* GroupNorm(1,C) adjoint; act: 0 none, 1 PReLU after the norm (C=64), 2 ReLU after the norm (C=256); red: double[B][2] zeroed by caller */
+int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
+                        float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream);
+int rtfs_gln_bwd_apply(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope,
+                       const double* red, float* dX, int accumulate, int B, int rows, int C, void* stream);
+/* adjoints of rtfs_dwconv_fwd */
+int rtfs_dwconv_bwd_input(const float* dOut, const float* w, float* dIn, int accumulate, int stride, int B, int Tin, int Fin, void* stream);
+int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* stats_in, const float* gamma, const float* beta, float slope, int mode,
+                           int stride, float* dW, float* dbias_or_null, int B, int Tin, int Fin, void* stream);
+/* adjoints of rtfs_pool_fwd / rtfs_tfar_mix_fwd; rtfs_expand_fwd materialises the TFAR tail for d(residual_conv.weight) */
+int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* stream);
+int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                 const double* gate_stats, const float* gate_g, const float* gate_b, float* dNloc, float* dNgate, float* dNglob, int B, int T, int F, int Tg,
+                 int Fg, void* stream);
+int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                    const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b, const float* cgate,
+                    const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream);
+int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* dgw, float* dgb,
+                     float* dslope, long long rows, void* stream);
+/* weight gradient of any 1x1 conv / linear map (rows may be segmented: Toeplitz structure of unfold / ConvTranspose1d) */
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int NOUT, int KIN,
+               int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream);
+/* adjoints of rtfs_dp_unfold_gemm_fwd (input side) and rtfs_dp_convt_fwd */
+int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt /*[64][2048]*/, float* dxn, int B, int T2, int dim, void* stream);
+int rtfs_convt_bwd_input(const float* dG, const float* Wt /*[64][512]*/, float* dH3, int B, int T2, int dim, void* stream);
+/* SRU recurrence: training forward (stores the cell state) and adjoint */
+int rtfs_sru_scan_train_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, float* C, int S, int L,
+                            int km, void* stream);
+int rtfs_sru_scan_bwd(const float* U, const float* X, const float* C, const float* wc, const float* bias, float scale_x, const float* dH, float* dU,
+                      float* dX, float* dwc, float* dbias, int S, int L, int km, void* stream);
+int rtfs_ln4d_c_bwd(const float* dxn, const float* G, const float* gamma, float* dG, float* dgamma, float* dbeta, long long rows, void* stream);
+int rtfs_seq_gather(const float* G, const float* gamma, const float* beta, int ln, float* out, int B, int T2, int dim, void* stream);
+/* attention adjoints */
+int rtfs_attn_out_norm_bwd(const float* dOut, const float* Ypre, float slope, const float* gamma_fc, float* dYpre, float* dgamma_fc, float* dbeta_fc,
+                           float* dslope, int ntok, void* stream);
+int rtfs_attn_qkv_norm_bwd(const float* dQ, const float* dK, const float* dV, const float* Ypre, const float* slope, const float* gq, const float* gk,
+                           const float* gv, float* dYpre, float* dgq, float* dbq, float* dgk, float* dbk, float* dgv, float* dbv, float* dslope, int B,
+                           int T2, void* stream);
+int rtfs_attn_core_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE, float* Dws, float* dQ,
+                       float* dK, float* dV, int B, int T2, void* stream);
+int rtfs_transpose_tok(const float* in, float* out, int ntok, void* stream);
+/* S3 mask, CAF (training-mode BatchNorm), decoder / encoder ends */
+int rtfs_mask_bwd_elem(const float* dmasked, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows, void* stream);
+int rtfs_prelu_bwd(const float* dy, const float* x, float slope, float* dx, int accumulate, float* dslope, long long n, void* stream);
+int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, void* stream);
+int rtfs_caf_bwd_reduce(const float* dOut, const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att,
+                        const float* rsz, float* datt, float* drsz, float* R, int B, int T, int Tv, void* stream);
+int rtfs_caf_bwd_apply(const float* dOut, const float* x, const float* ks, const float* kb, const float* att, const float* rsz, const float* coef,
+                       float* dx, int accumulate, int B, int T, int Tv, void* stream);
+int rtfs_istft_bwd(const float* dout, float* dspec, float* dtaps, int B, int L, void* stream);
+int rtfs_spec_patches(const float* spec, float* patches, int B, int T, void* stream);
 
 #ifdef __cplusplus
 }

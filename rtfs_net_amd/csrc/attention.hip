@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
                                                        const float* __restrict__ slope, const float* __restrict__ gq, const float* __restrict__ bq,
                                                        const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
                                                        const float* __restrict__ bv, float* __restrict__ Q, float* __restrict__ Kx,
-                                                       float* __restrict__ V, int BT, int T2) {
+                                                       float* __restrict__ V, float* __restrict__ Ypre, int BT, int T2) {
     constexpr int LDA = 68, LDY = 97;
     // one LDS arena: [X tile | W] during the GEMM, then re-used as the post-PReLU tile Ys (61 KB -> two workgroups per CU)
     __shared__ __attribute__((aligned(16))) float arena[(128 + kQkvN) * LDA];
@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = w * 32 + acc_row(r), col = n * 32 + (lane & 31);
-            Ys[row * LDY + col] = prelu(acc[0][n][r] + bias[col], slope[col]);
+            const float pre = acc[0][n][r] + bias[col];
+            if (Ypre && row < ntok * 64) Ypre[((size_t)tok0 * 64 + row) * kQkvN + col] = pre;  // training: pre-activation for the adjoint
+            Ys[row * LDY + col] = prelu(pre, slope[col]);
         }
     __syncthreads();
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 template <int MAXKT>
 __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
-                                                           float* __restrict__ O, int T2) {
+                                                           float* __restrict__ O, float* __restrict__ LSE, int T2) {
     constexpr int LDS_S = MAXKT * 32 + 4;
     __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -176,7 +178,9 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
             v[j] = (col < T2) ? __expf(v[j] - mx) : 0.f;
             sum += v[j];
         }
-        const float inv = 1.0f / wave_sum(sum);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        if (LSE && lane == 0 && q0 + w * 8 + rr < T2) LSE[headoff + q0 + w * 8 + rr] = mx + __logf(sum);  // training: log-sum-exp of the scaled scores
 #pragma unroll
         for (int j = 0; j < MAXKT / 2; ++j) {
             const int col = lane + j * 64;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__ O, const float* __restrict__ W, const float* __restrict__ bias,
                                                        float slope, const float* __restrict__ gamma_fc, const float* __restrict__ beta_fc,
-                                                       float* __restrict__ G) {
+                                                       float* __restrict__ G, float* __restrict__ Ypre) {
     constexpr int LD = 68, LDY = 65;
     __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
     __shared__ __attribute__((aligned(16))) float Xs[64 * LD];
@@ -258,7 +262,9 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = wm * 32 + acc_row(r), f = wn * 32 + (lane & 31);
-        const float y = prelu(acc[0][0][r] + bias[co], slope);
+        const float pre = acc[0][0][r] + bias[co];
+        if (Ypre) Ypre[tok * 4096 + f * 64 + co] = pre;  // training: pre-activation, channels-last [f][co]
+        const float y = prelu(pre, slope);
         Ys[co * LDY + f] = y;
         s += y;
     }
@@ -291,32 +297,33 @@ using namespace rtfs;
 extern "C" {
 
 int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
-                      const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, void* stream) {
+                      const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2,
+                      void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
     const int BT = B * T2;
-    hipLaunchKernelGGL(attn_qkv_kernel, dim3((BT + 1) / 2), dim3(256), 0, (hipStream_t)stream, G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, BT,
-                       T2);
+    hipLaunchKernelGGL(attn_qkv_kernel, dim3((BT + 1) / 2), dim3(256), 0, (hipStream_t)stream, G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V,
+                       Ypre_or_null, BT, T2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, int B, int T2, void* stream) {
+int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0 || T2 > 512) return RTFS_EINVAL;
     dim3 grid((T2 + 31) / 32, kHeads, B);
     if (T2 <= 128)
-        hipLaunchKernelGGL((attn_core_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+        hipLaunchKernelGGL((attn_core_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else if (T2 <= 256)
-        hipLaunchKernelGGL((attn_core_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+        hipLaunchKernelGGL((attn_core_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else
-        hipLaunchKernelGGL((attn_core_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+        hipLaunchKernelGGL((attn_core_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
-                      int T2, void* stream) {
+int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
+                      float* Ypre_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(attn_out_kernel, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G);
+    hipLaunchKernelGGL(attn_out_kernel, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

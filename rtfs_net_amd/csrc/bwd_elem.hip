@@ -1,0 +1,485 @@
+// Backward primitives of the bandwidth-bound stages (training step, BASELINE configs 3-5).  The reference has no
+// backward code: it is torch autograd over the forward modules, so every kernel here is the hand-derived adjoint of
+// the forward kernel it names; parity is checked against autograd of the oracle (tests/test_hip_backward.py).
+//
+//   rtfs_colsum_add           bias gradients: out[n] += sum_rows X[row][n]
+//   rtfs_gln_bwd_reduce/apply GroupNorm(1,C) backward (adjoint of "normalise on read"), optional PReLU after the norm
+//   rtfs_dwconv_bwd_input     transposed depth-wise 4x4 convolution (stride 1 / 2)
+//   rtfs_dwconv_bwd_weight    tap / bias gradients of a depth-wise convolution, input re-normalised on read
+//   rtfs_pool_bwd             adjoint of adaptive_avg_pool2d + add            (tdanet.py:117-118)
+//   rtfs_mix_bwd              adjoint of InjectionMultiSum's gate/upsample mix (fusion.py:59-67)
+//   rtfs_expand_fwd           materialise `expanded` (TFAR tail) for the residual_conv weight gradient
+//   rtfs_gateway_bwd          gateway (dw1x1 + PReLU) backward with parameter-gradient reductions
+//   rtfs_axpy                 y += a * x
+#include "common.h"
+
+namespace rtfs {
+
+struct NormArg {
+    const float* x;      // pre-norm tensor [B][rows][C]
+    const double* slot;  // forward (sum, sumsq) per utterance
+    double inv_n;
+    const float *gamma, *beta;
+};
+
+__device__ __forceinline__ float4 sub4(float4 a, float s) { return f4(a.x - s, a.y - s, a.z - s, a.w - s); }
+__device__ __forceinline__ float hsum4(float4 a) { return a.x + a.y + a.z + a.w; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// Reduce per-thread float4 partials that share a channel quad (thread = (row = tid / QUADS, quad = tid % QUADS)) and add
+// the workgroup total to out[quad*4 ..] with one atomic per channel.  lds: 1024 floats.
+template <int QUADS>
+__device__ __forceinline__ void quad_reduce_atomic(float4 v, float* lds, float* out) {
+    st4(lds + threadIdx.x * 4, v);
+    __syncthreads();
+    if (threadIdx.x < QUADS) {
+        float4 s = f4(0, 0, 0, 0);
+#pragma unroll 4
+        for (int r = 0; r < 256 / QUADS; ++r) s = s + ld4(lds + (r * QUADS + threadIdx.x) * 4);
+        atomicAdd(out + threadIdx.x * 4 + 0, s.x);
+        atomicAdd(out + threadIdx.x * 4 + 1, s.y);
+        atomicAdd(out + threadIdx.x * 4 + 2, s.z);
+        atomicAdd(out + threadIdx.x * 4 + 3, s.w);
+    }
+    __syncthreads();
+}
+
+// block-wide sum of a scalar -> one atomicAdd (float) by thread 0.  lds: >= 4 floats
+__device__ __forceinline__ void scalar_reduce_atomic(float v, float* lds, float* out) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, lds[0] + lds[1] + lds[2] + lds[3]);
+    __syncthreads();
+}
+
+// ---- colsum ---------------------------------------------------------------------------------------------------------
+template <int QUADS>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, long long M, int rows_per_wg) {
+    __shared__ __attribute__((aligned(16))) float lds[1024];
+    constexpr int N = QUADS * 4;
+    const int quad = threadIdx.x % QUADS, rsub = threadIdx.x / QUADS;
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
+    float4 s = f4(0, 0, 0, 0);
+    for (long long r = r0 + rsub; r < r1; r += 256 / QUADS) s = s + ld4(X + r * N + quad * 4);
+    quad_reduce_atomic<QUADS>(s, lds, out);
+}
+
+// ---- gLN backward ---------------------------------------------------------------------------------------------------
+// y = xhat*gamma + beta, xhat = (x-mean)*rstd over one utterance (N elements).  g = dL/dy; with ACT == 1 the forward
+// applied PReLU after the norm: the incoming gradient is w.r.t. prelu(y) and g = dY * prelu'(y).
+//   a = g*gamma;  S1 = sum a;  S2 = sum a*xhat;   dgamma_c = sum g*xhat;  dbeta_c = sum g;
+//   dx = rstd * (a - S1/N - xhat*S2/N)
+template <int C, int ACT>
+__global__ __launch_bounds__(256) void gln_bwd_reduce_kernel(const float* __restrict__ dY, NormArg n, float slope, double* __restrict__ red,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
+                                                             int rows, int rows_per_wg) {
+    constexpr int QUADS = C / 4;
+    __shared__ __attribute__((aligned(16))) float lds[1024];
+    __shared__ float redl[8];
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x % QUADS) * 4, rsub = threadIdx.x / QUADS;
+    float mean, rstd;
+    stats_finalize(n.slot, b, n.inv_n, mean, rstd);
+    const float4 g4 = ld4(n.gamma + c4), be4 = ld4(n.beta + c4);
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    float4 dg = f4(0, 0, 0, 0), db = f4(0, 0, 0, 0);
+    float s1 = 0.f, s2 = 0.f, dsl = 0.f;
+    for (int r = r0 + rsub; r < r1; r += 256 / QUADS) {
+        const size_t o = ((size_t)b * rows + r) * C + c4;
+        const float4 xh = sub4(ld4(n.x + o), mean) * rstd;
+        float4 g = ld4(dY + o);
+        if (ACT == 1) {
+            const float4 y = fma4(xh, g4, be4);
+            dsl += (y.x > 0.f ? 0.f : g.x * y.x) + (y.y > 0.f ? 0.f : g.y * y.y) + (y.z > 0.f ? 0.f : g.z * y.z) + (y.w > 0.f ? 0.f : g.w * y.w);
+            g = f4(y.x > 0.f ? g.x : g.x * slope, y.y > 0.f ? g.y : g.y * slope, y.z > 0.f ? g.z : g.z * slope, y.w > 0.f ? g.w : g.w * slope);
+        }
+        if (ACT == 2) {
+            const float4 y = fma4(xh, g4, be4);
+            g = f4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+        }
+        db = db + g;
+        dg = fma4(g, xh, dg);
+        const float4 a = g * g4;
+        s1 += hsum4(a);
+        s2 += dot4(a, xh);
+    }
+    quad_reduce_atomic<QUADS>(dg, lds, dgamma);
+    quad_reduce_atomic<QUADS>(db, lds, dbeta);
+    if (ACT == 1) scalar_reduce_atomic(dsl, lds, dslope);
+    block_stats_commit(s1, s2, redl, red, b);
+}
+
+// dX (= or +=) rstd * (a - S1/N - xhat*S2/N)
+template <int C, int ACT, bool ACCUM>
+__global__ __launch_bounds__(256) void gln_bwd_apply_kernel(const float* __restrict__ dY, NormArg n, float slope, const double* __restrict__ red,
+                                                            float* __restrict__ dX, int rows) {
+    constexpr int QUADS = C / 4;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * (256 / QUADS) + threadIdx.x / QUADS;
+    if (r >= rows) return;
+    const int c4 = (threadIdx.x % QUADS) * 4;
+    float mean, rstd;
+    stats_finalize(n.slot, b, n.inv_n, mean, rstd);
+    const float m1 = (float)(red[2 * b] * n.inv_n), m2 = (float)(red[2 * b + 1] * n.inv_n);
+    const float4 g4 = ld4(n.gamma + c4);
+    const size_t o = ((size_t)b * rows + r) * C + c4;
+    const float4 xh = sub4(ld4(n.x + o), mean) * rstd;
+    float4 g = ld4(dY + o);
+    if (ACT == 1) {
+        const float4 y = fma4(xh, g4, ld4(n.beta + c4));
+        g = f4(y.x > 0.f ? g.x : g.x * slope, y.y > 0.f ? g.y : g.y * slope, y.z > 0.f ? g.z : g.z * slope, y.w > 0.f ? g.w : g.w * slope);
+    }
+    if (ACT == 2) {
+        const float4 y = fma4(xh, g4, ld4(n.beta + c4));
+        g = f4(y.x > 0.f ? g.x : 0.f, y.y > 0.f ? g.y : 0.f, y.z > 0.f ? g.z : 0.f, y.w > 0.f ? g.w : 0.f);
+    }
+    const float4 a = g * g4;
+    float4 d = f4((a.x - m1 - xh.x * m2) * rstd, (a.y - m1 - xh.y * m2) * rstd, (a.z - m1 - xh.z * m2) * rstd, (a.w - m1 - xh.w * m2) * rstd);
+    if (ACCUM) d = d + ld4(dX + o);
+    st4(dX + o, d);
+}
+
+// ---- depth-wise conv backward -----------------------------------------------------------------------------------------
+// forward: out[to][fo] = bias + sum_{dt,df} w[dt*4+df] * in[to*S-1+dt][fo*S-1+df]  (zero outside), per channel.
+// dIn[ti][fi] (= or +=) sum_{dt,df : (ti+1-dt) % S == 0, (fi+1-df) % S == 0} w[dt*4+df] * dOut[(ti+1-dt)/S][(fi+1-df)/S]
+template <int STRIDE, bool ACCUM>
+__global__ __launch_bounds__(256) void dwconv_bwd_input_kernel(const float* __restrict__ dOut, const float* __restrict__ w, float* __restrict__ dIn,
+                                                               int Tin, int Fin, int Tout, int Fout) {
+    __shared__ __attribute__((aligned(16))) float ws[16 * 64];
+    for (int i = threadIdx.x; i < 256; i += 256) st4(&ws[i * 4], ld4(w + i * 4));
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= Tin * Fin) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int ti = p / Fin, fi = p - ti * Fin;
+    float4 acc = f4(0, 0, 0, 0);
+    const float* ob = dOut + (size_t)b * Tout * Fout * kH + c4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int tn = ti + 1 - dt;
+        if (tn < 0 || (tn % STRIDE) != 0) continue;
+        const int to = tn / STRIDE;
+        if (to >= Tout) continue;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+            const int fn = fi + 1 - df;
+            if (fn < 0 || (fn % STRIDE) != 0) continue;
+            const int fo = fn / STRIDE;
+            if (fo >= Fout) continue;
+            acc = fma4(ld4(&ws[(dt * 4 + df) * 64 + c4]), ld4(ob + ((size_t)to * Fout + fo) * kH), acc);
+        }
+    }
+    float* o = dIn + ((size_t)b * Tin * Fin + p) * kH + c4;
+    if (ACCUM) acc = acc + ld4(o);
+    st4(o, acc);
+}
+
+// dW[tap][c] += sum_{b,to,fo} dOut[to][fo][c] * xin[to*S-1+dt][fo*S-1+df][c];  dbias[c] += sum dOut.
+// xin = transformed forward input (MODE 0 raw, 1 gLN, 2 PReLU(gLN)).  Thread = (pixel lane, channel quad); each
+// workgroup walks `pix_per_wg` output pixels, keeps 16 tap partials in registers and reduces them once.
+template <int STRIDE, int MODE>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dOut, NormArg n, float slope, float* __restrict__ dW,
+                                                                float* __restrict__ dbias, int Tin, int Fin, int Tout, int Fout, int pix_per_wg) {
+    __shared__ __attribute__((aligned(16))) float lds[1024];
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 15) * 4, psub = threadIdx.x >> 4;
+    float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
+    if (MODE >= 1) {
+        float mean, rstd;
+        stats_finalize(n.slot, b, n.inv_n, mean, rstd);
+        const float4 g = ld4(n.gamma + c4), be = ld4(n.beta + c4);
+        sc = g * rstd;
+        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+    }
+    float4 part[16], pb = f4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = f4(0, 0, 0, 0);
+    const int npix = Tout * Fout;
+    const int p0 = blockIdx.x * pix_per_wg, p1 = min(npix, p0 + pix_per_wg);
+    const float* inb = n.x + (size_t)b * Tin * Fin * kH + c4;
+    for (int p = p0 + psub; p < p1; p += 16) {
+        const int to = p / Fout, fo = p - to * Fout;
+        const float4 g = ld4(dOut + ((size_t)b * npix + p) * kH + c4);
+        pb = pb + g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int ti = to * STRIDE - 1 + dt;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const int fi = fo * STRIDE - 1 + df;
+                if (ti >= 0 && ti < Tin && fi >= 0 && fi < Fin) {
+                    float4 x = ld4(inb + ((size_t)ti * Fin + fi) * kH);
+                    if (MODE >= 1) x = fma4(x, sc, sh);
+                    if (MODE == 2) x = prelu4(x, slope);
+                    part[dt * 4 + df] = fma4(g, x, part[dt * 4 + df]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) quad_reduce_atomic<16>(part[i], lds, dW + i * 64);
+    if (dbias) quad_reduce_atomic<16>(pb, lds, dbias);
+}
+
+// ---- pool backward ----------------------------------------------------------------------------------------------------
+// forward: G[t2][f2] = mean_{window(t2) x window(f2)} n(D0) + n(D1);  window(i) = [floor(i*in/out), ceil((i+1)*in/out)).
+// dN_D0[t][f] += sum over windows containing (t,f) of dG / |window|.   (dN_D1 += dG is an rtfs_axpy.)
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dG, float* __restrict__ dN0, int T, int T2) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T * kF) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = p / kF, f = p - t * kF;
+    float4 acc = f4(0, 0, 0, 0);
+    const int tc = (t * T2) / T, fc = (f * kF2) / kF;
+    for (int t2 = max(tc - 1, 0); t2 <= min(tc + 1, T2 - 1); ++t2) {
+        const int ts = (t2 * T) / T2, te = ((t2 + 1) * T + T2 - 1) / T2;
+        if (t < ts || t >= te) continue;
+        for (int f2 = max(fc - 1, 0); f2 <= min(fc + 1, kF2 - 1); ++f2) {
+            const int fs = (f2 * kF) / kF2, fe = ((f2 + 1) * kF + kF2 - 1) / kF2;
+            if (f < fs || f >= fe) continue;
+            const float inv = 1.0f / (float)((te - ts) * (fe - fs));
+            acc = fma4(ld4(dG + (((size_t)b * T2 + t2) * kF2 + f2) * kH + c4), f4(inv, inv, inv, inv), acc);
+        }
+    }
+    float* o = dN0 + ((size_t)b * T * kF + p) * kH + c4;
+    st4(o, acc + ld4(o));
+}
+
+// ---- mix backward -----------------------------------------------------------------------------------------------------
+// forward: out[p] = n(loc)[p] * sigmoid(n(gate)[up(p)]) + n(glob)[up(p)],  up = nearest (floor(dst*in/out)).
+// full-resolution part: dNloc[p] = dOut[p] * sigmoid(n(gate)[up(p)])
+__global__ __launch_bounds__(256) void mix_bwd_loc_kernel(const float* __restrict__ dOut, NormArg gate, float* __restrict__ dNloc, int T, int F, int Tg,
+                                                          int Fg) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T * F) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = p / F, f = p - t * F;
+    const int tg = nearest_src(t, Tg, T), fg = nearest_src(f, Fg, F);
+    float mean, rstd;
+    stats_finalize(gate.slot, b, gate.inv_n, mean, rstd);
+    const float4 g = ld4(gate.gamma + c4), be = ld4(gate.beta + c4);
+    const float4 s = sigmoid4(fma4(sub4(ld4(gate.x + (((size_t)b * Tg + tg) * Fg + fg) * kH + c4), mean) * rstd, g, be));
+    const size_t o = ((size_t)b * T * F + p) * kH + c4;
+    st4(dNloc + o, ld4(dOut + o) * s);
+}
+
+// low-resolution part: over the footprint {p : up(p) = q}:  A = sum dOut*n(loc), Bs = sum dOut
+//   dNgate[q] = A * s(1-s), s = sigmoid(n(gate)[q]);   dNglob[q] = Bs
+__global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, float* __restrict__ dNgate,
+                                                           float* __restrict__ dNglob, int T, int F, int Tg, int Fg) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= Tg * Fg) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int tg = q / Fg, fg = q - tg * Fg;
+    // footprint of nearest up-sampling: t with floor(t*Tg/T) == tg  <=>  ceil(tg*T/Tg) <= t < ceil((tg+1)*T/Tg)
+    const int t0 = (tg * T + Tg - 1) / Tg, t1 = min(T, ((tg + 1) * T + Tg - 1) / Tg);
+    const int f0 = (fg * F + Fg - 1) / Fg, f1 = min(F, ((fg + 1) * F + Fg - 1) / Fg);
+    float lm, lr, gm, gr;
+    stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
+    stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
+    const float4 lg = ld4(loc.gamma + c4), lb = ld4(loc.beta + c4);
+    float4 A = f4(0, 0, 0, 0), Bs = f4(0, 0, 0, 0);
+    for (int t = t0; t < t1; ++t)
+        for (int f = f0; f < f1; ++f) {
+            const size_t o = (((size_t)b * T + t) * F + f) * kH + c4;
+            const float4 d = ld4(dOut + o);
+            A = fma4(d, fma4(sub4(ld4(loc.x + o), lm) * lr, lg, lb), A);
+            Bs = Bs + d;
+        }
+    const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
+    const float4 s = sigmoid4(fma4(sub4(ld4(gate.x + o), gm) * gr, ld4(gate.gamma + c4), ld4(gate.beta + c4)));
+    st4(dNgate + o, f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w)));
+    st4(dNglob + o, Bs);
+}
+
+// ---- expanded (TFAR tail), materialised for the residual_conv weight gradient ---------------------------------------
+__global__ __launch_bounds__(256) void expand_kernel(NormArg cl, NormArg d0, NormArg cg, NormArg cgate, float* __restrict__ E, int T, int T2) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T * kF) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = p / kF, f = p - t * kF;
+    const int t2 = nearest_src(t, T2, T), f2 = nearest_src(f, kF2, kF);
+    const size_t hi = ((size_t)b * T * kF + p) * kH + c4, lo = (((size_t)b * T2 + t2) * kF2 + f2) * kH + c4;
+    auto nrm = [&](const NormArg& r, size_t o) {
+        float m, rs;
+        stats_finalize(r.slot, b, r.inv_n, m, rs);
+        return fma4(sub4(ld4(r.x + o), m) * rs, ld4(r.gamma + c4), ld4(r.beta + c4));
+    };
+    st4(E + hi, fma4(nrm(cl, hi), sigmoid4(nrm(cgate, lo)), nrm(cg, lo)) + nrm(d0, hi));
+}
+
+// ---- gateway backward -------------------------------------------------------------------------------------------------
+// forward: G = prelu(u), u = s*gw + gb (per channel).  dG -> ds (= or +=), dgw += sum du*s, dgb += sum du, dslope += sum dG*u*[u<=0]
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void gateway_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ s, const float* __restrict__ gw,
+                                                          const float* __restrict__ gb, float slope, float* __restrict__ ds, float* __restrict__ dgw,
+                                                          float* __restrict__ dgb, float* __restrict__ dslope, long long rows, int rows_per_wg) {
+    __shared__ __attribute__((aligned(16))) float lds[1024];
+    const int c4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
+    const float4 w4 = ld4(gw + c4), b4 = ld4(gb + c4);
+    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    float4 aw = f4(0, 0, 0, 0), ab = f4(0, 0, 0, 0);
+    float asl = 0.f;
+    for (long long r = r0 + rsub; r < r1; r += 4) {
+        const size_t o = (size_t)r * kC + c4;
+        const float4 sv = ld4(s + o), g = ld4(dG + o);
+        const float4 u = fma4(sv, w4, b4);
+        asl += (u.x > 0.f ? 0.f : g.x * u.x) + (u.y > 0.f ? 0.f : g.y * u.y) + (u.z > 0.f ? 0.f : g.z * u.z) + (u.w > 0.f ? 0.f : g.w * u.w);
+        const float4 du = f4(u.x > 0.f ? g.x : g.x * slope, u.y > 0.f ? g.y : g.y * slope, u.z > 0.f ? g.z : g.z * slope, u.w > 0.f ? g.w : g.w * slope);
+        aw = fma4(du, sv, aw);
+        ab = ab + du;
+        float4 d = du * w4;
+        if (ACCUM) d = d + ld4(ds + o);
+        st4(ds + o, d);
+    }
+    quad_reduce_atomic<64>(aw, lds, dgw);
+    quad_reduce_atomic<64>(ab, lds, dgb);
+    scalar_reduce_atomic(asl, lds, dslope);
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) st4(y + i * 4, fma4(ld4(x + i * 4), f4(a, a, a, a), ld4(y + i * 4)));
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+#define LAUNCH(kernel, grid, ...)                                                           \
+    hipLaunchKernelGGL(kernel, grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);      \
+    RTFS_LAUNCH_CHECK();
+
+extern "C" {
+
+int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream) {
+    if (M <= 0) return RTFS_EINVAL;
+    const int per = 512;
+    dim3 grid((unsigned)((M + per - 1) / per));
+    switch (N) {
+        case 32: LAUNCH((colsum_kernel<8>), grid, X, out, M, per); break;
+        case 64: LAUNCH((colsum_kernel<16>), grid, X, out, M, per); break;
+        case 96: LAUNCH((colsum_kernel<24>), grid, X, out, M, per); break;
+        case 256: LAUNCH((colsum_kernel<64>), grid, X, out, M, per); break;
+        default: return RTFS_EINVAL;
+    }
+    return RTFS_OK;
+}
+
+// red: double[B][2], zeroed by the caller.  act: 0 none, 1 PReLU(slope) after the norm (C = 64; dslope accumulates), 2 ReLU after the norm (C = 256).
+int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
+                        float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream) {
+    if (B <= 0 || rows <= 0 || (C != 64 && C != 256)) return RTFS_EINVAL;
+    NormArg n{X, stats, 1.0 / ((double)rows * C), gamma, beta};
+    const int per = 256;
+    dim3 grid((rows + per - 1) / per, B);
+    if (C == 64) {
+        if (act == 1) { LAUNCH((gln_bwd_reduce_kernel<64, 1>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<64, 0>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        else return RTFS_EINVAL;
+    } else {
+        if (act == 2) { LAUNCH((gln_bwd_reduce_kernel<256, 2>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<256, 0>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        else return RTFS_EINVAL;
+    }
+    return RTFS_OK;
+}
+
+int rtfs_gln_bwd_apply(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope,
+                       const double* red, float* dX, int accumulate, int B, int rows, int C, void* stream) {
+    if (B <= 0 || rows <= 0 || (C != 64 && C != 256)) return RTFS_EINVAL;
+    NormArg n{X, stats, 1.0 / ((double)rows * C), gamma, beta};
+    dim3 grid((rows + (1024 / C) - 1) / (1024 / C), B);
+#define GLN_APPLY(CC, AA, AC) LAUNCH((gln_bwd_apply_kernel<CC, AA, AC>), grid, dY, n, slope, red, dX, rows)
+    if (C == 64) {
+        if (act == 1) { if (accumulate) { GLN_APPLY(64, 1, true); } else { GLN_APPLY(64, 1, false); } }
+        else if (act == 0) { if (accumulate) { GLN_APPLY(64, 0, true); } else { GLN_APPLY(64, 0, false); } }
+        else return RTFS_EINVAL;
+    } else {
+        if (act == 2) { if (accumulate) { GLN_APPLY(256, 2, true); } else { GLN_APPLY(256, 2, false); } }
+        else if (act == 0) { if (accumulate) { GLN_APPLY(256, 0, true); } else { GLN_APPLY(256, 0, false); } }
+        else return RTFS_EINVAL;
+    }
+#undef GLN_APPLY
+    return RTFS_OK;
+}
+
+int rtfs_dwconv_bwd_input(const float* dOut, const float* w, float* dIn, int accumulate, int stride, int B, int Tin, int Fin, void* stream) {
+    if (B <= 0 || (stride != 1 && stride != 2)) return RTFS_EINVAL;
+    const int Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1, Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
+    dim3 grid((Tin * Fin + 15) / 16, B);
+    if (stride == 1) {
+        if (accumulate) { LAUNCH((dwconv_bwd_input_kernel<1, true>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
+        else { LAUNCH((dwconv_bwd_input_kernel<1, false>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
+    } else {
+        if (accumulate) { LAUNCH((dwconv_bwd_input_kernel<2, true>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
+        else { LAUNCH((dwconv_bwd_input_kernel<2, false>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
+    }
+    return RTFS_OK;
+}
+
+// mode: transform of the forward input (0 raw, 1 gLN, 2 PReLU(gLN)); dbias may be NULL.
+int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* stats_in, const float* gamma, const float* beta, float slope, int mode,
+                           int stride, float* dW, float* dbias, int B, int Tin, int Fin, void* stream) {
+    if (B <= 0 || (stride != 1 && stride != 2) || mode < 0 || mode > 2) return RTFS_EINVAL;
+    const int Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1, Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
+    NormArg n{in, stats_in, 1.0 / ((double)Tin * Fin * kH), gamma, beta};
+    const int per = 512;
+    dim3 grid((Tout * Fout + per - 1) / per, B);
+#define DWW(S, M) LAUNCH((dwconv_bwd_weight_kernel<S, M>), grid, dOut, n, slope, dW, dbias, Tin, Fin, Tout, Fout, per)
+    if (stride == 1) { if (mode == 0) { DWW(1, 0); } else if (mode == 1) { DWW(1, 1); } else { DWW(1, 2); } }
+    else { if (mode == 0) { DWW(2, 0); } else if (mode == 1) { DWW(2, 1); } else { DWW(2, 2); } }
+#undef DWW
+    return RTFS_OK;
+}
+
+int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* stream) {
+    if (B <= 0) return RTFS_EINVAL;
+    LAUNCH(pool_bwd_kernel, dim3((T * kF + 15) / 16, B), dG, dN0, T, T2);
+    return RTFS_OK;
+}
+
+// loc at (T,F) with stats/gamma/beta; gate/glob at (Tg,Fg).  Outputs: dNloc [B][T][F][64], dNgate/dNglob [B][Tg][Fg][64].
+int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                 const double* gate_stats, const float* gate_g, const float* gate_b, float* dNloc, float* dNgate, float* dNglob, int B, int T, int F, int Tg,
+                 int Fg, void* stream) {
+    if (B <= 0) return RTFS_EINVAL;
+    NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b};
+    LAUNCH(mix_bwd_glob_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, dNgate, dNglob, T, F, Tg, Fg);
+    LAUNCH(mix_bwd_loc_kernel, dim3((T * F + 15) / 16, B), dOut, g, dNloc, T, F, Tg, Fg);
+    return RTFS_OK;
+}
+
+int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                    const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b, const float* cgate,
+                    const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream) {
+    if (B <= 0) return RTFS_EINVAL;
+    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
+    NormArg a{cl, cl_stats, nf, cl_g, cl_b}, d{d0, d0_stats, nf, d0_g, d0_b}, g{cg, cg_stats, nl, cg_g, cg_b}, s{cgate, cgate_stats, nl, cgate_g, cgate_b};
+    LAUNCH(expand_kernel, dim3((T * kF + 15) / 16, B), a, d, g, s, E, T, T2);
+    return RTFS_OK;
+}
+
+int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* dgw, float* dgb,
+                     float* dslope, long long rows, void* stream) {
+    if (rows <= 0) return RTFS_EINVAL;
+    const int per = 128;
+    dim3 grid((unsigned)((rows + per - 1) / per));
+    if (accumulate) { LAUNCH((gateway_bwd_kernel<true>), grid, dG, s, gw, gb, slope, ds, dgw, dgb, dslope, rows, per); }
+    else { LAUNCH((gateway_bwd_kernel<false>), grid, dG, s, gw, gb, slope, ds, dgw, dgb, dslope, rows, per); }
+    return RTFS_OK;
+}
+
+int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream) {
+    if (n <= 0 || (n & 3)) return RTFS_EINVAL;
+    LAUNCH(axpy_kernel, dim3((unsigned)((n / 4 + 255) / 256)), x, a, y, n / 4);
+    return RTFS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,247 @@
+// Backward GEMMs of the training step.
+//
+//   rtfs_wgrad               dW[n][k] += sum_rows dY[row][n] * X[row][k]   (weight gradient of every 1x1 conv / linear map;
+//                            X may be re-derived on load: gateway, PReLU, ReLU(gLN); rows may be segmented with an offset,
+//                            which turns the unfold / conv-transpose Toeplitz structure into 8 plain calls)
+//   rtfs_fold_gemm_bwd       d(LN4D output) of the dual-path layer-0 GEMM:  dxn[pos][c] = sum_kk dU0[pos-kk] . W0[kk*64+c]
+//   rtfs_convt_bwd_input     dH3[l][j] = sum_{k,c} dG[l+k][c] * Wct[j][c][k]   (adjoint of rtfs_dp_convt_fwd)
+//   (input gradients of the 1x1 convs are plain row GEMMs: rtfs_gemm_rows_fwd with the transposed weight)
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) with the ROW index as the contraction dimension: both operands sit in LDS
+// row-major as they are in HBM and are read with ds_read_b32 (lanes = consecutive columns, conflict-free).
+#include "common.h"
+
+namespace rtfs {
+
+// acc[a][b] += sum_k A[k][arow] * B[k][brow]; A, B stored [k][row] in LDS (row contiguous).  kdepth multiple of 8.
+template <int TA, int TB>
+__device__ __forceinline__ void mma_block_kk(floatx16 (&acc)[TA][TB], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const float* ap = As + (kh * 4) * lda + i;
+    const float* bp = Bs + (kh * 4) * ldb + i;
+#pragma unroll 2
+    for (int q = 0; q < kdepth; q += 8) {
+        float a[TA][4], b[TB][4];
+#pragma unroll
+        for (int m = 0; m < TA; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[m][r] = ap[(q + r) * lda + m * 32];
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b[n][r] = bp[(q + r) * ldb + n * 32];
+#pragma unroll
+        for (int m = 0; m < TA; ++m)
+#pragma unroll
+            for (int n = 0; n < TB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][r], b[n][r], acc[m][n], 0, 0, 0);
+    }
+}
+
+struct WgradArgs {
+    const float* dY;
+    int ldy;
+    const float* X;
+    int ldx;
+    float* dW;
+    int ldw;
+    long long M;       // rows of dY
+    int seg_len;       // rows per segment of dY
+    int x_seg;         // rows per segment of X
+    int x_off;         // X row inside the segment = l + x_off (invalid -> zero row)
+    int NOUT, KIN;     // multiples of 32
+    int rows_per_wg;
+    // prologue parameters
+    const float *p0, *p1;  // gateway: gw, gb;  relu(gLN): gamma, beta
+    float slope;
+    const double* slot;
+    double inv_n;
+    int rows_per_b;
+};
+
+// PRO: 0 plain, 1 gateway prelu(x*gw+gb), 2 prelu(x), 3 relu(gLN(x))
+template <int PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int LD = 132;
+    __shared__ __attribute__((aligned(16))) float Ys[32 * LD];
+    __shared__ __attribute__((aligned(16))) float Xs[32 * LD];
+    const int kblocks = (a.KIN + 127) / 128;
+    const int nb = blockIdx.y / kblocks, kb = blockIdx.y % kblocks;
+    const int n0 = nb * 128, k0 = kb * 128;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wn = w >> 1, wk = w & 1;
+    const long long r0 = (long long)blockIdx.x * a.rows_per_wg;
+    const long long r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
+
+    floatx16 acc[2][2];
+    acc_zero(acc);
+    const int srow = threadIdx.x >> 5, sc4 = (threadIdx.x & 31) * 4;  // 8 rows x 32 quads per pass, 4 passes
+    for (long long rb = r0; rb < r1; rb += 32) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int lr = srow + it * 8;
+            const long long r = rb + lr;
+            float4 y = f4(0, 0, 0, 0), x = f4(0, 0, 0, 0);
+            if (r < r1) {
+                if (n0 + sc4 < a.NOUT) y = ld4(a.dY + (size_t)r * a.ldy + n0 + sc4);
+                if (k0 + sc4 < a.KIN) {
+                    const long long seq = r / a.seg_len;
+                    const int xl = (int)(r - seq * a.seg_len) + a.x_off;
+                    if (xl >= 0 && xl < a.x_seg) {
+                        const int kc = k0 + sc4;
+                        x = ld4(a.X + (size_t)(seq * a.x_seg + xl) * a.ldx + kc);
+                        if (PRO == 1) x = prelu4(fma4(x, ld4(a.p0 + kc), ld4(a.p1 + kc)), a.slope);
+                        if (PRO == 2) x = prelu4(x, a.slope);
+                        if (PRO == 3) {
+                            float mean, rstd;
+                            stats_finalize(a.slot, (int)(r / a.rows_per_b), a.inv_n, mean, rstd);
+                            x = relu4(norm4(x, mean, rstd, ld4(a.p0 + kc), ld4(a.p1 + kc)));
+                        }
+                    }
+                }
+            }
+            st4(Ys + lr * LD + sc4, y);
+            st4(Xs + lr * LD + sc4, x);
+        }
+        __syncthreads();
+        mma_block_kk<2, 2>(acc, Ys + wn * 64, LD, Xs + wk * 64, LD, 32);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int nn = n0 + wn * 64 + m * 32, kk = k0 + wk * 64 + n * 32 + (lane & 31);
+            if (nn < a.NOUT && kk < a.KIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) atomicAdd(a.dW + (size_t)(nn + acc_row(r)) * a.ldw + kk, acc[m][n][r]);
+            }
+        }
+}
+
+// ---- Toeplitz input gradients ---------------------------------------------------------------------------------------------
+struct SeqMapB {
+    int seq_div;
+    long long stride_hi, stride_lo, pos_stride;
+    int npos, L;
+    __device__ __forceinline__ size_t base(int s) const { return (size_t)(s / seq_div) * stride_hi + (size_t)(s % seq_div) * stride_lo; }
+};
+
+// MODE 2 (conv-transpose input gradient): slab = dG rows m0..m0+70 of sequence s (G layout), K = 8*64, out dH[s][l][64]
+// MODE 3 (fold, unfold-GEMM input gradient): slab = zero-padded dU0 rows (m0-7)..(m0+63), width 256, K = 8*256,
+//         out dxn in G layout (plain store).
+// Weights Wt: [64][K] k-contiguous.  64-row tile, 4 waves as 2x2 of 32x32, weights first (lanes = positions).
+template <int MODE>
+__global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const float* __restrict__ src, const float* __restrict__ Wt, float* __restrict__ dst) {
+    constexpr int SW = MODE == 2 ? 64 : 256, LDSL = SW + 4, K = 8 * SW, BK = 64, LDB = BK + 4;
+    constexpr int ROWS = 71;
+    __shared__ __attribute__((aligned(16))) float slab[ROWS * LDSL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDB];
+    const int s = blockIdx.y, m0 = blockIdx.x * 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w >> 1, wn = w & 1;
+    const size_t sbase = map.base(s);
+    ChunkRegs<64, BK> breg;
+    breg.load(Wt, K, 0);
+    for (int idx = threadIdx.x; idx < ROWS * (SW / 4); idx += 256) {
+        const int row = idx / (SW / 4), c4 = (idx % (SW / 4)) * 4;
+        float4 v = f4(0, 0, 0, 0);
+        if (MODE == 2) {
+            const int pos = m0 + row;
+            if (pos < map.npos) v = ld4(src + sbase + (size_t)pos * map.pos_stride + c4);
+        } else {
+            const int l = m0 + row - 7;
+            if (l >= 0 && l < map.L) v = ld4(src + ((size_t)s * map.L + l) * 256 + c4);
+        }
+        st4(slab + row * LDSL + c4, v);
+    }
+    breg.store(Bs[0], LDB);
+    __syncthreads();
+    floatx16 acc[1][1];
+    acc_zero(acc);
+    constexpr int NK = K / BK;
+#pragma unroll 1
+    for (int kc = 0; kc < NK; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < NK) breg.load(Wt, K, (kc + 1) * BK);
+        const int k0 = kc * BK, kk = k0 / SW, c0 = k0 % SW;
+        mma_block<1, 1>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab + (wm * 32 + kk) * LDSL + c0, LDSL, BK);
+        if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
+        __syncthreads();
+    }
+    const int row = m0 + wm * 32 + (lane & 31);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = wn * 32 + 8 * g + 4 * (lane >> 5);
+        const float4 v = acc_group(acc[0][0], g);
+        if (MODE == 2) {
+            if (row < map.L) st4(dst + ((size_t)s * map.L + row) * 64 + col, v);
+        } else {
+            if (row < map.npos) st4(dst + sbase + (size_t)row * map.pos_stride + col, v);
+        }
+    }
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+static SeqMapB make_map(int dim, int T2) {
+    SeqMapB m;
+    if (dim == 4) {
+        m.seq_div = 1, m.stride_hi = (long long)kF2 * kH, m.stride_lo = 0, m.pos_stride = kH, m.npos = kF2;
+    } else {
+        m.seq_div = kF2, m.stride_hi = (long long)T2 * kF2 * kH, m.stride_lo = kH, m.pos_stride = (long long)kF2 * kH, m.npos = T2;
+    }
+    m.L = m.npos - 7;
+    return m;
+}
+
+extern "C" {
+
+// dW[n][k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r)][k];  r = seq*seg_len + l, xrow = seq*x_seg + l + x_off (zero if outside).
+// pro: 0 plain; 1 X' = prelu(X*p0+p1, slope) (gateway); 2 X' = prelu(X, slope); 3 X' = relu(gLN(X)) with stats slot / p0=gamma,p1=beta,
+// rows_per_b rows per utterance (inv_n = 1/(rows_per_b*KIN)).  NOUT, KIN multiples of 32.
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int NOUT, int KIN,
+               int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
+    if (M <= 0 || (NOUT & 31) || (KIN & 31) || pro < 0 || pro > 3) return RTFS_EINVAL;
+    WgradArgs a;
+    a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.M = M;
+    a.seg_len = seg_len > 0 ? seg_len : (int)M, a.x_seg = x_seg > 0 ? x_seg : (int)M, a.x_off = x_off;
+    a.NOUT = NOUT, a.KIN = KIN, a.rows_per_wg = 2048;
+    a.p0 = p0, a.p1 = p1, a.slope = slope, a.slot = stats, a.rows_per_b = rows_per_b > 0 ? rows_per_b : 1;
+    a.inv_n = 1.0 / ((double)a.rows_per_b * KIN);
+    dim3 grid((unsigned)((M + a.rows_per_wg - 1) / a.rows_per_wg), ((NOUT + 127) / 128) * ((KIN + 127) / 128));
+    hipStream_t st = (hipStream_t)stream;
+    switch (pro) {
+        case 0: hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, a); break;
+    }
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]
+int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int T2, int dim, void* stream) {
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+    SeqMapB m = make_map(dim, T2);
+    const int S = dim == 4 ? B * T2 : B * kF2;
+    hipLaunchKernelGGL(toeplitz_bwd_kernel<3>, dim3((m.npos + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
+int rtfs_convt_bwd_input(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+    SeqMapB m = make_map(dim, T2);
+    const int S = dim == 4 ? B * T2 : B * kF2;
+    hipLaunchKernelGGL(toeplitz_bwd_kernel<2>, dim3((m.L + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dG, Wt, dH3);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // extern "C"

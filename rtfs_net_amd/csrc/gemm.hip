@@ -90,13 +90,18 @@ struct ProExpanded {
 // ------------------------------------------------------------------------------------------------
 // Epilogues work on 16-byte vectors: the kernel multiplies WEIGHTS x PIXELS (see mma_block), so a lane owns one
 // pixel row and, per accumulator register group, 4 consecutive output channels `col..col+3`.
-template <bool HAS_BIAS>
-struct EpiBias {  // y = acc (+ bias)
+template <bool HAS_BIAS, bool ACCUM = false>
+struct EpiBias {  // y (= or +=) acc (+ bias)
     float* __restrict__ y;
     const float* __restrict__ bias;
     int N;
     __device__ float4 colconst(int col) const { return HAS_BIAS ? ld4(bias + col) : f4(0, 0, 0, 0); }
-    __device__ void store(int b, int Mb, int row, int col, float4 v, float4 cc) const { st4(y + ((size_t)b * Mb + row) * N + col, v + cc); }
+    __device__ void store(int b, int Mb, int row, int col, float4 v, float4 cc) const {
+        float* o = y + ((size_t)b * Mb + row) * N + col;
+        v = v + cc;
+        if (ACCUM) v = v + ld4(o);
+        st4(o, v);
+    }
 };
 
 // argument pack of proj_kernel: y = acc + bias, plus the gLN partial sums of y
@@ -122,10 +127,15 @@ struct EpiMask {
     float* __restrict__ y;
     const float* __restrict__ bias;
     const float* __restrict__ emb;
+    float* __restrict__ m_out;  // training: the post-ReLU mask itself (needed by the adjoint), or null
     __device__ void store2(int b, int Mb, int row, int col, float4 vr, float4 vi) const {
         const size_t o = ((size_t)b * Mb + row) * kC + col;
         const float4 er = ld4(emb + o), ei = ld4(emb + o + 128);
         const float4 mr = relu4(vr + ld4(bias + col)), mi = relu4(vi + ld4(bias + col + 128));
+        if (m_out) {
+            st4(m_out + o, mr);
+            st4(m_out + o + 128, mi);
+        }
         st4(y + o, f4(er.x * mr.x - ei.x * mi.x, er.y * mr.y - ei.y * mi.y, er.z * mr.z - ei.z * mi.z, er.w * mr.w - ei.w * mi.w));
         st4(y + o + 128, f4(fmaf(er.x, mi.x, ei.x * mr.x), fmaf(er.y, mi.y, ei.y * mr.y), fmaf(er.z, mi.z, ei.z * mr.z), fmaf(er.w, mi.w, ei.w * mr.w)));
     }
@@ -423,6 +433,17 @@ static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb
 
 using namespace rtfs;
 
+template <int K, int N, int BM, int WM, int WN>
+static int rows_gemm(const float* X, const float* Wt, const float* bias, float* Y, int M, int accumulate, hipStream_t st) {
+    ProPlain pro{X, K};
+    if (bias) {
+        if (accumulate) return launch<K, N, BM, WM, WN, false>(pro, EpiBias<true, true>{Y, bias, N}, Wt, 1, M, st);
+        return launch<K, N, BM, WM, WN, false>(pro, EpiBias<true, false>{Y, bias, N}, Wt, 1, M, st);
+    }
+    if (accumulate) return launch<K, N, BM, WM, WN, false>(pro, EpiBias<false, true>{Y, nullptr, N}, Wt, 1, M, st);
+    return launch<K, N, BM, WM, WN, false>(pro, EpiBias<false, false>{Y, nullptr, N}, Wt, 1, M, st);
+}
+
 extern "C" {
 
 // a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
@@ -467,26 +488,35 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
 }
 
 // masked = complex_mul(relu(Wm . prelu(x) + bias), a_emb)   all [B][TF][256]
-int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bias, const float* a_emb, float* masked, int B, int TF,
-                  void* stream) {
+int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
+                  int TF, void* stream) {
     ProPrelu pro{x, slope};
-    EpiMask epi{masked, bias, a_emb};
+    EpiMask epi{masked, bias, a_emb, m_or_null};
     return launch<256, 256, 64, 2, 2, true, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
 }
 
-// Y[M][N] = X[M][K] . Wt[N][K]^T (+ bias), row-major.  Supported (K,N): (64,192), (256,32).
-int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {
-    if (K == 64 && N == 192) {
-        ProPlain pro{X, 64};
-        if (bias_or_null) return launch<64, 192, 64, 1, 3, false>(pro, EpiBias<true>{Y, bias_or_null, 192}, Wt, 1, M, (hipStream_t)stream);
-        return launch<64, 192, 64, 1, 3, false>(pro, EpiBias<false>{Y, nullptr, 192}, Wt, 1, M, (hipStream_t)stream);
-    }
-    if (K == 256 && N == 32) {
-        ProPlain pro{X, 256};
-        if (bias_or_null) return launch<256, 32, 128, 1, 1, false>(pro, EpiBias<true>{Y, bias_or_null, 32}, Wt, 1, M, (hipStream_t)stream);
-        return launch<256, 32, 128, 1, 1, false>(pro, EpiBias<false>{Y, nullptr, 32}, Wt, 1, M, (hipStream_t)stream);
-    }
+// Y[M][N] (= or +=) X[M][K] . Wt[N][K]^T (+ bias), row-major.  Used for the SRU layer 1-3 projections, the decoder taps,
+// the attention projections in training mode and every input-gradient GEMM of the backward pass (Wt = transposed weight).
+int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+#define RG(KK, NN, BM, WM, WN) \
+    if (K == KK && N == NN) return rows_gemm<KK, NN, BM, WM, WN>(X, Wt, bias_or_null, Y, M, accumulate, st);
+    RG(64, 192, 64, 1, 3)
+    RG(256, 32, 128, 1, 1)
+    RG(192, 64, 128, 2, 1)
+    RG(256, 64, 128, 2, 1)
+    RG(64, 256, 64, 2, 2)
+    RG(32, 256, 64, 2, 2)
+    RG(256, 256, 64, 2, 2)
+    RG(64, 64, 128, 2, 1)
+    RG(64, 96, 128, 1, 3)
+    RG(96, 64, 128, 2, 1)
+#undef RG
     return RTFS_EINVAL;
+}
+
+int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {
+    return rtfs_gemm_rows(X, Wt, bias_or_null, Y, M, K, N, 0, stream);
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_void_p
 
 import torch
 
@@ -17,6 +17,7 @@ LIB_NAME = "librtfs_hip.so"
 P = c_void_p
 I = c_int
 F = c_float
+LL = c_longlong
 
 # name -> argtypes, in the order of include/rtfs_hip.h
 SIGNATURES = {
@@ -30,15 +31,45 @@ SIGNATURES = {
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
-    "rtfs_attn_qkv_fwd": [P] * 13 + [I, I, P],
-    "rtfs_attn_core_fwd": [P, P, P, P, I, I, P],
-    "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, I, I, P],
+    "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],
+    "rtfs_attn_core_fwd": [P, P, P, P, P, I, I, P],
+    "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, P, I, I, P],
     "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
     "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
     "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
     "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
-    "rtfs_mask_fwd": [P, F, P, P, P, P, I, I, P],
+    "rtfs_mask_fwd": [P, F, P, P, P, P, P, I, I, P],
     "rtfs_istft_fwd": [P, P, P, I, I, P],
+    # ---- backward (training step) ----
+    "rtfs_gemm_rows": [P, P, P, P, I, I, I, I, P],
+    "rtfs_colsum_add": [P, P, LL, I, P],
+    "rtfs_axpy": [P, F, P, LL, P],
+    "rtfs_gln_bwd_reduce": [P, P, P, P, P, I, F, P, P, P, P, I, I, I, P],
+    "rtfs_gln_bwd_apply": [P, P, P, P, P, I, F, P, P, I, I, I, I, P],
+    "rtfs_dwconv_bwd_input": [P, P, P, I, I, I, I, I, P],
+    "rtfs_dwconv_bwd_weight": [P, P, P, P, P, F, I, I, P, P, I, I, I, P],
+    "rtfs_pool_bwd": [P, P, I, I, I, P],
+    "rtfs_mix_bwd": [P] * 12 + [I, I, I, I, I, P],
+    "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],
+    "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, P, P, LL, P],
+    "rtfs_wgrad": [P, I, P, I, P, I, LL, I, I, I, I, I, I, P, P, F, P, I, P],
+    "rtfs_fold_gemm_bwd": [P, P, P, I, I, I, P],
+    "rtfs_convt_bwd_input": [P, P, P, I, I, I, P],
+    "rtfs_sru_scan_train_fwd": [P, P, P, P, F, P, P, I, I, I, P],
+    "rtfs_sru_scan_bwd": [P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
+    "rtfs_ln4d_c_bwd": [P, P, P, P, P, P, LL, P],
+    "rtfs_seq_gather": [P, P, P, I, P, I, I, I, P],
+    "rtfs_attn_out_norm_bwd": [P, P, F, P, P, P, P, P, I, P],
+    "rtfs_attn_qkv_norm_bwd": [P] * 16 + [I, I, P],
+    "rtfs_attn_core_bwd": [P] * 10 + [I, I, P],
+    "rtfs_transpose_tok": [P, P, I, P],
+    "rtfs_mask_bwd_elem": [P, P, P, P, P, LL, P],
+    "rtfs_prelu_bwd": [P, P, F, P, I, P, LL, P],
+    "rtfs_chan_stats": [P, P, P, LL, P],
+    "rtfs_caf_bwd_reduce": [P] * 11 + [I, I, I, P],
+    "rtfs_caf_bwd_apply": [P] * 8 + [I, I, I, I, P],
+    "rtfs_istft_bwd": [P, P, P, I, I, P],
+    "rtfs_spec_patches": [P, P, I, I, P],
 }
 
 _lib = None

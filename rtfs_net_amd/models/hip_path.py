@@ -194,10 +194,10 @@ class HipForward:
         Q = torch.empty(B * 4 * T2 * 256, device=dev)
         K = torch.empty_like(Q)
         V = torch.empty(B * 4 * T2 * 1024, device=dev)
-        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, B, T2)
+        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, None, B, T2)
         O = torch.empty(B * T2 * 4096, device=dev)
-        lib.call("rtfs_attn_core_fwd", Q, K, V, O, B, T2)
-        lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, B, T2)
+        lib.call("rtfs_attn_core_fwd", Q, K, V, O, None, B, T2)
+        lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, None, B, T2)
         if tap is not None:
             tap["attn"] = G.clone()
         # TFAR (a5.6)
@@ -286,7 +286,7 @@ class HipForward:
             s, x = x, s
         # a11: S3 mask; a12: decoder taps + iSTFT
         masked = x
-        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], a_emb, masked, B, TF)
+        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], a_emb, masked, None, B, TF)
         tapbuf = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_gemm_rows_fwd", masked, w["dec_w"], None, tapbuf, B * TF, 256, 32)
         frames = torch.empty(B * T * 256, device=dev)

@@ -118,3 +118,31 @@ def test_vp_block_matches_oracle_on_cpu():
         got = model.refinement_module.video_net.get_block(0)(emb)
         ref = tdanet_block(emb, P(sd, "refinement_module.video_net.blocks."), cfg["video_params"])
     assert float((got - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_ctypes_signatures_match_header():
+    """argument count and kind (pointer / int / float / long long) of every binding equals the C prototype"""
+    import ctypes
+
+    from rtfs_net_amd import lib
+
+    header = open(os.path.join(ROOT, "include", "rtfs_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = dict(re.findall(r"^int (rtfs_\w+)\(([^;]*?)\);", header, flags=re.M | re.S))
+    assert set(protos) == set(lib.SIGNATURES)
+    kind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_float: "F", ctypes.c_longlong: "L"}
+    for name, args in protos.items():
+        want = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if "*" in a:
+                want.append("P")
+            elif a.startswith("long long"):
+                want.append("L")
+            elif a.startswith("float"):
+                want.append("F")
+            elif a.startswith("int"):
+                want.append("I")
+            else:
+                raise AssertionError(f"{name}: cannot classify '{a}'")
+        got = [kind[t] for t in lib.SIGNATURES[name]]
+        assert got == want, (name, "".join(got), "".join(want))
