@@ -155,9 +155,38 @@ class AVNet(nn.Module):
             x = x.reshape(x.shape[0], -1)
         if mouth_embedding is None:
             raise ValueError("RTFS-Net needs the lip embedding tensor [B, 512, Tv]")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()) and self.training):
-            raise NotImplementedError("backward through the HIP path is not built yet: call under torch.no_grad() with model.eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(x, mouth_embedding)
+        if self.training:
+            raise NotImplementedError("training-mode forward without autograd is not supported: use torch.no_grad() with model.eval(), or enable grad")
         return self._hip(x, mouth_embedding)
+
+    # names of the parameters whose gradients come from the HIP backward chain (everything but the video-side glue)
+    def _hip_param_names(self):
+        skip = ("refinement_module.video_net.", ".attention_embed.", ".resize.")
+        return tuple(n for n, _ in self.named_parameters() if not any(s in n for s in skip))
+
+    def _forward_autograd(self, x, mouth_embedding):
+        """Training step: VP block + CAF video projections in torch autograd (glue); the audio branch is ONE
+        autograd.Function whose forward and backward are HIP kernel chains (models/hip_train.py)."""
+        from .hip_train import AVNetHipFunction, HipTrainer
+
+        if not x.is_cuda:
+            raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
+        if not self.refinement_module.audio_net.shared:
+            raise NotImplementedError("the HIP backward accumulates into ONE shared RTFS block (audio_params.shared: true)")
+        if getattr(self, "_trainer", None) is None:
+            self._trainer = HipTrainer(self)
+        rm = self.refinement_module
+        v1 = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding.to(torch.float32)))
+        cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm
+        B = v1.shape[0]
+        att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)  # layers/fusion.py:262-264
+        att = torch.softmax(att, -1).transpose(1, 2).contiguous()                                   # [B, Tv, 256]
+        rsz = cell.resize(v1).transpose(1, 2).contiguous()
+        names = self._hip_param_names()
+        params = dict(self.named_parameters())
+        return AVNetHipFunction.apply(self._trainer, names, x.to(torch.float32), att, rsz, *[params[n] for n in names])
 
     # ---- BaseAVModel API (TDAVNet/base_av_model.py) ---------------------------------------------
     @staticmethod

@@ -1,0 +1,588 @@
+"""Training step of the HIP separation path: forward with saved activations + hand-written backward chain.
+
+The reference trains through torch autograd over its forward modules (train.py:148, src/system/core.py:94-117) and
+sru's CUDA backward kernel.  Here the audio branch is ONE `torch.autograd.Function` (`AVNetHipFunction`) whose forward
+and backward are sequences of include/rtfs_hip.h entry points; PyTorch autograd only sees its inputs (waveform,
+the CAF video-side tables `att`/`rsz`, the audio-branch parameters) and output, and differentiates the small
+video-side glue (VP block, CAF video projections) itself.
+
+Activations are saved, not recomputed (B=32, R=6 needs ~40 GB of the 288 GB).  Parameter gradients are accumulated in
+kernel layout and mapped back to the reference parameter shapes at the end (`_grads_to_reference`).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import lib
+from .hip_path import C, F2, F_BINS, H, PreparedWeights, _f32
+
+
+def _t(x):
+    return x.t().contiguous()
+
+
+class TrainWeights(PreparedWeights):
+    """PreparedWeights + the transposed / re-ordered copies the input-gradient GEMMs need."""
+
+    def __init__(self, model):
+        super().__init__(model)
+        w = self.w
+        w["bn_wT"], w["mask_wT"], w["dec_wT"] = _t(w["bn_w"]), _t(w["mask_w"]), _t(w["dec_w"])
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        p0 = "refinement_module.audio_net.blocks."
+        shared = model.refinement_module.audio_net.shared
+        for i, b in enumerate(self.blocks):
+            p = p0 if shared else f"{p0}{i}."
+            b["rwT"], b["pwT"] = _t(b["rw"]), _t(b["pw"])
+            for j in (0, 1):
+                d = b[f"dp{j}"]
+                d["fold_w"] = _f32(d["w0"].view(256, 8, 64).flip(1).permute(2, 1, 0).reshape(64, 2048))
+                d["ctbi_w"] = _f32(sd[f"{p}globalatt.{j}.linear.weight"].float().permute(0, 2, 1).reshape(64, 512))
+                for lw in d["layers"][1:]:
+                    lw["wT"] = _t(lw["w"])
+            a = b["attn"]
+            a["wT"], a["owT"] = _t(a["w"]), _t(a["ow"])
+        # raw CAF depth-wise weights and BatchNorm parameters (training mode uses batch statistics)
+        caf = "refinement_module.crossmodal_fusion.fusion_module." + ("" if model.refinement_module.crossmodal_fusion.fusion_shared else "0.") + "audio_lstm."
+        self.caf_prefix = caf
+        for tag in ("key", "value"):
+            q = f"{caf}{tag}_embed.full_layer."
+            w[f"caf_{tag}_dw"] = _f32(sd[q + "2.weight"].reshape(C))
+            w[f"caf_{tag}_g"], w[f"caf_{tag}_be"] = _f32(sd[q + "3.weight"]), _f32(sd[q + "3.bias"])
+
+
+class Ctx:
+    """bag of saved tensors"""
+
+
+def _zeros(n, dev, dtype=torch.float32):
+    return torch.zeros(n, device=dev, dtype=dtype)
+
+
+class HipTrainer:
+    def __init__(self, model):
+        self.model = model
+        self._prep = None
+
+    def weights(self) -> TrainWeights:
+        fp = PreparedWeights.fingerprint(self.model)
+        if self._prep is None or self._prep.version != fp:
+            self._prep = TrainWeights(self.model)
+        return self._prep
+
+    # ================================================= forward =================================================
+    def _dual_path_fwd(self, G, d, B, T2, dim, save):
+        S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
+        L = npos - 7
+        dev = G.device
+        save.G_in = G.clone()
+        save.U, save.h, save.c = [], [], []
+        U0 = torch.empty(S * L * 256, device=dev)
+        lib.call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim)
+        h = torch.empty(S * L * 64, device=dev)
+        c = torch.empty_like(h)
+        l0 = d["layers"][0]
+        lib.call("rtfs_sru_scan_train_fwd", U0, None, l0["wc"], l0["bias"], l0["scale_x"], h, c, S, L, 4)
+        save.U.append(U0), save.h.append(h), save.c.append(c)
+        for lw in d["layers"][1:]:
+            U = torch.empty(S * L * 192, device=dev)
+            lib.call("rtfs_gemm_rows", h, lw["w"], None, U, S * L, 64, 192, 0)
+            h2, c2 = torch.empty_like(h), torch.empty_like(h)
+            lib.call("rtfs_sru_scan_train_fwd", U, h, lw["wc"], lw["bias"], lw["scale_x"], h2, c2, S, L, 3)
+            save.U.append(U), save.h.append(h2), save.c.append(c2)
+            h = h2
+        lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
+
+    def _block_fwd(self, s_in, out, a0_or_none, bw, st, B, T, T2):
+        dev = s_in.device
+        TF = T * F_BINS
+        full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
+        low = lambda: torch.empty(B * T2 * F2 * H, device=dev)  # noqa: E731
+        k = Ctx()
+        k.s_in, k.st, k.has_a0 = s_in, st, a0_or_none is not None
+        k.y0 = full()
+        lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], k.y0, st[0], B, TF)
+        d0w, d0b, d0g, d0be = bw["d0"]
+        d1w, d1b, d1g, d1be = bw["d1"]
+        k.D0, k.D1 = full(), low()
+        lib.call("rtfs_dwconv_fwd", k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [k.D0], [st[1]], B, T, F_BINS)
+        lib.call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [k.D1], [st[2]], B, T, F_BINS)
+        G = low()
+        lib.call("rtfs_pool_fwd", k.D0, st[1], d0g, d0be, k.D1, st[2], d1g, d1be, G, B, T, T2)
+        k.dp = [Ctx(), Ctx()]
+        self._dual_path_fwd(G, bw["dp0"], B, T2, 4, k.dp[0])
+        self._dual_path_fwd(G, bw["dp1"], B, T2, 3, k.dp[1])
+        a = bw["attn"]
+        k.G2 = G.clone()
+        k.Q = torch.empty(B * 4 * T2 * 256, device=dev)
+        k.K = torch.empty_like(k.Q)
+        k.V = torch.empty(B * 4 * T2 * 1024, device=dev)
+        k.Ypre96 = torch.empty(B * T2 * 64 * 96, device=dev)
+        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], k.Q, k.K, k.V, k.Ypre96, B, T2)
+        k.O = torch.empty(B * T2 * 4096, device=dev)
+        k.LSE = torch.empty(B * 4 * T2, device=dev)
+        lib.call("rtfs_attn_core_fwd", k.Q, k.K, k.V, k.O, k.LSE, B, T2)
+        k.Ypre_o = torch.empty(B * T2 * 4096, device=dev)
+        lib.call("rtfs_attn_out_fwd", k.O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, k.Ypre_o, B, T2)
+        k.G3 = G
+        f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
+        f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
+        cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
+        k.l0, k.l1 = full(), low()
+        lib.call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [k.l0], [st[3]], B, T, F_BINS)
+        lib.call("rtfs_dwconv_fwd", k.D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [k.l1], [st[4]], B, T2, F2)
+        k.g0, k.gg0, k.g1, k.gg1 = low(), low(), low(), low()
+        lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [k.g0, k.gg0, k.g1, k.gg1],
+                 [st[5], st[6], st[7], st[8]], B, T2, F2)
+        k.F0, k.F1 = full(), low()
+        lib.call("rtfs_tfar_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], k.F0, B, T, F_BINS, T2, F2)
+        lib.call("rtfs_tfar_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], k.F1, B, T2, F2, T2, F2)
+        k.cl, k.cg, k.cgate = full(), low(), low()
+        lib.call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
+        lib.call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
+        lib.call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
+                 cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+        return k
+
+    def forward(self, wav, att, rsz):
+        """wav [B,L]; att, rsz [B,Tv,256] (video side of the CAF cell, torch glue).  Returns (out [B,1,L], ctx)."""
+        m = self.model
+        pw = self.weights()
+        w = pw.w
+        wav = wav.to(torch.float32).contiguous()
+        B, L = wav.shape
+        T = 1 + L // 128
+        T2 = (T - 2) // 2 + 1
+        if T2 < 8:
+            raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
+        TF = T * F_BINS
+        dev = wav.device
+        R = m.refinement_module.audio_net.repeats
+        c = Ctx()
+        c.B, c.L, c.T, c.T2, c.R, c.Tv = B, L, T, T2, R, att.shape[1]
+        c.stats = torch.zeros(1 + 12 * R, B, 2, dtype=torch.float64, device=dev)
+        stats = c.stats
+        c.spec = torch.empty(B * TF * 2, device=dev)
+        lib.call("rtfs_stft_fwd", wav, c.spec, B, L)
+        c.a_emb = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_enc_conv_fwd", c.spec, w["enc"], c.a_emb, stats[0], B, T)
+        c.a0 = torch.empty_like(c.a_emb)
+        lib.call("rtfs_bottleneck_fwd", c.a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], c.a0, B, TF)
+        blocks = pw.blocks
+        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        c.blk = []
+        x = torch.empty_like(c.a_emb)
+        c.blk.append(self._block_fwd(c.a0, x, None, bw(0), stats[1:13], B, T, T2))
+        c.x0 = x
+        # CAF with training-mode BatchNorm2d (batch statistics over B,T,F of the depth-wise conv output)
+        c.att, c.rsz = att.contiguous(), rsz.contiguous()
+        c.caf = self._caf_coeffs(x, w, B * TF, m.training)
+        s = torch.empty_like(c.a_emb)
+        last = R == 1
+        lib.call("rtfs_caf_fuse_fwd", x, c.caf["ks"], c.caf["kb"], c.caf["vs"], c.caf["vb"], c.att, c.rsz, None if last else c.a0, s, B, T, c.Tv)
+        for i in range(1, R):
+            last = i == R - 1
+            nxt = torch.empty_like(c.a_emb)
+            c.blk.append(self._block_fwd(s, nxt, None if last else c.a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2))
+            s = nxt
+        c.refined = s
+        c.masked = torch.empty_like(c.a_emb)
+        c.m = torch.empty_like(c.a_emb)
+        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], c.a_emb, c.masked, c.m, B, TF)
+        tapbuf = torch.empty(B * TF * 32, device=dev)
+        lib.call("rtfs_gemm_rows", c.masked, w["dec_w"], None, tapbuf, B * TF, 256, 32, 0)
+        frames = torch.empty(B * T * 256, device=dev)
+        out = torch.empty(B, L, device=dev)
+        lib.call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
+        return out.view(B, 1, L), c
+
+    def _caf_coeffs(self, x, w, rows, training):
+        """folded (scale, shift) of key/value BatchNorm2d; training: batch statistics (+ running-stat update)."""
+        m = self.model
+        cell = m.refinement_module.crossmodal_fusion.get_fusion_block(0).audio_lstm
+        out = {"training": training}
+        if training:
+            sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
+            lib.call("rtfs_chan_stats", x, sums[0], sums[1], rows)
+            n = float(rows)
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and getattr(m, "sync_batchnorm", False):
+                cnt = torch.tensor([n], dtype=torch.float64, device=x.device)
+                torch.distributed.all_reduce(sums)
+                torch.distributed.all_reduce(cnt)
+                n = float(cnt.item())
+            mean_x = sums[0] / n
+            var_x = (sums[1] / n - mean_x * mean_x).clamp_min(0)
+            out["mean_x"], out["var_x"], out["n"] = mean_x.float(), var_x.float(), n
+        for tag, mod in (("key", cell.key_embed), ("value", cell.value_embed)):
+            dw, g, be = w[f"caf_{tag}_dw"], w[f"caf_{tag}_g"], w[f"caf_{tag}_be"]
+            bn = mod.full_layer[3]
+            if training:
+                mean_u, var_u = dw * out["mean_x"], dw * dw * out["var_x"]
+                with torch.no_grad():
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1 - mom).add_(mom * mean_u)
+                    bn.running_var.mul_(1 - mom).add_(mom * var_u * out["n"] / max(out["n"] - 1, 1))
+                    bn.num_batches_tracked += 1
+            else:
+                mean_u, var_u = bn.running_mean.float(), bn.running_var.float()
+            inv = torch.rsqrt(var_u + bn.eps)
+            out[tag + "_inv"], out[tag + "_mean_u"] = inv, mean_u
+            s = dw * g * inv
+            out["ks" if tag == "key" else "vs"] = s.contiguous()
+            out["kb" if tag == "key" else "vb"] = (be - mean_u * g * inv).contiguous()
+        return out
+
+    # ================================================= backward ================================================
+    def _gln_bwd(self, dN, X, st, gamma, beta, dX, accumulate, gr, key, B, rows, Cc=H, act=0, slope=0.0, dslope=None):
+        """dN: gradient w.r.t. (act of) the normalised tensor; X: pre-norm; result dX (= or +=); gamma/beta grads into gr[key]."""
+        dev = dN.device
+        red = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        dg, db = gr.setdefault(key + ".g", _zeros(Cc, dev)), gr.setdefault(key + ".b", _zeros(Cc, dev))
+        lib.call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
+        lib.call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
+
+    def _dw_bwd(self, dOut, conv, inp, in_st, in_g, in_b, in_slope, mode, stride, dIn, accumulate, gr, key, B, Tin, Fin, has_bias):
+        """depth-wise conv adjoint: input gradient (w.r.t. the transformed input) and tap/bias gradients."""
+        dev = dOut.device
+        dW = gr.setdefault(key + ".w", _zeros(16 * 64, dev))
+        dbias = gr.setdefault(key + ".bias", _zeros(64, dev)) if has_bias else None
+        lib.call("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
+        if dIn is not None:
+            lib.call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
+
+    def _dual_path_bwd(self, dG, d, sv, B, T2, dim, gr, key):
+        """dG: gradient w.r.t. the stage output (G layout), updated IN PLACE to the gradient w.r.t. the stage input."""
+        S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
+        L = npos - 7
+        dev = dG.device
+        g = lambda name, n: gr.setdefault(f"{key}.{name}", _zeros(n, dev))  # noqa: E731
+        # ConvTranspose1d + bias + residual
+        dG_seq = torch.empty(S * npos * 64, device=dev)
+        lib.call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
+        lib.call("rtfs_colsum_add", dG_seq, g("ct_b", 64), S * npos, 64)
+        dct = g("ct_w", 64 * 512)
+        for kp in range(8):
+            lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct[kp * 64:], 512, S * npos, npos, L, kp - 7, 64, 64, 0, None, None, 0.0, None, 0)
+        dh = torch.empty(S * L * 64, device=dev)
+        lib.call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
+        # SRU layers 3..1
+        for l in (3, 2, 1):
+            lw = d["layers"][l]
+            dU = torch.empty(S * L * 192, device=dev)
+            dx = torch.empty(S * L * 64, device=dev)
+            lib.call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
+                     S, L, 3)
+            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, S * L, 0, 0, 0, 192, 64, 0, None, None, 0.0, None, 0)
+            lib.call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
+            dh = dx
+        l0 = d["layers"][0]
+        dU0 = torch.empty(S * L * 256, device=dev)
+        lib.call("rtfs_sru_scan_bwd", sv.U[0], None, sv.c[0], l0["wc"], l0["bias"], l0["scale_x"], dh, dU0, None, g("l0.wc", 128), g("l0.bias", 128), S, L, 4)
+        # layer-0 GEMM: weight gradient over the Toeplitz windows, input gradient by folding
+        xn_seq = torch.empty(S * npos * 64, device=dev)
+        lib.call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
+        dw0 = g("w0", 256 * 512)
+        for kk in range(8):
+            lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0[kk * 64:], 512, S * L, L, npos, kk, 256, 64, 0, None, None, 0.0, None, 0)
+        dxn = torch.empty(B * T2 * F2 * 64, device=dev)
+        lib.call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
+        lib.call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
+
+    def _attn_bwd(self, dG, a, k, B, T2, gr, key):
+        """dG: gradient w.r.t. the attention output, updated in place to the gradient w.r.t. its input."""
+        dev = dG.device
+        g = lambda name, n: gr.setdefault(f"{key}.{name}", _zeros(n, dev))  # noqa: E731
+        ntok = B * T2
+        rows = ntok * 64
+        dYo = torch.empty(rows * 64, device=dev)
+        lib.call("rtfs_attn_out_norm_bwd", dG, k.Ypre_o, a["oslope"], a["og"], dYo, g("og", 4096), g("obe", 4096), g("oslope", 1), ntok)
+        lib.call("rtfs_colsum_add", dYo, g("ob", 64), rows, 64)
+        Ocl = torch.empty(rows * 64, device=dev)
+        lib.call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
+        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, rows, 0, 0, 0, 64, 64, 0, None, None, 0.0, None, 0)
+        dOcl = torch.empty(rows * 64, device=dev)
+        lib.call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
+        dO = torch.empty(rows * 64, device=dev)
+        lib.call("rtfs_transpose_tok", dOcl, dO, ntok)  # back to the O layout [c][f]
+        dQ, dK, dV = torch.empty_like(k.Q), torch.empty_like(k.K), torch.empty_like(k.V)
+        Dws = torch.empty(B * 4 * T2, device=dev)
+        lib.call("rtfs_attn_core_bwd", k.Q, k.K, k.V, k.O, dO, k.LSE, Dws, dQ, dK, dV, B, T2)
+        dY96 = torch.empty(rows * 96, device=dev)
+        lib.call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
+                 g("bk", 1024), g("gv", 4096), g("bv", 4096), g("slope", 12), B, T2)
+        lib.call("rtfs_colsum_add", dY96, g("bias", 96), rows, 96)
+        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, rows, 0, 0, 0, 96, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
+
+    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0):
+        """dx: gradient w.r.t. the block output [B,TF,256].  Returns ds (gradient w.r.t. the block input).
+        (No buffer re-use: every intermediate gradient gets its own allocation; correctness first.)"""
+        dev = dx.device
+        TF, lo = T * F_BINS, T2 * F2
+        st = k.st
+        full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
+        low = lambda: torch.empty(B * lo * H, device=dev)  # noqa: E731
+        g = lambda name, n: gr.setdefault(f"blk.{name}", _zeros(n, dev))  # noqa: E731
+        d0w, d0b, d0g, d0be = bw["d0"]
+        d1w, d1b, d1g, d1be = bw["d1"]
+        f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
+        f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
+        cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
+        if k.has_a0:
+            lib.call("rtfs_axpy", dx, 1.0, da0, B * TF * C)
+        # residual_conv: bias, weight (needs `expanded`), input gradient
+        lib.call("rtfs_colsum_add", dx, g("rb", C), B * TF, C)
+        E = full()
+        lib.call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
+        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, B * TF, 0, 0, 0, C, H, 0, None, None, 0.0, None, 0)
+        dE = full()
+        lib.call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
+        # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as a copy of dE
+        dN_cl, dN_cgate, dN_cg = full(), low(), low()
+        lib.call("rtfs_mix_bwd", dE, k.cl, st[9], cl_[2], cl_[3], k.cgate, st[11], cgate_[2], cgate_[3], dN_cl, dN_cgate, dN_cg, B, T, F_BINS, T2, F2)
+        dN_D0 = dE.clone()
+        # concat layer: gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
+        dcl, dcg, dcgate = full(), low(), low()
+        self._gln_bwd(dN_cl, k.cl, st[9], cl_[2], cl_[3], dcl, False, gr, "blk.cl", B, TF)
+        self._gln_bwd(dN_cg, k.cg, st[10], cg_[2], cg_[3], dcg, False, gr, "blk.cg", B, lo)
+        self._gln_bwd(dN_cgate, k.cgate, st[11], cgate_[2], cgate_[3], dcgate, False, gr, "blk.cgate", B, lo)
+        dF0, dF1 = full(), low()
+        self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, "blk.cl", B, T, F_BINS, False)
+        self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, "blk.cg", B, T2, F2, False)
+        self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, "blk.cgate", B, T2, F2, False)
+        # fusion layers' mixes
+        dN_l0, dN_gg0, dN_g0 = full(), low(), low()
+        lib.call("rtfs_mix_bwd", dF0, k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], dN_l0, dN_gg0, dN_g0, B, T, F_BINS, T2, F2)
+        dN_l1, dN_gg1, dN_g1 = low(), low(), low()
+        lib.call("rtfs_mix_bwd", dF1, k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], dN_l1, dN_gg1, dN_g1, B, T2, F2, T2, F2)
+        dl0, dl1 = full(), low()
+        self._gln_bwd(dN_l0, k.l0, st[3], f0l[2], f0l[3], dl0, False, gr, "blk.f0l", B, TF)
+        self._gln_bwd(dN_l1, k.l1, st[4], f1l[2], f1l[3], dl1, False, gr, "blk.f1l", B, lo)
+        dgs = [low() for _ in range(4)]
+        for dN, X, sidx, conv, nm, dst in ((dN_g0, k.g0, 5, f0g, "f0g", dgs[0]), (dN_gg0, k.gg0, 6, f0gate, "f0gate", dgs[1]),
+                                           (dN_g1, k.g1, 7, f1g, "f1g", dgs[2]), (dN_gg1, k.gg1, 8, f1gate, "f1gate", dgs[3])):
+            self._gln_bwd(dN, X, st[sidx], conv[2], conv[3], dst, False, gr, "blk." + nm, B, lo)
+        # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
+        dN_D1 = low()
+        self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, "blk.f0l", B, T, F_BINS, False)
+        self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, "blk.f1l", B, T2, F2, False)
+        dG = low()  # gradient w.r.t. G3 (attention output)
+        for j, (conv, nm) in enumerate(((f0g, "f0g"), (f0gate, "f0gate"), (f1g, "f1g"), (f1gate, "f1gate"))):
+            self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, "blk." + nm, B, T2, F2, False)
+        # attention, dual paths (each updates dG in place to the gradient w.r.t. its input)
+        self._attn_bwd(dG, bw["attn"], k, B, T2, gr, "blk.attn")
+        self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, "blk.dp1")
+        self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, "blk.dp0")
+        # pooled = avgpool(D0n) + D1n
+        lib.call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
+        lib.call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
+        # downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
+        dD1 = low()
+        self._gln_bwd(dN_D1, k.D1, st[2], d1g, d1be, dD1, False, gr, "blk.d1", B, lo)
+        self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, "blk.d1", B, T, F_BINS, True)
+        dD0 = full()
+        self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, "blk.d0", B, TF)
+        dP = full()
+        self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, "blk.d0", B, T, F_BINS, True)
+        # projection: PReLU + gLN adjoint, then the 1x1 conv
+        dy0 = full()
+        self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
+        lib.call("rtfs_colsum_add", dy0, g("pb", H), B * TF, H)
+        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, B * TF, 0, 0, 0, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
+        dGate = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_gemm_rows", dy0, bw["pwT"], None, dGate, B * TF, H, C, 0)
+        lib.call("rtfs_axpy", dx, 1.0, dGate, B * TF * C)  # + the gateway residual path
+        ds = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_gateway_bwd", dGate, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, g("gw", C), g("gb", C), g("gslope", 1), B * TF)
+        return ds
+
+    def backward(self, c, dout):
+        """dout [B,1,L] -> (datt, drsz, grads dict in kernel layout)."""
+        m = self.model
+        pw = self.weights()
+        w = pw.w
+        B, L, T, T2, R, Tv = c.B, c.L, c.T, c.T2, c.R, c.Tv
+        TF = T * F_BINS
+        dev = dout.device
+        gr = {}
+        g = lambda name, n: gr.setdefault(name, _zeros(n, dev))  # noqa: E731
+        dout = dout.reshape(B, L).to(torch.float32).contiguous()
+        # iSTFT + decoder taps
+        dspec = torch.empty(B * TF * 2, device=dev)
+        dtaps = torch.empty(B * TF * 32, device=dev)
+        lib.call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
+        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, B * TF, 0, 0, 0, 32, C, 0, None, None, 0.0, None, 0)
+        dmasked = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
+        # S3 mask
+        da_emb = _zeros(B * TF * C, dev)
+        dz = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
+        lib.call("rtfs_colsum_add", dz, g("mask_b", C), B * TF, C)
+        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, B * TF, 0, 0, 0, C, C, 2, None, None, w["mask_slope"], None, 0)
+        dpre = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
+        dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
+        lib.call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
+        # RTFS blocks R-1 .. 1, CAF, block 0
+        da0 = _zeros(B * TF * C, dev)
+        blocks = pw.blocks
+        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        for i in range(R - 1, 0, -1):
+            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0)
+            # block input was (previous output + a0): the a0 part is added by the producer's has_a0 / CAF branch
+        # CAF: out = key*rsz^ + att^*val (+ a0)
+        if R > 1:
+            lib.call("rtfs_axpy", dx, 1.0, da0, B * TF * C)
+        datt, drsz = _zeros(B * Tv * C, dev), _zeros(B * Tv * C, dev)
+        Rr = _zeros(4 * C, dev)
+        cf = c.caf
+        lib.call("rtfs_caf_bwd_reduce", dx, c.x0, cf["ks"], cf["kb"], cf["vs"], cf["vb"], c.att, c.rsz, datt, drsz, Rr, B, T, Tv)
+        coef = self._caf_bwd_coeffs(cf, w, Rr.view(4, C), gr, m)
+        dx0 = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
+        ds0 = self._block_bwd(dx0, c.blk[0], bw(0), B, T, T2, gr, da0)
+        lib.call("rtfs_axpy", ds0, 1.0, da0, B * TF * C)  # block 0's input is a0 itself
+        # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
+        lib.call("rtfs_colsum_add", da0, g("bn_bias", C), B * TF, C)
+        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, B * TF, 0, 0, 0, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
+        dR = torch.empty(B * TF * C, device=dev)
+        lib.call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
+        self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
+        # encoder conv weight
+        patches = torch.empty(B * TF * 32, device=dev)
+        lib.call("rtfs_spec_patches", c.spec, patches, B, T)
+        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, B * TF, 0, 0, 0, C, 32, 0, None, None, 0.0, None, 0)
+        return datt.view(B, Tv, C), drsz.view(B, Tv, C), gr
+
+    def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
+        """BatchNorm adjoint of the CAF key/value embeddings -> per-channel coefficients for rtfs_caf_bwd_apply + parameter grads."""
+        dev = Rr.device
+        coef = torch.zeros(6, C, device=dev)
+        for j, tag in enumerate(("key", "value")):
+            dw, gm = w[f"caf_{tag}_dw"], w[f"caf_{tag}_g"]
+            inv = cf[tag + "_inv"]
+            A, Bx = Rr[2 * j], Rr[2 * j + 1]
+            if cf["training"]:
+                n, mean_x, var_x = cf["n"], cf["mean_x"], cf["var_x"]
+                if torch.distributed.is_available() and torch.distributed.is_initialized() and getattr(m, "sync_batchnorm", False):
+                    AB = torch.stack([A, Bx])
+                    torch.distributed.all_reduce(AB)
+                    A, Bx = AB[0], AB[1]
+                Q = dw * inv * (Bx - mean_x * A)                      # sum dk * uhat
+                c1 = dw * gm * inv
+                c3 = -c1 * (Q / n) * (dw * inv)
+                c2 = -c1 * A / n - c3 * mean_x
+                gr[f"caf_{tag}_dw"] = gm * inv * (Bx - A * mean_x - Q * dw * inv * var_x)
+            else:
+                mean_u = cf[tag + "_mean_u"]
+                Q = inv * (dw * Bx - mean_u * A)
+                c1, c2, c3 = dw * gm * inv, torch.zeros_like(A), torch.zeros_like(A)
+                gr[f"caf_{tag}_dw"] = gm * inv * Bx
+            gr[f"caf_{tag}_g"], gr[f"caf_{tag}_be"] = Q, A.clone()
+            coef[3 * j], coef[3 * j + 1], coef[3 * j + 2] = c1, c2, c3
+        return coef.contiguous()
+
+
+# ============================================ reference-layout mapping ============================================
+def grads_to_reference(model, pw: TrainWeights, gr: dict) -> dict:
+    """kernel-layout gradient buffers -> {reference parameter name: gradient tensor of the parameter's shape}"""
+    out = {}
+    z = lambda name, n: gr.get(name)  # noqa: E731
+
+    def put(name, t, shape):
+        if t is not None:
+            out[name] = t.reshape(shape).contiguous()
+
+    put("encoder.conv.full_layer.2.weight", gr["enc"].view(C, 32)[:, :18], (C, 2, 3, 3))
+    put("audio_bottleneck.full_layer.0.norm.weight", gr["bn.g"], (C,))
+    put("audio_bottleneck.full_layer.0.norm.bias", gr["bn.b"], (C,))
+    put("audio_bottleneck.full_layer.2.weight", gr["bn_w"], (C, C, 1, 1))
+    put("audio_bottleneck.full_layer.2.bias", gr["bn_bias"], (C,))
+    p = "refinement_module.audio_net.blocks."
+    b = "blk."
+    put(p + "gateway.full_layer.2.weight", gr[b + "gw"], (C, 1, 1, 1))
+    put(p + "gateway.full_layer.2.bias", gr[b + "gb"], (C,))
+    put(p + "gateway.full_layer.4.weight", gr[b + "gslope"], (1,))
+    put(p + "projection.full_layer.2.weight", gr[b + "pw"], (H, C, 1, 1))
+    put(p + "projection.full_layer.2.bias", gr[b + "pb"], (H,))
+    put(p + "projection.full_layer.3.norm.weight", gr[b + "p.g"], (H,))
+    put(p + "projection.full_layer.3.norm.bias", gr[b + "p.b"], (H,))
+    put(p + "projection.full_layer.4.weight", gr[b + "pslope"], (1,))
+
+    def dw(prefix, key, bias):
+        put(prefix + "full_layer.2.weight", gr[key + ".w"].view(16, 64).t(), (64, 1, 4, 4))
+        if bias:
+            put(prefix + "full_layer.2.bias", gr[key + ".bias"], (64,))
+        put(prefix + "full_layer.3.norm.weight", gr[key + ".g"], (64,))
+        put(prefix + "full_layer.3.norm.bias", gr[key + ".b"], (64,))
+
+    dw(p + "downsample_layers.0.", b + "d0", True)
+    dw(p + "downsample_layers.1.", b + "d1", True)
+    for name, key in (("fusion_layers.0.local_embedding", "f0l"), ("fusion_layers.0.global_embedding", "f0g"), ("fusion_layers.0.global_gate", "f0gate"),
+                      ("fusion_layers.1.local_embedding", "f1l"), ("fusion_layers.1.global_embedding", "f1g"), ("fusion_layers.1.global_gate", "f1gate"),
+                      ("concat_layers.0.local_embedding", "cl"), ("concat_layers.0.global_embedding", "cg"), ("concat_layers.0.global_gate", "cgate")):
+        dw(f"{p}{name}.", b + key, False)
+    put(p + "residual_conv.full_layer.2.weight", gr[b + "rw"], (C, H, 1, 1))
+    put(p + "residual_conv.full_layer.2.bias", gr[b + "rb"], (C,))
+    for j in (0, 1):
+        q, k = f"{p}globalatt.{j}.", f"{b}dp{j}."
+        put(q + "norm.gamma", gr[k + "g"], (1, 64, 1, 1))
+        put(q + "norm.beta", gr[k + "b"], (1, 64, 1, 1))
+        put(q + "rnn.rnn_lst.0.weight", gr[k + "w0"].view(256, 8, 64).permute(2, 1, 0), (512, 256))
+        for l in range(4):
+            put(q + f"rnn.rnn_lst.{l}.weight_c", gr[k + f"l{l}.wc"], (128,))
+            put(q + f"rnn.rnn_lst.{l}.bias", gr[k + f"l{l}.bias"], (128,))
+            if l > 0:
+                put(q + f"rnn.rnn_lst.{l}.weight", gr[k + f"l{l}.w"].view(3, 64, 64).permute(2, 1, 0), (64, 192))
+        put(q + "linear.weight", gr[k + "ct_w"].view(64, 8, 64).permute(2, 0, 1).flip(2), (64, 64, 8))
+        put(q + "linear.bias", gr[k + "ct_b"], (64,))
+    q, k = p + "globalatt.2.", b + "attn."
+    wq = gr[k + "w"].view(96, 64)
+    bq = gr[k + "bias"]
+    sl = gr[k + "slope"]
+    off = 0
+    for mi, (name, nch, gk, bk) in enumerate((("Queries", 4, "gq", "bq"), ("Keys", 4, "gk", "bk"), ("Values", 16, "gv", "bv"))):
+        for h in range(4):
+            put(f"{q}{name}.{h}.conv.weight", wq[off:off + nch], (nch, 64, 1, 1))
+            put(f"{q}{name}.{h}.conv.bias", bq[off:off + nch], (nch,))
+            put(f"{q}{name}.{h}.act.weight", sl[mi * 4 + h:mi * 4 + h + 1], (1,))
+            put(f"{q}{name}.{h}.norm.gamma", gr[k + gk].view(4, -1)[h], (1, nch, 1, 64))
+            put(f"{q}{name}.{h}.norm.beta", gr[k + bk].view(4, -1)[h], (1, nch, 1, 64))
+            off += nch
+    put(q + "attn_concat_proj.conv.weight", gr[k + "ow"], (64, 64, 1, 1))
+    put(q + "attn_concat_proj.conv.bias", gr[k + "ob"], (64,))
+    put(q + "attn_concat_proj.act.weight", gr[k + "oslope"], (1,))
+    put(q + "attn_concat_proj.norm.gamma", gr[k + "og"].view(64, 64).t(), (1, 64, 1, 64))
+    put(q + "attn_concat_proj.norm.beta", gr[k + "obe"].view(64, 64).t(), (1, 64, 1, 64))
+    caf = pw.caf_prefix
+    for tag in ("key", "value"):
+        put(f"{caf}{tag}_embed.full_layer.2.weight", gr[f"caf_{tag}_dw"], (C, 1, 1, 1))
+        put(f"{caf}{tag}_embed.full_layer.3.weight", gr[f"caf_{tag}_g"], (C,))
+        put(f"{caf}{tag}_embed.full_layer.3.bias", gr[f"caf_{tag}_be"], (C,))
+    put("mask_generator.mask_generator.0.weight", gr["mask_slope"], (1,))
+    put("mask_generator.mask_generator.1.full_layer.2.weight", gr["mask_w"], (C, C, 1, 1))
+    put("mask_generator.mask_generator.1.full_layer.2.bias", gr["mask_b"], (C,))
+    put("decoder.decoder.weight", gr["dec_w"].view(32, C)[:18].t(), (C, 2, 3, 3))
+    return out
+
+
+class AVNetHipFunction(torch.autograd.Function):
+    """out = AVNet audio branch (wav, att, rsz; audio parameters).  `names` lists the reference names of `params`."""
+
+    @staticmethod
+    def forward(ctx, trainer, names, wav, att, rsz, *params):
+        with torch.no_grad():
+            out, saved = trainer.forward(wav, att, rsz)
+        ctx.trainer, ctx.names, ctx.saved = trainer, names, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        trainer = ctx.trainer
+        with torch.no_grad():
+            datt, drsz, gr = trainer.backward(ctx.saved, dout)
+            ref = grads_to_reference(trainer.model, trainer.weights(), gr)
+        grads = tuple(ref.get(n) for n in ctx.names)
+        ctx.saved = None
+        return (None, None, None, datt, drsz) + grads
