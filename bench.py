@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--layers", type=int, default=6, help="RTFS-Net-R (audio_params.repeats)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: separation forward (headline metric); train: forward + backward + AdamW (+ RCCL gradient all-reduce for N>1)")
     ap.add_argument("--roofline-kernel", default="rtfs_dp_unfold_gemm_fwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -119,14 +121,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
+    if args.mode == "infer":
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                out = model(mix, emb)
+            barrier()
+            lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model(mix, emb)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            prof = lib.profile_end()
+    else:
+        # training step as in train.py:98-101,135-146 + config yaml:117-120: neg-SNR loss, AdamW(lr 1e-3, wd 0.1), clip 5.0,
+        # DDP gradient all-reduce (one 2.96 MB bucket) and SyncBatchNorm over RCCL when N > 1
+        model.train()
+        target = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)[1].to(dev)
+        net = model
+        if dist is not None:
+            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            est = net(mix, emb)[:, 0]
+            noise = est - target
+            loss = -(10 * torch.log10(target.square().sum(-1) / (noise.square().sum(-1) + 1e-8) + 1e-8)).mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            return est
+
         for _ in range(args.warmup):
-            out = model(mix, emb)
+            out = step()
         barrier()
-        lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
+        lib.profile_begin(args.roofline_kernel)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = model(mix, emb)
+            out = step()
         barrier()
         elapsed = time.perf_counter() - t0
         prof = lib.profile_end()
@@ -140,7 +174,7 @@ def main():
     if rank == 0:
         frames = world * args.batch * T * args.steps
         res = {
-            "metric": "separated STFT frames/sec",
+            "metric": "separated STFT frames/sec" if args.mode == "infer" else "trained STFT frames/sec (fwd+bwd+optimizer)",
             "value": frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -153,8 +187,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), {args.seconds:g} s @16 kHz, "
-                            f"batch {args.batch} per GPU, fp32, random-init weights",
+                "workload": (f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), " if args.mode == "infer" else
+                             f"RTFS-Net-{args.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
+                            + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, fp32, random-init weights",
+                "mode": args.mode,
                 "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
                 "parallelism": f"utterance-sharded x{world}, no data-path collective",
             },

@@ -205,7 +205,9 @@ class HipTrainer:
             sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
             lib.call("rtfs_chan_stats", x, sums[0], sums[1], rows)
             n = float(rows)
-            if torch.distributed.is_available() and torch.distributed.is_initialized() and getattr(m, "sync_batchnorm", False):
+            out["sync"] = (torch.distributed.is_available() and torch.distributed.is_initialized()
+                           and isinstance(cell.key_embed.full_layer[3], torch.nn.SyncBatchNorm))  # train.py:145 sync_batchnorm=True
+            if out["sync"]:
                 cnt = torch.tensor([n], dtype=torch.float64, device=x.device)
                 torch.distributed.all_reduce(sums)
                 torch.distributed.all_reduce(cnt)
@@ -465,7 +467,7 @@ class HipTrainer:
             A, Bx = Rr[2 * j], Rr[2 * j + 1]
             if cf["training"]:
                 n, mean_x, var_x = cf["n"], cf["mean_x"], cf["var_x"]
-                if torch.distributed.is_available() and torch.distributed.is_initialized() and getattr(m, "sync_batchnorm", False):
+                if cf.get("sync"):
                     AB = torch.stack([A, Bx])
                     torch.distributed.all_reduce(AB)
                     A, Bx = AB[0], AB[1]
