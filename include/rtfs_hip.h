@@ -130,9 +130,10 @@ int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, 
                     const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream);
 int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* dgw, float* dgb,
                      float* dslope, long long rows, void* stream);
-/* weight gradient of any 1x1 conv / linear map (rows may be segmented: Toeplitz structure of unfold / ConvTranspose1d) */
-int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int NOUT, int KIN,
-               int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream);
+/* weight gradient of any 1x1 conv / linear map; rows may be segmented and nshift > 1 computes the taps of a Toeplitz map
+ * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k] */
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int nshift,
+               int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream);
 /* adjoints of rtfs_dp_unfold_gemm_fwd (input side) and rtfs_dp_convt_fwd */
 int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt /*[64][2048]*/, float* dxn, int B, int T2, int dim, void* stream);
 int rtfs_convt_bwd_input(const float* dG, const float* Wt /*[64][512]*/, float* dH3, int B, int T2, int dim, void* stream);

@@ -46,12 +46,13 @@ struct WgradArgs {
     int ldx;
     float* dW;
     int ldw;
-    long long M;       // rows of dY
-    int seg_len;       // rows per segment of dY
+    int M;             // rows of dY
+    int seg_len;       // rows per segment of dY (0: one segment)
     int x_seg;         // rows per segment of X
-    int x_off;         // X row inside the segment = l + x_off (invalid -> zero row)
+    int x_off;         // X row inside the segment = l + x_off + shift (invalid -> zero row)
+    int nshift;        // number of shifts (Toeplitz taps) computed by this launch; shift z writes dW columns z*KIN..
     int NOUT, KIN;     // multiples of 32
-    int rows_per_wg;
+    int rows_per_wg, ngroups;
     // prologue parameters
     const float *p0, *p1;  // gateway: gw, gb;  relu(gLN): gamma, beta
     float slope;
@@ -61,63 +62,151 @@ struct WgradArgs {
 };
 
 // PRO: 0 plain, 1 gateway prelu(x*gw+gb), 2 prelu(x), 3 relu(gLN(x))
-template <int PRO>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    constexpr int LD = 132;
-    __shared__ __attribute__((aligned(16))) float Ys[32 * LD];
-    __shared__ __attribute__((aligned(16))) float Xs[32 * LD];
-    const int kblocks = (a.KIN + 127) / 128;
-    const int nb = blockIdx.y / kblocks, kb = blockIdx.y % kblocks;
-    const int n0 = nb * 128, k0 = kb * 128;
+// One workgroup = a (32*NT) x (32*KT) tile of dW over rows_per_wg rows of one shift.  The 4 waves split the ROWS of every
+// 32-row LDS stage (8 each) and all hold the whole tile (no zero-padded MFMA work for the 64-wide maps); they are summed
+// through LDS at the end and the tile leaves with one coalesced fp32 atomic per element.  Global loads of stage i+1 are in
+// flight during the MFMAs of stage i (register prefetch, two LDS stages, one barrier per stage).  1-D grid decoded so that
+// all (shift, tile) workgroups of one row range run back-to-back on ONE XCD: the 8 taps re-read the same rows from that L2.
+template <int NT, int KT, int PRO>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int NW = NT * 32, KW = KT * 32, LDY = NW + 4, LDX = KW + 4, CH = 32, STAGE = CH * (LDY + LDX);
+    static_assert(NW * LDX <= 2 * STAGE, "reduction buffer aliases the stages");
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    const int kblocks = (a.KIN + KW - 1) / KW, nblocks = (a.NOUT + NW - 1) / NW;
+    const int per_group = a.nshift * kblocks * nblocks;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int group = (local / per_group) * 8 + xcd, inner = local % per_group;
+    if (group >= a.ngroups) return;
+    const int z = inner % a.nshift, blk = inner / a.nshift;
+    const int n0 = (blk / kblocks) * NW, k0 = (blk % kblocks) * KW;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wn = w >> 1, wk = w & 1;
-    const long long r0 = (long long)blockIdx.x * a.rows_per_wg;
-    const long long r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
+    const int r0 = group * a.rows_per_wg;
+    const int r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
+    const int xoff = a.x_off + z;
 
-    floatx16 acc[2][2];
-    acc_zero(acc);
-    const int srow = threadIdx.x >> 5, sc4 = (threadIdx.x & 31) * 4;  // 8 rows x 32 quads per pass, 4 passes
-    for (long long rb = r0; rb < r1; rb += 32) {
+    float4 yr[NT], xr[KT];
+    unsigned xvalid = 0;
+    int xb[KT];
+    auto load = [&](int rb) {
+        xvalid = 0;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int lr = srow + it * 8;
-            const long long r = rb + lr;
-            float4 y = f4(0, 0, 0, 0), x = f4(0, 0, 0, 0);
-            if (r < r1) {
-                if (n0 + sc4 < a.NOUT) y = ld4(a.dY + (size_t)r * a.ldy + n0 + sc4);
-                if (k0 + sc4 < a.KIN) {
-                    const long long seq = r / a.seg_len;
-                    const int xl = (int)(r - seq * a.seg_len) + a.x_off;
-                    if (xl >= 0 && xl < a.x_seg) {
-                        const int kc = k0 + sc4;
-                        x = ld4(a.X + (size_t)(seq * a.x_seg + xl) * a.ldx + kc);
-                        if (PRO == 1) x = prelu4(fma4(x, ld4(a.p0 + kc), ld4(a.p1 + kc)), a.slope);
-                        if (PRO == 2) x = prelu4(x, a.slope);
-                        if (PRO == 3) {
-                            float mean, rstd;
-                            stats_finalize(a.slot, (int)(r / a.rows_per_b), a.inv_n, mean, rstd);
-                            x = relu4(norm4(x, mean, rstd, ld4(a.p0 + kc), ld4(a.p1 + kc)));
-                        }
-                    }
-                }
-            }
-            st4(Ys + lr * LD + sc4, y);
-            st4(Xs + lr * LD + sc4, x);
+        for (int it = 0; it < NT; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx / (NW / 4), q4 = (idx % (NW / 4)) * 4;
+            const int r = rb + lr;
+            const bool ok = r < r1 && n0 + q4 < a.NOUT;
+            const int rc = r < r1 ? r : r1 - 1, qc = n0 + q4 < a.NOUT ? n0 + q4 : 0;
+            yr[it] = ld4(a.dY + (size_t)rc * a.ldy + qc);
+            if (!ok) yr[it] = f4(0, 0, 0, 0);
         }
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx / (KW / 4), q4 = (idx % (KW / 4)) * 4;
+            const int r = rb + lr, rc = r < r1 ? r : r1 - 1;
+            int seq = 0, l = rc;
+            if (a.seg_len) seq = (int)((unsigned)rc / (unsigned)a.seg_len), l = rc - seq * a.seg_len;
+            const int xl = l + xoff;
+            const bool ok = r < r1 && k0 + q4 < a.KIN && xl >= 0 && xl < a.x_seg;
+            const int xlc = xl < 0 ? 0 : (xl < a.x_seg ? xl : a.x_seg - 1), qc = k0 + q4 < a.KIN ? k0 + q4 : 0;
+            xr[it] = ld4(a.X + ((size_t)seq * a.x_seg + xlc) * a.ldx + qc);
+            xvalid |= (ok ? 1u : 0u) << it;
+            if (PRO == 3) xb[it] = rc / a.rows_per_b;
+        }
+    };
+    auto store = [&](float* st) {
+        float* Ys = st;
+        float* Xs = st + CH * LDY;
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx / (NW / 4), q4 = (idx % (NW / 4)) * 4;
+            st4(Ys + lr * LDY + q4, yr[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < KT; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx / (KW / 4), q4 = (idx % (KW / 4)) * 4;
+            float4 x = xr[it];
+            const int kc = k0 + q4 < a.KIN ? k0 + q4 : 0;
+            if (PRO == 1) x = prelu4(fma4(x, ld4(a.p0 + kc), ld4(a.p1 + kc)), a.slope);
+            if (PRO == 2) x = prelu4(x, a.slope);
+            if (PRO == 3) {
+                float mean, rstd;
+                stats_finalize(a.slot, xb[it], a.inv_n, mean, rstd);
+                x = relu4(norm4(x, mean, rstd, ld4(a.p0 + kc), ld4(a.p1 + kc)));
+            }
+            if (!((xvalid >> it) & 1u)) x = f4(0, 0, 0, 0);
+            st4(Xs + lr * LDX + q4, x);
+        }
+    };
+
+    floatx16 acc[NT][KT];
+    acc_zero(acc);
+    load(r0);
+    store(lds);
+    __syncthreads();
+    const int i = lane & 31, kh = lane >> 5;
+    int cur = 0;
+#pragma unroll 1
+    for (int rb = r0; rb < r1; rb += CH) {
+        const bool more = rb + CH < r1;
+        if (more) load(rb + CH);
+        const float* yp = lds + cur * STAGE + (w * 8 + kh * 4) * LDY + i;
+        const float* xp = lds + cur * STAGE + CH * LDY + (w * 8 + kh * 4) * LDX + i;
+        float av[NT][4], bv[KT][4];
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[m][r] = yp[r * LDY + m * 32];
+#pragma unroll
+        for (int n = 0; n < KT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[n][r] = xp[r * LDX + n * 32];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int n = 0; n < KT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bv[n][r], acc[m][n], 0, 0, 0);
+        if (more) store(lds + (cur ^ 1) * STAGE);
         __syncthreads();
-        mma_block_kk<2, 2>(acc, Ys + wn * 64, LD, Xs + wk * 64, LD, 32);
+        cur ^= 1;
+    }
+    // cross-wave sum of the 4 row-partials, then one atomic per element
+    float* red = lds;
+#pragma unroll 1
+    for (int w0 = 0; w0 < 4; ++w0) {
+        if (w == w0) {
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int n = 0; n < KT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* p = red + (m * 32 + acc_row(r)) * LDX + n * 32 + i;
+                        *p = w0 == 0 ? acc[m][n][r] : *p + acc[m][n][r];
+                    }
+        }
         __syncthreads();
     }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int nn = n0 + wn * 64 + m * 32, kk = k0 + wk * 64 + n * 32 + (lane & 31);
-            if (nn < a.NOUT && kk < a.KIN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(a.dW + (size_t)(nn + acc_row(r)) * a.ldw + kk, acc[m][n][r]);
-            }
-        }
+    float* dWz = a.dW + (size_t)z * a.KIN;
+    for (int idx = threadIdx.x; idx < NW * KW; idx += 256) {
+        const int nn = idx / KW, kk = idx % KW;
+        if (n0 + nn < a.NOUT && k0 + kk < a.KIN) atomicAdd(dWz + (size_t)(n0 + nn) * a.ldw + k0 + kk, red[nn * LDX + kk]);
+    }
+}
+
+template <int NT, int KT>
+static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
+    WgradArgs a = a0;
+    const int nblk = ((a.NOUT + NT * 32 - 1) / (NT * 32)) * ((a.KIN + KT * 32 - 1) / (KT * 32)) * a.nshift;
+    long long rpw = ((long long)a.M * nblk / 2048 + 31) / 32 * 32;  // ~2048 workgroups, at least 256 rows each
+    a.rows_per_wg = (int)(rpw < 256 ? 256 : rpw);
+    a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
+    const dim3 grid((unsigned)((a.ngroups + 7) / 8 * 8 * nblk));
+    switch (pro) {
+        case 0: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 0>), grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 1>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 2>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 3>), grid, dim3(256), 0, st, a); break;
+    }
 }
 
 // ---- Toeplitz input gradients ---------------------------------------------------------------------------------------------
@@ -200,26 +289,24 @@ static SeqMapB make_map(int dim, int T2) {
 
 extern "C" {
 
-// dW[n][k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r)][k];  r = seq*seg_len + l, xrow = seq*x_seg + l + x_off (zero if outside).
+// dW[n][z*KIN + k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r, z)][k] for the shifts z = 0..nshift-1;
+// r = seq*seg_len + l, xrow = seq*x_seg + l + x_off + z (zero row if outside its segment).  nshift = 1 for the plain maps; the
+// unfold / conv-transpose Toeplitz weight gradients are ONE launch with nshift = 8.
 // pro: 0 plain; 1 X' = prelu(X*p0+p1, slope) (gateway); 2 X' = prelu(X, slope); 3 X' = relu(gLN(X)) with stats slot / p0=gamma,p1=beta,
 // rows_per_b rows per utterance (inv_n = 1/(rows_per_b*KIN)).  NOUT, KIN multiples of 32.
-int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int NOUT, int KIN,
-               int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
-    if (M <= 0 || (NOUT & 31) || (KIN & 31) || pro < 0 || pro > 3) return RTFS_EINVAL;
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int nshift,
+               int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
+    if (M <= 0 || M >= (1ll << 31) || (NOUT & 31) || (KIN & 31) || pro < 0 || pro > 3 || nshift < 1) return RTFS_EINVAL;
     WgradArgs a;
-    a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.M = M;
-    a.seg_len = seg_len > 0 ? seg_len : (int)M, a.x_seg = x_seg > 0 ? x_seg : (int)M, a.x_off = x_off;
-    a.NOUT = NOUT, a.KIN = KIN, a.rows_per_wg = 2048;
+    a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.M = (int)M;
+    a.seg_len = seg_len > 0 && seg_len < M ? seg_len : 0, a.x_seg = x_seg > 0 ? x_seg : (int)M, a.x_off = x_off, a.nshift = nshift;
+    a.NOUT = NOUT, a.KIN = KIN;
     a.p0 = p0, a.p1 = p1, a.slope = slope, a.slot = stats, a.rows_per_b = rows_per_b > 0 ? rows_per_b : 1;
     a.inv_n = 1.0 / ((double)a.rows_per_b * KIN);
-    dim3 grid((unsigned)((M + a.rows_per_wg - 1) / a.rows_per_wg), ((NOUT + 127) / 128) * ((KIN + 127) / 128));
     hipStream_t st = (hipStream_t)stream;
-    switch (pro) {
-        case 0: hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, st, a); break;
-        case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(256), 0, st, a); break;
-    }
+    if (NOUT >= 128) wgrad_launch<4, 2>(a, pro, st);
+    else if (KIN >= 128) wgrad_launch<2, 4>(a, pro, st);
+    else wgrad_launch<2, 2>(a, pro, st);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

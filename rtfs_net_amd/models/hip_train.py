@@ -263,8 +263,7 @@ class HipTrainer:
         lib.call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
         lib.call("rtfs_colsum_add", dG_seq, g("ct_b", 64), S * npos, 64)
         dct = g("ct_w", 64 * 512)
-        for kp in range(8):
-            lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct[kp * 64:], 512, S * npos, npos, L, kp - 7, 64, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
         lib.call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
         # SRU layers 3..1
@@ -274,7 +273,7 @@ class HipTrainer:
             dx = torch.empty(S * L * 64, device=dev)
             lib.call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
                      S, L, 3)
-            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, S * L, 0, 0, 0, 192, 64, 0, None, None, 0.0, None, 0)
+            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
             lib.call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
             dh = dx
         l0 = d["layers"][0]
@@ -284,8 +283,7 @@ class HipTrainer:
         xn_seq = torch.empty(S * npos * 64, device=dev)
         lib.call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
         dw0 = g("w0", 256 * 512)
-        for kk in range(8):
-            lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0[kk * 64:], 512, S * L, L, npos, kk, 256, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
         dxn = torch.empty(B * T2 * F2 * 64, device=dev)
         lib.call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
         lib.call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
@@ -301,7 +299,7 @@ class HipTrainer:
         lib.call("rtfs_colsum_add", dYo, g("ob", 64), rows, 64)
         Ocl = torch.empty(rows * 64, device=dev)
         lib.call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
-        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, rows, 0, 0, 0, 64, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
         dOcl = torch.empty(rows * 64, device=dev)
         lib.call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
         dO = torch.empty(rows * 64, device=dev)
@@ -313,7 +311,7 @@ class HipTrainer:
         lib.call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
                  g("bk", 1024), g("gv", 4096), g("bv", 4096), g("slope", 12), B, T2)
         lib.call("rtfs_colsum_add", dY96, g("bias", 96), rows, 96)
-        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, rows, 0, 0, 0, 96, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
         lib.call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
     def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0):
@@ -336,7 +334,7 @@ class HipTrainer:
         lib.call("rtfs_colsum_add", dx, g("rb", C), B * TF, C)
         E = full()
         lib.call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
-        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, B * TF, 0, 0, 0, C, H, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
         lib.call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as a copy of dE
@@ -390,7 +388,7 @@ class HipTrainer:
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
         lib.call("rtfs_colsum_add", dy0, g("pb", H), B * TF, H)
-        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, B * TF, 0, 0, 0, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
+        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
         dGate = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", dy0, bw["pwT"], None, dGate, B * TF, H, C, 0)
         lib.call("rtfs_axpy", dx, 1.0, dGate, B * TF * C)  # + the gateway residual path
@@ -413,7 +411,7 @@ class HipTrainer:
         dspec = torch.empty(B * TF * 2, device=dev)
         dtaps = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
-        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, B * TF, 0, 0, 0, 32, C, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
         dmasked = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
         # S3 mask
@@ -421,7 +419,7 @@ class HipTrainer:
         dz = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
         lib.call("rtfs_colsum_add", dz, g("mask_b", C), B * TF, C)
-        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, B * TF, 0, 0, 0, C, C, 2, None, None, w["mask_slope"], None, 0)
+        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dpre = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
@@ -447,14 +445,14 @@ class HipTrainer:
         lib.call("rtfs_axpy", ds0, 1.0, da0, B * TF * C)  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
         lib.call("rtfs_colsum_add", da0, g("bn_bias", C), B * TF, C)
-        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, B * TF, 0, 0, 0, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
+        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
         self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_spec_patches", c.spec, patches, B, T)
-        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, B * TF, 0, 0, 0, C, 32, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
         return datt.view(B, Tv, C), drsz.view(B, Tv, C), gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):

@@ -67,6 +67,27 @@ def _make_act(kind):
     raise ValueError(f"Could not interpret activation identifier: {kind}")
 
 
+def _conv1d_glue(conv, x):
+    """Conv1d of the VP branch without MIOpen: every conv there is pointwise or depthwise (TDANet.py:24-66, 135-160), and at
+    [B, <=512, <=Tv] MIOpen falls back to per-sample im2col + GEMM loops (thousands of 4 us launches per training step).
+    Pointwise = one batched GEMM; depthwise = pad + strided window view + one multiply-reduce."""
+    k, s, w = conv.kernel_size[0], conv.stride[0], conv.weight
+    if k == 1 and conv.groups == 1 and s == 1:
+        y = torch.matmul(w[:, :, 0], x)
+    elif conv.groups == conv.in_channels == conv.out_channels and conv.dilation[0] == 1:
+        if k == 1 and s == 1:
+            y = x * w.view(1, -1, 1)
+        else:
+            if isinstance(conv.padding, str):  # 'same', stride 1: total k-1, left (k-1)//2 (torch puts the extra sample on the right)
+                lp, rp = (k - 1) // 2, k - 1 - (k - 1) // 2
+            else:
+                lp = rp = conv.padding[0]
+            y = (F.pad(x, (lp, rp)).unfold(-1, k, s) * w.view(1, -1, 1, k)).sum(-1)
+    else:
+        return conv(x)
+    return y if conv.bias is None else y + conv.bias.view(1, -1, 1)
+
+
 class ConvNormAct(nn.Module):
     """pre_norm -> pre_act -> conv -> norm -> act, padding 'same' for stride 1 else dil*(k-1)//2."""
 
@@ -87,7 +108,13 @@ class ConvNormAct(nn.Module):
                                         _make_norm(norm_type, self.out_chan), _make_act(act_type))
 
     def forward(self, x):  # used by the VP (video) branch only
-        return self.full_layer(x)
+        pre_norm, pre_act, conv, norm, act = self.full_layer
+        x = pre_act(pre_norm(x))
+        if isinstance(conv, nn.Conv1d):
+            x = _conv1d_glue(conv, x)
+        else:
+            x = conv(x)
+        return act(norm(x))
 
     def get_config(self):
         return {k: v for k, v in self.__dict__.items() if not k.startswith("_") and k != "training"}
