@@ -128,11 +128,12 @@ int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, c
 int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                     const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b, const float* cgate,
                     const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream);
-int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* dgw, float* dgb,
-                     float* dslope, long long rows, void* stream);
+int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* acc,
+                     int acc_mode /* 0 none, 1 acc = ds, 2 acc += ds (running d(a0)) */, float* dgw, float* dgb, float* dslope, long long rows,
+                     void* stream);
 /* weight gradient of any 1x1 conv / linear map; rows may be segmented and nshift > 1 computes the taps of a Toeplitz map
  * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k] */
-int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int nshift,
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias_or_null, long long M, int seg_len, int x_seg, int x_off, int nshift,
                int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream);
 /* adjoints of rtfs_dp_unfold_gemm_fwd (input side) and rtfs_dp_convt_fwd */
 int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt /*[64][2048]*/, float* dxn, int B, int T2, int dim, void* stream);

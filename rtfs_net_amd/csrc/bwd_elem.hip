@@ -27,19 +27,17 @@ __device__ __forceinline__ float hsum4(float4 a) { return a.x + a.y + a.z + a.w;
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
 // Reduce per-thread float4 partials that share a channel quad (thread = (row = tid / QUADS, quad = tid % QUADS)) and add
-// the workgroup total to out[quad*4 ..] with one atomic per channel.  lds: 1024 floats.
+// the workgroup total to out[0 .. 4*QUADS) with ONE coalesced atomic request per 128-byte line.  lds: 1024 floats.
 template <int QUADS>
 __device__ __forceinline__ void quad_reduce_atomic(float4 v, float* lds, float* out) {
-    st4(lds + threadIdx.x * 4, v);
+    constexpr int NC = QUADS * 4, ROWS = 256 / QUADS;
+    st4(lds + threadIdx.x * 4, v);  // element (row, channel) sits at row*NC + channel
     __syncthreads();
-    if (threadIdx.x < QUADS) {
-        float4 s = f4(0, 0, 0, 0);
+    if (threadIdx.x < NC) {
+        float s = 0.f;
 #pragma unroll 4
-        for (int r = 0; r < 256 / QUADS; ++r) s = s + ld4(lds + (r * QUADS + threadIdx.x) * 4);
-        atomicAdd(out + threadIdx.x * 4 + 0, s.x);
-        atomicAdd(out + threadIdx.x * 4 + 1, s.y);
-        atomicAdd(out + threadIdx.x * 4 + 2, s.z);
-        atomicAdd(out + threadIdx.x * 4 + 3, s.w);
+        for (int r = 0; r < ROWS; ++r) s += lds[r * NC + threadIdx.x];
+        atomicAdd(out + threadIdx.x, s);
     }
     __syncthreads();
 }
@@ -53,16 +51,19 @@ __device__ __forceinline__ void scalar_reduce_atomic(float v, float* lds, float*
     __syncthreads();
 }
 
+// this workgroup's copy of the spread scratch (spread.hip)
+__device__ __forceinline__ float* spread_copy(float* scr, unsigned wg) { return scr + (size_t)(wg & (kSpread - 1)) * kSpreadCap; }
+
 // ---- colsum ---------------------------------------------------------------------------------------------------------
 template <int QUADS>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ out, long long M, int rows_per_wg) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ scr, long long M, int rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float lds[1024];
     constexpr int N = QUADS * 4;
     const int quad = threadIdx.x % QUADS, rsub = threadIdx.x / QUADS;
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < M ? r0 + rows_per_wg : M;
     float4 s = f4(0, 0, 0, 0);
     for (long long r = r0 + rsub; r < r1; r += 256 / QUADS) s = s + ld4(X + r * N + quad * 4);
-    quad_reduce_atomic<QUADS>(s, lds, out);
+    quad_reduce_atomic<QUADS>(s, lds, spread_copy(scr, blockIdx.x));
 }
 
 // ---- gLN backward ---------------------------------------------------------------------------------------------------
@@ -72,8 +73,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 //   dx = rstd * (a - S1/N - xhat*S2/N)
 template <int C, int ACT>
 __global__ __launch_bounds__(256) void gln_bwd_reduce_kernel(const float* __restrict__ dY, NormArg n, float slope, double* __restrict__ red,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
-                                                             int rows, int rows_per_wg) {
+                                                             float* __restrict__ scr, int rows, int rows_per_wg) {
     constexpr int QUADS = C / 4;
     __shared__ __attribute__((aligned(16))) float lds[1024];
     __shared__ float redl[8];
@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256) void gln_bwd_reduce_kernel(const float* __rest
         s1 += hsum4(a);
         s2 += dot4(a, xh);
     }
-    quad_reduce_atomic<QUADS>(dg, lds, dgamma);
-    quad_reduce_atomic<QUADS>(db, lds, dbeta);
-    if (ACT == 1) scalar_reduce_atomic(dsl, lds, dslope);
+    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y);  // [dgamma C | dbeta C | dslope]
+    quad_reduce_atomic<QUADS>(dg, lds, mine);
+    quad_reduce_atomic<QUADS>(db, lds, mine + C);
+    if (ACT == 1) scalar_reduce_atomic(dsl, lds, mine + 2 * C);
     block_stats_commit(s1, s2, redl, red, b);
 }
 
@@ -177,14 +178,26 @@ __global__ __launch_bounds__(256) void dwconv_bwd_input_kernel(const float* __re
 }
 
 // dW[tap][c] += sum_{b,to,fo} dOut[to][fo][c] * xin[to*S-1+dt][fo*S-1+df][c];  dbias[c] += sum dOut.
-// xin = transformed forward input (MODE 0 raw, 1 gLN, 2 PReLU(gLN)).  Thread = (pixel lane, channel quad); each
-// workgroup walks `pix_per_wg` output pixels, keeps 16 tap partials in registers and reduces them once.
+// xin = transformed forward input (MODE 0 raw, 1 gLN, 2 PReLU(gLN)).  Same sliding-window walk as the forward kernel
+// (tfar.hip dwconv_kernel): thread = (output time row, channel quad) keeps a 4-column x 4-row register window of xin while
+// it walks a frequency segment, so xin is loaded once per overlapping time row instead of 16x; the 16 tap partials + the
+// bias partial stay in registers.  Lane = quad*4 + (row & 3): the 4 rows of a wave are summed with two quad_perm DPP adds,
+// the 4 waves through LDS, and the workgroup leaves with one coalesced fp32 atomic per (tap, channel).
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lanes [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // lanes [2,3,0,1]
+    return v;
+}
+
 template <int STRIDE, int MODE>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dOut, NormArg n, float slope, float* __restrict__ dW,
-                                                                float* __restrict__ dbias, int Tin, int Fin, int Tout, int Fout, int pix_per_wg) {
-    __shared__ __attribute__((aligned(16))) float lds[1024];
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_weight_kernel(const float* __restrict__ dOut, NormArg n, float slope, float* __restrict__ scr,
+                                                                   int Tin, int Fin, int Tout, int Fout, int fseg) {
+    __shared__ __attribute__((aligned(16))) float red[4][17][64];
     const int b = blockIdx.y;
-    const int c4 = (threadIdx.x & 15) * 4, psub = threadIdx.x >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = (lane >> 2) * 4;
+    const int to = blockIdx.x * 16 + wave * 4 + (lane & 3);
+    const int f0 = blockIdx.z * fseg, f1 = min(Fout, f0 + fseg);
     float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
     if (MODE >= 1) {
         float mean, rstd;
@@ -193,34 +206,79 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __r
         sc = g * rstd;
         sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
     }
+    const bool tvalid = to < Tout;
+    const float* rowp[4];
+    float rmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ti = to * STRIDE - 1 + r;
+        const bool ok = tvalid && ti >= 0 && ti < Tin;
+        rmask[r] = ok ? 1.f : 0.f;
+        rowp[r] = n.x + (((size_t)b * Tin + min(max(ti, 0), Tin - 1)) * Fin) * kH + c4;
+    }
+    auto load_col = [&](int c, float4(&col)[4]) {
+        const float cm = (c >= 0 && c < Fin) ? 1.f : 0.f;
+        const size_t off = (size_t)min(max(c, 0), Fin - 1) * kH;
+        float4 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ld4(rowp[r] + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 v = x[r];
+            if (MODE >= 1) v = fma4(v, sc, sh);
+            if (MODE == 2) v = prelu4(v, slope);
+            col[r] = v * (cm * rmask[r]);
+        }
+    };
+    float4 win[4][4];  // [column slot][time row]; column c of the input lives in slot (c+1)&3
+    if (STRIDE == 1) {
+        load_col(f0 - 1, win[0]);
+        load_col(f0, win[1]);
+        load_col(f0 + 1, win[2]);
+    } else {
+        load_col(2 * f0 - 1, win[0]);
+        load_col(2 * f0, win[1]);
+    }
     float4 part[16], pb = f4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) part[i] = f4(0, 0, 0, 0);
-    const int npix = Tout * Fout;
-    const int p0 = blockIdx.x * pix_per_wg, p1 = min(npix, p0 + pix_per_wg);
-    const float* inb = n.x + (size_t)b * Tin * Fin * kH + c4;
-    for (int p = p0 + psub; p < p1; p += 16) {
-        const int to = p / Fout, fo = p - to * Fout;
-        const float4 g = ld4(dOut + ((size_t)b * npix + p) * kH + c4);
-        pb = pb + g;
+    const float* grow = dOut + (((size_t)b * Tout + (tvalid ? to : 0)) * Fout) * kH + c4;
+    constexpr int STEPS = 4 / STRIDE;
+#pragma unroll 1
+    for (int f = f0; f < f1; f += STEPS) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int ti = to * STRIDE - 1 + dt;
-#pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const int fi = fo * STRIDE - 1 + df;
-                if (ti >= 0 && ti < Tin && fi >= 0 && fi < Fin) {
-                    float4 x = ld4(inb + ((size_t)ti * Fin + fi) * kH);
-                    if (MODE >= 1) x = fma4(x, sc, sh);
-                    if (MODE == 2) x = prelu4(x, slope);
-                    part[dt * 4 + df] = fma4(g, x, part[dt * 4 + df]);
-                }
+        for (int j = 0; j < STEPS; ++j) {
+            const int fo = f + j;
+            float4 g = ld4(grow + (size_t)min(fo, Fout - 1) * kH);
+            int base;
+            if (STRIDE == 1) {
+                load_col(fo + 2, win[(j + 3) & 3]);
+                base = j;
+            } else {
+                load_col(2 * fo + 1, win[(2 * j + 2) & 3]);
+                load_col(2 * fo + 2, win[(2 * j + 3) & 3]);
+                base = 2 * j;
             }
+            g = g * ((tvalid && fo < f1) ? 1.f : 0.f);
+            pb = pb + g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int df = 0; df < 4; ++df) part[dt * 4 + df] = fma4(g, win[(base + df) & 3][dt], part[dt * 4 + df]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) quad_reduce_atomic<16>(part[i], lds, dW + i * 64);
-    if (dbias) quad_reduce_atomic<16>(pb, lds, dbias);
+    for (int i = 0; i < 17; ++i) {
+        const float4 v = i < 16 ? part[i] : pb;
+        const float4 t = f4(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z), quad_sum(v.w));
+        if ((lane & 3) == 0) st4(&red[wave][i][c4], t);
+    }
+    __syncthreads();
+    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y + blockIdx.z);  // [dW 16*64 | dbias 64]
+    for (int idx = threadIdx.x; idx < 17 * 64; idx += 256) {
+        const int i = idx >> 6, c = idx & 63;
+        atomicAdd(mine + idx, red[0][i][c] + red[1][i][c] + red[2][i][c] + red[3][i][c]);
+    }
 }
 
 // ---- pool backward ----------------------------------------------------------------------------------------------------
@@ -315,32 +373,50 @@ __global__ __launch_bounds__(256) void expand_kernel(NormArg cl, NormArg d0, Nor
 }
 
 // ---- gateway backward -------------------------------------------------------------------------------------------------
-// forward: G = prelu(u), u = s*gw + gb (per channel).  dG -> ds (= or +=), dgw += sum du*s, dgb += sum du, dslope += sum dG*u*[u<=0]
-template <bool ACCUM>
+// forward: G = prelu(u), u = s*gw + gb (per channel).  dG -> ds (= or +=), dgw += sum du*s, dgb += sum du, dslope += sum dG*u*[u<=0].
+// ACCM: the same gradient also feeds the running d(a0) sum (block input = previous output + a0): 1 store it, 2 add it.
+template <bool ACCUM, int ACCM>
 __global__ __launch_bounds__(256) void gateway_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ s, const float* __restrict__ gw,
-                                                          const float* __restrict__ gb, float slope, float* __restrict__ ds, float* __restrict__ dgw,
-                                                          float* __restrict__ dgb, float* __restrict__ dslope, long long rows, int rows_per_wg) {
+                                                          const float* __restrict__ gb, float slope, float* __restrict__ ds, float* __restrict__ acc,
+                                                          float* __restrict__ scr, long long rows, int rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float lds[1024];
     const int c4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
     const float4 w4 = ld4(gw + c4), b4 = ld4(gb + c4);
     const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
     float4 aw = f4(0, 0, 0, 0), ab = f4(0, 0, 0, 0);
     float asl = 0.f;
-    for (long long r = r0 + rsub; r < r1; r += 4) {
-        const size_t o = (size_t)r * kC + c4;
-        const float4 sv = ld4(s + o), g = ld4(dG + o);
-        const float4 u = fma4(sv, w4, b4);
-        asl += (u.x > 0.f ? 0.f : g.x * u.x) + (u.y > 0.f ? 0.f : g.y * u.y) + (u.z > 0.f ? 0.f : g.z * u.z) + (u.w > 0.f ? 0.f : g.w * u.w);
-        const float4 du = f4(u.x > 0.f ? g.x : g.x * slope, u.y > 0.f ? g.y : g.y * slope, u.z > 0.f ? g.z : g.z * slope, u.w > 0.f ? g.w : g.w * slope);
-        aw = fma4(du, sv, aw);
-        ab = ab + du;
-        float4 d = du * w4;
-        if (ACCUM) d = d + ld4(ds + o);
-        st4(ds + o, d);
+    constexpr int U = 4;  // rows in flight per thread
+    for (long long rb = r0 + rsub; rb < r1; rb += 4 * U) {
+        float4 sv[U], g[U], old[U], ao[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const long long r = rb + 4 * j < r1 ? rb + 4 * j : r1 - 1;  // clamped: loads stay unconditional
+            const size_t o = (size_t)r * kC + c4;
+            sv[j] = ld4(s + o), g[j] = ld4(dG + o);
+            if (ACCUM) old[j] = ld4(ds + o);
+            if (ACCM == 2) ao[j] = ld4(acc + o);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (rb + 4 * j >= r1) break;
+            const size_t o = (size_t)(rb + 4 * j) * kC + c4;
+            const float4 u = fma4(sv[j], w4, b4), gj = g[j];
+            asl += (u.x > 0.f ? 0.f : gj.x * u.x) + (u.y > 0.f ? 0.f : gj.y * u.y) + (u.z > 0.f ? 0.f : gj.z * u.z) + (u.w > 0.f ? 0.f : gj.w * u.w);
+            const float4 du = f4(u.x > 0.f ? gj.x : gj.x * slope, u.y > 0.f ? gj.y : gj.y * slope, u.z > 0.f ? gj.z : gj.z * slope,
+                                 u.w > 0.f ? gj.w : gj.w * slope);
+            aw = fma4(du, sv[j], aw);
+            ab = ab + du;
+            float4 d = du * w4;
+            if (ACCM == 1) st4(acc + o, d);
+            if (ACCM == 2) st4(acc + o, d + ao[j]);
+            if (ACCUM) d = d + old[j];
+            st4(ds + o, d);
+        }
     }
-    quad_reduce_atomic<64>(aw, lds, dgw);
-    quad_reduce_atomic<64>(ab, lds, dgb);
-    scalar_reduce_atomic(asl, lds, dslope);
+    float* mine = spread_copy(scr, blockIdx.x);  // [dgw 256 | dgb 256 | dslope]
+    quad_reduce_atomic<64>(aw, lds, mine);
+    quad_reduce_atomic<64>(ab, lds, mine + kC);
+    scalar_reduce_atomic(asl, lds, mine + 2 * kC);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long n4) {
@@ -360,35 +436,38 @@ extern "C" {
 
 int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream) {
     if (M <= 0) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
     const int per = 512;
     dim3 grid((unsigned)((M + per - 1) / per));
     switch (N) {
-        case 32: LAUNCH((colsum_kernel<8>), grid, X, out, M, per); break;
-        case 64: LAUNCH((colsum_kernel<16>), grid, X, out, M, per); break;
-        case 96: LAUNCH((colsum_kernel<24>), grid, X, out, M, per); break;
-        case 256: LAUNCH((colsum_kernel<64>), grid, X, out, M, per); break;
+        case 32: LAUNCH((colsum_kernel<8>), grid, X, scr, M, per); break;
+        case 64: LAUNCH((colsum_kernel<16>), grid, X, scr, M, per); break;
+        case 256: LAUNCH((colsum_kernel<64>), grid, X, scr, M, per); break;
         default: return RTFS_EINVAL;
     }
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{out, nullptr, nullptr, nullptr}, {N, 0, 0, 0}}, (hipStream_t)stream);
 }
 
 // red: double[B][2], zeroed by the caller.  act: 0 none, 1 PReLU(slope) after the norm (C = 64; dslope accumulates), 2 ReLU after the norm (C = 256).
 int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
                         float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream) {
     if (B <= 0 || rows <= 0 || (C != 64 && C != 256)) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
     NormArg n{X, stats, 1.0 / ((double)rows * C), gamma, beta};
     const int per = 256;
     dim3 grid((rows + per - 1) / per, B);
     if (C == 64) {
-        if (act == 1) { LAUNCH((gln_bwd_reduce_kernel<64, 1>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
-        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<64, 0>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        if (act == 1) { LAUNCH((gln_bwd_reduce_kernel<64, 1>), grid, dY, n, slope, red, scr, rows, per); }
+        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<64, 0>), grid, dY, n, slope, red, scr, rows, per); }
         else return RTFS_EINVAL;
     } else {
-        if (act == 2) { LAUNCH((gln_bwd_reduce_kernel<256, 2>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
-        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<256, 0>), grid, dY, n, slope, red, dgamma, dbeta, dslope, rows, per); }
+        if (act == 2) { LAUNCH((gln_bwd_reduce_kernel<256, 2>), grid, dY, n, slope, red, scr, rows, per); }
+        else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<256, 0>), grid, dY, n, slope, red, scr, rows, per); }
         else return RTFS_EINVAL;
     }
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dgamma, dbeta, act == 1 ? dslope : nullptr, nullptr}, {C, C, act == 1 ? 1 : 0, 0}}, (hipStream_t)stream);
 }
 
 int rtfs_gln_bwd_apply(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope,
@@ -430,13 +509,15 @@ int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* sta
     if (B <= 0 || (stride != 1 && stride != 2) || mode < 0 || mode > 2) return RTFS_EINVAL;
     const int Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1, Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
     NormArg n{in, stats_in, 1.0 / ((double)Tin * Fin * kH), gamma, beta};
-    const int per = 512;
-    dim3 grid((Tout * Fout + per - 1) / per, B);
-#define DWW(S, M) LAUNCH((dwconv_bwd_weight_kernel<S, M>), grid, dOut, n, slope, dW, dbias, Tin, Fin, Tout, Fout, per)
+    const int nseg = 2, fseg = (((Fout + nseg - 1) / nseg) + 3) / 4 * 4;
+    dim3 grid((Tout + 15) / 16, B, (Fout + fseg - 1) / fseg);
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+#define DWW(S, M) LAUNCH((dwconv_bwd_weight_kernel<S, M>), grid, dOut, n, slope, scr, Tin, Fin, Tout, Fout, fseg)
     if (stride == 1) { if (mode == 0) { DWW(1, 0); } else if (mode == 1) { DWW(1, 1); } else { DWW(1, 2); } }
     else { if (mode == 0) { DWW(2, 0); } else if (mode == 1) { DWW(2, 1); } else { DWW(2, 2); } }
 #undef DWW
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dW, dbias, nullptr, nullptr}, {16 * 64, 64, 0, 0}}, (hipStream_t)stream);
 }
 
 int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* stream) {
@@ -466,14 +547,20 @@ int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, 
     return RTFS_OK;
 }
 
-int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* dgw, float* dgb,
-                     float* dslope, long long rows, void* stream) {
-    if (rows <= 0) return RTFS_EINVAL;
-    const int per = 128;
+int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* acc, int acc_mode,
+                     float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
+    if (rows <= 0 || acc_mode < 0 || acc_mode > 2 || (acc_mode && (!acc || accumulate))) return RTFS_EINVAL;
+    const int per = 256;
     dim3 grid((unsigned)((rows + per - 1) / per));
-    if (accumulate) { LAUNCH((gateway_bwd_kernel<true>), grid, dG, s, gw, gb, slope, ds, dgw, dgb, dslope, rows, per); }
-    else { LAUNCH((gateway_bwd_kernel<false>), grid, dG, s, gw, gb, slope, ds, dgw, dgb, dslope, rows, per); }
-    return RTFS_OK;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+#define GWB(A, M) LAUNCH((gateway_bwd_kernel<A, M>), grid, dG, s, gw, gb, slope, ds, acc, scr, rows, per)
+    if (accumulate) { GWB(true, 0); }
+    else if (acc_mode == 0) { GWB(false, 0); }
+    else if (acc_mode == 1) { GWB(false, 1); }
+    else { GWB(false, 2); }
+#undef GWB
+    return spread_finish(scr, SpreadOut{{dgw, dgb, dslope, nullptr}, {kC, kC, 1, 0}}, (hipStream_t)stream);
 }
 
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream) {

@@ -46,6 +46,7 @@ struct WgradArgs {
     int ldx;
     float* dW;
     int ldw;
+    float* dbias;      // optional: dbias[n] += sum_r dY[r][n] (the conv bias gradient rides along; tile column 0, shift 0 only)
     int M;             // rows of dY
     int seg_len;       // rows per segment of dY (0: one segment)
     int x_seg;         // rows per segment of X
@@ -84,7 +85,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
     const int xoff = a.x_off + z;
 
-    float4 yr[NT], xr[KT];
+    float4 yr[NT], xr[KT], bs[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) bs[it] = f4(0, 0, 0, 0);
+    const bool want_bias = a.dbias != nullptr && z == 0 && (blk % kblocks) == 0;  // uniform over the workgroup
     unsigned xvalid = 0;
     int xb[KT];
     auto load = [&](int rb) {
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         for (int it = 0; it < NT; ++it) {
             const int idx = threadIdx.x + it * 256, lr = idx / (NW / 4), q4 = (idx % (NW / 4)) * 4;
             st4(Ys + lr * LDY + q4, yr[it]);
+            bs[it] = bs[it] + yr[it];  // this thread's column quad is the same in every stage
         }
 #pragma unroll
         for (int it = 0; it < KT; ++it) {
@@ -168,6 +173,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         if (more) store(lds + (cur ^ 1) * STAGE);
         __syncthreads();
         cur ^= 1;
+    }
+    if (want_bias) {
+        constexpr int Q = NW / 4;  // column quads; thread t and stage slot `it` always hold quad t % Q
+#pragma unroll
+        for (int it = 0; it < NT; ++it) st4(lds + (it * 256 + threadIdx.x) * 4, bs[it]);
+        __syncthreads();
+        if (threadIdx.x < Q && n0 + threadIdx.x * 4 < a.NOUT) {
+            float4 t = f4(0, 0, 0, 0);
+            for (int j = 0; j < NT * 256 / Q; ++j) t = t + ld4(lds + (j * Q + threadIdx.x) * 4);
+            float* o = a.dbias + n0 + threadIdx.x * 4;
+            atomicAdd(o, t.x), atomicAdd(o + 1, t.y), atomicAdd(o + 2, t.z), atomicAdd(o + 3, t.w);
+        }
+        __syncthreads();
     }
     // cross-wave sum of the 4 row-partials, then one atomic per element
     float* red = lds;
@@ -292,13 +310,14 @@ extern "C" {
 // dW[n][z*KIN + k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r, z)][k] for the shifts z = 0..nshift-1;
 // r = seq*seg_len + l, xrow = seq*x_seg + l + x_off + z (zero row if outside its segment).  nshift = 1 for the plain maps; the
 // unfold / conv-transpose Toeplitz weight gradients are ONE launch with nshift = 8.
+// dbias (optional): dbias[n] += sum_r dY[r][n].
 // pro: 0 plain; 1 X' = prelu(X*p0+p1, slope) (gateway); 2 X' = prelu(X, slope); 3 X' = relu(gLN(X)) with stats slot / p0=gamma,p1=beta,
 // rows_per_b rows per utterance (inv_n = 1/(rows_per_b*KIN)).  NOUT, KIN multiples of 32.
-int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, long long M, int seg_len, int x_seg, int x_off, int nshift,
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off, int nshift,
                int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
     if (M <= 0 || M >= (1ll << 31) || (NOUT & 31) || (KIN & 31) || pro < 0 || pro > 3 || nshift < 1) return RTFS_EINVAL;
     WgradArgs a;
-    a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.M = (int)M;
+    a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.dbias = dbias, a.M = (int)M;
     a.seg_len = seg_len > 0 && seg_len < M ? seg_len : 0, a.x_seg = x_seg > 0 ? x_seg : (int)M, a.x_off = x_off, a.nshift = nshift;
     a.NOUT = NOUT, a.KIN = KIN;
     a.p0 = p0, a.p1 = p1, a.slope = slope, a.slot = stats, a.rows_per_b = rows_per_b > 0 ? rows_per_b : 1;

@@ -51,8 +51,8 @@ SIGNATURES = {
     "rtfs_pool_bwd": [P, P, I, I, I, P],
     "rtfs_mix_bwd": [P] * 12 + [I, I, I, I, I, P],
     "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],
-    "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, P, P, LL, P],
-    "rtfs_wgrad": [P, I, P, I, P, I, LL, I, I, I, I, I, I, I, P, P, F, P, I, P],
+    "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
+    "rtfs_wgrad": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, P],
     "rtfs_fold_gemm_bwd": [P, P, P, I, I, I, P],
     "rtfs_convt_bwd_input": [P, P, P, I, I, I, P],
     "rtfs_sru_scan_train_fwd": [P, P, P, P, F, P, P, I, I, I, P],
@@ -122,8 +122,8 @@ _prof_events = []
 
 def profile_begin(name: str):
     """Time every launch of ONE entry point with HIP events recorded on the launch stream (bench.py roofline)."""
-    global _prof_name, _prof_events
-    _prof_name, _prof_events = name, []
+    global _prof_name, _prof_events, _prof_labels
+    _prof_name, _prof_events, _prof_labels = name, [], []
 
 
 def profile_end():
@@ -132,6 +132,11 @@ def profile_end():
     _prof_name = None
     torch.cuda.synchronize()
     return [a.elapsed_time(b) for a, b in _prof_events]
+
+
+def profile_labels():
+    """labels of the launches recorded by profile_begin("*"), in the order of profile_end()'s durations"""
+    return list(_prof_labels)
 
 
 def call(name: str, *args):
@@ -147,12 +152,14 @@ def call(name: str, *args):
             conv.append(ctypes.cast(arr, c_void_p))
         else:
             conv.append(a)
-    if name == _prof_name:
+    if name == _prof_name or _prof_name == "*":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # torch's current stream == the stream handed to the kernel
         rc = getattr(load(), name)(*conv, _stream())
         e1.record()
         _prof_events.append((e0, e1))
+        if _prof_name == "*":  # tools/train_breakdown.py: label = entry point + its integer arguments (shapes / modes)
+            _prof_labels.append(name + str(tuple(a for a in args if isinstance(a, int))))
     else:
         rc = getattr(load(), name)(*conv, _stream())
     if rc != 0:

@@ -261,9 +261,8 @@ class HipTrainer:
         # ConvTranspose1d + bias + residual
         dG_seq = torch.empty(S * npos * 64, device=dev)
         lib.call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
-        lib.call("rtfs_colsum_add", dG_seq, g("ct_b", 64), S * npos, 64)
         dct = g("ct_w", 64 * 512)
-        lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
         lib.call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
         # SRU layers 3..1
@@ -273,7 +272,7 @@ class HipTrainer:
             dx = torch.empty(S * L * 64, device=dev)
             lib.call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
                      S, L, 3)
-            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
+            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
             lib.call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
             dh = dx
         l0 = d["layers"][0]
@@ -283,7 +282,7 @@ class HipTrainer:
         xn_seq = torch.empty(S * npos * 64, device=dev)
         lib.call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
         dw0 = g("w0", 256 * 512)
-        lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
         dxn = torch.empty(B * T2 * F2 * 64, device=dev)
         lib.call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
         lib.call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
@@ -296,10 +295,9 @@ class HipTrainer:
         rows = ntok * 64
         dYo = torch.empty(rows * 64, device=dev)
         lib.call("rtfs_attn_out_norm_bwd", dG, k.Ypre_o, a["oslope"], a["og"], dYo, g("og", 4096), g("obe", 4096), g("oslope", 1), ntok)
-        lib.call("rtfs_colsum_add", dYo, g("ob", 64), rows, 64)
         Ocl = torch.empty(rows * 64, device=dev)
         lib.call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
-        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, g("ob", 64), rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
         dOcl = torch.empty(rows * 64, device=dev)
         lib.call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
         dO = torch.empty(rows * 64, device=dev)
@@ -310,13 +308,13 @@ class HipTrainer:
         dY96 = torch.empty(rows * 96, device=dev)
         lib.call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
                  g("bk", 1024), g("gv", 4096), g("bv", 4096), g("slope", 12), B, T2)
-        lib.call("rtfs_colsum_add", dY96, g("bias", 96), rows, 96)
-        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
         lib.call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
-    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0):
-        """dx: gradient w.r.t. the block output [B,TF,256].  Returns ds (gradient w.r.t. the block input).
-        (No buffer re-use: every intermediate gradient gets its own allocation; correctness first.)"""
+    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode):
+        """dx: gradient w.r.t. the block output [B,TF,256] (overwritten).  Returns ds (gradient w.r.t. the block input).
+        a0_mode: how ds also enters the running d(a0) sum `da0` -- 1: da0 = ds, 2: da0 += ds (blocks whose input was
+        `previous + a0`), 3: block 0, whose input IS a0: ds is accumulated straight into da0, 4: same but da0 is empty (R = 1)."""
         dev = dx.device
         TF, lo = T * F_BINS, T2 * F2
         st = k.st
@@ -328,13 +326,10 @@ class HipTrainer:
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
-        if k.has_a0:
-            lib.call("rtfs_axpy", dx, 1.0, da0, B * TF * C)
         # residual_conv: bias, weight (needs `expanded`), input gradient
-        lib.call("rtfs_colsum_add", dx, g("rb", C), B * TF, C)
         E = full()
         lib.call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
-        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
         lib.call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as a copy of dE
@@ -387,13 +382,14 @@ class HipTrainer:
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
-        lib.call("rtfs_colsum_add", dy0, g("pb", H), B * TF, H)
-        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
-        dGate = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gemm_rows", dy0, bw["pwT"], None, dGate, B * TF, H, C, 0)
-        lib.call("rtfs_axpy", dx, 1.0, dGate, B * TF * C)  # + the gateway residual path
+        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
+        lib.call("rtfs_gemm_rows", dy0, bw["pwT"], None, dx, B * TF, H, C, 1)  # dx (gateway residual path) += dy0 . Wp  = d(gateway out)
+        if a0_mode >= 3:
+            lib.call("rtfs_gateway_bwd", dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0, g("gw", C), g("gb", C),
+                     g("gslope", 1), B * TF)
+            return da0
         ds = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gateway_bwd", dGate, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, g("gw", C), g("gb", C), g("gslope", 1), B * TF)
+        lib.call("rtfs_gateway_bwd", dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C), g("gslope", 1), B * TF)
         return ds
 
     def backward(self, c, dout):
@@ -411,29 +407,25 @@ class HipTrainer:
         dspec = torch.empty(B * TF * 2, device=dev)
         dtaps = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
-        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
         dmasked = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
         # S3 mask
         da_emb = _zeros(B * TF * C, dev)
         dz = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
-        lib.call("rtfs_colsum_add", dz, g("mask_b", C), B * TF, C)
-        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
+        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dpre = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
         lib.call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
         # RTFS blocks R-1 .. 1, CAF, block 0
-        da0 = _zeros(B * TF * C, dev)
+        da0 = torch.empty(B * TF * C, device=dev)  # running sum of the gradients of every block input (each is `... + a0`)
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         for i in range(R - 1, 0, -1):
-            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0)
-            # block input was (previous output + a0): the a0 part is added by the producer's has_a0 / CAF branch
+            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0, 1 if i == R - 1 else 2)
         # CAF: out = key*rsz^ + att^*val (+ a0)
-        if R > 1:
-            lib.call("rtfs_axpy", dx, 1.0, da0, B * TF * C)
         datt, drsz = _zeros(B * Tv * C, dev), _zeros(B * Tv * C, dev)
         Rr = _zeros(4 * C, dev)
         cf = c.caf
@@ -441,18 +433,16 @@ class HipTrainer:
         coef = self._caf_bwd_coeffs(cf, w, Rr.view(4, C), gr, m)
         dx0 = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
-        ds0 = self._block_bwd(dx0, c.blk[0], bw(0), B, T, T2, gr, da0)
-        lib.call("rtfs_axpy", ds0, 1.0, da0, B * TF * C)  # block 0's input is a0 itself
+        self._block_bwd(dx0, c.blk[0], bw(0), B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
-        lib.call("rtfs_colsum_add", da0, g("bn_bias", C), B * TF, C)
-        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
+        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
         self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_spec_patches", c.spec, patches, B, T)
-        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
+        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
         return datt.view(B, Tv, C), drsz.view(B, Tv, C), gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
