@@ -26,8 +26,7 @@ __device__ __forceinline__ float block_sum(float v, float* red /*4*/) {
 // in registers and are committed once per workgroup.
 __global__ __launch_bounds__(256) void attn_out_norm_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ Ypre, float slope,
                                                                 const float* __restrict__ gamma_fc, float* __restrict__ dYpre,
-                                                                float* __restrict__ dgamma_fc, float* __restrict__ dbeta_fc, float* __restrict__ dslope,
-                                                                int ntok, int tok_per_wg) {
+                                                                float* __restrict__ scr, int ntok, int tok_per_wg) {
     __shared__ float red[4];
     float ag[16], ab[16], gam[16];
 #pragma unroll
@@ -72,13 +71,14 @@ __global__ __launch_bounds__(256) void attn_out_norm_bwd_kernel(const float* __r
             dYpre[base + threadIdx.x + 256 * k] = yp[k] > 0.f ? dz : dz * slope;
         }
     }
+    float* mine = spread_copy(scr, blockIdx.x);  // [dgamma 4096 | dbeta 4096 | dslope]
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        atomicAdd(dgamma_fc + threadIdx.x + 256 * k, ag[k]);
-        atomicAdd(dbeta_fc + threadIdx.x + 256 * k, ab[k]);
+        atomicAdd(mine + threadIdx.x + 256 * k, ag[k]);
+        atomicAdd(mine + 4096 + threadIdx.x + 256 * k, ab[k]);
     }
     asl = block_sum(asl, red);
-    if (threadIdx.x == 0) atomicAdd(dslope, asl);
+    if (threadIdx.x == 0) atomicAdd(mine + 8192, asl);
 }
 
 // ---- Q/K/V projection tails -----------------------------------------------------------------------------------------------
@@ -89,9 +89,7 @@ __global__ __launch_bounds__(256) void attn_out_norm_bwd_kernel(const float* __r
 __global__ __launch_bounds__(256) void attn_qkv_norm_bwd_kernel(const float* __restrict__ dQ, const float* __restrict__ dK, const float* __restrict__ dV,
                                                                 const float* __restrict__ Ypre, const float* __restrict__ slope,
                                                                 const float* __restrict__ gq, const float* __restrict__ gk, const float* __restrict__ gv,
-                                                                float* __restrict__ dYpre, float* __restrict__ dgq, float* __restrict__ dbq,
-                                                                float* __restrict__ dgk, float* __restrict__ dbk, float* __restrict__ dgv,
-                                                                float* __restrict__ dbv, float* __restrict__ dslope, int BT, int T2, int tok_per_wg) {
+                                                                float* __restrict__ dYpre, float* __restrict__ scr, int BT, int T2, int tok_per_wg) {
     constexpr int LDY = 97;
     __shared__ float Ys[64 * LDY];       // prelu(ypre) then zhat
     __shared__ float Ds[64 * LDY];       // dN then dYpre
@@ -176,7 +174,9 @@ __global__ __launch_bounds__(256) void attn_qkv_norm_bwd_kernel(const float* __r
             dYpre[(size_t)bt * 6144 + i] = Ds[f * LDY + n];
         }
     }
-    // commit parameter gradients
+    // commit parameter gradients into this workgroup's scratch copy: [dgq 1024 | dbq 1024 | dgk 1024 | dbk 1024 | dgv 4096 | dbv 4096 | dslope 12]
+    float* mine = spread_copy(scr, blockIdx.x);
+    float *dgq = mine, *dbq = mine + 1024, *dgk = mine + 2048, *dbk = mine + 3072, *dgv = mine + 4096, *dbv = mine + 8192, *dslope = mine + 12288;
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
         const int i = threadIdx.x + 256 * k, n = i >> 6, f = i & 63;
@@ -447,22 +447,26 @@ extern "C" {
 int rtfs_attn_out_norm_bwd(const float* dOut, const float* Ypre, float slope, const float* gamma_fc, float* dYpre, float* dgamma_fc, float* dbeta_fc,
                            float* dslope, int ntok, void* stream) {
     if (ntok <= 0) return RTFS_EINVAL;
-    const int per = 16;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int per = 4;
     hipLaunchKernelGGL(attn_out_norm_bwd_kernel, dim3((ntok + per - 1) / per), dim3(256), 0, (hipStream_t)stream, dOut, Ypre, slope, gamma_fc, dYpre,
-                       dgamma_fc, dbeta_fc, dslope, ntok, per);
+                       scr, ntok, per);
     RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dgamma_fc, dbeta_fc, dslope}, {4096, 4096, 1}}, (hipStream_t)stream);
 }
 
 int rtfs_attn_qkv_norm_bwd(const float* dQ, const float* dK, const float* dV, const float* Ypre, const float* slope, const float* gq, const float* gk,
                            const float* gv, float* dYpre, float* dgq, float* dbq, float* dgk, float* dbk, float* dgv, float* dbv, float* dslope, int B,
                            int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
-    const int per = 16, BT = B * T2;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int per = 4, BT = B * T2;
     hipLaunchKernelGGL(attn_qkv_norm_bwd_kernel, dim3((BT + per - 1) / per), dim3(256), 0, (hipStream_t)stream, dQ, dK, dV, Ypre, slope, gq, gk, gv, dYpre,
-                       dgq, dbq, dgk, dbk, dgv, dbv, dslope, BT, T2, per);
+                       scr, BT, T2, per);
     RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dgq, dbq, dgk, dbk, dgv, dbv, dslope}, {1024, 1024, 1024, 1024, 4096, 4096, 12}}, (hipStream_t)stream);
 }
 
 // Q,K,dQ,dK: [B][4][T2][256]; V,dV: [B][4][T2][1024]; O,dO: [B][T2][64][64] (O layout); LSE, Dws: [B][4][T2]

@@ -51,9 +51,6 @@ __device__ __forceinline__ void scalar_reduce_atomic(float v, float* lds, float*
     __syncthreads();
 }
 
-// this workgroup's copy of the spread scratch (spread.hip)
-__device__ __forceinline__ float* spread_copy(float* scr, unsigned wg) { return scr + (size_t)(wg & (kSpread - 1)) * kSpreadCap; }
-
 // ---- colsum ---------------------------------------------------------------------------------------------------------
 template <int QUADS>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ scr, long long M, int rows_per_wg) {
@@ -175,6 +172,61 @@ __global__ __launch_bounds__(256) void dwconv_bwd_input_kernel(const float* __re
     float* o = dIn + ((size_t)b * Tin * Fin + p) * kH + c4;
     if (ACCUM) acc = acc + ld4(o);
     st4(o, acc);
+}
+
+// Stride-1 input gradient in sliding-window form (the transposed convolution is itself a 4x4 depth-wise convolution of dOut with
+// the flipped taps): dIn[ti][fi] = sum_{r,cc} w[(3-r)*4 + (3-cc)] * dOut[ti-2+r][fi-2+cc].  Thread = (input time row, channel
+// quad) walking a frequency segment with a 4x4 register window of dOut (column c in slot (c+2)&3) and the 16 taps in registers:
+// dOut is loaded once per overlapping time row instead of 16x.  grid (ceil(T/16), B, nseg), fseg % 4 == 0.
+template <bool ACCUM>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_input_s1_kernel(const float* __restrict__ dOut, const float* __restrict__ w, float* __restrict__ dIn,
+                                                                     int T, int F, int fseg) {
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int ti = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    const bool tvalid = ti < T;
+    const float* rowp[4];
+    float rmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int to = ti - 2 + r;
+        rmask[r] = (tvalid && to >= 0 && to < T) ? 1.f : 0.f;
+        rowp[r] = dOut + (((size_t)b * T + min(max(to, 0), T - 1)) * F) * kH + c4;
+    }
+    auto load_col = [&](int c, float4(&col)[4]) {
+        const float cm = (c >= 0 && c < F) ? 1.f : 0.f;
+        const size_t off = (size_t)min(max(c, 0), F - 1) * kH;
+        float4 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ld4(rowp[r] + off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) col[r] = x[r] * (cm * rmask[r]);
+    };
+    float4 wreg[16];  // wreg[r*4+cc] = w[(3-r)*4 + (3-cc)]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wreg[i] = ld4(w + (15 - i) * 64 + c4);
+    float4 win[4][4];
+    load_col(f0 - 2, win[0]);
+    load_col(f0 - 1, win[1]);
+    load_col(f0, win[2]);
+    float* orow = dIn + (((size_t)b * T + (tvalid ? ti : 0)) * F) * kH + c4;
+#pragma unroll 1
+    for (int f = f0; f < f1; f += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int fi = f + j;
+            load_col(fi + 1, win[(j + 3) & 3]);
+            float4 old = f4(0, 0, 0, 0);
+            if (ACCUM) old = ld4(orow + (size_t)min(fi, F - 1) * kH);
+            float4 acc = f4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc = fma4(wreg[r * 4 + cc], win[(j + cc) & 3][r], acc);
+            if (tvalid && fi < f1) st4(orow + (size_t)fi * kH, ACCUM ? acc + old : acc);
+        }
+    }
 }
 
 // dW[tap][c] += sum_{b,to,fo} dOut[to][fo][c] * xin[to*S-1+dt][fo*S-1+df][c];  dbias[c] += sum dOut.
@@ -446,7 +498,7 @@ int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream
         case 256: LAUNCH((colsum_kernel<64>), grid, X, scr, M, per); break;
         default: return RTFS_EINVAL;
     }
-    return spread_finish(scr, SpreadOut{{out, nullptr, nullptr, nullptr}, {N, 0, 0, 0}}, (hipStream_t)stream);
+    return spread_finish(scr, SpreadOut{{out}, {N}}, (hipStream_t)stream);
 }
 
 // red: double[B][2], zeroed by the caller.  act: 0 none, 1 PReLU(slope) after the norm (C = 64; dslope accumulates), 2 ReLU after the norm (C = 256).
@@ -467,7 +519,7 @@ int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, co
         else if (act == 0) { LAUNCH((gln_bwd_reduce_kernel<256, 0>), grid, dY, n, slope, red, scr, rows, per); }
         else return RTFS_EINVAL;
     }
-    return spread_finish(scr, SpreadOut{{dgamma, dbeta, act == 1 ? dslope : nullptr, nullptr}, {C, C, act == 1 ? 1 : 0, 0}}, (hipStream_t)stream);
+    return spread_finish(scr, SpreadOut{{dgamma, dbeta, act == 1 ? dslope : nullptr}, {C, C, act == 1 ? 1 : 0}}, (hipStream_t)stream);
 }
 
 int rtfs_gln_bwd_apply(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope,
@@ -494,8 +546,10 @@ int rtfs_dwconv_bwd_input(const float* dOut, const float* w, float* dIn, int acc
     const int Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1, Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
     dim3 grid((Tin * Fin + 15) / 16, B);
     if (stride == 1) {
-        if (accumulate) { LAUNCH((dwconv_bwd_input_kernel<1, true>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
-        else { LAUNCH((dwconv_bwd_input_kernel<1, false>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
+        const int nseg = Fin >= 96 ? 4 : 2, fseg = (((Fin + nseg - 1) / nseg) + 3) / 4 * 4;
+        dim3 g1((Tin + 15) / 16, B, (Fin + fseg - 1) / fseg);
+        if (accumulate) { LAUNCH((dwconv_bwd_input_s1_kernel<true>), g1, dOut, w, dIn, Tin, Fin, fseg); }
+        else { LAUNCH((dwconv_bwd_input_s1_kernel<false>), g1, dOut, w, dIn, Tin, Fin, fseg); }
     } else {
         if (accumulate) { LAUNCH((dwconv_bwd_input_kernel<2, true>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
         else { LAUNCH((dwconv_bwd_input_kernel<2, false>), grid, dOut, w, dIn, Tin, Fin, Tout, Fout); }
@@ -517,7 +571,7 @@ int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* sta
     if (stride == 1) { if (mode == 0) { DWW(1, 0); } else if (mode == 1) { DWW(1, 1); } else { DWW(1, 2); } }
     else { if (mode == 0) { DWW(2, 0); } else if (mode == 1) { DWW(2, 1); } else { DWW(2, 2); } }
 #undef DWW
-    return spread_finish(scr, SpreadOut{{dW, dbias, nullptr, nullptr}, {16 * 64, 64, 0, 0}}, (hipStream_t)stream);
+    return spread_finish(scr, SpreadOut{{dW, dbias}, {16 * 64, 64}}, (hipStream_t)stream);
 }
 
 int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* stream) {
@@ -560,7 +614,7 @@ int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const flo
     else if (acc_mode == 1) { GWB(false, 1); }
     else { GWB(false, 2); }
 #undef GWB
-    return spread_finish(scr, SpreadOut{{dgw, dgb, dslope, nullptr}, {kC, kC, 1, 0}}, (hipStream_t)stream);
+    return spread_finish(scr, SpreadOut{{dgw, dgb, dslope}, {kC, kC, 1}}, (hipStream_t)stream);
 }
 
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream) {

@@ -215,8 +215,10 @@ template <int NT, int KT>
 static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     WgradArgs a = a0;
     const int nblk = ((a.NOUT + NT * 32 - 1) / (NT * 32)) * ((a.KIN + KT * 32 - 1) / (KT * 32)) * a.nshift;
-    long long rpw = ((long long)a.M * nblk / 2048 + 31) / 32 * 32;  // ~2048 workgroups, at least 256 rows each
-    a.rows_per_wg = (int)(rpw < 256 ? 256 : rpw);
+    // ~2048 workgroups, but at least 1024 rows each: every workgroup ends with a cross-wave LDS sum and one atomic request per
+    // line of its tile, and requests to one line are served serially (~27 ns) - a few hundred row groups keep that tail short
+    long long rpw = ((long long)a.M * nblk / 2048 + 31) / 32 * 32;
+    a.rows_per_wg = (int)(rpw < 1024 ? 1024 : rpw);
     a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
     const dim3 grid((unsigned)((a.ngroups + 7) / 8 * 8 * nblk));
     switch (pro) {
@@ -323,7 +325,7 @@ int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int
     a.p0 = p0, a.p1 = p1, a.slope = slope, a.slot = stats, a.rows_per_b = rows_per_b > 0 ? rows_per_b : 1;
     a.inv_n = 1.0 / ((double)a.rows_per_b * KIN);
     hipStream_t st = (hipStream_t)stream;
-    if (NOUT >= 128) wgrad_launch<4, 2>(a, pro, st);
+    if (NOUT >= 128 && NOUT % 128 == 0) wgrad_launch<4, 2>(a, pro, st);
     else if (KIN >= 128) wgrad_launch<2, 4>(a, pro, st);
     else wgrad_launch<2, 2>(a, pro, st);
     RTFS_LAUNCH_CHECK();

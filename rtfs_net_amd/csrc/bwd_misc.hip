@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void mask_bwd_elem_kernel(const float* __restr
 
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float slope, float* __restrict__ dx,
-                                                        float* __restrict__ dslope, long long n4) {
+                                                        float* __restrict__ scr, long long n4) {
     __shared__ float red[4];
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict_
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dslope, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(spread_copy(scr, blockIdx.x), red[0] + red[1] + red[2] + red[3]);
 }
 
 // sum[c], sumsq[c] over rows of x [rows][256]  (fp64 accumulation across workgroups)
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
     st4(lds + threadIdx.x * 4, s);
     st4(lds + 1024 + threadIdx.x * 4, q);
     __syncthreads();
-    if (threadIdx.x < 64) {
-        float4 ts = f4(0, 0, 0, 0), tq = f4(0, 0, 0, 0);
-        for (int r = 0; r < 4; ++r) ts = ts + ld4(lds + (r * 64 + threadIdx.x) * 4), tq = tq + ld4(lds + 1024 + (r * 64 + threadIdx.x) * 4);
-        atomicAdd(sum + c4 + 0, (double)ts.x), atomicAdd(sum + c4 + 1, (double)ts.y), atomicAdd(sum + c4 + 2, (double)ts.z), atomicAdd(sum + c4 + 3, (double)ts.w);
-        atomicAdd(sumsq + c4 + 0, (double)tq.x), atomicAdd(sumsq + c4 + 1, (double)tq.y), atomicAdd(sumsq + c4 + 2, (double)tq.z), atomicAdd(sumsq + c4 + 3, (double)tq.w);
-    }
+    // thread = channel: one coalesced fp64 atomic request per line (same-line requests are served serially, ~27 ns each)
+    const int c = threadIdx.x;
+    const float ts = lds[c] + lds[256 + c] + lds[512 + c] + lds[768 + c];
+    const float tq = lds[1024 + c] + lds[1280 + c] + lds[1536 + c] + lds[1792 + c];
+    atomicAdd(sum + c, (double)ts);
+    atomicAdd(sumsq + c, (double)tq);
 }
 
 // CAF forward (fusion.py:259-272) with folded BatchNorm: key = relu(x*ks+kb), val = x*vs+vb, out = key*rsz^ + att^*val.
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void caf_bwd_reduce_kernel(const float* __restrict__ dOut, const float* __restrict__ x, const float* __restrict__ ks,
                                                              const float* __restrict__ kb, const float* __restrict__ vs, const float* __restrict__ vb,
                                                              const float* __restrict__ att, const float* __restrict__ rsz, float* __restrict__ datt,
-                                                             float* __restrict__ drsz, float* __restrict__ R /*[4][256]*/, int T, int Tv) {
+                                                             float* __restrict__ drsz, float* __restrict__ scr /* R [4][256] spread */, int T, int Tv) {
     __shared__ __attribute__((aligned(16))) float lds[1024];
     const int t = blockIdx.x, b = blockIdx.y;
     const int c4 = (threadIdx.x & 63) * 4, fsub = threadIdx.x >> 6;
@@ -101,18 +101,16 @@ __global__ __launch_bounds__(256) void caf_bwd_reduce_kernel(const float* __rest
         const float4 dv = g * a4;
         r0 = r0 + dk, r1 = fma4(dk, xv, r1), r2 = r2 + dv, r3 = fma4(dv, xv, r3);
     }
-    auto commit = [&](float4 v, float* out) {
+    auto commit = [&](float4 v, float* out) {  // thread = channel after the LDS transpose: one coalesced request per line
         st4(lds + threadIdx.x * 4, v);
         __syncthreads();
-        if (threadIdx.x < 64) {
-            float4 s = f4(0, 0, 0, 0);
-            for (int r = 0; r < 4; ++r) s = s + ld4(lds + (r * 64 + threadIdx.x) * 4);
-            atomicAdd(out + c4 + 0, s.x), atomicAdd(out + c4 + 1, s.y), atomicAdd(out + c4 + 2, s.z), atomicAdd(out + c4 + 3, s.w);
-        }
+        const int c = threadIdx.x;
+        atomicAdd(out + c, lds[c] + lds[256 + c] + lds[512 + c] + lds[768 + c]);
         __syncthreads();
     };
     commit(arsz, drsz + ((size_t)b * Tv + tv) * kC);
     commit(aatt, datt + ((size_t)b * Tv + tv) * kC);
+    float* R = spread_copy(scr, blockIdx.x + blockIdx.y);
     commit(r0, R), commit(r1, R + 256), commit(r2, R + 512), commit(r3, R + 768);
 }
 
@@ -265,14 +263,16 @@ int rtfs_prelu_bwd(const float* dy, const float* x, float slope, float* dx, int 
     if (n <= 0 || (n & 3)) return RTFS_EINVAL;
     const long long n4 = n / 4;
     dim3 grid((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096));
-    if (accumulate) { LAUNCH(prelu_bwd_kernel<true>, grid, dy, x, slope, dx, dslope, n4); }
-    else { LAUNCH(prelu_bwd_kernel<false>, grid, dy, x, slope, dx, dslope, n4); }
-    return RTFS_OK;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    if (accumulate) { LAUNCH(prelu_bwd_kernel<true>, grid, dy, x, slope, dx, scr, n4); }
+    else { LAUNCH(prelu_bwd_kernel<false>, grid, dy, x, slope, dx, scr, n4); }
+    return spread_finish(scr, SpreadOut{{dslope}, {1}}, (hipStream_t)stream);
 }
 
 int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, void* stream) {
     if (rows <= 0) return RTFS_EINVAL;
-    const int per = 256;
+    const int per = 2048;
     LAUNCH(chan_stats_kernel, dim3((unsigned)((rows + per - 1) / per)), x, sum, sumsq, rows, per);
     return RTFS_OK;
 }
@@ -280,8 +280,10 @@ int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, 
 int rtfs_caf_bwd_reduce(const float* dOut, const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att,
                         const float* rsz, float* datt, float* drsz, float* R, int B, int T, int Tv, void* stream) {
     if (B <= 0 || T <= 0 || Tv <= 0) return RTFS_EINVAL;
-    LAUNCH(caf_bwd_reduce_kernel, dim3(T, B), dOut, x, ks, kb, vs, vb, att, rsz, datt, drsz, R, T, Tv);
-    return RTFS_OK;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    LAUNCH(caf_bwd_reduce_kernel, dim3(T, B), dOut, x, ks, kb, vs, vb, att, rsz, datt, drsz, scr, T, Tv);
+    return spread_finish(scr, SpreadOut{{R}, {1024}}, (hipStream_t)stream);
 }
 
 int rtfs_caf_bwd_apply(const float* dOut, const float* x, const float* ks, const float* kb, const float* att, const float* rsz, const float* coef,

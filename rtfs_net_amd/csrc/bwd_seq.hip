@@ -71,7 +71,7 @@ template <int KM>
 __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restrict__ U, const float* __restrict__ X, const float* __restrict__ Cst,
                                                            const float* __restrict__ wc, const float* __restrict__ bias, float scale_x,
                                                            const float* __restrict__ dH, float* __restrict__ dU, float* __restrict__ dX,
-                                                           float* __restrict__ dwc, float* __restrict__ dbias, int S, int L) {
+                                                           float* __restrict__ scr, int S, int L) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
     const int lane = threadIdx.x & 63;
@@ -121,16 +121,16 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restri
             dX[o64 + (size_t)l * 64] = dxp * scale_x;
         }
     }
-    atomicAdd(dwc + lane, awf);
-    atomicAdd(dwc + 64 + lane, awr);
-    atomicAdd(dbias + lane, abf);
-    atomicAdd(dbias + 64 + lane, abr);
+    float* mine = spread_copy(scr, blockIdx.x);  // [dwc 128 | dbias 128]
+    atomicAdd(mine + lane, awf);
+    atomicAdd(mine + 64 + lane, awr);
+    atomicAdd(mine + 128 + lane, abf);
+    atomicAdd(mine + 192 + lane, abr);
 }
 
 // LN4D over channels, adjoint.  dxn, G, dG in G layout [rows][64]; dG += dx; dgamma/dbeta += per-channel sums.
 __global__ __launch_bounds__(256) void ln4d_c_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ G, const float* __restrict__ gamma,
-                                                         float* __restrict__ dG, float* __restrict__ dgamma, float* __restrict__ dbeta, long long rows,
-                                                         int rows_per_wg) {
+                                                         float* __restrict__ dG, float* __restrict__ scr, long long rows, int rows_per_wg) {
     __shared__ __attribute__((aligned(16))) float lds[1024];
     const int c4 = (threadIdx.x & 15) * 4, rsub = threadIdx.x >> 4;
     const float4 g4 = ld4(gamma + c4);
@@ -168,23 +168,24 @@ __global__ __launch_bounds__(256) void ln4d_c_bwd_kernel(const float* __restrict
         ag = fma4(g, xh, ag);
         ab = ab + g;
     }
-    // quad_reduce: threads (rsub, quad) -> per channel
+    // threads (rsub, quad) -> per channel, one coalesced atomic request per array into this workgroup's scratch copy [dgamma 64 | dbeta 64]
+    float* mine = spread_copy(scr, blockIdx.x);
     st4(lds + threadIdx.x * 4, ag);
     __syncthreads();
-    if (threadIdx.x < 16) {
-        float4 t = f4(0, 0, 0, 0);
-        for (int r = 0; r < 16; ++r) t = t + ld4(lds + (r * 16 + threadIdx.x) * 4);
-        atomicAdd(dgamma + threadIdx.x * 4 + 0, t.x), atomicAdd(dgamma + threadIdx.x * 4 + 1, t.y);
-        atomicAdd(dgamma + threadIdx.x * 4 + 2, t.z), atomicAdd(dgamma + threadIdx.x * 4 + 3, t.w);
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) t += lds[r * 64 + threadIdx.x];
+        atomicAdd(mine + threadIdx.x, t);
     }
     __syncthreads();
     st4(lds + threadIdx.x * 4, ab);
     __syncthreads();
-    if (threadIdx.x < 16) {
-        float4 t = f4(0, 0, 0, 0);
-        for (int r = 0; r < 16; ++r) t = t + ld4(lds + (r * 16 + threadIdx.x) * 4);
-        atomicAdd(dbeta + threadIdx.x * 4 + 0, t.x), atomicAdd(dbeta + threadIdx.x * 4 + 1, t.y);
-        atomicAdd(dbeta + threadIdx.x * 4 + 2, t.z), atomicAdd(dbeta + threadIdx.x * 4 + 3, t.w);
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) t += lds[r * 64 + threadIdx.x];
+        atomicAdd(mine + 64 + threadIdx.x, t);
     }
 }
 
@@ -247,24 +248,27 @@ int rtfs_sru_scan_train_fwd(const float* U, const float* X, const float* wc, con
 int rtfs_sru_scan_bwd(const float* U, const float* X, const float* C, const float* wc, const float* bias, float scale_x, const float* dH, float* dU,
                       float* dX, float* dwc, float* dbias, int S, int L, int km, void* stream) {
     if (S <= 0 || L <= 0) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
     dim3 grid((S + 3) / 4);
     if (km == 4)
-        hipLaunchKernelGGL((sru_scan_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, dwc, dbias, S, L);
+        hipLaunchKernelGGL((sru_scan_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, scr, S, L);
     else if (km == 3)
-        hipLaunchKernelGGL((sru_scan_bwd_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, dwc, dbias, S, L);
+        hipLaunchKernelGGL((sru_scan_bwd_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, scr, S, L);
     else
         return RTFS_EINVAL;
     RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dwc, dbias}, {128, 128}}, (hipStream_t)stream);
 }
 
 int rtfs_ln4d_c_bwd(const float* dxn, const float* G, const float* gamma, float* dG, float* dgamma, float* dbeta, long long rows, void* stream) {
     if (rows <= 0) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
     const int per = 256;
-    hipLaunchKernelGGL(ln4d_c_bwd_kernel, dim3((unsigned)((rows + per - 1) / per)), dim3(256), 0, (hipStream_t)stream, dxn, G, gamma, dG, dgamma, dbeta,
-                       rows, per);
+    hipLaunchKernelGGL(ln4d_c_bwd_kernel, dim3((unsigned)((rows + per - 1) / per)), dim3(256), 0, (hipStream_t)stream, dxn, G, gamma, dG, scr, rows, per);
     RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    return spread_finish(scr, SpreadOut{{dgamma, dbeta}, {64, 64}}, (hipStream_t)stream);
 }
 
 // ln != 0: LN4D-normalise (gamma, beta) while gathering.  out: [S][npos][64]

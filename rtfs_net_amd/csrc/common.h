@@ -84,15 +84,18 @@ __device__ __forceinline__ void block_stats_commit(float s, float q, float* red,
 // ---- spread accumulators (spread.hip) ------------------------------------------------------------------------------
 constexpr int kSpread = 32;         // scratch copies; a workgroup adds into copy (its index % kSpread)
 constexpr int kSpreadCap = 16384;   // floats per copy
-struct SpreadOut {                  // up to 4 accumulators of one kernel; region j starts at the 32-float-aligned running offset
-    float* dst[4];
-    int n[4];
+constexpr int kSpreadSlots = 8;
+struct SpreadOut {                  // up to 8 accumulators of one kernel; region j starts at the 32-float-aligned running offset
+    float* dst[kSpreadSlots];
+    int n[kSpreadSlots];
     __host__ __device__ int off(int j) const {
         int o = 0;
         for (int k = 0; k < j; ++k) o += (n[k] + 31) & ~31;
         return o;
     }
 };
+// this workgroup's copy of the scratch
+__device__ __forceinline__ float* spread_copy(float* scr, unsigned wg) { return scr + (size_t)(wg & (kSpread - 1)) * kSpreadCap; }
 float* spread_scratch();                                             // zeroed [kSpread][kSpreadCap] floats of this device (nullptr on failure)
 int spread_finish(float* scr, const SpreadOut& o, hipStream_t st);   // dst[j][i] += sum over copies; re-zeroes the scratch
 

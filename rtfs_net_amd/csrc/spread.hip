@@ -18,9 +18,9 @@ __global__ __launch_bounds__(256) void spread_finish_kernel(float* __restrict__ 
     const int e = blockIdx.x * 256 + threadIdx.x;
     int j = 0, base = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < kSpreadSlots - 1; ++k) {
         const int span = (o.n[j] + 31) & ~31;
-        if (j < 3 && e >= base + span) base += span, ++j;
+        if (j < kSpreadSlots - 1 && e >= base + span) base += span, ++j;
     }
     const int i = e - base;
     if (i >= o.n[j]) return;
@@ -53,7 +53,7 @@ float* spread_scratch() {
 
 int spread_finish(float* scr, const SpreadOut& o, hipStream_t st) {
     int total = 0;
-    for (int j = 0; j < 4; ++j) total += (o.n[j] + 31) & ~31;
+    for (int j = 0; j < kSpreadSlots; ++j) total += (o.n[j] + 31) & ~31;
     if (total <= 0) return RTFS_OK;
     if (total > kSpreadCap) return RTFS_EINVAL;
     hipLaunchKernelGGL(spread_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scr, o);
