@@ -1,4 +1,5 @@
-/* rtfs_hip.h -- C-ABI of librtfs_hip.so: the MI355X (gfx950) kernels behind RTFS-Net's separation forward path.
+/* rtfs_hip.h -- C-ABI of librtfs_hip.so: the MI355X (gfx950) kernels behind RTFS-Net's separation path
+ * (forward, and the adjoint chain of the training step).
  *
  * The reference (spkgyk/RTFS-Net) is pure Python: its "plugin interface" for this path is the nn.Module API
  * `src.models.AVNet` (src/models/tdavnet.py:14-97); there is no FFI in it.  This header is the boundary BELOW
@@ -6,7 +7,8 @@
  * `sru` calls each reference function makes.  Every entry point
  *   - takes raw DEVICE pointers and sizes only (no torch types), caller-allocated outputs and workspaces,
  *   - enqueues on the given `hipStream_t` (passed as void*; NULL = default stream) and never synchronises,
- *   - keeps no global state and is re-entrant per stream,
+ *   - keeps no global state and is re-entrant per stream (exception: the parameter-gradient reducers of the training step share
+ *     one zeroed 2 MB scratch per device, csrc/spread.hip -- order their launches on one stream per device),
  *   - returns 0 on success, RTFS_EINVAL (-1) for unsupported shapes, RTFS_ELAUNCH (-2) if the launch failed.
  *
  * Tensor layout below the boundary is CHANNELS-LAST fp32:

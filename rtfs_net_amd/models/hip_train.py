@@ -207,14 +207,8 @@ class HipTrainer:
             n = float(rows)
             out["sync"] = (torch.distributed.is_available() and torch.distributed.is_initialized()
                            and isinstance(cell.key_embed.full_layer[3], torch.nn.SyncBatchNorm))  # train.py:145 sync_batchnorm=True
-            if out["sync"]:
-                cnt = torch.tensor([n], dtype=torch.float64, device=x.device)
-                torch.distributed.all_reduce(sums)
-                torch.distributed.all_reduce(cnt)
-                n = float(cnt.item())
-            mean_x = sums[0] / n
-            var_x = (sums[1] / n - mean_x * mean_x).clamp_min(0)
-            out["mean_x"], out["var_x"], out["n"] = mean_x.float(), var_x.float(), n
+            mean_x, var_x, n, lsum, lsq = caf_bn_batch_stats(sums, n, out["sync"])
+            out["mean_x"], out["var_x"], out["n"], out["lsum"], out["lsq"] = mean_x, var_x, n, lsum, lsq  # lsq: sum_local (x-mean) x
         for tag, mod in (("key", cell.key_embed), ("value", cell.value_embed)):
             dw, g, be = w[f"caf_{tag}_dw"], w[f"caf_{tag}_g"], w[f"caf_{tag}_be"]
             bn = mod.full_layer[3]
@@ -454,16 +448,8 @@ class HipTrainer:
             inv = cf[tag + "_inv"]
             A, Bx = Rr[2 * j], Rr[2 * j + 1]
             if cf["training"]:
-                n, mean_x, var_x = cf["n"], cf["mean_x"], cf["var_x"]
-                if cf.get("sync"):
-                    AB = torch.stack([A, Bx])
-                    torch.distributed.all_reduce(AB)
-                    A, Bx = AB[0], AB[1]
-                Q = dw * inv * (Bx - mean_x * A)                      # sum dk * uhat
-                c1 = dw * gm * inv
-                c3 = -c1 * (Q / n) * (dw * inv)
-                c2 = -c1 * A / n - c3 * mean_x
-                gr[f"caf_{tag}_dw"] = gm * inv * (Bx - A * mean_x - Q * dw * inv * var_x)
+                c1, c2, c3, Q, A, gdw = caf_bn_adjoint(A, Bx, cf["lsum"], cf["lsq"], cf["n"], cf["mean_x"], cf["var_x"], dw, gm, inv, cf.get("sync", False))
+                gr[f"caf_{tag}_dw"] = gdw
             else:
                 mean_u = cf[tag + "_mean_u"]
                 Q = inv * (dw * Bx - mean_u * A)
@@ -472,6 +458,40 @@ class HipTrainer:
             gr[f"caf_{tag}_g"], gr[f"caf_{tag}_be"] = Q, A.clone()
             coef[3 * j], coef[3 * j + 1], coef[3 * j + 2] = c1, c2, c3
         return coef.contiguous()
+
+
+def caf_bn_batch_stats(sums, n_local, sync):
+    """sums: fp64 [2, C] = (sum x, sum x^2) over this rank's n_local positions.  -> (mean, biased var, n, local sum x, local sum (x-mean)x)
+    in fp32; with sync (nn.SyncBatchNorm, train.py:145 sync_batchnorm=True) the statistics are those of the union of all ranks."""
+    local, n = sums, float(n_local)
+    if sync:
+        buf = torch.cat([sums.reshape(-1), torch.tensor([n], dtype=torch.float64, device=sums.device)])
+        torch.distributed.all_reduce(buf)
+        sums, n = buf[:-1].view(2, -1), float(buf[-1].item())
+    mean = sums[0] / n
+    var = (sums[1] / n - mean * mean).clamp_min(0)
+    lcov = local[1] - mean * local[0]  # sum_local (x - mean) x, differenced in fp64
+    return mean.float(), var.float(), n, local[0].float(), lcov.float()
+
+
+def caf_bn_adjoint(A, Bx, lsum, lcov, n, mean_x, var_x, dw, gm, inv, sync):
+    """Adjoint of u = dw*x -> BatchNorm(batch statistics) -> y = gm*uhat + be, given this rank's per-channel reductions
+    A = sum dy, Bx = sum dy*x.  Input gradient dx = dy*c1 + c2 + c3*x (coefficients use the statistics of ALL ranks when sync);
+    parameter gradients are this rank's share (DDP averages them afterwards, as with nn.SyncBatchNorm).
+    -> (c1, c2, c3, dgamma, dbeta, d(dw))"""
+    A_g, Bx_g = A, Bx
+    if sync:
+        AB = torch.stack([A, Bx])
+        torch.distributed.all_reduce(AB)
+        A_g, Bx_g = AB[0], AB[1]
+    Q_g = dw * inv * (Bx_g - mean_x * A_g)  # sum dy * uhat over all ranks
+    Q_l = dw * inv * (Bx - mean_x * A)
+    c1 = dw * gm * inv
+    c3 = -c1 * (Q_g / n) * (dw * inv)
+    c2 = -c1 * A_g / n - c3 * mean_x
+    # d(dw) = sum_local du*x, du = gm*inv*(dy - A_g/n - uhat*Q_g/n)
+    gdw = gm * inv * (Bx - (A_g / n) * lsum - (Q_g / n) * dw * inv * lcov)
+    return c1, c2, c3, Q_l, A.clone(), gdw
 
 
 # ============================================ reference-layout mapping ============================================

@@ -54,3 +54,52 @@ def test_two_rank_gloo_roundtrip():
     for rank, full, mx, sm in res:
         assert full == [float(i) for i in range(gb)]
         assert mx == 2.0 and sm == float(gb)
+
+
+# ---- SyncBatchNorm math of the CAF key/value embeddings across ranks (train.py:145 sync_batchnorm=True) ----------------------
+def _bn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtfs_net_amd.models.hip_train import caf_bn_adjoint, caf_bn_batch_stats
+
+    g = torch.Generator().manual_seed(5)
+    C, ns = 6, (40, 25)  # ragged shards
+    xs = [torch.randn(n, C, generator=g, dtype=torch.float64) * 2 + 0.5 for n in ns]
+    dys = [torch.randn(n, C, generator=g, dtype=torch.float64) for n in ns]
+    dw, gm, be = (torch.randn(C, generator=g, dtype=torch.float64) for _ in range(3))
+    eps = 1e-5
+    # this rank's share, as the HIP path sees it: per-channel sums only
+    x, dy = xs[rank], dys[rank]
+    sums = torch.stack([x.sum(0), (x * x).sum(0)])
+    mean, var, n, lsum, lcov = caf_bn_batch_stats(sums, x.shape[0], True)
+    inv = torch.rsqrt(dw.float() ** 2 * var + eps)
+    c1, c2, c3, dgamma, dbeta, gdw = caf_bn_adjoint(dy.sum(0).float(), (dy * x).sum(0).float(), lsum, lcov, n, mean, var, dw.float(), gm.float(), inv, True)
+    dx = dy.float() * c1 + c2 + c3 * x.float()
+    pg = torch.stack([gdw, dgamma, dbeta])
+    dist.all_reduce(pg)  # DDP would average; the sum must equal the single-process gradient
+    # single-process truth over the union of both shards
+    X = torch.cat(xs).requires_grad_(True)
+    p = [t.clone().requires_grad_(True) for t in (dw, gm, be)]
+    u = X * p[0]
+    y = (u - u.mean(0)) / torch.sqrt(u.var(0, unbiased=False) + eps) * p[1] + p[2]
+    (y * torch.cat(dys)).sum().backward()
+    lo = sum(ns[:rank])
+    q.put((rank, float((dx.double() - X.grad[lo:lo + ns[rank]]).abs().max()), float((pg.double() - torch.stack([t.grad for t in p])).abs().max()), n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_adjoint():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, edx, epg, n in res:
+        assert n == 65.0
+        assert edx < 1e-4 and epg < 1e-3, (rank, edx, epg)

@@ -69,9 +69,13 @@ def test_edge_lengths_against_oracle():
         assert rel(out, ref) < WAVE_TOL, (L, Tv)
 
 
-def test_train_mode_is_refused_loudly():
+def test_train_mode_runs_under_autograd_and_is_refused_without():
+    """train() + grad enabled = the HIP training step (tests/test_hip_backward.py checks its numbers); train() under no_grad
+    (BatchNorm batch statistics + dropout but nothing to differentiate) is not a path of the reference's train.py/test.py: refused loudly."""
     model, _, _ = make_model(4, "cuda")
     model.train()
     mix, _, emb = synth.synth_inputs(1, 8000, 12)
-    with pytest.raises(NotImplementedError):
+    out = model(mix.cuda(), emb.cuda())
+    assert out.requires_grad and out.grad_fn is not None and torch.isfinite(out).all()
+    with torch.no_grad(), pytest.raises(NotImplementedError):
         model(mix.cuda(), emb.cuda())
