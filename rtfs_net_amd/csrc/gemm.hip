@@ -234,22 +234,22 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
 // residual_conv (K = 64 -> N = 256) with the operands SWAPPED: out^T[n][p] = W[n][k] . E^T[k][p].
 //  * the weight is the MFMA A operand and lives in registers for the whole workgroup (64 VGPRs per
 //    wave: wave w owns output channels [64w, 64w+64)), so nothing but the 64-pixel E tile goes through LDS;
-//  * in the accumulator layout a lane owns pixel p = lane&31 and, per 4-register group, 4 CONSECUTIVE
-//    output channels -> the epilogue (gateway residual, +a0, store) is all 16-byte vector access;
-//  * 17 KB of LDS and ~170 VGPRs -> several workgroups per CU hide the HBM latency of the epilogue.
+//  * the accumulator (lane = pixel, 4-register group = 4 consecutive channels) is transposed through LDS one 32-pixel
+//    half at a time, so the epilogue (gateway residual, +a0, store) moves whole 1 KB pixel rows per wave-instruction;
+//  * 52 KB of LDS -> 2-3 workgroups per CU overlap one's MFMA phase with the others' memory phases.
 // Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
 // ------------------------------------------------------------------------------------------------
 template <bool HAS_A0>
 __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDE = 68;
+    constexpr int LDO = 260;
     __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
-    __shared__ __attribute__((aligned(16))) float Cs[3][kC];  // bias | gateway weight | gateway bias
+    __shared__ __attribute__((aligned(16))) float Ot[32 * LDO];  // one 32-pixel half of the output tile, pixel-major
     const int b = blockIdx.y;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     pro.init(b);
-    Cs[0][threadIdx.x] = epi.bias[threadIdx.x];
-    Cs[1][threadIdx.x] = epi.gw[threadIdx.x];
-    Cs[2][threadIdx.x] = epi.gb[threadIdx.x];
+    const int cq = (threadIdx.x & 63) * 4;  // this thread's channel quad in the coalesced epilogue
+    const float4 cbias = ld4(epi.bias + cq), cgw = ld4(epi.gw + cq), cgb = ld4(epi.gb + cq);
     // fold (mean, rstd, gamma, beta) of the four gLNs into scale/shift tables once: Ns[tensor][scale|shift][channel]
     __shared__ __attribute__((aligned(16))) float Ns[4][2][kH];
     const int c4 = (threadIdx.x & 15) * 4;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
-    __syncthreads();  // Cs / Ns tables
+    __syncthreads();  // Ns tables
 
     const int tile0 = blockIdx.x * tiles_per_wg;
 #pragma unroll 1
@@ -311,110 +311,110 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e1.w, acc[nt][1], 0, 0, 0);
             }
         }
-        __syncthreads();  // Es may be overwritten by the next tile while this wave is still in its epilogue
-        // epilogue: rows of the accumulator are output channels; register group g holds channels n0 + 8g + 4kh .. +3.
-        // All loads of one pixel sub-tile are issued before the first use (no data-dependent branch in between).
+        // Epilogue through LDS.  In the accumulator a lane owns ONE pixel and 16 B of channels, so a direct global epilogue makes
+        // every b128 access touch 32 pixel rows x 32 B (measured: 50 L1 tag accesses per wave-instruction, TA 60 % busy, the
+        // kernel issue-stalled behind it).  Transposed through LDS, thread = (channel quad, pixel row): one wave-instruction is
+        // one pixel's whole 1 KB row - 8 lines - for s_in, a0 and the store; the per-channel constants sit in registers.
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const int p = m0 + pt * 32 + i;
-            const size_t base = ((size_t)b * Mb + min(p, Mb - 1)) * kC + 64 * w + 4 * kh;
             float4 sv[8], av[8];
+            const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sv[j] = ld4(epi.s_in + base + 32 * (j >> 2) + 8 * (j & 3));
-            if (HAS_A0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = ld4(epi.a0 + base + 32 * (j >> 2) + 8 * (j & 3));
+            for (int it = 0; it < 8; ++it) {
+                const size_t o = ((size_t)b * Mb + min(prow + 4 * it, Mb - 1)) * kC + cq;
+                sv[it] = ld4(epi.s_in + o);
+                if (HAS_A0) av[it] = ld4(epi.a0 + o);
             }
+            __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int nt = j >> 2, g = j & 3;
-                const int n = 64 * w + 32 * nt + 8 * g + 4 * kh;
-                float4 v = f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]);
-                v = v + ld4(&Cs[0][n]) + prelu4(fma4(sv[j], ld4(&Cs[1][n]), ld4(&Cs[2][n])), epi.slope);
-                if (HAS_A0) v = v + av[j];
-                if (p < Mb) st4(epi.y + base + 32 * nt + 8 * g, v);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    st4(Ot + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh,
+                        f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]));
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = (threadIdx.x >> 6) + 4 * it;
+                float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4(fma4(sv[it], cgw, cgb), epi.slope);
+                if (HAS_A0) v = v + av[it];
+                if (prow + 4 * it < Mb) st4(epi.y + ((size_t)b * Mb + prow + 4 * it) * kC + cq, v);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// gateway + projection (K = 256 -> N = 64), operands swapped like resid_kernel: y^T[n][p] = Wp[n][k] . A^T[k][p].
-// Wave w = (nt = w&1: 32 output channels, kq = w>>1: one half of K); its weight fragments (64 VGPRs) stay in
-// registers; the 32-pixel A tile (gateway applied on load) is the only thing in LDS (33 KB -> 3-4 workgroups
-// per CU keep ~100 KB of loads in flight per CU).  The two K halves are summed through LDS; the epilogue
-// (bias, 16-byte stores, gLN partial sums) runs on the kq = 0 waves.
+// gateway + projection (K = 256 -> N = 64) on v_mfma_f32_16x16x4_f32, operands swapped like resid_kernel:
+// y^T[n][p] = Wp[n][k] . A^T[k][p].  64-pixel tile; wave w owns output channels 16w..16w+15 for ALL 64 pixels and the
+// WHOLE K, so there is no cross-wave reduction and every wave has the same epilogue.  The MFMA's K index is free as long
+// as both operands agree: lane group kk = lane>>4 takes k = 64kk + s at step s, which makes a lane's weights 64
+// consecutive floats (16 x float4, resident in VGPRs for the life of the workgroup) and its pixel operand 4 consecutive
+// floats per ds_read_b128 (feeds 4 MFMAs).  4 independent accumulators (the 4 pixel sub-tiles) are interleaved, so the
+// 40-cycle dependent latency of the 32-cycle instruction never shows.  The A tile (gateway applied on its way in) is the
+// only thing in LDS (66.6 KB -> 2 workgroups per CU: one in its 256-MFMA phase while the other stores / fetches /
+// writes back).  ~180 VGPRs, no spills (the 32x32x2 variants of this kernel needed 128 VGPRs of weights and spilled).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void proj_kernel(ProGateway pro, EpiBiasStats epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
-    constexpr int LDA = 260, LDR = 33;
-    __shared__ __attribute__((aligned(16))) float As[32 * LDA];
-    __shared__ float Rs[2][32 * LDR * 1];  // partial sums of the kq = 1 waves: [nt][n][p]
+__global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasStats epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+    constexpr int LDA = 260, TM = 64;
+    __shared__ __attribute__((aligned(16))) float As[TM * LDA];
     __shared__ float red[8];
     const int b = blockIdx.y;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
-    const int nt = w & 1, kq = w >> 1;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kk = lane >> 4;
 
-    float4 wf[16];
+    float4 wf[16];  // W[16w + j][64kk .. 64kk+63]
 #pragma unroll
-    for (int q = 0; q < 16; ++q) wf[q] = ld4(Wt + (size_t)(32 * nt + i) * 256 + 128 * kq + 8 * q + 4 * kh);
+    for (int t = 0; t < 16; ++t) wf[t] = ld4(Wt + (size_t)(16 * w + j) * 256 + 64 * kk + 4 * t);
+    const float4 bias4 = ld4(epi.bias + 16 * w + 4 * kk);
     const int c4 = (threadIdx.x & 63) * 4;  // this thread's channel quad of the A tile (constant across rows)
     const float4 gw4 = ld4(pro.gw + c4), gb4 = ld4(pro.gb + c4);
-    float4 bias4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias4[g] = ld4(epi.bias + 32 * nt + 8 * g + 4 * kh);
 
     float s = 0.f, qq = 0.f;
     const int tile0 = blockIdx.x * tiles_per_wg;
-    // raw A rows of the NEXT tile are fetched while the current tile is in its MFMA / epilogue phase
-    float4 araw[8];
+    float4 araw[16];
     auto fetch = [&](int m0) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) araw[it] = ld4(pro.x + ((size_t)b * Mb + min(m0 + (int)(threadIdx.x >> 6) + it * 4, Mb - 1)) * kC + c4);
+        for (int it = 0; it < 16; ++it) araw[it] = ld4(pro.x + ((size_t)b * Mb + min(m0 + w + it * 4, Mb - 1)) * kC + c4);
     };
-    fetch(tile0 * 32);
+    fetch(tile0 * TM);
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
-        const int m0 = (tile0 + tl) * 32;
+        const int m0 = (tile0 + tl) * TM;
         if (m0 >= Mb) break;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) st4(As + ((threadIdx.x >> 6) + it * 4) * LDA + c4, prelu4(fma4(araw[it], gw4, gb4), pro.slope));
-        if (tl + 1 < tiles_per_wg) fetch(min(m0 + 32, Mb - 1));
+        for (int it = 0; it < 16; ++it) st4(As + (w + it * 4) * LDA + c4, prelu4(fma4(araw[it], gw4, gb4), pro.slope));
+        if (tl + 1 < tiles_per_wg) fetch(min(m0 + TM, Mb - 1));  // flies under this tile's MFMAs
         __syncthreads();
-        floatx16 acc;
+        floatx4 acc[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int pt = 0; pt < 4; ++pt) acc[pt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const float* ap = As + j * LDA + 64 * kk;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 e = ld4(As + i * LDA + 128 * kq + 8 * q + 4 * kh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e.w, acc, 0, 0, 0);
+        for (int t = 0; t < 16; ++t) {
+            float4 e[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) e[pt] = ld4(ap + pt * 16 * LDA + 4 * t);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, e[pt].x, acc[pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].y, e[pt].y, acc[pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].z, e[pt].z, acc[pt], 0, 0, 0);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].w, e[pt].w, acc[pt], 0, 0, 0);
         }
-        if (kq == 1) {
+        __syncthreads();  // As consumed by every wave: the next tile may overwrite it while the epilogues run
+        // accumulator of sub-tile pt: channels 16w + 4kk .. +3 (registers 0..3) of pixel m0 + 16pt + j
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Rs[nt][acc_row(r) * LDR + i] = acc[r];
-        }
-        __syncthreads();  // As consumed by every wave; Rs published
-        if (kq == 0) {
-            const int p = m0 + i;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = 32 * nt + 8 * g + 4 * kh;
-                float4 v;
-                v.x = acc[4 * g] + Rs[nt][(8 * g + 4 * kh) * LDR + i];
-                v.y = acc[4 * g + 1] + Rs[nt][(8 * g + 4 * kh + 1) * LDR + i];
-                v.z = acc[4 * g + 2] + Rs[nt][(8 * g + 4 * kh + 2) * LDR + i];
-                v.w = acc[4 * g + 3] + Rs[nt][(8 * g + 4 * kh + 3) * LDR + i];
-                v = v + bias4[g];
-                if (p < Mb) {
-                    st4(epi.y + ((size_t)b * Mb + p) * kH + n, v);
-                    s += v.x + v.y + v.z + v.w;
-                    qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                }
+        for (int pt = 0; pt < 4; ++pt) {
+            const int p = m0 + 16 * pt + j;
+            if (p < Mb) {
+                const float4 v = f4(acc[pt][0], acc[pt][1], acc[pt][2], acc[pt][3]) + bias4;
+                st4(epi.y + ((size_t)b * Mb + p) * kH + 16 * w + 4 * kk, v);
+                s += v.x + v.y + v.z + v.w;
+                qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
             }
         }
-        // the next tile's As stores are ordered after this tile's Rs reads by the barrier that follows them
     }
     __syncthreads();
     block_stats_commit(s, qq, red, epi.slot, b);
@@ -460,7 +460,7 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
     ProGateway pro{s, gw, gb, gslope};
     EpiBiasStats epi{y, bias, kH, stats_out};
     if (B <= 0 || TF <= 0) return RTFS_EINVAL;
-    const int tiles = (TF + 31) / 32, per = 16;  // swept 4..64: flat between 8 and 64
+    const int tiles = (TF + 63) / 64, per = 8;
     hipLaunchKernelGGL(proj_kernel, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, TF, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
