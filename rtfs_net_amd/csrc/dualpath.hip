@@ -283,6 +283,109 @@ __global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SRU layers 1-3, input projection FUSED into the recurrence: U = h_prev . W never exists in HBM.
+// One wave per sequence.  Per 32-step chunk the wave computes its own six 32x32 tiles U_(d,m)[step][j] = h_prev[t_d(step)] . W_(m,d,j)
+// on the MFMA pipe (rows = the chunk's 32 steps in the scan order of direction d: t_0 = step, t_1 = L-1-step; columns = the 32
+// hidden units) - 192 MFMAs - then every lane swaps one half of its accumulators with lane ^ 32, which leaves lane (d, j) holding
+// all 32 steps of ITS column for m = 0,1,2 in registers, and the recurrence runs out of registers.  HBM traffic per layer: read h_prev, write h (2 x 58 MB at B = 32) instead of
+// GEMM + scan's 524 MB; the weight (48 KB) sits in LDS for the 4 waves of the workgroup.
+//   A operand: lane (i, kh) supplies h_prev[t(i)][32kh + s] at MFMA step s (the K order is free as long as A and B agree), i.e.
+//   32 consecutive floats of one row = 8 x 16-byte loads;  B operand: W[(m, d, j=i)][32kh + s] via ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+template <bool SAVE_C>
+__global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
+                                                           const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
+                                                           float* __restrict__ Cout, int S, int L) {
+    constexpr int LDW = 68;
+    __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
+    for (int idx = threadIdx.x; idx < 192 * 16; idx += 256) {
+        const int n = idx >> 4, q4 = (idx & 15) * 4;
+        st4(Ws + n * LDW + q4, ld4(Wt + n * 64 + q4));
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const bool rev = lane >= 32;
+    const float wf = wc[lane], wr = wc[64 + lane], bf = bias[lane], br = bias[64 + lane];
+    const float* hp = Hprev + (size_t)s * L * 64;
+    float* ho = Hout + (size_t)s * L * 64 + lane;
+    float* co = Cout + (size_t)s * L * 64 + lane;
+    float c = 0.f;
+    const int nch = (L + 31) >> 5;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int sl0 = ch * 32;
+        // A fragments of the two directions (rows past the end are clamped; their steps are never scanned)
+        const int ta = min(sl0 + i, L - 1), tb = max(L - 1 - (sl0 + i), 0);
+        float4 a0[8], a1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a0[q] = ld4(hp + (size_t)ta * 64 + 32 * kh + 4 * q);
+            a1[q] = ld4(hp + (size_t)tb * 64 + 32 * kh + 4 * q);
+        }
+        floatx16 acc[2][3];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[dd][m][r] = 0.f;
+        const float* wp = Ws + i * LDW + 32 * kh;
+        asm volatile("" : "+v"(wp));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk loop
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float4 b0 = ld4(wp + (m * 64) * LDW + 4 * q), b1 = ld4(wp + (m * 64 + 32) * LDW + 4 * q);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, b0.y, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, b1.y, acc[1][m], 0, 0, 0);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, b0.z, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, b1.z, acc[1][m], 0, 0, 0);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, b0.w, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, b1.w, acc[1][m], 0, 0, 0);
+            }
+        }
+        // skip inputs of this lane's own 32 steps (rows just read as A fragments: L1/L2 hits), issued once the A registers are dead
+        float xp[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int sl = min(sl0 + k, L - 1);
+            xp[k] = hp[(size_t)(rev ? L - 1 - sl : sl) * 64 + lane];
+        }
+        // lanes 0-31 keep dir 0, lanes 32-63 take dir 1: each lane hands its partner (lane ^ 32) the half it does not need
+        // (ds_bpermute; hipcc miscompiles a chain of __builtin_amdgcn_permlane32_swap on accumulator elements).  Afterwards
+        // acc[0][m][r] -> local step rho(r), acc[1][m][r] -> rho(r) + 4,  rho(r) = (r & 3) + 8 (r >> 2).
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x0 = acc[0][m][r], y0 = acc[1][m][r];
+                const float got = __shfl_xor(rev ? x0 : y0, 32, 64);
+                acc[0][m][r] = rev ? got : x0;
+                acc[1][m][r] = rev ? y0 : got;
+            }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int sl = sl0 + k;
+            if (sl < L) {  // wave-uniform
+                const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
+                const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
+                const int t = rev ? L - 1 - sl : sl;
+                const float x = xp[k] * scale_x;
+                const float f = sigmoidf_fast(u1 + bf + wf * c);
+                const float rg = sigmoidf_fast(u2 + br + wr * c);
+                c = u0 + (c - u0) * f;
+                ho[(size_t)t * 64] = x + (c - x) * rg;
+                if (SAVE_C) co[(size_t)t * 64] = c;
+            }
+        }
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -337,6 +440,20 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
         hipLaunchKernelGGL((sru_scan_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, wc, bias, scale_x, H, S, L);
     else
         return RTFS_EINVAL;
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// SRU layers 1-3 with the input projection fused: Hprev, Hout [S][L][64]; Wt [192][64], row = m*64 + dir*32 + j (k contiguous);
+// Cout (optional, training): cell states [S][L][64].  Replaces rtfs_gemm_rows_fwd(64 -> 192) + rtfs_sru_scan_fwd(km = 3).
+int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null, int S,
+                       int L, void* stream) {
+    if (S <= 0 || L <= 0 || Hprev == Hout) return RTFS_EINVAL;
+    dim3 grid((S + 3) / 4);
+    if (Cout_or_null)
+        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, S, L);
+    else
+        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, S, L);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -29,6 +29,7 @@ SIGNATURES = {
     "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
+    "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, I, I, P],
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],

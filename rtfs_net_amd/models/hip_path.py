@@ -159,10 +159,10 @@ class HipForward:
         h = torch.empty(S * L * 64, device=dev)
         l0 = d["layers"][0]
         lib.call("rtfs_sru_scan_fwd", U, None, l0["wc"], l0["bias"], l0["scale_x"], h, S, L, 4)
-        for lw in d["layers"][1:]:
-            lib.call("rtfs_gemm_rows_fwd", h, lw["w"], None, U, S * L, 64, 192)
+        del U
+        for lw in d["layers"][1:]:  # input projection fused into the recurrence
             h2 = torch.empty_like(h)
-            lib.call("rtfs_sru_scan_fwd", U, h, lw["wc"], lw["bias"], lw["scale_x"], h2, S, L, 3)
+            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, S, L)
             h = h2
         lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
 
