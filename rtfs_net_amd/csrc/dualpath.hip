@@ -14,6 +14,8 @@
 // ConvTranspose1d is the same structure on the zero-padded SRU output: y[n] = sum_k' hpad[n + k'] . W'[k'].
 #include "common.h"
 
+#include <type_traits>
+
 namespace rtfs {
 
 struct SeqMap {  // sequence s -> base element offset; positions are pos_stride apart; channels contiguous
@@ -314,17 +316,21 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
     float* co = Cout + (size_t)s * L * 64 + lane;
     float c = 0.f;
     const int nch = (L + 31) >> 5;
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-        const int sl0 = ch * 32;
-        // A fragments of the two directions (rows past the end are clamped; their steps are never scanned)
+    // A fragments of the two directions (rows past the end are clamped; their steps are never scanned); the next chunk's are
+    // fetched as soon as the MFMAs have consumed the current ones, i.e. under the 32 recurrence steps
+    float4 a0[8], a1[8];
+    auto load_a = [&](int sl0) {
         const int ta = min(sl0 + i, L - 1), tb = max(L - 1 - (sl0 + i), 0);
-        float4 a0[8], a1[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             a0[q] = ld4(hp + (size_t)ta * 64 + 32 * kh + 4 * q);
             a1[q] = ld4(hp + (size_t)tb * 64 + 32 * kh + 4 * q);
         }
+    };
+    load_a(0);
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int sl0 = ch * 32;
         floatx16 acc[2][3];
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd)
@@ -332,8 +338,10 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[dd][m][r] = 0.f;
-        const float* wp = Ws + i * LDW + 32 * kh;
-        asm volatile("" : "+v"(wp));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk loop
+        int woff = i * LDW + 32 * kh;
+        asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
+                                        // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
+        const float* wp = Ws + woff;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -349,13 +357,7 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                 acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, b1.w, acc[1][m], 0, 0, 0);
             }
         }
-        // skip inputs of this lane's own 32 steps (rows just read as A fragments: L1/L2 hits), issued once the A registers are dead
-        float xp[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int sl = min(sl0 + k, L - 1);
-            xp[k] = hp[(size_t)(rev ? L - 1 - sl : sl) * 64 + lane];
-        }
+        if (ch + 1 < nch) load_a(sl0 + 32);
         // lanes 0-31 keep dir 0, lanes 32-63 take dir 1: each lane hands its partner (lane ^ 32) the half it does not need
         // (ds_bpermute; hipcc miscompiles a chain of __builtin_amdgcn_permlane32_swap on accumulator elements).  Afterwards
         // acc[0][m][r] -> local step rho(r), acc[1][m][r] -> rho(r) + 4,  rho(r) = (r & 3) + 8 (r >> 2).
@@ -368,21 +370,43 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                 acc[0][m][r] = rev ? got : x0;
                 acc[1][m][r] = rev ? y0 : got;
             }
+        // recurrence: 4 groups of 8 steps; a group's skip inputs x' (rows just read as A fragments: L1/L2 hits) are fetched one
+        // group ahead
+        float xa[8], xb[8];
+        auto load_x = [&](float(&xv)[8], int g) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int sl = sl0 + k;
-            if (sl < L) {  // wave-uniform
-                const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
-                const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
-                const int t = rev ? L - 1 - sl : sl;
-                const float x = xp[k] * scale_x;
-                const float f = sigmoidf_fast(u1 + bf + wf * c);
-                const float rg = sigmoidf_fast(u2 + br + wr * c);
-                c = u0 + (c - u0) * f;
-                ho[(size_t)t * 64] = x + (c - x) * rg;
-                if (SAVE_C) co[(size_t)t * 64] = c;
+            for (int k = 0; k < 8; ++k) {
+                const int sl = min(sl0 + 8 * g + k, L - 1);
+                xv[k] = hp[(size_t)(rev ? L - 1 - sl : sl) * 64 + lane];
             }
-        }
+        };
+        auto steps = [&](const float(&xv)[8], int g, auto G) {
+            constexpr int gg = decltype(G)::value;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int sl = sl0 + 8 * g + k8;
+                if (sl < L) {  // wave-uniform
+                    const int k = 8 * gg + k8;
+                    const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
+                    const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
+                    const int t = rev ? L - 1 - sl : sl;
+                    const float x = xv[k8] * scale_x;
+                    const float f = sigmoidf_fast(u1 + bf + wf * c);
+                    const float rg = sigmoidf_fast(u2 + br + wr * c);
+                    c = u0 + (c - u0) * f;
+                    ho[(size_t)t * 64] = x + (c - x) * rg;
+                    if (SAVE_C) co[(size_t)t * 64] = c;
+                }
+            }
+        };
+        load_x(xa, 0);
+        load_x(xb, 1);
+        steps(xa, 0, std::integral_constant<int, 0>{});
+        load_x(xa, 2);
+        steps(xb, 1, std::integral_constant<int, 1>{});
+        load_x(xb, 3);
+        steps(xa, 2, std::integral_constant<int, 2>{});
+        steps(xb, 3, std::integral_constant<int, 3>{});
     }
 }
 
