@@ -99,7 +99,11 @@ __device__ __forceinline__ float* spread_copy(float* scr, unsigned wg) { return 
 float* spread_scratch();                                             // zeroed [kSpread][kSpreadCap] floats of this device (nullptr on failure)
 int spread_finish(float* scr, const SpreadOut& o, hipStream_t st);   // dst[j][i] += sum over copies; re-zeroes the scratch
 
-__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each).  __frcp_rn expands to the full IEEE division sequence
+// (div_scale / rcp / 4 fma / div_fmas / div_fixup: 10 VALU instructions per gate), which dominated the recurrence kernels.
+constexpr float kNegLog2e = -1.4426950408889634f;
+__device__ __forceinline__ float sigmoid_from_exp2arg(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }  // a = -x log2 e
+__device__ __forceinline__ float sigmoidf_fast(float x) { return sigmoid_from_exp2arg(x * kNegLog2e); }
 __device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -301,16 +301,19 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                                                            float* __restrict__ Cout, int S, int L) {
     constexpr int LDW = 68;
     __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
+    // the gate rows (m = 1, 2) are pre-scaled by -log2(e): the recurrence then needs fma, v_exp, add, v_rcp per gate and nothing else
     for (int idx = threadIdx.x; idx < 192 * 16; idx += 256) {
         const int n = idx >> 4, q4 = (idx & 15) * 4;
-        st4(Ws + n * LDW + q4, ld4(Wt + n * 64 + q4));
+        const float sc = n >= 64 ? kNegLog2e : 1.0f;
+        st4(Ws + n * LDW + q4, ld4(Wt + n * 64 + q4) * sc);
     }
     __syncthreads();
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
     const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const bool rev = lane >= 32;
-    const float wf = wc[lane], wr = wc[64 + lane], bf = bias[lane], br = bias[64 + lane];
+    const float wf = wc[lane] * kNegLog2e, wr = wc[64 + lane] * kNegLog2e;
+    const float bf = bias[lane] * kNegLog2e, br = bias[64 + lane] * kNegLog2e;
     const float* hp = Hprev + (size_t)s * L * 64;
     float* ho = Hout + (size_t)s * L * 64 + lane;
     float* co = Cout + (size_t)s * L * 64 + lane;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dd][m][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[dd][m][r] = 0.f;  // (bias as initial value costs 64 live VGPRs at the loop top: spills)
         int woff = i * LDW + 32 * kh;
         asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
                                         // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int sl = min(sl0 + 8 * g + k, L - 1);
-                xv[k] = hp[(size_t)(rev ? L - 1 - sl : sl) * 64 + lane];
+                xv[k] = hp[(rev ? L - 1 - sl : sl) * 64 + lane];
             }
         };
         auto steps = [&](const float(&xv)[8], int g, auto G) {
@@ -391,11 +394,11 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                     const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
                     const int t = rev ? L - 1 - sl : sl;
                     const float x = xv[k8] * scale_x;
-                    const float f = sigmoidf_fast(u1 + bf + wf * c);
-                    const float rg = sigmoidf_fast(u2 + br + wr * c);
+                    const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
+                    const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
                     c = u0 + (c - u0) * f;
-                    ho[(size_t)t * 64] = x + (c - x) * rg;
-                    if (SAVE_C) co[(size_t)t * 64] = c;
+                    ho[t * 64] = x + (c - x) * rg;
+                    if (SAVE_C) co[t * 64] = c;
                 }
             }
         };
