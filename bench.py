@@ -144,15 +144,19 @@ def main():
             net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
 
+        from rtfs_net_amd.losses import PITLossWrapper, pairwise_neg_snr
+
+        loss_fn = PITLossWrapper(pairwise_neg_snr, pit_from="pw_mtx")  # train.py:98-101; HIP loss head (csrc/loss.hip)
+        target = target.unsqueeze(1)
+
         def step():
             opt.zero_grad(set_to_none=True)
-            est = net(mix, emb)[:, 0]
-            noise = est - target
-            loss = -(10 * torch.log10(target.square().sum(-1) / (noise.square().sum(-1) + 1e-8) + 1e-8)).mean()
+            est = net(mix, emb)
+            loss = loss_fn(est, target)
             loss.backward()
             torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
             opt.step()
-            return est
+            return est.detach()
 
         for _ in range(args.warmup):
             out = step()

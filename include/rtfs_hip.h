@@ -171,6 +171,15 @@ int rtfs_caf_bwd_apply(const float* dOut, const float* x, const float* ks, const
 int rtfs_istft_bwd(const float* dout, float* dspec, float* dtaps, int B, int L, void* stream);
 int rtfs_spec_patches(const float* spec, float* patches, int B, int T, void* stream);
 
+/* ---- f1: loss head, PairwiseNegSDR.forward src/losses/matrix.py:13-53 (the PIT search over the tiny [B][n][n] matrix stays on the host,
+ * src/losses/pit_wrapper.py:82-107) ------------------------------------------------------------------------------------------- */
+/* est, tgt [B][n_src][T]; sums [B][n_src][n_src][6] doubles, zeroed by the caller: (S_e, S_t, S_ee, S_tt, S_et, S_(e-t)^2) of pair (est i, target j) */
+int rtfs_neg_sdr_sums(const float* est, const float* tgt, double* sums, int B, int n_src, int T, void* stream);
+/* kind 0 snr / 1 sisdr / 2 sdsdr -> pw [B][n][n] = -10 log10(sdr + EPS) (take_log) and coef [B][n][n][4] = (ce, ct, mean e, mean t) */
+int rtfs_neg_sdr_finish(const double* sums, int kind, int zero_mean, int take_log, float* pw, float* coef, int B, int n_src, int T, void* stream);
+/* dest [B][n][T] = sum_j G[b][i][j] (ce (e_i - mean e_i) + ct (t_j - mean t_j)): the adjoint of pw w.r.t. the estimates */
+int rtfs_neg_sdr_grad(const float* est, const float* tgt, const float* coef, const float* G, float* dest, int B, int n_src, int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,9 @@ SIGNATURES = {
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
     "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, I, I, P],
+    "rtfs_neg_sdr_sums": [P, P, P, I, I, I, P],
+    "rtfs_neg_sdr_finish": [P, I, I, I, P, P, I, I, I, P],
+    "rtfs_neg_sdr_grad": [P, P, P, P, P, I, I, I, P],
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],

@@ -1,0 +1,58 @@
+"""Loss / PIT head: oracle vs the reference's golden vectors on CPU; HIP kernels vs both on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.loss_ref import pairwise_neg_sdr, pit_pw_mtx
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss.npz"))
+CASES = [(tag, kind) for tag in ("b3n1", "b2n2", "b2n3") for kind in ("snr", "sisdr", "sdsdr")]
+
+
+@pytest.mark.parametrize("tag,kind", CASES)
+def test_oracle_matches_reference_golden(tag, kind):
+    est, tgt = torch.from_numpy(GOLD[f"{tag}.est"]).requires_grad_(True), torch.from_numpy(GOLD[f"{tag}.tgt"])
+    pw = pairwise_neg_sdr(est, tgt, kind)
+    loss, _ = pit_pw_mtx(pw)
+    loss.backward()
+    assert np.allclose(pw.detach().numpy(), GOLD[f"{tag}.{kind}.pw"], rtol=1e-6, atol=1e-5)
+    assert abs(float(loss) - float(GOLD[f"{tag}.{kind}.loss"])) < 1e-5
+    assert np.allclose(est.grad.numpy(), GOLD[f"{tag}.{kind}.grad"], rtol=1e-4, atol=1e-8)
+
+
+def test_shape_errors_like_the_reference():
+    with pytest.raises(TypeError):
+        pairwise_neg_sdr(torch.zeros(2, 100), torch.zeros(2, 100))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kind", CASES)
+def test_hip_loss_matches_golden(tag, kind):
+    from rtfs_net_amd.losses import PairwiseNegSDR, PITLossWrapper
+
+    est = torch.from_numpy(GOLD[f"{tag}.est"]).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(GOLD[f"{tag}.tgt"]).cuda()
+    fn = PairwiseNegSDR(kind)
+    pw = fn(est, tgt)
+    loss = PITLossWrapper(fn, pit_from="pw_mtx")(est, tgt)
+    loss.backward()
+    assert np.allclose(pw.detach().cpu().numpy(), GOLD[f"{tag}.{kind}.pw"], rtol=1e-5, atol=1e-4)  # dB values
+    assert abs(float(loss) - float(GOLD[f"{tag}.{kind}.loss"])) < 1e-4
+    ref = GOLD[f"{tag}.{kind}.grad"]
+    assert np.abs(est.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+@pytest.mark.gpu
+def test_hip_loss_full_size_and_high_snr():
+    """B = 32 x 2 s utterances; an estimate 60 dB above the noise keeps its SNR to 1e-3 dB (S_dd is accumulated directly)"""
+    from rtfs_net_amd.losses import pairwise_neg_sisdr, pairwise_neg_snr
+
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.randn(32, 1, 32000, generator=g)
+    est = tgt + 1e-3 * torch.randn(32, 1, 32000, generator=g)
+    for fn, kind in ((pairwise_neg_snr, "snr"), (pairwise_neg_sisdr, "sisdr")):
+        out = fn(est.cuda(), tgt.cuda()).cpu()
+        ref = pairwise_neg_sdr(est.double(), tgt.double(), kind).float()
+        assert float((out - ref).abs().max()) < (1e-3 if kind == "snr" else 5e-2), kind
