@@ -107,6 +107,14 @@ __device__ __forceinline__ float sigmoidf_fast(float x) { return sigmoid_from_ex
 __device__ __forceinline__ float prelu(float x, float a) { return x >= 0.f ? x : a * x; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// wave-uniform base + 32-bit BYTE offset: selects the `global_load v, v_off, s[base]` form (no 64-bit VALU address math; a float
+// index would be scaled after the zero-extension and fall back to 64-bit adds)
+__device__ __forceinline__ float4 ld4_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st4_off(float* base, unsigned byte_off, float4 v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -122,6 +130,11 @@ __device__ __forceinline__ float4 norm4(float4 x, float mean, float rstd, float4
     return fma4(x, sc, sh);
 }
 __device__ __forceinline__ float4 prelu4(float4 x, float a) { return f4(prelu(x.x, a), prelu(x.y, a), prelu(x.z, a), prelu(x.w, a)); }
+// prelu(x) = x + (a - 1) min(x, 0): 2 (packable) instructions per pair instead of compare + select + multiply per element.
+// Differs from a*x by one rounding of (a - 1) x + x.   am1 = a - 1.
+__device__ __forceinline__ float4 prelu4_minfma(float4 x, float am1) {
+    return f4(fmaf(fminf(x.x, 0.f), am1, x.x), fmaf(fminf(x.y, 0.f), am1, x.y), fmaf(fminf(x.z, 0.f), am1, x.z), fmaf(fminf(x.w, 0.f), am1, x.w));
+}
 __device__ __forceinline__ float4 relu4(float4 x) { return f4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f)); }
 __device__ __forceinline__ float4 sigmoid4(float4 x) {
     return f4(sigmoidf_fast(x.x), sigmoidf_fast(x.y), sigmoidf_fast(x.z), sigmoidf_fast(x.w));

@@ -268,6 +268,14 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
     __syncthreads();  // Ns tables
 
+    // per-utterance base pointers (wave-uniform): everything below addresses with 32-bit offsets (an utterance is < 2^31 bytes)
+    const float* cl_b = pro.cl.x + (size_t)b * Mb * kH;
+    const float* d0_b = pro.d0.x + (size_t)b * Mb * kH;
+    const float* cg_b = pro.cg.x + (size_t)b * pro.T2 * kF2 * kH;
+    const float* cgate_b = pro.cgate.x + (size_t)b * pro.T2 * kF2 * kH;
+    const float* s_b = epi.s_in + (size_t)b * Mb * kC;
+    const float* a0_b = HAS_A0 ? epi.a0 + (size_t)b * Mb * kC : nullptr;
+    float* y_b = epi.y + (size_t)b * Mb * kC;
     const int tile0 = blockIdx.x * tiles_per_wg;
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
@@ -281,9 +289,8 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 const int row = min(m0 + (threadIdx.x >> 4) + it * 16, Mb - 1);
                 const int t = row / kF, f = row - t * kF;
                 const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
-                const size_t hi = ((size_t)b * Mb + row) * kH + c4;
-                const size_t lo = (((size_t)b * pro.T2 + t2) * kF2 + f2) * kH + c4;
-                xa[it] = ld4(pro.cl.x + hi), xd[it] = ld4(pro.d0.x + hi), xg[it] = ld4(pro.cg.x + lo), xs[it] = ld4(pro.cgate.x + lo);
+                const unsigned hi = ((unsigned)row * kH + c4) * 4u, lo = (((unsigned)t2 * kF2 + f2) * kH + c4) * 4u;  // byte offsets in the utterance
+                xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi), xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -321,9 +328,9 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const size_t o = ((size_t)b * Mb + min(prow + 4 * it, Mb - 1)) * kC + cq;
-                sv[it] = ld4(epi.s_in + o);
-                if (HAS_A0) av[it] = ld4(epi.a0 + o);
+                const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
+                sv[it] = ld4_off(s_b, o);
+                if (HAS_A0) av[it] = ld4_off(a0_b, o);
             }
             __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
 #pragma unroll
@@ -336,9 +343,9 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int r = (threadIdx.x >> 6) + 4 * it;
-                float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4(fma4(sv[it], cgw, cgb), epi.slope);
+                float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[it], cgw, cgb), epi.slope - 1.0f);
                 if (HAS_A0) v = v + av[it];
-                if (prow + 4 * it < Mb) st4(epi.y + ((size_t)b * Mb + prow + 4 * it) * kC + cq, v);
+                if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
             }
         }
     }
