@@ -137,6 +137,9 @@ int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, 
 int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* acc,
                      int acc_mode /* 0 none, 1 acc = ds, 2 acc += ds (running d(a0)) */, float* dgw, float* dgb, float* dslope, long long rows,
                      void* stream);
+/* the same adjoint applied to dG = dx + dy0 . Wp, formed on the fly (WpT [256][64]): replaces rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd */
+int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                          int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream);
 /* weight gradient of any 1x1 conv / linear map; rows may be segmented and nshift > 1 computes the taps of a Toeplitz map
  * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k] */
 int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias_or_null, long long M, int seg_len, int x_seg, int x_off, int nshift,

@@ -229,6 +229,122 @@ static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     }
 }
 
+// ---- projection input gradient + gateway adjoint, fused ------------------------------------------------------------------------
+// forward: G = prelu(u), u = s*gw + gb;  y0 = Wp . G + bp;  block output = ... + G.   Given dy0 [rows][64] and dx [rows][256] (the
+// gradient that reaches G through the residual), this kernel forms dG = dx + dy0 . Wp in registers (same 64 -> 256 GEMM shape as
+// resid_kernel: weights resident in VGPRs, 64-pixel tiles, accumulators transposed through LDS one 32-pixel half at a time) and
+// applies the gateway adjoint on the way out:  ds (= or +=) dG*prelu'(u)*gw, the running d(a0) sum, and the three parameter
+// reductions.  dG never exists in HBM: 2 GB less traffic per block than rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd.
+// ACCM: 0 none, 1 acc = ds, 2 acc += ds.   Wt: [256][64] (output channel major, k contiguous).
+template <bool ACCUM, int ACCM>
+__global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* __restrict__ dy0, const float* __restrict__ Wt, const float* __restrict__ dx,
+                                                                  const float* __restrict__ s_in, const float* __restrict__ gw,
+                                                                  const float* __restrict__ gb, float slope, float* __restrict__ ds,
+                                                                  float* __restrict__ acc_out, float* __restrict__ scr, int M, int tiles_per_wg) {
+    constexpr int LDE = 68, LDO = 260;
+    __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
+    __shared__ __attribute__((aligned(16))) float Ot[32 * LDO];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int cq = (threadIdx.x & 63) * 4, c4 = (threadIdx.x & 15) * 4;
+    const float4 cgw = ld4(gw + cq), cgb = ld4(gb + cq);
+    float4 wf[2][8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
+    float4 aw = f4(0, 0, 0, 0), ab = f4(0, 0, 0, 0);
+    float asl = 0.f;
+    const int tile0 = blockIdx.x * tiles_per_wg;
+#pragma unroll 1
+    for (int tl = 0; tl < tiles_per_wg; ++tl) {
+        const int m0 = (tile0 + tl) * 64;
+        if (m0 >= M) break;
+        {
+            float4 xa[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) xa[it] = ld4_off(dy0, ((unsigned)min(m0 + (int)(threadIdx.x >> 4) + it * 16, M - 1) * kH + c4) * 4u);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, xa[it]);
+        }
+        __syncthreads();
+        floatx16 acc[2][2];
+        acc_zero(acc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 e0 = ld4(Es + i * LDE + 8 * q + 4 * kh);
+            const float4 e1 = ld4(Es + (32 + i) * LDE + 8 * q + 4 * kh);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e0.x, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e1.x, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e0.y, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e1.y, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e0.z, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e1.z, acc[nt][1], 0, 0, 0);
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e0.w, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e1.w, acc[nt][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            // two sub-passes of 4 pixel rows per thread keep the loaded operands at 16 float4
+            const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
+            __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    st4(Ot + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh,
+                        f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]));
+            __syncthreads();
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float4 sv[4], xv[4], old[4], ao[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned o = ((unsigned)min(prow + 4 * (4 * half + k), M - 1) * kC + cq) * 4u;
+                    sv[k] = ld4_off(s_in, o), xv[k] = ld4_off(dx, o);
+                    if (ACCUM) old[k] = ld4_off(ds, o);
+                    if (ACCM == 2) ao[k] = ld4_off(acc_out, o);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = (threadIdx.x >> 6) + 4 * (4 * half + k), row = prow + 4 * (4 * half + k);
+                    if (row < M) {
+                        const float4 g = ld4(Ot + r * LDO + cq) + xv[k];
+                        const float4 u = fma4(sv[k], cgw, cgb);
+                        asl += (u.x > 0.f ? 0.f : g.x * u.x) + (u.y > 0.f ? 0.f : g.y * u.y) + (u.z > 0.f ? 0.f : g.z * u.z) + (u.w > 0.f ? 0.f : g.w * u.w);
+                        const float4 du = f4(u.x > 0.f ? g.x : g.x * slope, u.y > 0.f ? g.y : g.y * slope, u.z > 0.f ? g.z : g.z * slope,
+                                             u.w > 0.f ? g.w : g.w * slope);
+                        aw = fma4(du, sv[k], aw);
+                        ab = ab + du;
+                        float4 d = du * cgw;
+                        const unsigned o = ((unsigned)row * kC + cq) * 4u;
+                        if (ACCM == 1) st4_off(acc_out, o, d);
+                        if (ACCM == 2) st4_off(acc_out, o, d + ao[k]);
+                        if (ACCUM) d = d + old[k];
+                        st4_off(ds, o, d);
+                    }
+                }
+            }
+        }
+    }
+    // parameter gradients: threads (wave, cq) -> per channel over the 4 waves, one coalesced request per line into this
+    // workgroup's copy of the spread scratch [dgw 256 | dgb 256 | dslope]
+    __syncthreads();
+    float* red = Ot;  // 2 x 1024 floats + 4
+    st4(red + threadIdx.x * 4, aw);
+    st4(red + 1024 + threadIdx.x * 4, ab);
+    asl = wave_sum(asl);
+    if (lane == 0) red[2048 + w] = asl;
+    __syncthreads();
+    float* mine = spread_copy(scr, blockIdx.x);
+    const int c = threadIdx.x;
+    atomicAdd(mine + c, red[c] + red[256 + c] + red[512 + c] + red[768 + c]);
+    atomicAdd(mine + kC + c, red[1024 + c] + red[1280 + c] + red[1536 + c] + red[1792 + c]);
+    if (c == 0) atomicAdd(mine + 2 * kC, red[2048] + red[2049] + red[2050] + red[2051]);
+}
+
 // ---- Toeplitz input gradients ---------------------------------------------------------------------------------------------
 struct SeqMapB {
     int seq_div;
@@ -330,6 +446,25 @@ int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int
     else wgrad_launch<2, 2>(a, pro, st);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+// ds (= or +=) gateway adjoint of (dx + dy0 . Wp); see proj_gateway_bwd_kernel.  rows * 1 KB must stay below 4 GB (32-bit byte offsets).
+int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                          int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
+    if (rows <= 0 || rows * 1024 >= (1ll << 32) || acc_mode < 0 || acc_mode > 2 || (acc_mode && (!acc || accumulate))) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int M = (int)rows, tiles = (M + 63) / 64, per = 16;
+    const dim3 grid((tiles + per - 1) / per);
+    hipStream_t st = (hipStream_t)stream;
+#define PGB(A, MODE) hipLaunchKernelGGL((proj_gateway_bwd_kernel<A, MODE>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per)
+    if (accumulate) PGB(true, 0);
+    else if (acc_mode == 0) PGB(false, 0);
+    else if (acc_mode == 1) PGB(false, 1);
+    else PGB(false, 2);
+#undef PGB
+    RTFS_LAUNCH_CHECK();
+    return spread_finish(scr, SpreadOut{{dgw, dgb, dslope}, {kC, kC, 1}}, st);
 }
 
 // dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]

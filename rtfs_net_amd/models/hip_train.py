@@ -377,13 +377,14 @@ class HipTrainer:
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
         lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
-        lib.call("rtfs_gemm_rows", dy0, bw["pwT"], None, dx, B * TF, H, C, 1)  # dx (gateway residual path) += dy0 . Wp  = d(gateway out)
+        # d(gateway out) = dx (residual path) + dy0 . Wp, formed inside the gateway adjoint
         if a0_mode >= 3:
-            lib.call("rtfs_gateway_bwd", dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0, g("gw", C), g("gb", C),
-                     g("gslope", 1), B * TF)
+            lib.call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0,
+                     g("gw", C), g("gb", C), g("gslope", 1), B * TF)
             return da0
         ds = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gateway_bwd", dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C), g("gslope", 1), B * TF)
+        lib.call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C),
+                 g("gslope", 1), B * TF)
         return ds
 
     def backward(self, c, dout):
