@@ -408,6 +408,76 @@ __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const fl
     }
 }
 
+// Fold (input gradient of the unfold + layer-0 GEMM), K-chunked: dxn[pos][c] = sum_{k', n} dU0[pos + k' - 7][n] * Wt[c][k'*256 + n].
+// toeplitz_bwd_kernel<3> keeps a 71-row x 256-wide slab of dU0 in LDS (107 KB with the weight stages -> ONE workgroup per CU, the
+// MFMA pipe idles through every slab load).  Here the 256 columns are walked in four 64-wide chunks: slab chunk (64*NP+7) x 64 and the
+// 64x64 weight stages fit 2-3 workgroups per CU, the next slab chunk / weight stage travel through registers under the MFMAs.
+// Workgroup tile = 64*NP positions x 64 channels, 4 waves as (channel half) x (position half), weights first (lanes = positions).
+template <int NP>
+__global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void fold_gemm_bwd_kernel(SeqMapB map, const float* __restrict__ dU0, const float* __restrict__ Wt,
+                                                               float* __restrict__ dst) {
+    constexpr int TP = 64 * NP, ROWS = TP + 7, LDSL = 68, LDB = 68, SQ = ROWS * 16, SPT = (SQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float slab[ROWS * LDSL];
+    __shared__ __attribute__((aligned(16))) float Bs[2][64 * LDB];
+    const int s = blockIdx.y, m0 = blockIdx.x * TP;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = w >> 1, wn = w & 1;
+    const float* src = dU0 + (size_t)s * map.L * 256;
+    float4 sreg[SPT];
+    auto load_slab = [&](int nc) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = threadIdx.x + i * 256, row = idx >> 4, c4 = (idx & 15) * 4;
+            const int l = m0 + row - 7;
+            const bool ok = idx < SQ && l >= 0 && l < map.L;
+            sreg[i] = ld4(src + (size_t)min(max(l, 0), map.L - 1) * 256 + nc * 64 + c4);
+            if (!ok) sreg[i] = f4(0, 0, 0, 0);
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int idx = threadIdx.x + i * 256, row = idx >> 4, c4 = (idx & 15) * 4;
+            if (idx < SQ) st4(slab + row * LDSL + c4, sreg[i]);
+        }
+    };
+    ChunkRegs<64, 64> breg;
+    load_slab(0);
+    breg.load(Wt, 2048, 0);
+    store_slab();
+    breg.store(Bs[0], LDB);
+    __syncthreads();
+    floatx16 acc[1][NP];
+    acc_zero(acc);
+    int cur = 0;
+#pragma unroll 1
+    for (int nc = 0; nc < 4; ++nc) {
+        if (nc + 1 < 4) load_slab(nc + 1);  // in flight under the 8 taps of this chunk
+#pragma unroll 1
+        for (int kp = 0; kp < 8; ++kp) {
+            const bool last = nc == 3 && kp == 7;
+            if (!last) breg.load(Wt, 2048, (kp == 7 ? 0 : kp + 1) * 256 + (kp == 7 ? nc + 1 : nc) * 64);
+            mma_block<1, NP>(acc, Bs[cur] + wm * 32 * LDB, LDB, slab + (wn * 32 * NP + kp) * LDSL, LDSL, 64);
+            if (kp == 7 && nc + 1 < 4) {
+                __syncthreads();  // every wave is done with this slab chunk
+                store_slab();
+            }
+            if (!last) breg.store(Bs[cur ^ 1], LDB);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    const size_t sbase = map.base(s);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const int row = m0 + wn * 32 * NP + n * 32 + (lane & 31);
+        if (row < map.npos) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) st4(dst + sbase + (size_t)row * map.pos_stride + wm * 32 + 8 * g + 4 * (lane >> 5), acc_group(acc[0][n], g));
+        }
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -472,7 +542,10 @@ int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMapB m = make_map(dim, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
-    hipLaunchKernelGGL(toeplitz_bwd_kernel<3>, dim3((m.npos + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
+    if (m.npos > 64)
+        hipLaunchKernelGGL(fold_gemm_bwd_kernel<2>, dim3((m.npos + 127) / 128, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
+    else
+        hipLaunchKernelGGL(fold_gemm_bwd_kernel<1>, dim3((m.npos + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
