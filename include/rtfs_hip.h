@@ -65,9 +65,10 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
                       void* stream);
 /* SRU layers 1-3 with the input projection U = Hprev . W fused into the recurrence (U never reaches HBM): Wt [192][64], row = m*64 + dir*32 + j;
- * Cout_or_null: cell states for the training step.  Same result as rtfs_gemm_rows_fwd(64 -> 192) followed by rtfs_sru_scan_fwd(km = 3). */
+ * training (both or neither): Cout cell states [S][L][64] and Uout pre-activations [S][L][3][64] for rtfs_sru_scan_bwd.
+ * Same result as rtfs_gemm_rows_fwd(64 -> 192) followed by rtfs_sru_scan_fwd(km = 3). */
 int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
-                       int S, int L, void* stream);
+                       float* Uout_or_null, int S, int L, void* stream);
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream);
 /* generic row GEMM Y (= or +=) X . Wt^T (+bias): also every input-gradient GEMM of the backward pass (Wt = transposed weight) */
 int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream);

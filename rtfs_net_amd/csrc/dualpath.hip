@@ -295,10 +295,10 @@ __global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__
 //   A operand: lane (i, kh) supplies h_prev[t(i)][32kh + s] at MFMA step s (the K order is free as long as A and B agree), i.e.
 //   32 consecutive floats of one row = 8 x 16-byte loads;  B operand: W[(m, d, j=i)][32kh + s] via ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE_C>
+template <bool SAVE_C>  // training: also stores the cell states and the pre-activations U (the adjoint's inputs)
 __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
                                                            const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
-                                                           float* __restrict__ Cout, int S, int L) {
+                                                           float* __restrict__ Cout, float* __restrict__ Uout, int S, int L) {
     constexpr int LDW = 68;
     __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
     // the gate rows (m = 1, 2) are pre-scaled by -log2(e): the recurrence then needs fma, v_exp, add, v_rcp per gate and nothing else
@@ -317,6 +317,8 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
     const float* hp = Hprev + (size_t)s * L * 64;
     float* ho = Hout + (size_t)s * L * 64 + lane;
     float* co = Cout + (size_t)s * L * 64 + lane;
+    float* uo = Uout + (size_t)s * L * 192 + lane;  // [l][m][lane]
+    constexpr float kUnscale = 1.0f / kNegLog2e;
     float c = 0.f;
     const int nch = (L + 31) >> 5;
     // A fragments of the two directions (rows past the end are clamped; their steps are never scanned); the next chunk's are
@@ -398,7 +400,10 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                     const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
                     c = u0 + (c - u0) * f;
                     ho[t * 64] = x + (c - x) * rg;
-                    if (SAVE_C) co[t * 64] = c;
+                    if (SAVE_C) {
+                        co[t * 64] = c;
+                        uo[t * 192] = u0, uo[t * 192 + 64] = u1 * kUnscale, uo[t * 192 + 128] = u2 * kUnscale;
+                    }
                 }
             }
         };
@@ -472,15 +477,18 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
 }
 
 // SRU layers 1-3 with the input projection fused: Hprev, Hout [S][L][64]; Wt [192][64], row = m*64 + dir*32 + j (k contiguous);
-// Cout (optional, training): cell states [S][L][64].  Replaces rtfs_gemm_rows_fwd(64 -> 192) + rtfs_sru_scan_fwd(km = 3).
-int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null, int S,
-                       int L, void* stream) {
-    if (S <= 0 || L <= 0 || Hprev == Hout) return RTFS_EINVAL;
+// Training (both or neither): Cout cell states [S][L][64], Uout pre-activations [S][L][3][64] as rtfs_sru_scan_bwd reads them.
+// Replaces rtfs_gemm_rows_fwd(64 -> 192) + rtfs_sru_scan_fwd / rtfs_sru_scan_train_fwd (km = 3).
+int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
+                       float* Uout_or_null, int S, int L, void* stream) {
+    if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
     dim3 grid((S + 3) / 4);
     if (Cout_or_null)
-        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, S, L);
+        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
+                           Uout_or_null, S, L);
     else
-        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, S, L);
+        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
+                           Uout_or_null, S, L);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

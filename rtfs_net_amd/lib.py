@@ -29,7 +29,7 @@ SIGNATURES = {
     "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
-    "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, I, I, P],
+    "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, P, I, I, P],
     "rtfs_neg_sdr_sums": [P, P, P, I, I, I, P],
     "rtfs_neg_sdr_finish": [P, I, I, I, P, P, I, I, I, P],
     "rtfs_neg_sdr_grad": [P, P, P, P, P, I, I, I, P],

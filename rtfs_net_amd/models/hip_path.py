@@ -162,7 +162,7 @@ class HipForward:
         del U
         for lw in d["layers"][1:]:  # input projection fused into the recurrence
             h2 = torch.empty_like(h)
-            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, S, L)
+            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, None, S, L)
             h = h2
         lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
 

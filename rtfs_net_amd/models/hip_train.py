@@ -86,9 +86,8 @@ class HipTrainer:
         save.U.append(U0), save.h.append(h), save.c.append(c)
         for lw in d["layers"][1:]:
             U = torch.empty(S * L * 192, device=dev)
-            lib.call("rtfs_gemm_rows", h, lw["w"], None, U, S * L, 64, 192, 0)
             h2, c2 = torch.empty_like(h), torch.empty_like(h)
-            lib.call("rtfs_sru_scan_train_fwd", U, h, lw["wc"], lw["bias"], lw["scale_x"], h2, c2, S, L, 3)
+            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, c2, U, S, L)  # projection fused, U / c saved
             save.U.append(U), save.h.append(h2), save.c.append(c2)
             h = h2
         lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)

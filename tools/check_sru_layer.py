@@ -17,8 +17,9 @@ for S, L in ((5, 57), (3, 118), (2, 9), (4, 32), (1, 33), (7, 1)):
     ref = torch.empty_like(h)
     lib.call("rtfs_sru_scan_fwd", U, h, wc, bias, 0.7, ref, S, L, 3)
     out, cst = torch.empty_like(h), torch.empty_like(h)
-    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out, None, S, L)
+    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out, None, None, S, L)
     out2 = torch.empty_like(h)
-    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, S, L)
+    U2 = torch.empty_like(U)
+    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, U2, S, L)
     torch.cuda.synchronize()
-    print(S, L, float((out - ref).abs().max()), float((out2 - ref).abs().max()))
+    print(S, L, float((out - ref).abs().max()), float((out2 - ref).abs().max()), "U", float((U2 - U).abs().max()))
