@@ -56,3 +56,23 @@ def test_hip_loss_full_size_and_high_snr():
         out = fn(est.cuda(), tgt.cuda()).cpu()
         ref = pairwise_neg_sdr(est.double(), tgt.double(), kind).float()
         assert float((out - ref).abs().max()) < (1e-3 if kind == "snr" else 5e-2), kind
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4])
+def test_pit_search_host_logic_matches_oracle(n):
+    """PITLossWrapper.find_best_perm is host logic (torch): factorial search for n_src <= 3, Hungarian above (pit_wrapper.py:76-117)"""
+    from rtfs_net_amd.losses import PITLossWrapper
+
+    g = torch.Generator().manual_seed(n)
+    pw = torch.randn(5, n, n, generator=g)
+    min_loss, perm = PITLossWrapper.find_best_perm(pw)
+    ref_mean, ref_perm = pit_pw_mtx(pw)
+    assert abs(float(min_loss.mean()) - float(ref_mean)) < 1e-6
+    assert torch.equal(perm.cpu(), ref_perm)
+
+
+def test_loss_head_refuses_cpu_tensors():
+    from rtfs_net_amd.losses import pairwise_neg_snr
+
+    with pytest.raises(RuntimeError):
+        pairwise_neg_snr(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64))
