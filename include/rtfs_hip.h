@@ -175,6 +175,12 @@ int rtfs_caf_bwd_apply(const float* dOut, const float* x, const float* ks, const
 int rtfs_istft_bwd(const float* dout, float* dspec, float* dtaps, int B, int L, void* stream);
 int rtfs_spec_patches(const float* spec, float* patches, int B, int T, void* stream);
 
+/* ---- a9 / f3: VP block = TDANetBlock with is2d = False (separators/tdanet.py:106-133) + GlobalAttention (layers/attention.py:28-73,
+ * 192-220), eval mode, one launch: x, out [B][512][Tv] (NCT, as the reference hands the lip embedding); params: rtfs_vp_param_count()
+ * floats packed as VpOff in csrc/vp.hip (BatchNorm1d folded); pe: rows of the PositionalEncoding buffer [>= 16][64].  8 <= Tv <= 100. */
+int rtfs_vp_param_count(void);
+int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, float* out, int B, int Tv, void* stream);
+
 /* ---- f1: loss head, PairwiseNegSDR.forward src/losses/matrix.py:13-53 (the PIT search over the tiny [B][n][n] matrix stays on the host,
  * src/losses/pit_wrapper.py:82-107) ------------------------------------------------------------------------------------------- */
 /* est, tgt [B][n_src][T]; sums [B][n_src][n_src][6] doubles, zeroed by the caller: (S_e, S_t, S_ee, S_tt, S_et, S_(e-t)^2) of pair (est i, target j) */

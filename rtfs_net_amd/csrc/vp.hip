@@ -1,0 +1,324 @@
+// VP (video processing) block of the refinement module, eval mode, as ONE kernel:
+// TDANetBlock with is2d = False (separators/tdanet.py:106-133, config yaml:74-92) = gateway -> projection -> 4 depth-wise
+// down-samplings -> pooled sum -> GlobalAttention (MHSA with 8 heads + FFN, layers/attention.py:28-73,192-220) -> 4 + 3
+// InjectionMultiSum units (layers/fusion.py:54-69) -> residual conv + gateway residual.
+//
+// The whole block of one utterance is ~13 MFLOP on [64 x <=100] activations: one workgroup per utterance keeps every
+// intermediate in LDS (<= 158 KB at Tv = 100) and replaces the ~100 PyTorch launches of the glue path.  The two "large" maps
+// (512 -> 64 projection, 64 -> 512 residual conv) run lane = time step: the activation column sits in registers, the weights
+// are wave-uniform scalar loads, x / out are read / written coalesced along t.  BatchNorm1d is folded to (scale, shift) on the
+// host (eval statistics); training keeps the PyTorch glue (batch statistics / dropout).
+//
+// params: packed fp32 in the order of vp_off below (rtfs_net_amd/models/hip_path.py: pack_vp_params builds it).
+#include "common.h"
+
+namespace rtfs {
+
+constexpr int VIN = 512, VH = 64, VF = 128, VHEADS = 8, VHD = 8, VMAXT = 100, VSM = 8192;
+
+struct VpOff {  // float offsets into the packed parameter buffer
+    static constexpr int gw = 0, gb = gw + VIN, gslope = gb + VIN;
+    static constexpr int pw = gslope + 1, ps = pw + VH * VIN, psh = ps + VH, pslope = psh + VH;
+    static constexpr int down = pslope + 1;                 // 4 x (w[64][3], scale[64], shift[64])
+    static constexpr int down_sz = VH * 3 + 2 * VH;
+    static constexpr int ln1g = down + 4 * down_sz, ln1b = ln1g + VH;
+    static constexpr int inw = ln1b + VH, inb = inw + 3 * VH * VH, outw = inb + 3 * VH, outb = outw + VH * VH;
+    static constexpr int ln2g = outb + VH, ln2b = ln2g + VH;
+    static constexpr int encw = ln2b + VH, encg = encw + VF * VH, encb = encg + VF;
+    static constexpr int refw = encb + VF, refb = refw + VF * 3;
+    static constexpr int decw = refb + VF, decg = decw + VH * VF, decb = decg + VH;
+    static constexpr int ims = decb + VH;                   // 7 units x 3 convs x (w[64][3], scale[64], shift[64])
+    static constexpr int ims_conv = VH * 3 + 2 * VH, ims_unit = 3 * ims_conv;
+    static constexpr int rw = ims + 7 * ims_unit, rb = rw + VIN * VH;
+    static constexpr int total = rb + VIN;
+};
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// depth-wise conv k = 3 at output position t of a [64][Tin] LDS tensor: stride 1 'same' (pad 1,1) or stride 2 pad 1
+__device__ __forceinline__ float dw3(const float* in, int c, int Tin, int t, int stride, const float* w) {
+    const int c0 = t * stride - 1;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = c0 + k;
+        if (p >= 0 && p < Tin) s = fmaf(w[c * 3 + k], in[c * Tin + p], s);
+    }
+    return s;
+}
+
+// InjectionMultiSum with the global branch convolved at its own length then nearest-up-sampled (fusion.py:58-61; equal lengths
+// coincide with the other branch): out[c][t] = loc(local)[c][t] * sigmoid(gate(glob))[c][src] + emb(glob)[c][src] (+ res[c][t])
+__device__ void ims_unit(const float* P, const float* local, int Tn, const float* glob, int To, const float* res, float* out, float* ge, float* gg) {
+    const float *lw = P, *ls = P + VH * 3, *lsh = ls + VH;
+    const float *ew = P + VpOff::ims_conv, *es = ew + VH * 3, *esh = es + VH;
+    const float *gw_ = P + 2 * VpOff::ims_conv, *gs = gw_ + VH * 3, *gsh = gs + VH;
+    for (int idx = threadIdx.x; idx < VH * To; idx += 256) {
+        const int c = idx / To, t = idx - c * To;
+        ge[idx] = fmaf(es[c], dw3(glob, c, To, t, 1, ew), esh[c]);
+        gg[idx] = sigmoidf_fast(fmaf(gs[c], dw3(glob, c, To, t, 1, gw_), gsh[c]));
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < VH * Tn; idx += 256) {
+        const int c = idx / Tn, t = idx - c * Tn;
+        const int src = nearest_src(t, To, Tn);
+        float v = fmaf(fmaf(ls[c], dw3(local, c, Tn, t, 1, lw), lsh[c]), gg[c * To + src], ge[c * To + src]);
+        if (res) v += res[idx];
+        out[idx] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__ x, const float* __restrict__ P, const float* __restrict__ pe,
+                                                       float* __restrict__ out, int Tv) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    int T[4];
+    T[0] = Tv;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) T[i] = (T[i - 1] - 1) / 2 + 1;
+    const int Tg = T[3], sumT = T[0] + T[1] + T[2] + T[3];
+    float* DS = lds;                       // ds0..ds3, [64][Ti] each
+    float* W1 = DS + VH * sumT;            // three [64][T0] work buffers
+    float* W2 = W1 + VH * T[0];
+    float* W3 = W2 + VH * T[0];
+    float* SM = W3 + VH * T[0];            // VSM floats: pooled g + attention / IMS temporaries
+    float* dsp[4] = {DS, DS + VH * T[0], DS + VH * (T[0] + T[1]), DS + VH * (T[0] + T[1] + T[2])};
+    const float* xb = x + (size_t)b * VIN * Tv;
+    const float gslope = P[VpOff::gslope], pslope = P[VpOff::pslope];
+
+    // ---- S1: gateway (dw 1x1 + PReLU) + projection 512 -> 64 + BatchNorm + PReLU -> W1 [64][T0].  lane = t, wave = 16 channels.
+    for (int t0 = 0; t0 < Tv; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < Tv;
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll 1
+        for (int k0 = 0; k0 < VIN; k0 += 32) {
+            float g[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) g[k] = ok ? prelu(fmaf(xb[(size_t)(k0 + k) * Tv + t], P[VpOff::gw + k0 + k], P[VpOff::gb + k0 + k]), gslope) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float* wr = P + VpOff::pw + (size_t)(16 * w + j) * VIN + k0;  // wave-uniform: scalar loads
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc[j] = fmaf(wr[k], g[k], acc[j]);
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = 16 * w + j;
+                W1[c * Tv + t] = prelu(fmaf(P[VpOff::ps + c], acc[j], P[VpOff::psh + c]), pslope);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- S2: down-sampling chain (depth-wise k = 3 + bias + BatchNorm, stride 1 then 2, 2, 2)
+    for (int i = 0; i < 4; ++i) {
+        const float* dp = P + VpOff::down + i * VpOff::down_sz;
+        const float* in = i == 0 ? W1 : dsp[i - 1];
+        const int Tin = i == 0 ? T[0] : T[i - 1], To = T[i], stride = i == 0 ? 1 : 2;
+        for (int idx = tid; idx < VH * To; idx += 256) {
+            const int c = idx / To, t = idx - c * To;
+            dsp[i][idx] = fmaf(dp[VH * 3 + c], dw3(in, c, Tin, t, stride, dp), dp[VH * 4 + c]);
+        }
+        __syncthreads();
+    }
+    // ---- S3: g = sum_i adaptive_avg_pool1d(ds_i, Tg) -> SM[0 .. 64*Tg)
+    float* G = SM;
+    for (int idx = tid; idx < VH * Tg; idx += 256) {
+        const int c = idx / Tg, j = idx - c * Tg;
+        float s = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int st = (j * T[i]) / Tg, en = ((j + 1) * T[i] + Tg - 1) / Tg;
+            float a = 0.f;
+            for (int p = st; p < en; ++p) a += dsp[i][c * T[i] + p];
+            s += a / (float)(en - st);
+        }
+        G[idx] = s;
+    }
+    __syncthreads();
+    // ---- S4: GlobalAttention.  Temporaries in the (now free) W1..W3 span, 576 Tg <= 192 T0 floats: Y [Tg][64] (LN1 + PE, the
+    // attention residual), QKV [Tg][192], O [Tg][64], FFN hidden E / R2 [128][Tg]
+    float* Y = W1;
+    float* QKV = Y + Tg * VH;
+    float* O = QKV + Tg * 3 * VH;
+    float* E = O + Tg * VH;          // FFN hidden [128][Tg]
+    float* R2 = E + VF * Tg;         // FFN refined [128][Tg]
+    {
+        // LayerNorm over channels of g^T, + positional encoding (attention.py:48-52)
+        for (int t = w; t < Tg; t += 4) {
+            const float v = G[lane * Tg + t];
+            const float mean = wave_sum(v) * (1.f / 64.f);
+            const float d = v - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + kEps);
+            Y[t * VH + lane] = fmaf(d * rstd, P[VpOff::ln1g + lane], P[VpOff::ln1b + lane]) + pe[t * VH + lane];
+        }
+        __syncthreads();
+        // in-projection: QKV[t][n] = Y[t] . Win[n] + bin[n]
+        for (int idx = tid; idx < Tg * 3 * VH; idx += 256) {
+            const int t = idx / (3 * VH), n = idx - t * 3 * VH;
+            const float* wr = P + VpOff::inw + n * VH;
+            float s = P[VpOff::inb + n];
+            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], Y[t * VH + k], s);
+            QKV[idx] = s;
+        }
+        __syncthreads();
+        // per (head, query): softmax(q k^T / sqrt(8)) v
+        for (int idx = tid; idx < VHEADS * Tg; idx += 256) {
+            const int h = idx / Tg, tq = idx - h * Tg;
+            const float* q = QKV + tq * 3 * VH + h * VHD;
+            float sc[16], mx = -1e30f;
+            for (int tk = 0; tk < Tg; ++tk) {
+                const float* kx = QKV + tk * 3 * VH + VH + h * VHD;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < VHD; ++e) s = fmaf(q[e], kx[e], s);
+                sc[tk] = s * 0.35355339059327373f;
+                mx = fmaxf(mx, sc[tk]);
+            }
+            float den = 0.f;
+            for (int tk = 0; tk < Tg; ++tk) sc[tk] = __expf(sc[tk] - mx), den += sc[tk];
+            const float inv = 1.0f / den;
+#pragma unroll
+            for (int e = 0; e < VHD; ++e) {
+                float o = 0.f;
+                for (int tk = 0; tk < Tg; ++tk) o = fmaf(sc[tk], QKV[tk * 3 * VH + 2 * VH + h * VHD + e], o);
+                O[tq * VH + h * VHD + e] = o * inv;
+            }
+        }
+        __syncthreads();
+        // out-projection + residual (Y), LayerNorm2, transpose back, + block residual g  -> G (in place)
+        for (int t = w; t < Tg; t += 4) {
+            const float* wr = P + VpOff::outw + lane * VH;
+            float s = P[VpOff::outb + lane];
+            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], O[t * VH + k], s);
+            const float v = s + Y[t * VH + lane];
+            const float mean = wave_sum(v) * (1.f / 64.f);
+            const float d = v - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + kEps);
+            G[lane * Tg + t] += fmaf(d * rstd, P[VpOff::ln2g + lane], P[VpOff::ln2b + lane]);
+        }
+        __syncthreads();
+        // FFN: encoder 64 -> 128 (no bias) + gLN; refiner dw k = 3 + bias + ReLU; decoder 128 -> 64 + gLN; + residual
+        float ls = 0.f, lq = 0.f;
+        for (int idx = tid; idx < VF * Tg; idx += 256) {
+            const int n = idx / Tg, t = idx - n * Tg;
+            const float* wr = P + VpOff::encw + n * VH;
+            float s = 0.f;
+            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], G[k * Tg + t], s);
+            E[idx] = s;
+            ls += s, lq = fmaf(s, s, lq);
+        }
+        {
+            const float n = (float)(VF * Tg);
+            const float mean = block_sum256(ls, red) / n;
+            const float var = fmaxf(block_sum256(lq, red) / n - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + kEps);
+            for (int idx = tid; idx < VF * Tg; idx += 256) {
+                const int c = idx / Tg;
+                E[idx] = fmaf((E[idx] - mean) * rstd, P[VpOff::encg + c], P[VpOff::encb + c]);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < VF * Tg; idx += 256) {
+            const int c = idx / Tg, t = idx - c * Tg;
+            float s = P[VpOff::refb + c];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int p = t - 1 + k;
+                if (p >= 0 && p < Tg) s = fmaf(P[VpOff::refw + c * 3 + k], E[c * Tg + p], s);
+            }
+            R2[idx] = fmaxf(s, 0.f);
+        }
+        __syncthreads();
+        ls = 0.f, lq = 0.f;
+        float dv[4];  // this thread's decoder outputs (64*Tg <= 1024 -> at most 4 per thread)
+        for (int idx = tid, q = 0; idx < VH * Tg; idx += 256, ++q) {
+            const int c = idx / Tg, t = idx - c * Tg;
+            const float* wr = P + VpOff::decw + c * VF;
+            float s = 0.f;
+            for (int k = 0; k < VF; ++k) s = fmaf(wr[k], R2[k * Tg + t], s);
+            dv[q] = s;
+            ls += s, lq = fmaf(s, s, lq);
+        }
+        {
+            const float n = (float)(VH * Tg);
+            const float mean = block_sum256(ls, red) / n;
+            const float var = fmaxf(block_sum256(lq, red) / n - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + kEps);
+            for (int idx = tid, q = 0; idx < VH * Tg; idx += 256, ++q) {
+                const int c = idx / Tg;
+                G[idx] += fmaf((dv[q] - mean) * rstd, P[VpOff::decg + c], P[VpOff::decb + c]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- S5: fusion + concat chain (tdanet.py:124-129).  GE / GG temporaries after G in SM.
+    float* GE = SM + 1024;
+    float* GG = GE + VH * T[1];
+    const float* ims = P + VpOff::ims;
+    ims_unit(ims + 3 * VpOff::ims_unit, dsp[3], T[3], G, Tg, nullptr, W1, GE, GG);        // fused3 -> W1
+    ims_unit(ims + 2 * VpOff::ims_unit, dsp[2], T[2], G, Tg, nullptr, W2, GE, GG);        // fused2 -> W2
+    ims_unit(ims + 6 * VpOff::ims_unit, W2, T[2], W1, T[3], dsp[2], W3, GE, GG);          // exp2 = concat2(fused2, fused3) + ds2 -> W3
+    ims_unit(ims + 1 * VpOff::ims_unit, dsp[1], T[1], G, Tg, nullptr, W1, GE, GG);        // fused1 -> W1
+    ims_unit(ims + 5 * VpOff::ims_unit, W1, T[1], W3, T[2], dsp[1], W2, GE, GG);          // exp1 = concat1(fused1, exp2) + ds1 -> W2
+    ims_unit(ims + 0 * VpOff::ims_unit, dsp[0], T[0], G, Tg, nullptr, W1, GE, GG);        // fused0 -> W1
+    ims_unit(ims + 4 * VpOff::ims_unit, W1, T[0], W2, T[1], dsp[0], W3, GE, GG);          // exp0 = concat0(fused0, exp1) + ds0 -> W3
+    // ---- S6: residual conv 64 -> 512 + bias + gateway residual.  lane = t, wave = 128 output channels, exp0 column in registers.
+    float* ob = out + (size_t)b * VIN * Tv;
+    for (int t0 = 0; t0 < Tv; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < Tv;
+        float e[VH];
+#pragma unroll
+        for (int c = 0; c < VH; ++c) e[c] = ok ? W3[c * Tv + t] : 0.f;
+#pragma unroll 1
+        for (int j = 0; j < 128; ++j) {
+            const int co = 128 * w + j;
+            const float* wr = P + VpOff::rw + (size_t)co * VH;  // wave-uniform
+            float s = P[VpOff::rb + co];
+#pragma unroll
+            for (int c = 0; c < VH; ++c) s = fmaf(wr[c], e[c], s);
+            if (ok) ob[(size_t)co * Tv + t] = s + prelu(fmaf(xb[(size_t)co * Tv + t], P[VpOff::gw + co], P[VpOff::gb + co]), gslope);
+        }
+    }
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+extern "C" {
+
+int rtfs_vp_param_count(void) { return VpOff::total; }
+
+// x, out: [B][512][Tv] (the reference's NCT layout of the lip embedding); params: rtfs_vp_param_count() floats; pe: [>= Tg][64] rows
+// of the positional-encoding buffer.  8 <= Tv <= 100 (25 fps x 4 s).
+int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, float* out, int B, int Tv, void* stream) {
+    if (B <= 0 || Tv < 8 || Tv > VMAXT) return RTFS_EINVAL;
+    int T = Tv, sumT = Tv;
+    for (int i = 1; i < 4; ++i) T = (T - 1) / 2 + 1, sumT += T;
+    if (T > 16) return RTFS_EINVAL;
+    const size_t bytes = ((size_t)VH * (sumT + 3 * Tv) + VSM) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
+            return RTFS_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(vp_block_kernel, dim3(B), dim3(256), bytes, (hipStream_t)stream, x, params, pe, out, Tv);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+}  // extern "C"

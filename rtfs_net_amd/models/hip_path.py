@@ -9,6 +9,8 @@ Inference only for now (eval-mode BatchNorm, no autograd); training mode raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import lib
@@ -21,6 +23,41 @@ C = 256
 
 def _f32(t):
     return t.detach().to(torch.float32).contiguous()
+
+
+def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
+    """VP block parameters packed in the order of VpOff (csrc/vp.hip), BatchNorm1d folded with its running statistics (eval)."""
+    eps = 1e-5
+    f = lambda k: sd[prefix + k].detach().to(torch.float32)  # noqa: E731
+
+    def bn(name, conv_bias=None):
+        sc = f(name + ".weight") / torch.sqrt(f(name + ".running_var") + eps)
+        sh = f(name + ".bias") - f(name + ".running_mean") * sc
+        if conv_bias is not None:
+            sh = sh + sc * conv_bias
+        return sc, sh
+
+    parts = [f("gateway.full_layer.2.weight").reshape(-1), f("gateway.full_layer.2.bias"), f("gateway.full_layer.4.weight").reshape(-1)]
+    ps, psh = bn("projection.full_layer.3", f("projection.full_layer.2.bias"))
+    parts += [f("projection.full_layer.2.weight").reshape(64, 512).reshape(-1), ps, psh, f("projection.full_layer.4.weight").reshape(-1)]
+    for i in range(4):
+        q = f"downsample_layers.{i}.full_layer."
+        sc, sh = bn(q + "3", f(q + "2.bias"))
+        parts += [f(q + "2.weight").reshape(-1), sc, sh]
+    a = "globalatt.0.MHSA."
+    parts += [f(a + "norm1.weight"), f(a + "norm1.bias"), f(a + "attention.in_proj_weight").reshape(-1), f(a + "attention.in_proj_bias"),
+              f(a + "attention.out_proj.weight").reshape(-1), f(a + "attention.out_proj.bias"), f(a + "norm2.weight"), f(a + "norm2.bias")]
+    n = "globalatt.0.FFN."
+    parts += [f(n + "encoder.full_layer.2.weight").reshape(-1), f(n + "encoder.full_layer.3.norm.weight"), f(n + "encoder.full_layer.3.norm.bias"),
+              f(n + "refiner.full_layer.2.weight").reshape(-1), f(n + "refiner.full_layer.2.bias"),
+              f(n + "decoder.full_layer.2.weight").reshape(-1), f(n + "decoder.full_layer.3.norm.weight"), f(n + "decoder.full_layer.3.norm.bias")]
+    for unit in [f"fusion_layers.{i}" for i in range(4)] + [f"concat_layers.{i}" for i in range(3)]:
+        for e in ("local_embedding", "global_embedding", "global_gate"):
+            q = f"{unit}.{e}.full_layer."
+            sc, sh = bn(q + "3")
+            parts += [f(q + "2.weight").reshape(-1), sc, sh]
+    parts += [f("residual_conv.full_layer.2.weight").reshape(-1), f("residual_conv.full_layer.2.bias")]
+    return torch.cat([p_.reshape(-1) for p_ in parts]).contiguous()
 
 
 class PreparedWeights:
@@ -73,6 +110,18 @@ class PreparedWeights:
         wd = torch.zeros(32, C, device=dev)
         wd[:18] = sd["decoder.decoder.weight"].reshape(C, 18).t()
         w["dec_w"] = _f32(wd)
+        # a9 VP block (csrc/vp.hip): only the RTFS-Net family's video_params are built into the kernel; anything else keeps the glue path
+        w["vp"] = None
+        vn = model.refinement_module.video_net
+        vb = vn.get_block(0)
+        if (vn.shared and vn.repeats == 1 and vb.in_chan == 512 and vb.hid_chan == 64 and vb.kernel_size == 3 and vb.stride == 2
+                and vb.upsampling_depth == 4 and len(vb.globalatt) == 1 and type(vb.globalatt[0]).__name__ == "GlobalAttention"
+                and isinstance(vb.projection.full_layer[3], torch.nn.BatchNorm1d) and vb.globalatt[0].FFN.refiner.kernel_size == 3
+                and vb.globalatt[0].FFN.encoder.out_chan == 128 and vb.globalatt[0].MHSA.attention.num_heads == 8):
+            w["vp"] = _f32(pack_vp_params(sd)).to(dev)
+            if w["vp"].numel() != lib.load().rtfs_vp_param_count():
+                raise RuntimeError("VP parameter packing does not match csrc/vp.hip (VpOff)")
+            w["vp_pe"] = _f32(sd["refinement_module.video_net.blocks.globalatt.0.MHSA.pos_enc.pe"][0, :64]).to(dev)
         self.w = w
 
     @staticmethod
@@ -259,9 +308,14 @@ class HipForward:
             self._vp_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream()
         self._vp_stream.wait_stream(cur)
+        Tv = emb.shape[-1]
         with torch.cuda.stream(self._vp_stream):
-            v1 = m.refinement_module.video_net.get_block(0)(m.video_bottleneck(emb.to(torch.float32))).contiguous()
-        Tv = v1.shape[-1]
+            vin = m.video_bottleneck(emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
+            if w["vp"] is not None and 8 <= Tv <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
+                v1 = torch.empty_like(vin)
+                lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
+            else:  # other video_params / lengths: PyTorch-ROCm glue (models/modules.py)
+                v1 = m.refinement_module.video_net.get_block(0)(vin).contiguous()
 
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731

@@ -134,6 +134,8 @@ def test_ctypes_signatures_match_header():
     for name, args in protos.items():
         want = []
         for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a == "void":
+                continue
             if "*" in a:
                 want.append("P")
             elif a.startswith("long long"):

@@ -103,6 +103,31 @@ def test_block0(run):
     assert rel(_full(run, "block0", 256), run["otaps"]["block0"]) < STAGE_TOL
 
 
+def test_vp_block(run):
+    """a9 / f3: the one-launch VP block (csrc/vp.hip) against the oracle's TDANetBlock(is2d=False) + GlobalAttention"""
+    assert rel(run["taps"]["vp"], run["otaps"]["vp"]) < 5e-5
+
+
+@pytest.mark.parametrize("Tv", [8, 9, 25, 50, 63, 64, 65, 100])
+def test_vp_block_lengths_match_glue(Tv):
+    """every supported length (ragged down-sampling chains, two-pass lane = t loops) against the PyTorch-glue modules"""
+    import copy
+
+    import torch
+
+    from rtfs_net_amd import lib
+    from util import make_model
+
+    model, _, _ = make_model(2, "cuda")
+    pw = model._hip.weights().w
+    x = torch.randn(3, 512, Tv, generator=torch.Generator().manual_seed(Tv)).cuda()
+    out = torch.empty_like(x)
+    lib.call("rtfs_vp_block_fwd", x, pw["vp"], pw["vp_pe"], out, 3, Tv)
+    with torch.no_grad():
+        ref = model.refinement_module.video_net.get_block(0)(x)
+    assert rel(out.cpu(), ref.cpu()) < 2e-5
+
+
 def test_caf(run):
     got = _full(run, "caf_plus_a0", 256) - _full(run, "a0", 256)
     assert rel(got, run["otaps"]["caf"]) < STAGE_TOL
