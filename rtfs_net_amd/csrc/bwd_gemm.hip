@@ -211,6 +211,144 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Toeplitz weight gradient, all 8 taps in one workgroup:  dW[n][z*64 + k] += sum_r dY[r][n] * X[xrow(r) + z][k],  z = 0..7  (KIN = 64).
+// wgrad_kernel runs the taps as separate workgroups that each re-stage the same dY / X rows (24 KB of loads per 128 MFMAs);
+// here one 32-row stage = dY chunk [32][64] + the X slab of those rows (32 + 7 rows per segment touched, at most two segments)
+// feeds 512 MFMAs: wave w owns taps 2w, 2w+1 (2 x 2 x 2 accumulator tiles), so there is no cross-wave sum either.
+// The row index is the MFMA contraction index, hence uniform per k-step: the slab row of chunk row i is i (+7 once the chunk
+// has crossed into its second segment) + tap.  x_off shifts the window (conv-transpose: -7); rows outside [0, x_seg) are zero.
+__global__ __launch_bounds__(256, 2) void toeplitz_wgrad_kernel(WgradArgs a) {
+    constexpr int LD = 68, CH = 32, XR = CH + 14, STAGE = (CH + XR) * LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    __shared__ int s_nA[2];
+    const int nblocks = a.NOUT / 64;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int group = (local / nblocks) * 8 + xcd, nb = local % nblocks;
+    if (group >= a.ngroups) return;
+    const int n0 = nb * 64;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int r0 = group * a.rows_per_wg;
+    const int r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
+
+    // staging: thread -> (row, quad).  dY: 32 rows x 16 quads = 2 per thread; X slab: 46 rows x 16 quads = 736 -> 3 per thread
+    float4 yr[2], xr[3], bs[2];
+    bs[0] = bs[1] = f4(0, 0, 0, 0);
+    const bool want_bias = a.dbias != nullptr;
+    auto load = [&](int rb) {
+        // segment split of this chunk: rows [rb, rb+nA) lie in the first segment, the rest in the next one
+        const int seq0 = rb / a.seg_len, l0 = rb - seq0 * a.seg_len;
+        const int nA = min(CH, a.seg_len - l0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx >> 4, q4 = (idx & 15) * 4;
+            const int r = rb + lr;
+            yr[it] = ld4(a.dY + (size_t)min(r, r1 - 1) * a.ldy + n0 + q4);
+            if (r >= r1) yr[it] = f4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = threadIdx.x + it * 256, sr = idx >> 4, q4 = (idx & 15) * 4;  // slab row sr < 46
+            // piece A: slab rows [0, nA+7) <-> (seq0, l0 + x_off + sr); piece B: slab rows [nA+7, ..) <-> (seq0+1, x_off + sr - nA - 7)
+            const bool inB = sr >= nA + 7;
+            const int seq = seq0 + (inB ? 1 : 0);
+            const int xl = (inB ? sr - nA - 7 : l0 + sr) + a.x_off;
+            const bool ok = sr < XR && xl >= 0 && xl < a.x_seg && (size_t)seq * a.seg_len < (size_t)a.M;
+            const int xlc = min(max(xl, 0), a.x_seg - 1);
+            const long long srow = (long long)min(seq, (a.M - 1) / a.seg_len) * a.x_seg + xlc;
+            xr[it] = ld4(a.X + (size_t)srow * a.ldx + q4);
+            if (!ok) xr[it] = f4(0, 0, 0, 0);
+        }
+        return nA;
+    };
+    auto store = [&](float* st, int nA, int slot) {
+        float* Ys = st;
+        float* Xs = st + CH * LD;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = threadIdx.x + it * 256, lr = idx >> 4, q4 = (idx & 15) * 4;
+            st4(Ys + lr * LD + q4, yr[it]);
+            bs[it] = bs[it] + yr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = threadIdx.x + it * 256, sr = idx >> 4, q4 = (idx & 15) * 4;
+            if (sr < XR) st4(Xs + sr * LD + q4, xr[it]);
+        }
+        if (threadIdx.x == 0) s_nA[slot] = nA;
+    };
+
+    floatx16 acc[2][2][2];  // [tap of this wave][n tile][k tile]
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[z][m][n][r] = 0.f;
+    int nA = load(r0);
+    store(lds, nA, 0);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int rb = r0; rb < r1; rb += CH) {
+        const bool more = rb + CH < r1;
+        int nAn = 0;
+        if (more) nAn = load(rb + CH);
+        const float* Ys = lds + cur * STAGE;
+        const float* Xs = Ys + CH * LD;
+        const int nAc = s_nA[cur];
+#pragma unroll
+        for (int q = 0; q < CH; q += 8) {
+            float av[2][4], bv[2][2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q + kh * 4 + r;                    // chunk row = contraction index of this lane half
+                const int srow = row + (row >= nAc ? 7 : 0) + 2 * w;  // slab row of tap 2w
+#pragma unroll
+                for (int m = 0; m < 2; ++m) av[m][r] = Ys[row * LD + m * 32 + i];
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) bv[z][n][r] = Xs[(srow + z) * LD + n * 32 + i];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc[z][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bv[z][n][r], acc[z][m][n], 0, 0, 0);
+        }
+        if (more) store(lds + (cur ^ 1) * STAGE, nAn, cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // each wave owns its tiles: straight to the accumulator (one request per 128-byte line per tile row)
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    atomicAdd(a.dW + (size_t)(n0 + m * 32 + acc_row(r)) * a.ldw + (2 * w + z) * 64 + n * 32 + i, acc[z][m][n][r]);
+    if (want_bias) {
+        __syncthreads();
+        st4(lds + threadIdx.x * 4, bs[0]);
+        st4(lds + 1024 + threadIdx.x * 4, bs[1]);
+        __syncthreads();
+        if (threadIdx.x < 64) {  // column c = quad (tid & 15) * 4 + e: thread t sums the slots whose quad == t / 4
+            const int quad = threadIdx.x >> 2, e = threadIdx.x & 3;
+            float t = 0.f;
+            for (int j = 0; j < 32; ++j) t += lds[((j >> 4) * 256 + (j & 15) * 16 + quad) * 4 + e];
+            atomicAdd(a.dbias + n0 + threadIdx.x, t);
+        }
+    }
+}
+
 template <int NT, int KT>
 static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     WgradArgs a = a0;
@@ -511,6 +649,15 @@ int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int
     a.p0 = p0, a.p1 = p1, a.slope = slope, a.slot = stats, a.rows_per_b = rows_per_b > 0 ? rows_per_b : 1;
     a.inv_n = 1.0 / ((double)a.rows_per_b * KIN);
     hipStream_t st = (hipStream_t)stream;
+    if (nshift == 8 && KIN == 64 && NOUT % 64 == 0 && pro == 0 && a.seg_len >= 32 && a.seg_len) {  // unfold / conv-transpose weights
+        const int nblk = NOUT / 64;
+        long long rpw = ((long long)a.M * nblk / 1024 + 31) / 32 * 32;
+        a.rows_per_wg = (int)(rpw < 512 ? 512 : rpw);
+        a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
+        hipLaunchKernelGGL(toeplitz_wgrad_kernel, dim3((unsigned)((a.ngroups + 7) / 8 * 8 * nblk)), dim3(256), 0, st, a);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     if (NOUT >= 128 && NOUT % 128 == 0) wgrad_launch<4, 2>(a, pro, st);
     else if (KIN >= 128) wgrad_launch<2, 4>(a, pro, st);
     else wgrad_launch<2, 2>(a, pro, st);
