@@ -91,86 +91,91 @@ __global__ __launch_bounds__(256) void attn_qkv_norm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ gq, const float* __restrict__ gk, const float* __restrict__ gv,
                                                                 float* __restrict__ dYpre, float* __restrict__ scr, int BT, int T2, int tok_per_wg) {
     constexpr int LDY = 97;
-    __shared__ float Ys[64 * LDY];       // prelu(ypre) then zhat
-    __shared__ float Ds[64 * LDY];       // dN then dYpre
-    __shared__ float st[12][4];          // mean, rstd, s1, s2 per group
+    __shared__ float Yr[64 * LDY];       // raw ypre staged in memory order ([f][96]), read back in (n, f) ownership order
+    __shared__ float Ds[64 * LDY];       // dYpre staged in ownership order, written out in memory order
+    __shared__ float part[4][48];        // per-wave partial sums: 12 modules x (sum z, sum z^2, sum a, sum a z)
+    __shared__ float stat[12][4];        // mean, rstd, s1, s2 per module
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float ag[24], ab[24];
+    // element ownership: i = tid + 256k -> column n = wave + 4k, f = lane; the module of element k is a function of k alone
+    // (k for the Q/K modules, 8 + (k-8)/4 for V), so everything per-module below is a static register index.
+    float gam[24], ag[24], ab[24], asl[12];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) ag[k] = ab[k] = 0.f;
-    float asl[12];
+    for (int k = 0; k < 24; ++k) {
+        const int n = w + 4 * k, g = k < 8 ? k : 8 + ((k - 8) >> 2);
+        const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
+        const int e = (n - col0) * 64 + lane;
+        gam[k] = g < 4 ? gq[g * 256 + e] : (g < 8 ? gk[(g - 4) * 256 + e] : gv[(g - 8) * 1024 + e]);
+        ag[k] = ab[k] = 0.f;
+    }
 #pragma unroll
     for (int g = 0; g < 12; ++g) asl[g] = 0.f;
 
-    auto group_of = [](int n) { return n < 32 ? n >> 2 : 8 + ((n - 32) >> 4); };
     const int t0 = blockIdx.x * tok_per_wg, t1 = min(BT, t0 + tok_per_wg);
     for (int bt = t0; bt < t1; ++bt) {
         const int b = bt / T2, t = bt % T2;
-        __syncthreads();
-        // stage ypre (row-major [f][96]) -> Ys as prelu(ypre); keep raw ypre sign info by recomputing from Ypre later
-        for (int i = threadIdx.x; i < 64 * 96; i += 256) {
-            const int f = i / 96, n = i - f * 96;
-            Ys[f * LDY + n] = prelu(Ypre[(size_t)bt * 6144 + i], slope[n]);
+        float yraw[24], gN[24];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) yraw[k] = Ypre[(size_t)bt * 6144 + threadIdx.x + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {  // incoming gradients, already in ownership order (coalesced in f)
+            const int n = w + 4 * k;
+            if (k < 4) gN[k] = dQ[(((size_t)b * kHeadsB + (n >> 2)) * T2 + t) * 256 + (n & 3) * 64 + lane];
+            else if (k < 8) gN[k] = dK[(((size_t)b * kHeadsB + ((n - 16) >> 2)) * T2 + t) * 256 + ((n - 16) & 3) * 64 + lane];
+            else gN[k] = dV[(((size_t)b * kHeadsB + ((n - 32) >> 4)) * T2 + t) * 1024 + ((n - 32) & 15) * 64 + lane];
         }
-        // stage incoming gradients in (n,f) order (coalesced in f)
+        __syncthreads();  // previous token's Ds / Yr fully consumed
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
-            const int i = threadIdx.x + 256 * k, n = i >> 6, f = i & 63;
-            float g;
-            if (n < 16) g = dQ[(((size_t)b * kHeadsB + (n >> 2)) * T2 + t) * 256 + (n & 3) * 64 + f];
-            else if (n < 32) g = dK[(((size_t)b * kHeadsB + ((n - 16) >> 2)) * T2 + t) * 256 + ((n - 16) & 3) * 64 + f];
-            else g = dV[(((size_t)b * kHeadsB + ((n - 32) >> 4)) * T2 + t) * 1024 + ((n - 32) & 15) * 64 + f];
-            Ds[f * LDY + n] = g;
+            const int i = threadIdx.x + 256 * k, f = i / 96, n = i - f * 96;
+            Yr[f * LDY + n] = yraw[k];
         }
         __syncthreads();
-        // per-group statistics: wave w handles groups 3w .. 3w+2
-        for (int gi = 0; gi < 3; ++gi) {
-            const int g = w * 3 + gi;
-            const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16, ncol = g < 8 ? 4 : 16, cnt = 64 * ncol;
-            const float* gam = g < 4 ? gq + g * 256 : (g < 8 ? gk + (g - 4) * 256 : gv + (g - 8) * 1024);
-            float s = 0.f;
-            for (int i = lane; i < cnt; i += 64) s += Ys[(i & 63) * LDY + col0 + (i >> 6)];
-            const float mean = wave_sum(s) / cnt;
-            float q = 0.f;
-            for (int i = lane; i < cnt; i += 64) {
-                const float d = Ys[(i & 63) * LDY + col0 + (i >> 6)] - mean;
-                q = fmaf(d, d, q);
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / cnt + kEps);
-            float s1 = 0.f, s2 = 0.f;
-            for (int i = lane; i < cnt; i += 64) {  // i = c*64 + f inside the module
-                const float zh = (Ys[(i & 63) * LDY + col0 + (i >> 6)] - mean) * rstd;
-                const float a = Ds[(i & 63) * LDY + col0 + (i >> 6)] * gam[i];
-                s1 += a;
-                s2 = fmaf(a, zh, s2);
-            }
-            s1 = wave_sum(s1) / cnt, s2 = wave_sum(s2) / cnt;
-            if (lane == 0) st[g][0] = mean, st[g][1] = rstd, st[g][2] = s1, st[g][3] = s2;
-        }
-        __syncthreads();
-        // element-wise adjoint; results overwrite Ds
+        float yp[24], z[24], ps[48];
+#pragma unroll
+        for (int q = 0; q < 48; ++q) ps[q] = 0.f;
 #pragma unroll
         for (int k = 0; k < 24; ++k) {
-            const int i = threadIdx.x + 256 * k, n = i >> 6, f = i & 63;
-            const int g = group_of(n);
-            const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
-            const float gam = g < 4 ? gq[g * 256 + (n - col0) * 64 + f] : (g < 8 ? gk[(g - 4) * 256 + (n - col0) * 64 + f] : gv[(g - 8) * 1024 + (n - col0) * 64 + f]);
-            const float zh = (Ys[f * LDY + n] - st[g][0]) * st[g][1];
-            const float gN = Ds[f * LDY + n];
-            ag[k] = fmaf(gN, zh, ag[k]);
-            ab[k] += gN;
-            const float dz = (gN * gam - st[g][2] - zh * st[g][3]) * st[g][1];
-            const float yp = Ypre[(size_t)bt * 6144 + f * 96 + n];
-            if (yp <= 0.f) {
+            const int n = w + 4 * k, g = k < 8 ? k : 8 + ((k - 8) >> 2);
+            yp[k] = Yr[lane * LDY + n];
+            z[k] = prelu(yp[k], slope[n]);  // n is wave-uniform: scalar load
+            const float a = gN[k] * gam[k];
+            ps[4 * g] += z[k], ps[4 * g + 1] = fmaf(z[k], z[k], ps[4 * g + 1]), ps[4 * g + 2] += a, ps[4 * g + 3] = fmaf(a, z[k], ps[4 * g + 3]);
+        }
 #pragma unroll
-                for (int gg = 0; gg < 12; ++gg)
-                    if (gg == g) asl[gg] = fmaf(dz, yp, asl[gg]);
-            }
-            Ds[f * LDY + n] = yp > 0.f ? dz : dz * slope[n];
+        for (int q = 0; q < 48; ++q) {
+            const float v = wave_sum(ps[q]);
+            if (lane == 0) part[w][q] = v;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 64 * 96; i += 256) {
-            const int f = i / 96, n = i - f * 96;
+        if (threadIdx.x < 12) {
+            const int g = threadIdx.x;
+            const float cnt = g < 8 ? 256.f : 1024.f;
+            float sm[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sm[q] = part[0][4 * g + q] + part[1][4 * g + q] + part[2][4 * g + q] + part[3][4 * g + q];
+            const float mean = sm[0] / cnt;
+            const float var = fmaxf(sm[1] / cnt - mean * mean, 0.f);
+            const float rstd = 1.0f / sqrtf(var + kEps);
+            stat[g][0] = mean, stat[g][1] = rstd;
+            stat[g][2] = sm[2] / cnt;                              // s1 = mean(a)
+            stat[g][3] = (sm[3] - mean * sm[2]) * rstd / cnt;      // s2 = mean(a * zhat)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int n = w + 4 * k, g = k < 8 ? k : 8 + ((k - 8) >> 2);
+            const float mean = stat[g][0], rstd = stat[g][1];
+            const float zh = (z[k] - mean) * rstd;
+            ag[k] = fmaf(gN[k], zh, ag[k]);
+            ab[k] += gN[k];
+            const float dz = (gN[k] * gam[k] - stat[g][2] - zh * stat[g][3]) * rstd;
+            if (yp[k] <= 0.f) asl[g] = fmaf(dz, yp[k], asl[g]);
+            Ds[lane * LDY + n] = yp[k] > 0.f ? dz : dz * slope[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int i = threadIdx.x + 256 * k, f = i / 96, n = i - f * 96;
             dYpre[(size_t)bt * 6144 + i] = Ds[f * LDY + n];
         }
     }
@@ -179,10 +184,9 @@ __global__ __launch_bounds__(256) void attn_qkv_norm_bwd_kernel(const float* __r
     float *dgq = mine, *dbq = mine + 1024, *dgk = mine + 2048, *dbk = mine + 3072, *dgv = mine + 4096, *dbv = mine + 8192, *dslope = mine + 12288;
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
-        const int i = threadIdx.x + 256 * k, n = i >> 6, f = i & 63;
-        const int g = n < 32 ? n >> 2 : 8 + ((n - 32) >> 4);
+        const int n = w + 4 * k, g = k < 8 ? k : 8 + ((k - 8) >> 2);
         const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
-        const int e = (n - col0) * 64 + f;
+        const int e = (n - col0) * 64 + lane;
         float *pg, *pb;
         if (g < 4) pg = dgq + g * 256 + e, pb = dbq + g * 256 + e;
         else if (g < 8) pg = dgk + (g - 4) * 256 + e, pb = dbk + (g - 4) * 256 + e;
