@@ -164,6 +164,116 @@ __device__ __forceinline__ void norm_coef(const NormRefLite& r, int b, int c4, f
     sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
 }
 
+// Stride-1 depth-wise 4x4 convolution, LDS-staged.  The register-window kernel above issues one column's four loads per output
+// step and needs them in that same step, so every step pays a full memory latency (measured: 150-190 us for a 530 MB stream).
+// Here a workgroup stages the (16+3) x (8+3) pixel x 64 channel input block of 16 x 8 outputs with ALL loads in flight at once
+// (13 x 16 B per thread), applies the gLN / PReLU transform and the zero padding ONCE per element on the way into LDS, and the
+// sliding 4x4 window then walks LDS (100-cycle latency) instead of HBM.  53.5 KB of LDS: two workgroups per CU alternate
+// between their load and compute phases.   grid: (ceil(T/16), B, nseg); a workgroup walks its f segment in blocks of 8.
+template <int NCONV, int MODE>
+__global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
+    constexpr int TR = 16, TC = 8, R = TR + 3, CB = TC + 3, NLD = (R * CB * 16 + 255) / 256;
+    constexpr int RS = CB * 64;  // unpadded: ds_read_b128 serves lanes {0-3,12-15,20-27 | ...}, for which 256-byte rows at a multiple of
+                                 // 64 floats are already conflict-free (a +16 pad was measured 20 % slower)
+    __shared__ __attribute__((aligned(16))) float tile[R * RS];
+    __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NCONV * 256; i += 256) {
+        const int j = i >> 8, o = (i & 255) * 4;
+        st4(&ws[j][o], ld4(a.w[j] + o));
+    }
+    const int c4 = (threadIdx.x & 15) * 4, tr = threadIdx.x >> 4;
+    const int T = a.Tin, F = a.Fin;  // stride 1: output size == input size
+    const int t0 = blockIdx.x * TR, to = t0 + tr;
+    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
+    if (MODE >= 1) {
+        float mean, rstd;
+        stats_finalize(a.slot, b, a.inv_n, mean, rstd);
+        const float4 g = ld4(a.gamma + c4), be = ld4(a.beta + c4);
+        sc = g * rstd;
+        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+    }
+    const float* inb = a.in + (size_t)b * T * F * kH;
+    const bool tvalid = to < T;
+    float s[NCONV], q[NCONV];
+#pragma unroll
+    for (int j = 0; j < NCONV; ++j) s[j] = q[j] = 0.f;
+    float4 bias4[NCONV];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) bias4[k] = a.bias[k] ? ld4(a.bias[k] + c4) : f4(0, 0, 0, 0);
+    const size_t orow = (((size_t)b * T + (tvalid ? to : 0)) * F) * kH + c4;
+
+#pragma unroll 1
+    for (int fb = f0; fb < f1; fb += TC) {
+        // ---- stage input rows t0-1 .. t0+17, columns fb-1 .. fb+9 (transformed, zero outside the tensor)
+        float4 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256, r = idx / (CB * 16), rem = idx - r * (CB * 16), c = rem >> 4;
+            const int ti = t0 - 1 + r, fi = fb - 1 + c;
+            v[i] = ld4(inb + ((size_t)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4);
+        }
+        __syncthreads();  // previous block's window reads are done
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256, r = idx / (CB * 16), rem = idx - r * (CB * 16), c = rem >> 4;
+            const int ti = t0 - 1 + r, fi = fb - 1 + c;
+            float4 x = v[i];
+            if (MODE >= 1) x = fma4(x, sc, sh);
+            if (MODE == 2) x = prelu4(x, a.slope);
+            if (!(ti >= 0 && ti < T && fi >= 0 && fi < F)) x = f4(0, 0, 0, 0);
+            if (idx < R * CB * 16) st4(tile + r * RS + rem * 4, x);
+        }
+        __syncthreads();
+        // ---- 8 output columns from a sliding window over LDS (column c of the block lives in window slot c & 3)
+        const float* trow = tile + tr * RS + c4;
+        float4 win[4][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) win[c][r] = ld4(trow + r * RS + c * 64);
+#pragma unroll 1
+        for (int jb = 0; jb < TC; jb += 4) {
+        int woff = c4;
+        asm volatile("" : "+v"(woff));  // re-read the taps from LDS here: hoisted out of the loops they pin 64 VGPRs per convolution (spills)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jb + jj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) win[(jj + 3) & 3][r] = ld4(trow + r * RS + (j + 3) * 64);
+            float4 acc[NCONV];
+#pragma unroll
+            for (int k = 0; k < NCONV; ++k) acc[k] = bias4[k];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int df = 0; df < 4; ++df) {
+                    const float4 x = win[(jj + df) & 3][dt];
+#pragma unroll
+                    for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + woff]), x, acc[k]);  // taps: quad-broadcast LDS reads
+                }
+            const int fo = fb + j;
+            if (tvalid && fo < f1) {
+#pragma unroll
+                for (int k = 0; k < NCONV; ++k) {
+                    st4(a.out[k] + orow + (size_t)fo * kH, acc[k]);
+                    s[k] += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
+                    q[k] += acc[k].x * acc[k].x + acc[k].y * acc[k].y + acc[k].z * acc[k].z + acc[k].w * acc[k].w;
+                }
+            }
+        }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        __syncthreads();
+        block_stats_commit(s[k], q[k], red, a.stats[k], b);
+    }
+}
+
 // G = adaptive_avg_pool2d(gLN(D0p) -> (T2,F2)) + gLN(D1p); window [floor(i*in/out), ceil((i+1)*in/out)).
 __global__ __launch_bounds__(256) void pool_kernel(NormRefLite d0, NormRefLite d1, float* __restrict__ G, int T, int T2) {
     const int b = blockIdx.y;
@@ -302,6 +412,19 @@ using namespace rtfs;
 
 template <int STRIDE, int MODE>
 static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
+    if (STRIDE == 1) {  // LDS-staged kernel, f segments in multiples of its 8-column block
+        const int nseg = a.Fout >= 96 ? 4 : 2;
+        const int fseg = (((a.Fout + nseg - 1) / nseg) + 7) / 8 * 8;
+        dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
+        switch (a.nconv) {
+            case 1: hipLaunchKernelGGL((dwconv_s1_kernel<1, MODE>), grid, dim3(256), 0, st, a, fseg); break;
+            case 2: hipLaunchKernelGGL((dwconv_s1_kernel<2, MODE>), grid, dim3(256), 0, st, a, fseg); break;
+            case 4: hipLaunchKernelGGL((dwconv_s1_kernel<4, MODE>), grid, dim3(256), 0, st, a, fseg); break;
+            default: return RTFS_EINVAL;
+        }
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     const int nseg = a.Fout >= 96 ? 4 : 2;
     const int fseg = (((a.Fout + nseg - 1) / nseg) + 3) / 4 * 4;
     dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
