@@ -186,3 +186,26 @@ def test_istft_roundtrip():
     out = torch.empty(B, L, device="cuda")
     lib.call("rtfs_istft_fwd", taps, frames, out, B, L)
     assert rel(out, x) < 5e-6
+
+
+@pytest.mark.parametrize("S,L", [(5, 57), (3, 118), (2, 9), (4, 32), (1, 33), (7, 1)])
+def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
+    """rtfs_sru_layer_fwd (projection on MFMA inside the recurrence) == rtfs_gemm_rows_fwd(64->192) + rtfs_sru_scan_fwd, ragged lengths
+    (chunk boundaries at 32, single-step sequences), with and without the training saves (cell states, pre-activations)"""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(S * 131 + L)
+    h = torch.randn(S * L * 64, generator=g).cuda()
+    W = (torch.randn(192, 64, generator=g) * 0.2).cuda()
+    wc, bias = (torch.randn(128, generator=g) * 0.5).cuda(), (torch.randn(128, generator=g) * 0.5).cuda()
+    U = torch.empty(S * L * 192, device="cuda")
+    lib.call("rtfs_gemm_rows_fwd", h, W, None, U, S * L, 64, 192)
+    ref = torch.empty_like(h)
+    lib.call("rtfs_sru_scan_fwd", U, h, wc, bias, 0.7, ref, S, L, 3)
+    out, out2, cst, U2 = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h), torch.empty_like(U)
+    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out, None, None, S, L)
+    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, U2, S, L)
+    assert float((out - ref).abs().max()) < 2e-5 and float((out2 - ref).abs().max()) < 2e-5
+    assert float((U2 - U).abs().max()) < 2e-5
+    with pytest.raises(RuntimeError):  # saves come as a pair
+        lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
