@@ -18,8 +18,8 @@ constexpr int VIN = 512, VH = 64, VF = 128, VHEADS = 8, VHD = 8, VMAXT = 100, VS
 
 struct VpOff {  // float offsets into the packed parameter buffer
     static constexpr int gw = 0, gb = gw + VIN, gslope = gb + VIN;
-    static constexpr int pw = gslope + 1, ps = pw + VH * VIN, psh = ps + VH, pslope = psh + VH;
-    static constexpr int down = pslope + 1;                 // 4 x (w[64][3], scale[64], shift[64])
+    static constexpr int pw = gslope + 4, ps = pw + VH * VIN, psh = ps + VH, pslope = psh + VH;  // scalars padded to 4: rows stay 16-byte aligned
+    static constexpr int down = pslope + 4;                 // 4 x (w[64][3], scale[64], shift[64])
     static constexpr int down_sz = VH * 3 + 2 * VH;
     static constexpr int ln1g = down + 4 * down_sz, ln1b = ln1g + VH;
     static constexpr int inw = ln1b + VH, inb = inw + 3 * VH * VH, outw = inb + 3 * VH, outb = outw + VH * VH;
@@ -56,30 +56,64 @@ __device__ __forceinline__ float dw3(const float* in, int c, int Tin, int t, int
 // InjectionMultiSum with the global branch convolved at its own length then nearest-up-sampled (fusion.py:58-61; equal lengths
 // coincide with the other branch): out[c][t] = loc(local)[c][t] * sigmoid(gate(glob))[c][src] + emb(glob)[c][src] (+ res[c][t])
 __device__ void ims_unit(const float* P, const float* local, int Tn, const float* glob, int To, const float* res, float* out, float* ge, float* gg) {
-    const float *lw = P, *ls = P + VH * 3, *lsh = ls + VH;
-    const float *ew = P + VpOff::ims_conv, *es = ew + VH * 3, *esh = es + VH;
-    const float *gw_ = P + 2 * VpOff::ims_conv, *gs = gw_ + VH * 3, *gsh = gs + VH;
-    for (int idx = threadIdx.x; idx < VH * To; idx += 256) {
-        const int c = idx / To, t = idx - c * To;
-        ge[idx] = fmaf(es[c], dw3(glob, c, To, t, 1, ew), esh[c]);
-        gg[idx] = sigmoidf_fast(fmaf(gs[c], dw3(glob, c, To, t, 1, gw_), gsh[c]));
+    // thread = (channel c, time phase): the 3 x (3 taps, scale, shift) of ITS channel are loaded once into registers - a loop
+    // over (c, t) pairs would re-fetch them from global memory for every element, one exposed latency each
+    const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    float w_[3][3], sc_[3], sh_[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const float* q = P + e * VpOff::ims_conv;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w_[e][k] = q[c * 3 + k];
+        sc_[e] = q[VH * 3 + c], sh_[e] = q[VH * 4 + c];
+    }
+    auto conv = [&](const float* in, int Tin, int t, int e) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = t - 1 + k;
+            if (p >= 0 && p < Tin) s = fmaf(w_[e][k], in[c * Tin + p], s);
+        }
+        return fmaf(sc_[e], s, sh_[e]);
+    };
+    for (int t = ph; t < To; t += 4) {
+        ge[c * To + t] = conv(glob, To, t, 1);
+        gg[c * To + t] = sigmoidf_fast(conv(glob, To, t, 2));
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < VH * Tn; idx += 256) {
-        const int c = idx / Tn, t = idx - c * Tn;
+    for (int t = ph; t < Tn; t += 4) {
         const int src = nearest_src(t, To, Tn);
-        float v = fmaf(fmaf(ls[c], dw3(local, c, Tn, t, 1, lw), lsh[c]), gg[c * To + src], ge[c * To + src]);
-        if (res) v += res[idx];
-        out[idx] = v;
+        float v = fmaf(conv(local, Tn, t, 0), gg[c * To + src], ge[c * To + src]);
+        if (res) v += res[c * Tn + t];
+        out[c * Tn + t] = v;
     }
     __syncthreads();
+}
+
+// dot product of a global weight row (N floats, 16-byte aligned) with an LDS vector x[k * xs]: all N/4 weight loads are issued
+// before the first FMA (a rolled scalar loop pays one L2 latency per term)
+template <int N>
+__device__ __forceinline__ float dot_row(const float* __restrict__ wrow, const float* x, int xs, float init) {
+    float4 wv[N / 4];
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) wv[q] = ld4(wrow + 4 * q);
+    float s = init;
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        s = fmaf(wv[q].x, x[(4 * q) * xs], s);
+        s = fmaf(wv[q].y, x[(4 * q + 1) * xs], s);
+        s = fmaf(wv[q].z, x[(4 * q + 2) * xs], s);
+        s = fmaf(wv[q].w, x[(4 * q + 3) * xs], s);
+    }
+    return s;
 }
 
 __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__ x, const float* __restrict__ P, const float* __restrict__ pe,
                                                        float* __restrict__ out, int Tv) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: weight rows indexed by w become scalar (SMEM) loads
     int T[4];
     T[0] = Tv;
 #pragma unroll
@@ -98,6 +132,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     for (int t0 = 0; t0 < Tv; t0 += 64) {
         const int t = t0 + lane;
         const bool ok = t < Tv;
+        const int tc = ok ? t : Tv - 1;  // clamped: the loads below stay unconditional (a per-load branch serialises them)
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -105,7 +140,9 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         for (int k0 = 0; k0 < VIN; k0 += 32) {
             float g[32];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) g[k] = ok ? prelu(fmaf(xb[(size_t)(k0 + k) * Tv + t], P[VpOff::gw + k0 + k], P[VpOff::gb + k0 + k]), gslope) : 0.f;
+            for (int k = 0; k < 32; ++k) g[k] = xb[(size_t)(k0 + k) * Tv + tc];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) g[k] = prelu(fmaf(g[k], P[VpOff::gw + k0 + k], P[VpOff::gb + k0 + k]), gslope);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const float* wr = P + VpOff::pw + (size_t)(16 * w + j) * VIN + k0;  // wave-uniform: scalar loads
@@ -127,9 +164,17 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         const float* dp = P + VpOff::down + i * VpOff::down_sz;
         const float* in = i == 0 ? W1 : dsp[i - 1];
         const int Tin = i == 0 ? T[0] : T[i - 1], To = T[i], stride = i == 0 ? 1 : 2;
-        for (int idx = tid; idx < VH * To; idx += 256) {
-            const int c = idx / To, t = idx - c * To;
-            dsp[i][idx] = fmaf(dp[VH * 3 + c], dw3(in, c, Tin, t, stride, dp), dp[VH * 4 + c]);
+        {
+            const int c = tid & 63;
+            const float w0 = dp[c * 3], w1 = dp[c * 3 + 1], w2 = dp[c * 3 + 2], dsc = dp[VH * 3 + c], dsh = dp[VH * 4 + c];
+            for (int t = tid >> 6; t < To; t += 4) {
+                const int p0 = t * stride - 1;
+                float sacc = 0.f;
+                if (p0 >= 0) sacc = w0 * in[c * Tin + p0];
+                if (p0 + 1 < Tin) sacc = fmaf(w1, in[c * Tin + p0 + 1], sacc);
+                if (p0 + 2 < Tin) sacc = fmaf(w2, in[c * Tin + p0 + 2], sacc);
+                dsp[i][c * To + t] = fmaf(dsc, sacc, dsh);
+            }
         }
         __syncthreads();
     }
@@ -167,10 +212,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         // in-projection: QKV[t][n] = Y[t] . Win[n] + bin[n]
         for (int idx = tid; idx < Tg * 3 * VH; idx += 256) {
             const int t = idx / (3 * VH), n = idx - t * 3 * VH;
-            const float* wr = P + VpOff::inw + n * VH;
-            float s = P[VpOff::inb + n];
-            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], Y[t * VH + k], s);
-            QKV[idx] = s;
+            QKV[idx] = dot_row<VH>(P + VpOff::inw + n * VH, Y + t * VH, 1, P[VpOff::inb + n]);
         }
         __syncthreads();
         // per (head, query): softmax(q k^T / sqrt(8)) v
@@ -199,10 +241,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         __syncthreads();
         // out-projection + residual (Y), LayerNorm2, transpose back, + block residual g  -> G (in place)
         for (int t = w; t < Tg; t += 4) {
-            const float* wr = P + VpOff::outw + lane * VH;
-            float s = P[VpOff::outb + lane];
-            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], O[t * VH + k], s);
-            const float v = s + Y[t * VH + lane];
+            const float v = dot_row<VH>(P + VpOff::outw + lane * VH, O + t * VH, 1, P[VpOff::outb + lane]) + Y[t * VH + lane];
             const float mean = wave_sum(v) * (1.f / 64.f);
             const float d = v - mean;
             const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + kEps);
@@ -213,9 +252,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         float ls = 0.f, lq = 0.f;
         for (int idx = tid; idx < VF * Tg; idx += 256) {
             const int n = idx / Tg, t = idx - n * Tg;
-            const float* wr = P + VpOff::encw + n * VH;
-            float s = 0.f;
-            for (int k = 0; k < VH; ++k) s = fmaf(wr[k], G[k * Tg + t], s);
+            const float s = dot_row<VH>(P + VpOff::encw + n * VH, G + t, Tg, 0.f);
             E[idx] = s;
             ls += s, lq = fmaf(s, s, lq);
         }
@@ -245,9 +282,7 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
         float dv[4];  // this thread's decoder outputs (64*Tg <= 1024 -> at most 4 per thread)
         for (int idx = tid, q = 0; idx < VH * Tg; idx += 256, ++q) {
             const int c = idx / Tg, t = idx - c * Tg;
-            const float* wr = P + VpOff::decw + c * VF;
-            float s = 0.f;
-            for (int k = 0; k < VF; ++k) s = fmaf(wr[k], R2[k * Tg + t], s);
+            const float s = dot_row<VF>(P + VpOff::decw + c * VF, R2 + t, Tg, 0.f);
             dv[q] = s;
             ls += s, lq = fmaf(s, s, lq);
         }
@@ -279,17 +314,28 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
     for (int t0 = 0; t0 < Tv; t0 += 64) {
         const int t = t0 + lane;
         const bool ok = t < Tv;
+        const int tc = ok ? t : Tv - 1;
         float e[VH];
 #pragma unroll
-        for (int c = 0; c < VH; ++c) e[c] = ok ? W3[c * Tv + t] : 0.f;
+        for (int c = 0; c < VH; ++c) e[c] = W3[c * Tv + tc];
 #pragma unroll 1
-        for (int j = 0; j < 128; ++j) {
-            const int co = 128 * w + j;
-            const float* wr = P + VpOff::rw + (size_t)co * VH;  // wave-uniform
-            float s = P[VpOff::rb + co];
+        for (int j0 = 0; j0 < 128; j0 += 4) {
+            float xv[4], sv[4];
 #pragma unroll
-            for (int c = 0; c < VH; ++c) s = fmaf(wr[c], e[c], s);
-            if (ok) ob[(size_t)co * Tv + t] = s + prelu(fmaf(xb[(size_t)co * Tv + t], P[VpOff::gw + co], P[VpOff::gb + co]), gslope);
+            for (int u = 0; u < 4; ++u) xv[u] = xb[(size_t)(128 * w + j0 + u) * Tv + tc];  // unconditional, 4 rows in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int co = 128 * w + j0 + u;
+                const float* wr = P + VpOff::rw + (size_t)co * VH;  // wave-uniform: scalar loads
+                float acc1 = P[VpOff::rb + co];
+#pragma unroll
+                for (int c = 0; c < VH; ++c) acc1 = fmaf(wr[c], e[c], acc1);
+                sv[u] = acc1 + prelu(fmaf(xv[u], P[VpOff::gw + co], P[VpOff::gb + co]), gslope);
+            }
+            if (ok) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ob[(size_t)(128 * w + j0 + u) * Tv + t] = sv[u];
+            }
         }
     }
 }

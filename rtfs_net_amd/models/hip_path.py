@@ -37,9 +37,10 @@ def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
             sh = sh + sc * conv_bias
         return sc, sh
 
-    parts = [f("gateway.full_layer.2.weight").reshape(-1), f("gateway.full_layer.2.bias"), f("gateway.full_layer.4.weight").reshape(-1)]
+    pad4 = lambda t: torch.cat([t.reshape(-1), t.new_zeros(3)])  # noqa: E731  (scalars occupy 4 floats: weight rows stay 16-byte aligned)
+    parts = [f("gateway.full_layer.2.weight").reshape(-1), f("gateway.full_layer.2.bias"), pad4(f("gateway.full_layer.4.weight"))]
     ps, psh = bn("projection.full_layer.3", f("projection.full_layer.2.bias"))
-    parts += [f("projection.full_layer.2.weight").reshape(64, 512).reshape(-1), ps, psh, f("projection.full_layer.4.weight").reshape(-1)]
+    parts += [f("projection.full_layer.2.weight").reshape(64, 512).reshape(-1), ps, psh, pad4(f("projection.full_layer.4.weight"))]
     for i in range(4):
         q = f"downsample_layers.{i}.full_layer."
         sc, sh = bn(q + "3", f(q + "2.bias"))
