@@ -19,7 +19,8 @@
  * SRU hidden 32 x 2 directions, window 8, 4 attention heads, CAF "kernel_size" 4, lip embedding 512;
  * B, L (hence T, T2), Tv and the number of blocks are free.
  *
- * gLN statistics (`stats`): double[B][2] = (sum, sum of squares) over one utterance, ACCUMULATED by producers
+ * gLN statistics (`stats`): double[B][16], entries 0 and 1 = (sum, sum of squares) over one utterance (one 128-byte line per
+ * utterance so that the accumulating atomics of different utterances never queue on the same line), ACCUMULATED by producers
  * with fp64 atomics -- the caller zeroes the slot before the producing launch.
  */
 #ifndef RTFS_HIP_H
@@ -118,7 +119,7 @@ int rtfs_istft_fwd(const float* taps, float* frames, float* out, int B, int L, v
  * ====================================================================================================================== */
 int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream);
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream);
-/* GroupNorm(1,C) adjoint; act: 0 none, 1 PReLU after the norm (C=64), 2 ReLU after the norm (C=256); red: double[B][2] zeroed by caller */
+/* GroupNorm(1,C) adjoint; act: 0 none, 1 PReLU after the norm (C=64), 2 ReLU after the norm (C=256); red: double[B][16] (entries 0, 1 used) zeroed by caller */
 int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
                         float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream);
 int rtfs_gln_bwd_apply(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope,

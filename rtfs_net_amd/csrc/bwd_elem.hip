@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gln_bwd_apply_kernel(const float* __restr
     const int c4 = (threadIdx.x % QUADS) * 4;
     float mean, rstd;
     stats_finalize(n.slot, b, n.inv_n, mean, rstd);
-    const float m1 = (float)(red[2 * b] * n.inv_n), m2 = (float)(red[2 * b + 1] * n.inv_n);
+    const float m1 = (float)(red[kStatStride * b] * n.inv_n), m2 = (float)(red[kStatStride * b + 1] * n.inv_n);
     const float4 g4 = ld4(n.gamma + c4);
     const size_t o = ((size_t)b * rows + r) * C + c4;
     const float4 xh = sub4(ld4(n.x + o), mean) * rstd;

@@ -81,6 +81,11 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
 // grid: (ceil(T*F/64), B); each wave walks 16 pixels, each lane owns 4 output channels.
 __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__ spec, const float* __restrict__ Wp, float* __restrict__ a_emb,
                                                        double* __restrict__ stats, int T) {
+    // The 3x3 neighbourhood of pixel p = t*F + f is p + {-F,0,F} + {-1,0,1} in the flattened [T][F] spectrogram, so the 64 pixels of a
+    // workgroup need ONE contiguous range of 64 + 2(F+1) complex values: staged in LDS with a single coalesced load per thread, the
+    // per-pixel taps become wave-uniform LDS reads and nothing in the pixel loop waits on HBM (the kernel is a 1 GB write stream).
+    constexpr int HALO = kF + 1, NS = 64 + 2 * HALO;
+    __shared__ float2 sps[NS];
     __shared__ float red[8];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.y;
@@ -89,26 +94,34 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 18; ++i) wr[i] = ld4(Wp + i * 256 + lane * 4);
     const float2* sp = reinterpret_cast<const float2*>(spec) + (size_t)b * TF;
+    const int p0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < NS; i += 256) {
+        const int p = p0 - HALO + i;
+        sps[i] = (p >= 0 && p < TF) ? sp[p] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
     float s = 0.f, q = 0.f;
+#pragma unroll 4
     for (int i = 0; i < 16; ++i) {
-        const int p = blockIdx.x * 64 + w * 16 + i;
-        if (p >= TF) break;
-        const int t = p / kF, f = p - t * kF;
-        float4 acc = f4(0, 0, 0, 0);
+        const int p = p0 + w * 16 + i;
+        if (p < TF) {  // wave-uniform
+            const int t = p / kF, f = p - t * kF;
+            float4 acc = f4(0, 0, 0, 0);
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
+            for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-            for (int df = 0; df < 3; ++df) {
-                const int tt = t + dt - 1, ff = f + df - 1;
-                if (tt >= 0 && tt < T && ff >= 0 && ff < kF) {
-                    const float2 v = sp[tt * kF + ff];
-                    acc = fma4(wr[dt * 3 + df], f4(v.x, v.x, v.x, v.x), acc);
-                    acc = fma4(wr[9 + dt * 3 + df], f4(v.y, v.y, v.y, v.y), acc);
+                for (int df = 0; df < 3; ++df) {
+                    const int tt = t + dt - 1, ff = f + df - 1;
+                    const float m = (tt >= 0 && tt < T && ff >= 0 && ff < kF) ? 1.f : 0.f;  // 'same' zero padding (row wrap-around masked)
+                    const float2 v = sps[w * 16 + i + HALO + (dt - 1) * kF + (df - 1)];
+                    const float re = v.x * m, im = v.y * m;
+                    acc = fma4(wr[dt * 3 + df], f4(re, re, re, re), acc);
+                    acc = fma4(wr[9 + dt * 3 + df], f4(im, im, im, im), acc);
                 }
-            }
-        st4(a_emb + ((size_t)b * TF + p) * kC + lane * 4, acc);
-        s += acc.x + acc.y + acc.z + acc.w;
-        q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+            st4(a_emb + ((size_t)b * TF + p) * kC + lane * 4, acc);
+            s += acc.x + acc.y + acc.z + acc.w;
+            q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+        }
     }
     block_stats_commit(s, q, red, stats, b);
 }

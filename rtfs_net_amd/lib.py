@@ -14,6 +14,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "librtfs_hip.so"
 
+STAT_STRIDE = 16  # doubles per utterance in a gLN statistics slot (kStatStride in csrc/common.h): one 128-byte line each
+
 P = c_void_p
 I = c_int
 F = c_float

@@ -289,7 +289,7 @@ class HipForward:
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats
-        stats = torch.zeros(1 + 12 * R, B, 2, dtype=torch.float64, device=dev)
+        stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         taps = self.taps
 
         # a1: STFT + encoder conv

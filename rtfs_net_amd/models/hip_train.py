@@ -159,7 +159,7 @@ class HipTrainer:
         R = m.refinement_module.audio_net.repeats
         c = Ctx()
         c.B, c.L, c.T, c.T2, c.R, c.Tv = B, L, T, T2, R, att.shape[1]
-        c.stats = torch.zeros(1 + 12 * R, B, 2, dtype=torch.float64, device=dev)
+        c.stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         stats = c.stats
         c.spec = torch.empty(B * TF * 2, device=dev)
         lib.call("rtfs_stft_fwd", wav, c.spec, B, L)
@@ -231,7 +231,7 @@ class HipTrainer:
     def _gln_bwd(self, dN, X, st, gamma, beta, dX, accumulate, gr, key, B, rows, Cc=H, act=0, slope=0.0, dslope=None):
         """dN: gradient w.r.t. (act of) the normalised tensor; X: pre-norm; result dX (= or +=); gamma/beta grads into gr[key]."""
         dev = dN.device
-        red = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         dg, db = gr.setdefault(key + ".g", _zeros(Cc, dev)), gr.setdefault(key + ".b", _zeros(Cc, dev))
         lib.call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         lib.call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
