@@ -130,7 +130,10 @@ struct EpiMask {
     float* __restrict__ m_out;  // training: the post-ReLU mask itself (needed by the adjoint), or null
     __device__ void store2(int b, int Mb, int row, int col, float4 vr, float4 vi) const {
         const size_t o = ((size_t)b * Mb + row) * kC + col;
-        const float4 er = ld4(emb + o), ei = ld4(emb + o + 128);
+        store2e(b, Mb, row, col, vr, vi, ld4(emb + o), ld4(emb + o + 128));
+    }
+    __device__ void store2e(int b, int Mb, int row, int col, float4 vr, float4 vi, float4 er, float4 ei) const {
+        const size_t o = ((size_t)b * Mb + row) * kC + col;
         const float4 mr = relu4(vr + ld4(bias + col)), mi = relu4(vi + ld4(bias + col + 128));
         if (m_out) {
             st4(m_out + o, mr);
@@ -206,6 +209,54 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
     }
 
     const int i = lane & 31, kh = lane >> 5;
+    if constexpr (N == 256 && WGM == 1) {
+        // 256-wide outputs: accumulator-direct stores touch 32 pixel rows x 32 B per instruction (see resid_kernel).  Each 32-row
+        // tile is transposed through LDS (aliased on the weight stages, free after the last k-chunk) and leaves / meets its
+        // epilogue operands as whole 1 KB rows.
+        constexpr int LDO = 260;
+        static_assert(sizeof(Bs) >= 32 * LDO * sizeof(float), "output tile aliases the weight stages");
+        float* Ot = &Bs[0][0];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int rbase = m0 + m * 32;
+            // S3 mask: the embedding rows this thread will combine with are fetched (clamped, unconditional) before the transposition
+            float4 er[4], ei[4];
+            if constexpr (PAIRED) {
+                const int q4 = (threadIdx.x & 31) * 4;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const size_t o = ((size_t)b * Mb + min(rbase + (int)(threadIdx.x >> 5) + 8 * it, Mb - 1)) * kC + q4;
+                    er[it] = ld4(epi.emb + o), ei[it] = ld4(epi.emb + o + 128);
+                }
+            }
+            __syncthreads();  // m = 0: every wave left the k loop; m > 0: the previous tile has been read
+#pragma unroll
+            for (int n = 0; n < WN; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = PAIRED ? bcol0 + (n % (WN / 2)) * 32 + (n >= WN / 2 ? 128 : 0) + 8 * g + 4 * kh : bcol0 + n * 32 + 8 * g + 4 * kh;
+                    st4(Ot + i * LDO + col, acc_group(acc[n][m], g));
+                }
+            __syncthreads();
+            if constexpr (PAIRED) {
+                const int q4 = (threadIdx.x & 31) * 4;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = (threadIdx.x >> 5) + 8 * it;
+                    if (rbase + r < Mb) epi.store2e(b, Mb, rbase + r, q4, ld4(Ot + r * LDO + q4), ld4(Ot + r * LDO + 128 + q4), er[it], ei[it]);
+                }
+            } else {
+                const int cq = (threadIdx.x & 63) * 4;
+                const float4 cc = epi.colconst(cq);
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int r = (threadIdx.x >> 6) + 4 * it;
+                    if (rbase + r < Mb) epi.store(b, Mb, rbase + r, cq, ld4(Ot + r * LDO + cq), cc);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
         const int row = m0 + (wm * WM + m) * 32 + i;
