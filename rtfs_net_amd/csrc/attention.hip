@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
     for (int i = 0; i < 8; ++i) {
         const int idx = threadIdx.x + i * 256;
         const int row = idx >> 4, c4 = idx & 15;
-        float4 v = (row < ntok * 64) ? ld4(G + ((size_t)tok0 * 64 + row) * 64 + c4 * 4) : f4(0, 0, 0, 0);
+        float4 v = ld4(G + ((size_t)tok0 * 64 + min(row, ntok * 64 - 1)) * 64 + c4 * 4);  // clamped: loads stay unconditional and batched
+        if (row >= ntok * 64) v = f4(0, 0, 0, 0);
         st4(As + row * LDA + c4 * 4, v);
     }
 #pragma unroll
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
     // normalise and scatter into the per-head layouts
     for (int tok = 0; tok < ntok; ++tok) {
         const int bt = tok0 + tok, b = bt / T2, t = bt % T2;
-        for (int i = threadIdx.x; i < 4 * 256; i += 256) {  // Q and K: [h][e*64+f]
+#pragma unroll
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) {  // Q and K: [h][e*64+f]   (unrolled: the parameter loads of all iterations batch)
             const int h = i >> 8, ef = i & 255, e = ef >> 6, f = ef & 63;
             const size_t o = (((size_t)b * kHeads + h) * T2 + t) * 256 + ef;
             const float yq = Ys[(tok * 64 + f) * LDY + h * 4 + e], yk = Ys[(tok * 64 + f) * LDY + 16 + h * 4 + e];
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
             Q[o] = fmaf((yq - sq[0]) * sq[1], gq[i], bq[i]);
             Kx[o] = fmaf((yk - sk[0]) * sk[1], gk[i], bk[i]);
         }
+#pragma unroll
         for (int i = threadIdx.x; i < 4 * 1024; i += 256) {  // V: [h][c*64+f]
             const int h = i >> 10, cf = i & 1023, c = cf >> 6, f = cf & 63;
             const size_t o = (((size_t)b * kHeads + h) * T2 + t) * 1024 + cf;
@@ -283,6 +286,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) * (1.f / 4096.f) + kEps);
     float* g = G + tok * 4096;
+#pragma unroll
     for (int i = threadIdx.x; i < 4096; i += 256) {
         const int f = i >> 6, c = i & 63;
         const float y = (Ys[c * LDY + f] - mean) * rstd;
