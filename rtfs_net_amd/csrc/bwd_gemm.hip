@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const fl
         float4 v = f4(0, 0, 0, 0);
         if (MODE == 2) {
             const int pos = m0 + row;
-            if (pos < map.npos) v = ld4(src + sbase + (size_t)pos * map.pos_stride + c4);
+            v = ld4(src + sbase + (size_t)min(pos, map.npos - 1) * map.pos_stride + c4);
+            if (pos >= map.npos) v = f4(0, 0, 0, 0);
         } else {
             const int l = m0 + row - 7;
             if (l >= 0 && l < map.L) v = ld4(src + ((size_t)s * map.L + l) * 256 + c4);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
         if (MODE == 0) {
             const int pos = m0 + row;
             const bool ok = row < kSlabRows && pos < map.npos;
-            if (ok) v = ld4(src + sbase + (size_t)pos * map.pos_stride + c4 * 4);
+            v = ld4(src + sbase + (size_t)min(pos, map.npos - 1) * map.pos_stride + c4 * 4);
             // LayerNormalization4D over the 64 channels of this position (normalizations.py:33-37)
             float sum = v.x + v.y + v.z + v.w;
 #pragma unroll
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
             v = ok ? fma4(d * rstd, ld4(gamma + c4 * 4), ld4(beta + c4 * 4)) : f4(0, 0, 0, 0);
         } else {
             const int l = m0 + row - 7;
-            if (row < kSlabRows && l >= 0 && l < map.L) v = ld4(src + ((size_t)s * map.L + l) * 64 + c4 * 4);
+            v = ld4(src + ((size_t)s * map.L + min(max(l, 0), map.L - 1)) * 64 + c4 * 4);  // clamped + select: the slab loads stay batched
+            if (!(row < kSlabRows && l >= 0 && l < map.L)) v = f4(0, 0, 0, 0);
         }
         if (row < kSlabRows) st4(slab + row * kSlabLd + c4 * 4, v);
     }
@@ -113,6 +114,66 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
     }
 }
 
+
+// ConvTranspose1d (rnn_layers.py:153-156) as a Toeplitz GEMM with TWO 64-row slabs per workgroup (two sequences, or the two halves of
+// one): G[pos] += sum_{k', j} h3[pos + k' - 7][j] * Wt[c][k'*64 + j] + bias[c].  Against the 64-row toeplitz_gemm_kernel every 64 x 64
+// weight stage now feeds 128 rows (half the weight bytes and barriers per flop) and a wave owns 1 weight tile x 2 row tiles
+// (3 LDS reads per 8 MFMAs instead of 2 per 4).  Slab loads are unconditional (clamped + select).
+__global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias, float* __restrict__ dst, int tiles_per_seq, int total_tiles) {
+    constexpr int BK = 64, LDB = BK + 4, N = 64;
+    __shared__ __attribute__((aligned(16))) float slab[2][kSlabRows * kSlabLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][N * LDB];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int st = w >> 1, wn = w & 1;  // slab of this wave, column half (32 channels)
+    int seq[2], m0[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int gt = min((int)blockIdx.x * 2 + q, total_tiles - 1);
+        seq[q] = gt / tiles_per_seq;
+        m0[q] = (gt - seq[q] * tiles_per_seq) * 64;
+    }
+    ChunkRegs<N, BK> breg;
+    breg.load(Wt, 512, 0);
+    constexpr int NIT = (2 * kSlabRows * 16 + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = threadIdx.x + it * 256;
+        const int q = idx >= kSlabRows * 16 ? 1 : 0;
+        const int row = (idx - q * kSlabRows * 16) >> 4, c4 = (idx & 15) * 4;
+        const int l = m0[q] + row - 7;
+        float4 v = ld4(src + ((size_t)seq[q] * map.L + min(max(l, 0), map.L - 1)) * 64 + c4);
+        if (!(l >= 0 && l < map.L)) v = f4(0, 0, 0, 0);
+        if (idx < 2 * kSlabRows * 16) st4(slab[q] + row * kSlabLd + c4, v);
+    }
+    breg.store(Bs[0], LDB);
+    __syncthreads();
+    floatx16 acc[1][2];
+    acc_zero(acc);
+#pragma unroll 1
+    for (int kc = 0; kc < 8; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < 8) breg.load(Wt, 512, (kc + 1) * BK);
+        mma_block<1, 2>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab[st] + kc * kSlabLd, kSlabLd, BK);
+        if (kc + 1 < 8) breg.store(Bs[cur ^ 1], LDB);
+        __syncthreads();
+    }
+    if ((int)blockIdx.x * 2 + st < total_tiles) {
+        const size_t sbase = map.base(seq[st]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = m0[st] + m * 32 + (lane & 31);
+            if (row < map.npos) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wn * 32 + 8 * g + 4 * (lane >> 5);
+                    float* o = dst + sbase + (size_t)row * map.pos_stride + col;
+                    st4(o, acc_group(acc[0][m], g) + ld4(bias + col) + ld4(o));
+                }
+            }
+        }
+    }
+}
 
 // Layer-0 kernel, second generation: workgroup tile 128 rows x 256 columns = TWO 64-row slabs (two frequency
 // sequences, or the two halves of one time sequence), 4 waves as 2 (slab) x 2 (column half), each wave 64 x 128
@@ -455,8 +516,8 @@ int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
-    dim3 grid((m.npos + 63) / 64, S);
-    hipLaunchKernelGGL((toeplitz_gemm_kernel<64, 1, 1, 64, 1>), grid, dim3(256), 0, (hipStream_t)stream, m, H3, nullptr, nullptr, Wt, bias, G);
+    const int tps = (m.npos + 63) / 64, total = S * tps;
+    hipLaunchKernelGGL(convt_gemm2_kernel, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
