@@ -81,44 +81,60 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restri
     float* du = dU + (size_t)s * L * 64 * KM + (KM == 4 ? lane * 4 : lane);
     const size_t o64 = (size_t)s * L * 64 + lane;
     float dc = 0.f, awf = 0.f, awr = 0.f, abf = 0.f, abr = 0.f;
-#pragma unroll 2
-    for (int i = 0; i < L; ++i) {
-        // forward processed l_k = rev ? L-1-k : k for k = 0..L-1; the adjoint visits k = L-1-i
-        const int k = L - 1 - i;
-        const int l = rev ? L - 1 - k : k;
-        const int lp = rev ? l + 1 : l - 1;  // position processed just before l
-        const float cprev = (k > 0) ? Cst[o64 + (size_t)lp * 64] : 0.f;
-        const float c = Cst[o64 + (size_t)l * 64];
-        const float gh = dH[o64 + (size_t)l * 64];
-        float u0, u1, u2, xp;
-        if (KM == 4) {
-            const float4 v = ld4(u + (size_t)l * 256);
-            u0 = v.x, u1 = v.y, u2 = v.z, xp = v.w;
-        } else {
-            const float* p = u + (size_t)l * 192;
-            u0 = p[0], u1 = p[64], u2 = p[128];
-            xp = X[o64 + (size_t)l * 64] * scale_x;
+    // the loads of a step do not depend on the carried state: 8 steps are fetched (clamped, unconditional) ahead of the dependent
+    // chain, as in the forward scan (a per-step load pays one memory latency per step)
+    constexpr int UNR = 8;
+#pragma unroll 1
+    for (int i0 = 0; i0 < L; i0 += UNR) {
+        float cpv[UNR], cv[UNR], ghv[UNR], u0v[UNR], u1v[UNR], u2v[UNR], xpv[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            // forward processed l_k = rev ? L-1-k : k for k = 0..L-1; the adjoint visits k = L-1-i
+            const int k = max(L - 1 - (i0 + j), 0);
+            const int l = rev ? L - 1 - k : k;
+            const int lp = min(max(rev ? l + 1 : l - 1, 0), L - 1);  // position processed just before l (masked below when k == 0)
+            cpv[j] = Cst[o64 + (size_t)lp * 64];
+            cv[j] = Cst[o64 + (size_t)l * 64];
+            ghv[j] = dH[o64 + (size_t)l * 64];
+            if (KM == 4) {
+                const float4 v = ld4(u + (size_t)l * 256);
+                u0v[j] = v.x, u1v[j] = v.y, u2v[j] = v.z, xpv[j] = v.w;
+            } else {
+                const float* p = u + (size_t)l * 192;
+                u0v[j] = p[0], u1v[j] = p[64], u2v[j] = p[128];
+                xpv[j] = X[o64 + (size_t)l * 64] * scale_x;
+            }
         }
-        const float f = sigmoidf_fast(u1 + bf + wf * cprev);
-        const float r = sigmoidf_fast(u2 + br + wr * cprev);
-        const float dxp = gh * (1.f - r);
-        const float dr = gh * (c - xp);
-        const float du2 = dr * r * (1.f - r);
-        const float dct = gh * r + dc;
-        const float du0 = dct * (1.f - f);
-        const float df = dct * (cprev - u0);
-        const float du1 = df * f * (1.f - f);
-        dc = dct * f + du1 * wf + du2 * wr;
-        awf = fmaf(du1, cprev, awf);
-        awr = fmaf(du2, cprev, awr);
-        abf += du1;
-        abr += du2;
-        if (KM == 4) {
-            st4(du + (size_t)l * 256, f4(du0, du1, du2, dxp));
-        } else {
-            float* q = du + (size_t)l * 192;
-            q[0] = du0, q[64] = du1, q[128] = du2;
-            dX[o64 + (size_t)l * 64] = dxp * scale_x;
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int i = i0 + j;
+            if (i < L) {  // wave-uniform
+                const int k = L - 1 - i;
+                const int l = rev ? L - 1 - k : k;
+                const float cprev = k > 0 ? cpv[j] : 0.f;
+                const float c = cv[j], gh = ghv[j], u0 = u0v[j], u1 = u1v[j], u2 = u2v[j], xp = xpv[j];
+                const float f = sigmoidf_fast(u1 + bf + wf * cprev);
+                const float r = sigmoidf_fast(u2 + br + wr * cprev);
+                const float dxp = gh * (1.f - r);
+                const float dr = gh * (c - xp);
+                const float du2 = dr * r * (1.f - r);
+                const float dct = gh * r + dc;
+                const float du0 = dct * (1.f - f);
+                const float df = dct * (cprev - u0);
+                const float du1 = df * f * (1.f - f);
+                dc = dct * f + du1 * wf + du2 * wr;
+                awf = fmaf(du1, cprev, awf);
+                awr = fmaf(du2, cprev, awr);
+                abf += du1;
+                abr += du2;
+                if (KM == 4) {
+                    st4(du + (size_t)l * 256, f4(du0, du1, du2, dxp));
+                } else {
+                    float* q = du + (size_t)l * 192;
+                    q[0] = du0, q[64] = du1, q[128] = du2;
+                    dX[o64 + (size_t)l * 64] = dxp * scale_x;
+                }
+            }
         }
     }
     float* mine = spread_copy(scr, blockIdx.x);  // [dwc 128 | dbias 128]
