@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
         for (int i = 0; i < NLD; ++i) {
             const int idx = threadIdx.x + i * 256, r = idx / (CB * 16), rem = idx - r * (CB * 16), c = rem >> 4;
             const int ti = t0 - 1 + r, fi = fb - 1 + c;
-            v[i] = ld4(inb + ((size_t)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4);
+            v[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);  // saddr + 32-bit offset
         }
         __syncthreads();  // previous block's window reads are done
 #pragma unroll
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                     const float4 x = win[(jj + df) & 3][dt];
 #pragma unroll
                     for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + woff]), x, acc[k]);  // taps: quad-broadcast LDS reads
+                    // (register-resident taps for NCONV == 1 were measured slower: 64 more VGPRs -> spills in the staging phase)
                 }
             const int fo = fb + j;
             if (tvalid && fo < f1) {
