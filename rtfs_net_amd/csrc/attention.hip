@@ -76,14 +76,14 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
         const int g24 = w * 6 + gi;
         const int tok = g24 / 12, g = g24 % 12;
         const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
-        const int ncol = g < 8 ? 4 : 16;
+        const int sh = g < 8 ? 2 : 4, ncol = 1 << sh;  // 4 or 16 columns: shifts, not a runtime integer division per element
         const int cnt = 64 * ncol;
         float s = 0.f;
-        for (int i = lane; i < cnt; i += 64) s += Ys[(tok * 64 + i / ncol) * LDY + col0 + i % ncol];
+        for (int i = lane; i < cnt; i += 64) s += Ys[(tok * 64 + (i >> sh)) * LDY + col0 + (i & (ncol - 1))];
         const float mean = wave_sum(s) / cnt;
         float q = 0.f;
         for (int i = lane; i < cnt; i += 64) {
-            const float d = Ys[(tok * 64 + i / ncol) * LDY + col0 + i % ncol] - mean;
+            const float d = Ys[(tok * 64 + (i >> sh)) * LDY + col0 + (i & (ncol - 1))] - mean;
             q = fmaf(d, d, q);
         }
         q = wave_sum(q);
