@@ -356,11 +356,13 @@ int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, floa
     for (int i = 1; i < 4; ++i) T = (T - 1) / 2 + 1, sumT += T;
     if (T > 16) return RTFS_EINVAL;
     const size_t bytes = ((size_t)VH * (sumT + 3 * Tv) + VSM) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};  // the attribute is per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return RTFS_ELAUNCH;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(vp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess)
             return RTFS_ELAUNCH;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(vp_block_kernel, dim3(B), dim3(256), bytes, (hipStream_t)stream, x, params, pe, out, Tv);
     RTFS_LAUNCH_CHECK();
