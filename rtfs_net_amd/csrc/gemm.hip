@@ -518,7 +518,11 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
     ProGateway pro{s, gw, gb, gslope};
     EpiBiasStats epi{y, bias, kH, stats_out};
     if (B <= 0 || TF <= 0) return RTFS_EINVAL;
-    const int tiles = (TF + 63) / 64, per = 8;
+    // tiles per workgroup: as many as still leave ~512 workgroups (one round at 2 per CU) - the weight fragments are loaded once per
+    // workgroup and the tile loop pipelines itself.  Swept at B = 32: 2 -> 418 us, 8 -> 382, 32 -> 359, 64 -> 405 (too few workgroups).
+    const int tiles = (TF + 63) / 64;
+    const long long want = ((long long)tiles * B + 511) / 512;
+    const int per = (int)(want < 2 ? 2 : (want > 32 ? 32 : want));
     hipLaunchKernelGGL(proj_kernel, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, TF, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
