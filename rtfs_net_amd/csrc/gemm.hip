@@ -540,7 +540,11 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
     EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null};
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
-    const int Mb = T * kF, tiles = (Mb + 63) / 64, per = 16;  // swept 2..32 on MI355X: 16 is the minimum (0.84 ms at B=32)
+    // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
+    // 64 -> 804; small batches get more, smaller workgroups.
+    const int Mb = T * kF, tiles = (Mb + 63) / 64;
+    const long long want = ((long long)tiles * B + 1023) / 1024;
+    const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
     if (a0_or_null)
         hipLaunchKernelGGL(resid_kernel<true>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
     else
