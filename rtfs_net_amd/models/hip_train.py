@@ -59,6 +59,15 @@ def _zeros(n, dev, dtype=torch.float32):
     return torch.zeros(n, device=dev, dtype=dtype)
 
 
+def _acc(gr, key, n, dev):
+    """gradient accumulator `key` of the step, zero-filled on FIRST use only (the earlier dict-default idiom built - and filled - its
+    default tensor on every call: 768 fill launches per step)"""
+    t = gr.get(key)
+    if t is None:
+        t = gr[key] = torch.zeros(n, device=dev)
+    return t
+
+
 class HipTrainer:
     def __init__(self, model):
         self.model = model
@@ -232,15 +241,15 @@ class HipTrainer:
         """dN: gradient w.r.t. (act of) the normalised tensor; X: pre-norm; result dX (= or +=); gamma/beta grads into gr[key]."""
         dev = dN.device
         red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
-        dg, db = gr.setdefault(key + ".g", _zeros(Cc, dev)), gr.setdefault(key + ".b", _zeros(Cc, dev))
+        dg, db = _acc(gr, key + ".g", Cc, dev), _acc(gr, key + ".b", Cc, dev)
         lib.call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         lib.call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
     def _dw_bwd(self, dOut, conv, inp, in_st, in_g, in_b, in_slope, mode, stride, dIn, accumulate, gr, key, B, Tin, Fin, has_bias):
         """depth-wise conv adjoint: input gradient (w.r.t. the transformed input) and tap/bias gradients."""
         dev = dOut.device
-        dW = gr.setdefault(key + ".w", _zeros(16 * 64, dev))
-        dbias = gr.setdefault(key + ".bias", _zeros(64, dev)) if has_bias else None
+        dW = _acc(gr, key + ".w", 16 * 64, dev)
+        dbias = _acc(gr, key + ".bias", 64, dev) if has_bias else None
         lib.call("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
         if dIn is not None:
             lib.call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
@@ -250,7 +259,7 @@ class HipTrainer:
         S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
         L = npos - 7
         dev = dG.device
-        g = lambda name, n: gr.setdefault(f"{key}.{name}", _zeros(n, dev))  # noqa: E731
+        g = lambda name, n: _acc(gr, f"{key}.{name}", n, dev)  # noqa: E731
         # ConvTranspose1d + bias + residual
         dG_seq = torch.empty(S * npos * 64, device=dev)
         lib.call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
@@ -283,7 +292,7 @@ class HipTrainer:
     def _attn_bwd(self, dG, a, k, B, T2, gr, key):
         """dG: gradient w.r.t. the attention output, updated in place to the gradient w.r.t. its input."""
         dev = dG.device
-        g = lambda name, n: gr.setdefault(f"{key}.{name}", _zeros(n, dev))  # noqa: E731
+        g = lambda name, n: _acc(gr, f"{key}.{name}", n, dev)  # noqa: E731
         ntok = B * T2
         rows = ntok * 64
         dYo = torch.empty(rows * 64, device=dev)
@@ -313,7 +322,7 @@ class HipTrainer:
         st = k.st
         full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
         low = lambda: torch.empty(B * lo * H, device=dev)  # noqa: E731
-        g = lambda name, n: gr.setdefault(f"blk.{name}", _zeros(n, dev))  # noqa: E731
+        g = lambda name, n: _acc(gr, f"blk.{name}", n, dev)  # noqa: E731
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
@@ -395,7 +404,7 @@ class HipTrainer:
         TF = T * F_BINS
         dev = dout.device
         gr = {}
-        g = lambda name, n: gr.setdefault(name, _zeros(n, dev))  # noqa: E731
+        g = lambda name, n: _acc(gr, name, n, dev)  # noqa: E731
         dout = dout.reshape(B, L).to(torch.float32).contiguous()
         # iSTFT + decoder taps
         dspec = torch.empty(B * TF * 2, device=dev)

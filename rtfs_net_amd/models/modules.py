@@ -83,6 +83,11 @@ def _conv1d_glue(conv, x):
             else:
                 lp = rp = conv.padding[0]
             y = (F.pad(x, (lp, rp)).unfold(-1, k, s) * w.view(1, -1, 1, k)).sum(-1)
+    elif k == 1 and s == 1 and conv.groups > 1 and conv.in_channels % conv.groups == 0 and conv.out_channels % conv.groups == 0:
+        # grouped pointwise conv (CAF attention_embed / resize: 256 groups of 2 -> 4 / 2 -> 1, layers/fusion.py:208-228): one batched
+        # contraction instead of MIOpen's grouped-conv fallbacks (its weight-gradient kernel alone was ~1 ms per training step)
+        g_, ci, co = conv.groups, conv.in_channels // conv.groups, conv.out_channels // conv.groups
+        y = torch.einsum("bgit,goi->bgot", x.reshape(x.shape[0], g_, ci, x.shape[-1]), w.reshape(g_, co, ci)).reshape(x.shape[0], conv.out_channels, x.shape[-1])
     else:
         return conv(x)
     return y if conv.bias is None else y + conv.bias.view(1, -1, 1)
