@@ -178,12 +178,23 @@ class AVNet(nn.Module):
         if getattr(self, "_trainer", None) is None:
             self._trainer = HipTrainer(self)
         rm = self.refinement_module
-        v1 = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding.to(torch.float32)))
-        cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm
-        B = v1.shape[0]
-        att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)  # layers/fusion.py:262-264
-        att = torch.softmax(att, -1).transpose(1, 2).contiguous()                                   # [B, Tv, 256]
-        rsz = cell.resize(v1).transpose(1, 2).contiguous()
+        # the video branch (~150 tiny PyTorch launches in train mode) runs on a side stream underneath the encoder / first RTFS block
+        # of the HIP function, which waits for it right before the CAF cell; autograd runs its backward on that stream as well
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_glue_stream", None) is None or self._glue_stream.device != x.device:
+            self._glue_stream = torch.cuda.Stream(device=x.device)
+        side = self._glue_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            v1 = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding.to(torch.float32)))
+            cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm
+            B = v1.shape[0]
+            att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)  # layers/fusion.py:262-264
+            att = torch.softmax(att, -1).transpose(1, 2).contiguous()                                   # [B, Tv, 256]
+            rsz = cell.resize(v1).transpose(1, 2).contiguous()
+        att.record_stream(cur)
+        rsz.record_stream(cur)
+        self._trainer.video_stream = side
         names = self._hip_param_names()
         params = dict(self.named_parameters())
         return AVNetHipFunction.apply(self._trainer, names, x.to(torch.float32), att, rsz, *[params[n] for n in names])

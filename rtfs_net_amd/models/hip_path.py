@@ -64,7 +64,7 @@ def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
 class PreparedWeights:
     """Kernel-layout copies of the parameters (transposes / permutations done once, re-done when parameters change)."""
 
-    def __init__(self, model):
+    def __init__(self, model, pack_vp=True):
         self.version = self.fingerprint(model)
         dev = next(model.parameters()).device
         self.device = dev
@@ -115,7 +115,7 @@ class PreparedWeights:
         w["vp"] = None
         vn = model.refinement_module.video_net
         vb = vn.get_block(0)
-        if (vn.shared and vn.repeats == 1 and vb.in_chan == 512 and vb.hid_chan == 64 and vb.kernel_size == 3 and vb.stride == 2
+        if (pack_vp and vn.shared and vn.repeats == 1 and vb.in_chan == 512 and vb.hid_chan == 64 and vb.kernel_size == 3 and vb.stride == 2
                 and vb.upsampling_depth == 4 and len(vb.globalatt) == 1 and type(vb.globalatt[0]).__name__ == "GlobalAttention"
                 and isinstance(vb.projection.full_layer[3], torch.nn.BatchNorm1d) and vb.globalatt[0].FFN.refiner.kernel_size == 3
                 and vb.globalatt[0].FFN.encoder.out_chan == 128 and vb.globalatt[0].MHSA.attention.num_heads == 8):

@@ -25,7 +25,7 @@ class TrainWeights(PreparedWeights):
     """PreparedWeights + the transposed / re-ordered copies the input-gradient GEMMs need."""
 
     def __init__(self, model):
-        super().__init__(model)
+        super().__init__(model, pack_vp=False)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
         w = self.w
         w["bn_wT"], w["mask_wT"], w["dec_wT"] = _t(w["bn_w"]), _t(w["mask_w"]), _t(w["dec_w"])
         sd = {k: v.detach() for k, v in model.state_dict().items()}
@@ -183,6 +183,9 @@ class HipTrainer:
         c.blk.append(self._block_fwd(c.a0, x, None, bw(0), stats[1:13], B, T, T2))
         c.x0 = x
         # CAF with training-mode BatchNorm2d (batch statistics over B,T,F of the depth-wise conv output)
+        if getattr(self, "video_stream", None) is not None:  # att / rsz were produced on the glue stream (AVNet._forward_autograd)
+            torch.cuda.current_stream().wait_stream(self.video_stream)
+            self.video_stream = None
         c.att, c.rsz = att.contiguous(), rsz.contiguous()
         c.caf = self._caf_coeffs(x, w, B * TF, m.training)
         s = torch.empty_like(c.a_emb)
