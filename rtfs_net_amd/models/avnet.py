@@ -169,7 +169,7 @@ class AVNet(nn.Module):
     def _forward_autograd(self, x, mouth_embedding):
         """Training step: VP block + CAF video projections in torch autograd (glue); the audio branch is ONE
         autograd.Function whose forward and backward are HIP kernel chains (models/hip_train.py)."""
-        from .hip_train import AVNetHipFunction, HipTrainer
+        from .hip_train import AVNetHipStageA, AVNetHipStageB, HipTrainer, StepCtx
 
         if not x.is_cuda:
             raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
@@ -197,7 +197,9 @@ class AVNet(nn.Module):
         self._trainer.video_stream = side
         names = self._hip_param_names()
         params = dict(self.named_parameters())
-        return AVNetHipFunction.apply(self._trainer, names, x.to(torch.float32), att, rsz, *[params[n] for n in names])
+        step = StepCtx()
+        x0, a0, a_emb = AVNetHipStageA.apply(self._trainer, names, step, x.to(torch.float32), *[params[n] for n in names])
+        return AVNetHipStageB.apply(self._trainer, step, x0, a0, a_emb, att, rsz)
 
     # ---- BaseAVModel API (TDAVNet/base_av_model.py) ---------------------------------------------
     @staticmethod

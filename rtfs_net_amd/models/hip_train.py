@@ -154,6 +154,11 @@ class HipTrainer:
 
     def forward(self, wav, att, rsz):
         """wav [B,L]; att, rsz [B,Tv,256] (video side of the CAF cell, torch glue).  Returns (out [B,1,L], ctx)."""
+        c = self.forward_a(wav)
+        return self.forward_b(c, att, rsz), c
+
+    def forward_a(self, wav):
+        """STFT, encoder conv, bottleneck, RTFS block 0 (everything before the CAF cell) -> ctx with x0, a0, a_emb."""
         m = self.model
         pw = self.weights()
         w = pw.w
@@ -167,7 +172,7 @@ class HipTrainer:
         dev = wav.device
         R = m.refinement_module.audio_net.repeats
         c = Ctx()
-        c.B, c.L, c.T, c.T2, c.R, c.Tv = B, L, T, T2, R, att.shape[1]
+        c.B, c.L, c.T, c.T2, c.R = B, L, T, T2, R
         c.stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         stats = c.stats
         c.spec = torch.empty(B * TF * 2, device=dev)
@@ -182,6 +187,20 @@ class HipTrainer:
         x = torch.empty_like(c.a_emb)
         c.blk.append(self._block_fwd(c.a0, x, None, bw(0), stats[1:13], B, T, T2))
         c.x0 = x
+        return c
+
+    def forward_b(self, c, att, rsz):
+        """CAF cell, RTFS blocks 1..R-1, S3 mask, decoder, iSTFT -> out [B,1,L]."""
+        m = self.model
+        pw = self.weights()
+        w = pw.w
+        B, L, T, T2, R = c.B, c.L, c.T, c.T2, c.R
+        TF = T * F_BINS
+        dev = c.x0.device
+        stats, x = c.stats, c.x0
+        blocks = pw.blocks
+        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        c.Tv = att.shape[1]
         # CAF with training-mode BatchNorm2d (batch statistics over B,T,F of the depth-wise conv output)
         if getattr(self, "video_stream", None) is not None:  # att / rsz were produced on the glue stream (AVNet._forward_autograd)
             torch.cuda.current_stream().wait_stream(self.video_stream)
@@ -205,7 +224,7 @@ class HipTrainer:
         frames = torch.empty(B * T * 256, device=dev)
         out = torch.empty(B, L, device=dev)
         lib.call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
-        return out.view(B, 1, L), c
+        return out.view(B, 1, L)
 
     def _caf_coeffs(self, x, w, rows, training):
         """folded (scale, shift) of key/value BatchNorm2d; training: batch statistics (+ running-stat update)."""
@@ -400,13 +419,18 @@ class HipTrainer:
 
     def backward(self, c, dout):
         """dout [B,1,L] -> (datt, drsz, grads dict in kernel layout)."""
+        dx0, da0, da_emb, datt, drsz = self.backward_b(c, dout)
+        return datt, drsz, self.backward_a(c, dx0, da0, da_emb)
+
+    def backward_b(self, c, dout):
+        """adjoint of forward_b: dout [B,1,L] -> (d x0, d a0 or None, d a_emb, datt, drsz); parameter gradients go to c.gr."""
         m = self.model
         pw = self.weights()
         w = pw.w
         B, L, T, T2, R, Tv = c.B, c.L, c.T, c.T2, c.R, c.Tv
         TF = T * F_BINS
         dev = dout.device
-        gr = {}
+        gr = c.gr = {}
         g = lambda name, n: _acc(gr, name, n, dev)  # noqa: E731
         dout = dout.reshape(B, L).to(torch.float32).contiguous()
         # iSTFT + decoder taps
@@ -439,7 +463,22 @@ class HipTrainer:
         coef = self._caf_bwd_coeffs(cf, w, Rr.view(4, C), gr, m)
         dx0 = torch.empty(B * TF * C, device=dev)
         lib.call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
-        self._block_bwd(dx0, c.blk[0], bw(0), B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
+        return dx0, (da0 if R > 1 else None), da_emb, datt.view(B, Tv, C), drsz.view(B, Tv, C)
+
+    def backward_a(self, c, dx0, da0, da_emb):
+        """adjoint of forward_a.  dx0: gradient of block 0's output (overwritten); da0: running d(a0) sum of the later blocks (updated in
+        place) or None; da_emb: gradient that reached a_emb through the S3 mask (updated in place).  -> grads dict in kernel layout."""
+        pw = self.weights()
+        w = pw.w
+        B, T, T2, R = c.B, c.T, c.T2, c.R
+        TF = T * F_BINS
+        dev = dx0.device
+        gr = c.gr
+        g = lambda name, n: _acc(gr, name, n, dev)  # noqa: E731
+        blocks = pw.blocks
+        if da0 is None:
+            da0 = torch.empty(B * TF * C, device=dev)
+        self._block_bwd(dx0, c.blk[0], blocks[0], B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
         lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
@@ -449,7 +488,7 @@ class HipTrainer:
         patches = torch.empty(B * TF * 32, device=dev)
         lib.call("rtfs_spec_patches", c.spec, patches, B, T)
         lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
-        return datt.view(B, Tv, C), drsz.view(B, Tv, C), gr
+        return gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
         """BatchNorm adjoint of the CAF key/value embeddings -> per-channel coefficients for rtfs_caf_bwd_apply + parameter grads."""
@@ -590,7 +629,7 @@ def grads_to_reference(model, pw: TrainWeights, gr: dict) -> dict:
 
 
 class AVNetHipFunction(torch.autograd.Function):
-    """out = AVNet audio branch (wav, att, rsz; audio parameters).  `names` lists the reference names of `params`."""
+    """out = AVNet audio branch (wav, att, rsz; audio parameters) as ONE node (kept for tools / reports)."""
 
     @staticmethod
     def forward(ctx, trainer, names, wav, att, rsz, *params):
@@ -608,3 +647,60 @@ class AVNetHipFunction(torch.autograd.Function):
         grads = tuple(ref.get(n) for n in ctx.names)
         ctx.saved = None
         return (None, None, None, datt, drsz) + grads
+
+
+class AVNetHipStageA(torch.autograd.Function):
+    """(wav; audio parameters) -> (x0, a0, a_emb): everything before the CAF cell.  Its backward runs AFTER AVNetHipStageB's and returns
+    the gradients of ALL audio parameters (stage B leaves its share in the shared step context), so that autograd can run the video
+    glue's backward - which only needs stage B's datt / drsz - on its own stream underneath this node's kernels."""
+
+    @staticmethod
+    def forward(ctx, trainer, names, step, wav, *params):
+        with torch.no_grad():
+            c = trainer.forward_a(wav)
+        step.c = c
+        ctx.trainer, ctx.names, ctx.step = trainer, names, step
+        n = c.B * c.T * F_BINS
+        # fresh view objects: autograd attaches this node to the RETURNED tensors; the context keeps the plain buffers (no reference cycle)
+        return c.x0.view(n, C), c.a0.view(n, C), c.a_emb.view(n, C)
+
+    @staticmethod
+    def backward(ctx, dx0, da0, da_emb):
+        trainer, c = ctx.trainer, ctx.step.c
+        with torch.no_grad():
+            n = c.B * c.T * F_BINS * C
+            fix = lambda t: None if t is None else t.contiguous().view(n)  # noqa: E731
+            dx0, da0, da_emb = fix(dx0), fix(da0), fix(da_emb)
+            if dx0 is None:
+                dx0 = torch.zeros(n, device=c.x0.device)
+            if da_emb is None:
+                da_emb = torch.zeros(n, device=c.x0.device)
+            gr = trainer.backward_a(c, dx0, da0, da_emb)
+            ref = grads_to_reference(trainer.model, trainer.weights(), gr)
+        grads = tuple(ref.get(name) for name in ctx.names)
+        c.__dict__.clear()
+        ctx.step.c = None
+        return (None, None, None, None) + grads
+
+
+class AVNetHipStageB(torch.autograd.Function):
+    """(x0, a0, a_emb, att, rsz) -> out: CAF cell, blocks 1..R-1, S3 mask, decoder, iSTFT."""
+
+    @staticmethod
+    def forward(ctx, trainer, step, x0, a0, a_emb, att, rsz):
+        with torch.no_grad():
+            out = trainer.forward_b(step.c, att, rsz)
+        ctx.trainer, ctx.step = trainer, step
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.no_grad():
+            dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)
+        n = dx0.numel() // C
+        return None, None, dx0.view(n, C), (None if da0 is None else da0.view(n, C)), da_emb.view(n, C), datt, drsz
+
+
+class StepCtx:
+    """holder shared by the two stages of one training step"""
+    c = None
