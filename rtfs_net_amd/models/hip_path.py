@@ -70,6 +70,11 @@ class PreparedWeights:
         self.device = dev
         w = {}
         sd = {k: v.detach() for k, v in model.state_dict().items()}
+        # every one-element float tensor (PReLU slopes, SRU scale_x) in ONE device->host transfer: a .item() each is a stream
+        # synchronisation, and in training this object is rebuilt after every optimizer step
+        names1 = [k for k, v in sd.items() if v.numel() == 1 and v.is_floating_point()]
+        vals1 = torch.cat([sd[k].reshape(1).float() for k in names1]).tolist() if names1 else []
+        self._scal = dict(zip(names1, vals1))
 
         def g(name):
             return _f32(sd[name])
@@ -104,7 +109,7 @@ class PreparedWeights:
         w["caf_rs_g"], w["caf_rs_be"] = g(p + "3.norm.weight"), g(p + "3.norm.bias")
 
         # a11 mask
-        w["mask_slope"] = float(sd["mask_generator.mask_generator.0.weight"].item())
+        w["mask_slope"] = self._scal["mask_generator.mask_generator.0.weight"]
         w["mask_w"] = _f32(sd["mask_generator.mask_generator.1.full_layer.2.weight"].reshape(C, C))
         w["mask_b"] = g("mask_generator.mask_generator.1.full_layer.2.bias")
         # a12 decoder ConvTranspose2d weight [256 c][2 o][3][3] -> taps [32][256] (rows o*9+kt*3+kf, zero padded)
@@ -139,11 +144,11 @@ class PreparedWeights:
     def _prep_block(self, sd, p):
         b = {}
         b["gw"], b["gb"] = _f32(sd[p + "gateway.full_layer.2.weight"].reshape(C)), _f32(sd[p + "gateway.full_layer.2.bias"])
-        b["gslope"] = float(sd[p + "gateway.full_layer.4.weight"].item())
+        b["gslope"] = self._scal[p + "gateway.full_layer.4.weight"]
         b["pw"] = _f32(sd[p + "projection.full_layer.2.weight"].reshape(H, C))
         b["pb"] = _f32(sd[p + "projection.full_layer.2.bias"])
         b["pg"], b["pbe"] = _f32(sd[p + "projection.full_layer.3.norm.weight"]), _f32(sd[p + "projection.full_layer.3.norm.bias"])
-        b["pslope"] = float(sd[p + "projection.full_layer.4.weight"].item())
+        b["pslope"] = self._scal[p + "projection.full_layer.4.weight"]
         b["d0"] = self._dw(sd, p + "downsample_layers.0.")
         b["d1"] = self._dw(sd, p + "downsample_layers.1.")
         for i in (0, 1):  # dual-path: globalatt.0 (dim 4, along F), globalatt.1 (dim 3, along T)
@@ -154,7 +159,7 @@ class PreparedWeights:
             d["layers"] = []
             for l in range(4):
                 lw = {"wc": _f32(sd[q + f"rnn.rnn_lst.{l}.weight_c"]), "bias": _f32(sd[q + f"rnn.rnn_lst.{l}.bias"]),
-                      "scale_x": float(sd[q + f"rnn.rnn_lst.{l}.scale_x"].item())}
+                      "scale_x": self._scal[q + f"rnn.rnn_lst.{l}.scale_x"]}
                 if l > 0:  # [k][lane*3+m] -> [m*64+lane][k]
                     lw["w"] = _f32(sd[q + f"rnn.rnn_lst.{l}.weight"].float().reshape(H, 64, 3).permute(2, 1, 0).reshape(192, H))
                 d["layers"].append(lw)
@@ -174,7 +179,7 @@ class PreparedWeights:
         m = q + "attn_concat_proj."
         a["ow"] = _f32(sd[m + "conv.weight"].reshape(H, H))
         a["ob"] = _f32(sd[m + "conv.bias"])
-        a["oslope"] = float(sd[m + "act.weight"].item())
+        a["oslope"] = self._scal[m + "act.weight"]
         a["og"] = _f32(sd[m + "norm.gamma"].reshape(H, F2).t())  # [c][f] -> [f][c]
         a["obe"] = _f32(sd[m + "norm.beta"].reshape(H, F2).t())
         b["attn"] = a
