@@ -90,6 +90,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    # RTFS_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and talk over gloo, so the N > 1 code path of this script can be
+    # exercised on a single-GPU box; the reported number is then NOT a multi-GPU measurement (flagged in the JSON)
+    one_gpu = os.environ.get("RTFS_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -97,7 +102,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from oracle import synth  # synthetic inputs only (shared with the tests); the oracle itself is used for cpu_baseline below
     from rtfs_net_amd import AVNet, lib
@@ -196,7 +204,7 @@ def main():
                             + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, fp32, random-init weights",
                 "mode": args.mode,
                 "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
-                "parallelism": f"utterance-sharded x{world}, no data-path collective",
+                "parallelism": f"utterance-sharded x{world}, no data-path collective" + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
             },
         }
         # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----

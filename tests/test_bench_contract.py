@@ -1,0 +1,44 @@
+"""bench.py contract on the GPU box: the single-process line and the torch.distributed.run launch the driver uses for N > 1
+(two ranks sharing the one test GPU over gloo: RTFS_BENCH_ONE_GPU=1; on the 8-GPU node the same code runs over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"}
+
+
+def _last_json(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line():
+    r = subprocess.run([sys.executable, "bench.py", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-budget-s", "2"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _last_json(r.stdout)
+    assert KEYS <= set(res) and "cpu_baseline" in res
+    assert res["n_gpus"] == 1 and res["scaling"] == "weak" and res["dtype"] == "f32" and res["vs_baseline"] is None
+    assert res["value"] > 0 and "workload" in res["config"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(res["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(res["cpu_baseline"])
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_two_rank_launch(mode):
+    env = dict(os.environ, RTFS_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           "29531" if mode == "infer" else "29532", "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--mode", mode]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = _last_json(r.stdout)
+    assert KEYS <= set(res) and "cpu_baseline" not in res  # the CPU baseline is a rank-0, N = 1 measurement
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
