@@ -505,6 +505,11 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
     const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
+    if (npairs < 256) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
+        hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     hipLaunchKernelGGL(unfold_gemm128_kernel, dim3(npairs < resident ? npairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0,
                        tps, total);
     RTFS_LAUNCH_CHECK();
