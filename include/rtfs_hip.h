@@ -191,6 +191,23 @@ int rtfs_neg_sdr_finish(const double* sums, int kind, int zero_mean, int take_lo
 /* dest [B][n][T] = sum_j G[b][i][j] (ce (e_i - mean e_i) + ct (t_j - mean t_j)): the adjoint of pw w.r.t. the estimates */
 int rtfs_neg_sdr_grad(const float* est, const float* tgt, const float* coef, const float* G, float* dest, int B, int n_src, int T, void* stream);
 
+/* ---- f2: frozen lip encoder, FRCNNVideoModel with the ResNet-18 trunk, eval mode (src/models/videomodels/frcnn_videomodel.py:16-72,
+ * resnet.py:27-130); channels-last fp32 activations [frame][y][x][channel], BatchNorm folded into weight rows (scale) and bias (shift) ---- */
+/* frontend3D[0..2]: Conv3d(1->64, 5x7x7, stride (1,2,2), pad (2,3,3)) + BatchNorm3d + PReLU(64) (frcnn_videomodel.py:43-54).
+ * P: zero-padded frames [B][T+4][H+6][W+6]; Ws [64][256], k = (dt*7+dy)*7+dx (k >= 245 zero); tapoff [256] ints =
+ * (dt*(H+6)+dy)*(W+6)+dx (0 for k >= 245); bias, slope [64]; out [B*T][Hc][Wc][64], Hc = (H-1)/2+1, Wc = (W-1)/2+1. */
+int rtfs_lip_stem_fwd(const float* P, const float* Ws, const int* tapoff, const float* bias, const float* slope, float* out, int B, int T, int H,
+                      int W, void* stream);
+/* frontend3D[3]: MaxPool3d((1,3,3), (1,2,2), (0,1,1)) (frcnn_videomodel.py:55): in [N][H][W][64] -> out [N][(H-1)/2+1][(W-1)/2+1][64] */
+int rtfs_lip_maxpool_fwd(const float* in, float* out, int N, int H, int W, void* stream);
+/* conv3x3 / 1x1 downsample + BatchNorm2d (+ residual) (+ PReLU) of BasicBlock (resnet.py:5-13, 49-66): in [N][H][W][Cin];
+ * Wk [Cout][ks*ks*Cin], k = (dy*ks+dx)*Cin+ci; pad = ks/2; stride 1|2; bias, slope [Cout] or NULL; res [N][Ho][Wo][Cout] or NULL (added
+ * before the activation); out [N][Ho][Wo][Cout], Ho = (H+2*pad-ks)/stride+1.  Cin, Cout multiples of 64; ks 1 or 3. */
+int rtfs_conv_nhwc_fwd(const float* in, const float* Wk, const float* bias, const float* slope, const float* res, float* out, int N, int H, int W,
+                       int Cin, int Cout, int ks, int stride, void* stream);
+/* AdaptiveAvgPool2d(1) + view(B, T, C).transpose(1, 2) (resnet.py:124-126, frcnn_videomodel.py:66): in [B*T][HW][C] -> out [B][C][T] */
+int rtfs_lip_avgpool_fwd(const float* in, float* out, int B, int T, int HW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,10 +1,11 @@
 """Host-side mirror of the reference's `src.models` package (src/models/__init__.py:8-42):
-`AVNet` (alias `RTFSNet`), case-insensitive `get`, `register_model`."""
+`AVNet` (alias `RTFSNet`), the `videomodels` sub-package (train.py:17), case-insensitive `get`, `register_model`."""
+from . import videomodels
 from .avnet import AVNet
 
 RTFSNet = AVNet
 
-__all__ = ["AVNet", "RTFSNet", "get", "register_model"]
+__all__ = ["AVNet", "RTFSNet", "videomodels", "get", "register_model"]
 
 
 def register_model(custom_model):
