@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: separation forward (headline metric); train: forward + backward + AdamW (+ RCCL gradient all-reduce for N>1)")
+    ap.add_argument("--lip", action="store_true",
+                    help="infer mode: start from 88x88 mouth crops and run the HIP lip encoder (FRCNNVideoModel) inside the timed step "
+                         "(core.py:87-89); default: lip embeddings are the input, as BASELINE.json's configs state")
     ap.add_argument("--roofline-kernel", default="rtfs_dp_unfold_gemm_fwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -124,20 +127,36 @@ def main():
     mix, _, emb = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)
     mix, emb = mix.to(dev), emb.to(dev)
 
+    lipnet = crops = None
+    if args.lip:
+        if args.mode != "infer":
+            raise SystemExit("--lip is an inference option (the lip encoder is frozen)")
+        from oracle.lip_ref import lip_inputs
+        from rtfs_net_amd.models import videomodels
+
+        lipnet = videomodels.FRCNNVideoModel(print_macs=False)
+        lipnet.load_state_dict(synth.synth_state_dict(lipnet.state_dict(), salt=3))
+        lipnet = lipnet.to(dev)
+        lipnet.eval()
+        crops = lip_inputs(args.batch, Tv, seed=synth.INPUT_SEED + rank).to(dev)
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def forward():
+        return model(mix, lipnet(crops) if lipnet is not None else emb)
+
     if args.mode == "infer":
         with torch.no_grad():
             for _ in range(args.warmup):
-                out = model(mix, emb)
+                out = forward()
             barrier()
             lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                out = model(mix, emb)
+                out = forward()
             barrier()
             elapsed = time.perf_counter() - t0
             prof = lib.profile_end()
@@ -202,7 +221,7 @@ def main():
                 "workload": (f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), " if args.mode == "infer" else
                              f"RTFS-Net-{args.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
                             + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, fp32, random-init weights",
-                "mode": args.mode,
+                "mode": args.mode + ("+lip-encoder" if args.lip else ""),
                 "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
                 "parallelism": f"utterance-sharded x{world}, no data-path collective" + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
             },
