@@ -207,6 +207,10 @@ int rtfs_conv_nhwc_fwd(const float* in, const float* Wk, const float* bias, cons
                        int Cin, int Cout, int ks, int stride, void* stream);
 /* AdaptiveAvgPool2d(1) + view(B, T, C).transpose(1, 2) (resnet.py:124-126, frcnn_videomodel.py:66): in [B*T][HW][C] -> out [B][C][T] */
 int rtfs_lip_avgpool_fwd(const float* in, float* out, int B, int T, int HW, int C, void* stream);
+/* ---- f4: mouth-ROI preprocessing, get_preprocessing_pipelines() of src/datas/transform.py:151-167 (Normalize(0,255) -> Center/RandomCrop ->
+ * HorizontalFlip -> Normalize(0.421, 0.165)) fused with the stem's zero padding.  roi [B][T][H][W] uint8; crop [B][3] ints (dy, dx, flip)
+ * or NULL = centre crop (transform.py:96-101); lut [256] = the value map evaluated on the host in float64; P [B][T+4][ch+6][cw+6]. */
+int rtfs_lip_roi_fwd(const unsigned char* roi, const int* crop, const float* lut, float* P, int B, int T, int H, int W, int ch, int cw, void* stream);
 
 #ifdef __cplusplus
 }

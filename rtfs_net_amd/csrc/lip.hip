@@ -184,6 +184,33 @@ __global__ __launch_bounds__(256) void lip_avgpool_kernel(const float* __restric
     }
 }
 
+
+// Mouth-ROI preprocessing (src/datas/transform.py:151-167): uint8 grey frames [B][T][H][W] -> Normalize(0, 255) ->
+// crop ch x cw (centre, or per-clip offset) -> optional horizontal flip -> Normalize(mean, std), written straight into the zero-padded
+// clip P [B][T+4][ch+6][cw+6] the stem reads (borders included: no memset).  The value map is a 256-entry table computed on the
+// host in float64 exactly as numpy evaluates the reference's pipeline, so the result is bit-identical to it.
+__global__ __launch_bounds__(256) void lip_roi_kernel(const unsigned char* __restrict__ roi, const int* __restrict__ crop, const float* __restrict__ lut,
+                                                      float* __restrict__ P, int T, int H, int W, int ch, int cw, int dy0, int dx0) {
+    __shared__ float tab[256];
+    tab[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.z, tp = blockIdx.y;  // padded frame index 0 .. T+3
+    const int Hp = ch + 6, Wp = cw + 6;
+    const int dy = crop ? crop[3 * b] : dy0, dx = crop ? crop[3 * b + 1] : dx0;
+    const bool flip = crop ? crop[3 * b + 2] != 0 : false;
+    const int t = tp - 2;
+    float* out = P + ((size_t)b * (T + 4) + tp) * Hp * Wp;
+    const unsigned char* in = roi + ((size_t)b * T + max(min(t, T - 1), 0)) * H * W;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < Hp * Wp; idx += gridDim.x * 256) {
+        const int y = idx / Wp, x = idx - y * Wp;
+        const int cy = y - 3, cx = x - 3;
+        const bool inside = t >= 0 && t < T && cy >= 0 && cy < ch && cx >= 0 && cx < cw;
+        const int sx = flip ? cw - 1 - cx : cx;
+        const unsigned char u = in[min(max(dy + cy, 0), H - 1) * W + min(max(dx + sx, 0), W - 1)];
+        out[idx] = inside ? tab[u] : 0.f;
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -235,6 +262,17 @@ int rtfs_conv_nhwc_fwd(const float* in, const float* Wk, const float* bias, cons
 int rtfs_lip_avgpool_fwd(const float* in, float* out, int B, int T, int HW, int C, void* stream) {
     if (B <= 0 || T <= 0 || HW <= 0 || C <= 0) return RTFS_EINVAL;
     hipLaunchKernelGGL(lip_avgpool_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, in, out, HW, C, T);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// roi [B][T][H][W] uint8; crop [B][3] ints (dy, dx, flip) or NULL = centre crop (transform.py:96-101: delta = int(round(H - ch) / 2.0));
+// lut [256] floats; P [B][T+4][ch+6][cw+6] (whole buffer written).  0 <= dy <= H - ch, 0 <= dx <= W - cw is the caller's contract.
+int rtfs_lip_roi_fwd(const unsigned char* roi, const int* crop, const float* lut, float* P, int B, int T, int H, int W, int ch, int cw, void* stream) {
+    if (B <= 0 || T <= 0 || ch <= 0 || cw <= 0 || H < ch || W < cw) return RTFS_EINVAL;
+    const int plane = (ch + 6) * (cw + 6);
+    dim3 grid(min((plane + 255) / 256, 64), T + 4, B);
+    hipLaunchKernelGGL(lip_roi_kernel, grid, dim3(256), 0, (hipStream_t)stream, roi, crop, lut, P, T, H, W, ch, cw, (H - ch) / 2, (W - cw) / 2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rtfs_lip_maxpool_fwd": [P, P, I, I, I, P],
     "rtfs_conv_nhwc_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "rtfs_lip_avgpool_fwd": [P, P, I, I, I, I, P],
+    "rtfs_lip_roi_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],

@@ -2,8 +2,9 @@
 `FRCNNVideoModel` (the frozen lip encoder), `ResNet`, `BasicBlock`, `update_frcnn_parameter`,
 case-insensitive `get`, `register_model`.  Only the ResNet-18 backbone of the shipped configs is built."""
 from .frcnn_videomodel import BasicBlock, FRCNNVideoModel, ResNet, update_frcnn_parameter
+from .roi import MouthROI
 
-__all__ = ["ResNet", "BasicBlock", "FRCNNVideoModel", "update_frcnn_parameter", "get", "register_model"]
+__all__ = ["ResNet", "BasicBlock", "FRCNNVideoModel", "update_frcnn_parameter", "MouthROI", "get", "register_model"]
 
 
 def register_model(custom_model):

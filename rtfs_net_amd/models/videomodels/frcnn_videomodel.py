@@ -183,11 +183,26 @@ class FRCNNVideoModel(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("the HIP lip encoder is inference-only (frozen encoder, core.py:87-89): call it under torch.no_grad() "
                                "or freeze its parameters")
-        w = self._weights()
         B, _, T, H, W = x.shape
-        N = B * T
-        dev = x.device
         P = F.pad(x[:, 0].float(), (3, 3, 3, 3, 2, 2)).contiguous()  # the conv's zero padding, materialised once (H+6, W+6, T+4)
+        emb = self._encode_padded(P, B, T, H, W)
+        return emb.to(x.dtype) if x.dtype != torch.float32 else emb
+
+    def forward_rois(self, rois: torch.Tensor, crops: torch.Tensor = None, crop_size=(88, 88), mean=0.421, std=0.165):
+        """uint8 mouth ROIs [B, T, H, W] (the `.npz["data"]` arrays of the dataset, avspeech_dataset.py:121-124) -> [B, 512, T]:
+        the reference's preprocessing pipeline (transform.py:151-167) runs fused into the stem's padded input, see `MouthROI`."""
+        from .roi import MouthROI
+
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the HIP lip encoder is inference-only: call it under torch.no_grad() or freeze its parameters")
+        P = MouthROI(crop_size, mean, std).padded(rois, crops)
+        return self._encode_padded(P, rois.shape[0], rois.shape[1], crop_size[0], crop_size[1])
+
+    def _encode_padded(self, P: torch.Tensor, B: int, T: int, H: int, W: int) -> torch.Tensor:
+        """P: zero-padded clip [B, T+4, H+6, W+6] float32 on the GPU."""
+        w = self._weights()
+        N = B * T
+        dev = P.device
         Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         c1 = torch.empty(N, Hc, Wc, 64, device=dev)
         lib.call("rtfs_lip_stem_fwd", P, w.stem_w, w.taps(H, W, dev), w.stem_bias, w.stem_slope, c1, B, T, H, W)
@@ -210,7 +225,7 @@ class FRCNNVideoModel(nn.Module):
             cur, h, wd_ = out, ho, wo
         emb = torch.empty(B, self.backend_out, T, device=dev)
         lib.call("rtfs_lip_avgpool_fwd", cur, emb, B, T, h * wd_, self.backend_out)
-        return emb.to(x.dtype) if x.dtype != torch.float32 else emb
+        return emb
 
     # ---- reference protocol ----------------------------------------------------------------------
     def init_from(self, path):
