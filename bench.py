@@ -279,6 +279,17 @@ def main():
                     avnet_forward(sd, cfg, cmix, cemb)
                     runs += 1
                 dt = (time.perf_counter() - t0) / runs
+            # SI-SDRi parity (BASELINE.json metric): improvement over the mixture of the HIP estimate vs the oracle's, same utterance
+            with torch.no_grad():
+                c_or = avnet_forward(sd, cfg, cmix, cemb)
+                c_hip = model(cmix.to(dev), cemb.to(dev))
+            from rtfs_net_amd.metrics import separation_metrics
+
+            tgt = synth.synth_inputs(1, L, Tv)[1].to(dev)
+            m_hip = separation_metrics(cmix[0].to(dev), tgt, c_hip[0])
+            m_or = separation_metrics(cmix[0].to(dev), tgt, c_or[0].to(dev))
+            res["si_sdri_parity"] = {"hip_db": m_hip["si-snr_i"], "oracle_db": m_or["si-snr_i"], "abs_diff_db": abs(m_hip["si-snr_i"] - m_or["si-snr_i"]),
+                                     "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
             res["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": n, "kind": "port",
                                    "sample": f"oracle/avnet_ref.py, RTFS-Net-{args.layers}, batch 1 x {args.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
         print(json.dumps(res), flush=True)

@@ -76,3 +76,26 @@ def test_loss_head_refuses_cpu_tensors():
 
     with pytest.raises(RuntimeError):
         pairwise_neg_snr(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64))
+
+
+@pytest.mark.gpu
+def test_separation_metrics_follow_the_tracker():
+    """SI-SNR(i) / SDR(i) as ALLMetricsTracker computes them (allwrapper.py:35-55), HIP loss head vs the float64 oracle."""
+    from rtfs_net_amd.metrics import separation_metrics
+
+    g = torch.Generator().manual_seed(3)
+    clean = torch.randn(2, 16000, generator=g)
+    mix = clean.sum(0)
+    est = clean[[1, 0]] + 0.3 * torch.randn(2, 16000, generator=g)  # permuted on purpose: PIT must undo it
+    got = separation_metrics(mix.cuda(), clean.cuda(), est.cuda())
+
+    def pit(kind, e):
+        loss, _ = pit_pw_mtx(pairwise_neg_sdr(e.double().unsqueeze(0), clean.double().unsqueeze(0), kind))
+        return float(loss)
+
+    mx = torch.stack([mix, mix])
+    want = {"si-snr": -pit("sisdr", est), "si-snr_i": -(pit("sisdr", est) - pit("sisdr", mx)), "sdr": -pit("snr", est),
+            "sdr_i": -(pit("snr", est) - pit("snr", mx))}
+    for k in want:
+        assert abs(got[k] - want[k]) < 1e-3, (k, got[k], want[k])
+    assert got["si-snr_i"] > 5.0
