@@ -14,6 +14,7 @@
 // ConvTranspose1d is the same structure on the zero-padded SRU output: y[n] = sum_k' hpad[n + k'] . W'[k'].
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace rtfs {
@@ -295,6 +296,179 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, cons
     }
 }
 
+// Layer-0 kernel, third generation: the 64-row tiles are cut from the FLATTENED row index r = s * L + l, so no MFMA row is spent on
+// the padding of a sequence to a multiple of 64 (L = 57: 64 -> 57 rows per sequence, -10.9 % of the MFMAs; L = 118: 128 -> 118,
+// -7.8 %).  A tile then covers up to three sequences: its slab holds, per sequence segment, the segment's rows plus the 7 halo rows
+// (<= 64 + 21 rows), and output row i reads slab row i + 7 g(i) + tap, g = the segment of row i (a per-lane constant).  U0 is
+// [S][L][256] = [S*L][256], so the write-back is one contiguous block of rows.  LDS: the longer slabs are paid for by storing the
+// weight chunk unpadded (64-byte rows, 16-byte slot XOR-swizzled with (row >> 1) & 3: conflict-free for the 8-lane groups of a
+// ds_read_b128) - 79 KB, two workgroups per CU as before.  Otherwise as the second generation: 128 x 256 workgroup tile, persistent,
+// next tile's raw rows fetched under the current tile's k-loop.
+constexpr int kFlatRows = 64 + 21;
+struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
+    int r0, s0, l0, n0, n1;  // first flattened row, its (sequence, position); rows of segment 0, 1 (segment 2 = the rest)
+};
+__global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
+                                                                 int S, int total_tiles) {
+    constexpr int BK = 16, N = 256;
+    constexpr int NIT = (2 * kFlatRows * 16 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float slab[2][kFlatRows * kSlabLd];
+    __shared__ __attribute__((aligned(16))) float Bs[2][N * BK];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const float4 g4 = ld4(gamma + (threadIdx.x & 15) * 4), b4 = ld4(beta + (threadIdx.x & 15) * 4);
+    const int L = map.L;
+    const long long R = (long long)S * L;
+
+    auto tile_of = [&](int gt) {
+        FlatTile t;
+        t.r0 = gt * 64;
+        t.s0 = t.r0 / L;
+        t.l0 = t.r0 - t.s0 * L;
+        t.n0 = min(L - t.l0, 64);
+        t.n1 = min(L, 64 - t.n0);
+        return t;
+    };
+    // weight chunk: global -> registers -> LDS (row n = 16 floats = four 16-byte slots, slot c stored at c ^ ((n >> 1) & 3))
+    float4 breg[4];
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + it * 256, row = idx >> 2, c = idx & 3;
+            breg[it] = ld4(Wt + (size_t)row * 512 + k0 + c * 4);
+        }
+    };
+    auto store_b = [&](float* B) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = threadIdx.x + it * 256, row = idx >> 2, c = idx & 3;
+            st4(B + row * BK + ((c ^ ((row >> 1) & 3)) << 2), breg[it]);
+        }
+    };
+    float4 sraw[NIT];
+    // slab row j of a tile -> (sequence, position, valid)
+    auto slab_row = [&](const FlatTile& t, int j, int& sq, int& pos) {
+        const int e0 = t.n0 + 7, e1 = e0 + t.n1 + 7, n2 = 64 - t.n0 - t.n1;
+        const int g = (j >= e0) + (j >= e1);
+        const int jj = j - (g == 0 ? 0 : (g == 1 ? e0 : e1));
+        const int ng = g == 0 ? t.n0 : (g == 1 ? t.n1 : n2);
+        sq = t.s0 + g;
+        pos = (g == 0 ? t.l0 : 0) + jj;
+        return ng > 0 && jj < ng + 7 && sq < S && pos < map.npos;
+    };
+    auto fetch_slabs = [&](int pair) {
+        FlatTile t[2] = {tile_of(min(pair * 2, total_tiles - 1)), tile_of(min(pair * 2 + 1, total_tiles - 1))};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int st = idx >= kFlatRows * 16 ? 1 : 0;
+            const int j = min((idx - st * kFlatRows * 16) >> 4, kFlatRows - 1);
+            int sq, pos;
+            slab_row(t[st], j, sq, pos);
+            sraw[it] = ld4(src + map.base(min(sq, S - 1)) + (size_t)min(pos, map.npos - 1) * map.pos_stride + (threadIdx.x & 15) * 4);
+        }
+    };
+    // LayerNormalization4D over the 64 channels of each position (normalizations.py:33-37) -> LDS slabs
+    auto store_slabs = [&](int pair) {
+        FlatTile t[2] = {tile_of(min(pair * 2, total_tiles - 1)), tile_of(min(pair * 2 + 1, total_tiles - 1))};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int st = idx >= kFlatRows * 16 ? 1 : 0;
+            const int j = (idx - st * kFlatRows * 16) >> 4;
+            const bool inr = idx < 2 * kFlatRows * 16;
+            int sq, pos;
+            const bool ok = slab_row(t[st], min(j, kFlatRows - 1), sq, pos) && inr;
+            const float4 v = sraw[it];
+            float sum = v.x + v.y + v.z + v.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float mean = sum * (1.f / 64.f);
+            const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+            float sqs = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o, 64);
+            const float rstd = 1.0f / sqrtf(sqs * (1.f / 64.f) + kEps);
+            const float4 y = ok ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
+            if (inr) st4(slab[st] + j * kSlabLd + (threadIdx.x & 15) * 4, y);
+        }
+    };
+
+    int pair = blockIdx.x;
+    const int npairs = (total_tiles + 1) / 2;
+    load_b(0);
+    fetch_slabs(pair);
+    store_slabs(pair);
+    store_b(Bs[0]);
+    __syncthreads();
+
+    const int swz = (i >> 1) & 3;
+    const int bco0 = (kh ^ swz) << 2, bco1 = ((2 + kh) ^ swz) << 2;  // LDS slot of this lane's k quad in the two halves of a chunk
+    constexpr int NK = 512 / BK;
+#pragma unroll 1
+    while (true) {
+        const int next = pair + gridDim.x;
+        const bool has_next = next < npairs;
+        if (has_next) fetch_slabs(next);
+        const FlatTile t = tile_of(min(pair * 2 + wm, total_tiles - 1));
+        int prow[2];  // slab row of this lane's output row in the wave's two row tiles
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ri = 32 * m + i;
+            prow[m] = ri + 7 * ((ri >= t.n0) + (ri >= t.n0 + t.n1));
+        }
+        floatx16 acc[4][2];  // [weight tile][row tile]
+        acc_zero(acc);
+#pragma unroll 1
+        for (int kc = 0; kc < NK; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < NK) load_b((kc + 1) * BK);
+            const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
+            const float* ap = Bs[cur] + (wn * 128 + i) * BK;
+            const float* sp = slab[wm] + kk * kSlabLd + c0 + 4 * kh;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 a[4], b[2];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) a[n] = ld4(ap + n * 32 * BK + (h ? bco1 : bco0));
+#pragma unroll
+                for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * h);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].x, b[m].x, acc[n][m], 0, 0, 0);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].y, b[m].y, acc[n][m], 0, 0, 0);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].z, b[m].z, acc[n][m], 0, 0, 0);
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].w, b[m].w, acc[n][m], 0, 0, 0);
+                    }
+            }
+            if (kc + 1 < NK) store_b(Bs[cur ^ 1]);
+            __syncthreads();
+        }
+        if (has_next) load_b(0);
+        if (pair * 2 + wm < total_tiles) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const long long r = (long long)t.r0 + 32 * m + i;
+                if (r < R) {
+                    float* o = dst + r * N + wn * 128 + 4 * kh;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) st4(o + n * 32 + 8 * g, acc_group(acc[n][m], g));
+                }
+            }
+        }
+        if (!has_next) break;
+        pair = next;
+        store_slabs(pair);  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
+        store_b(Bs[0]);
+        __syncthreads();
+    }
+}
+
 // Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.
 //   KM == 4 (layer 0): U[s][l][lane][4] = (u0, u1, u2, x')          -> one 16-byte load per lane per step
 //   KM == 3 (layers 1-3): U[s][l][m][lane], m = 0..2, skip input x' = X[s][l][lane] * scale_x
@@ -507,6 +681,14 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
     const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
     if (npairs < 256) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
         hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
+    static const bool per_seq_tiles = getenv("RTFS_UNFOLD_PER_SEQ") != nullptr;  // second-generation kernel (tiles padded per sequence)
+    if (!per_seq_tiles) {
+        const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
+        hipLaunchKernelGGL(unfold_gemm128f_kernel, dim3(fpairs < resident ? fpairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
+                           Wt, U0, S, ftiles);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
