@@ -235,10 +235,10 @@ def main():
                 durs = prof  # launches alternate dim 4 (freq), dim 3 (time)
                 tot_ms = sum(durs)
                 tot_fl = (fl[4] + fl[3]) * (len(durs) // 2)
-                roof = {"kernel": "rtfs::unfold_gemm128_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
+                roof = {"kernel": "rtfs::unfold_gemm128f_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
                         "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "launches": len(durs), "avg_launch_ms": tot_ms / len(durs),
-                        "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128_kernel", args)}
+                        "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", args)}
             else:
                 km = kernel_models(args.batch, T, T2, Tv).get(name)
                 if km is not None:
