@@ -29,6 +29,15 @@ def test_single_process_line():
     assert res["value"] > 0 and "workload" in res["config"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(res["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(res["cpu_baseline"])
+    assert res["si_sdri_parity"]["abs_diff_db"] <= 0.01  # BASELINE.json metric: "...; SI-SDRi parity" (HIP vs oracle, same utterance)
+
+
+def test_lip_encoder_in_the_timed_step():
+    r = subprocess.run([sys.executable, "bench.py", "--lip", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _last_json(r.stdout)
+    assert KEYS <= set(res) and res["config"]["mode"] == "infer+lip-encoder" and res["value"] > 0
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])
