@@ -685,7 +685,7 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
         return RTFS_OK;
     }
     static const bool per_seq_tiles = getenv("RTFS_UNFOLD_PER_SEQ") != nullptr;  // second-generation kernel (tiles padded per sequence)
-    if (!per_seq_tiles) {
+    if (!per_seq_tiles && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
         hipLaunchKernelGGL(unfold_gemm128f_kernel, dim3(fpairs < resident ? fpairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
                            Wt, U0, S, ftiles);

@@ -209,3 +209,26 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
     assert float((U2 - U).abs().max()) < 2e-5
     with pytest.raises(RuntimeError):  # saves come as a pair
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
+
+
+@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
+    """rtfs_dp_unfold_gemm_fwd in isolation (LN4D over channels + 8-tap unfold + layer-0 GEMM, rnn_layers.py:146-150) against float64 on
+    the CPU, at sizes that take the large-batch kernel (tiles cut from the flattened row index: 2- and 3-sequence tiles, ragged end)
+    and a few that take the small-batch one."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(100 * B + T2 + dim)
+    G = torch.randn(B, T2, 64, 64, generator=g)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    Wt = torch.randn(256, 512, generator=g) * 0.05
+    x = G.double()
+    xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    seqs = xn.reshape(B * T2, 64, 64) if dim == 4 else xn.permute(0, 2, 1, 3).reshape(B * 64, T2, 64)  # [S][npos][64]
+    L = seqs.shape[1] - 7
+    win = torch.stack([seqs[:, k:k + L] for k in range(8)], dim=2).reshape(seqs.shape[0], L, 512)  # k index = tap * 64 + channel
+    want = win @ Wt.double().t()
+    U = torch.full((seqs.shape[0] * L * 256,), float("nan"), device="cuda")
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim)
+    assert rel(U.view(want.shape), want) < 2e-6
