@@ -118,6 +118,12 @@ __device__ __forceinline__ float4 ld4_off(const float* base, unsigned byte_off) 
 __device__ __forceinline__ void st4_off(float* base, unsigned byte_off, float4 v) {
     *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
+__device__ __forceinline__ float ld1_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st1_off(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

@@ -543,16 +543,20 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
         st4(Ws + n * LDW + q4, ld4(Wt + n * 64 + q4) * sc);
     }
     __syncthreads();
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: bases below live in SGPRs
     if (s >= S) return;
     const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const bool rev = lane >= 32;
     const float wf = wc[lane] * kNegLog2e, wr = wc[64 + lane] * kNegLog2e;
     const float bf = bias[lane] * kNegLog2e, br = bias[64 + lane] * kNegLog2e;
     const float* hp = Hprev + (size_t)s * L * 64;
-    float* ho = Hout + (size_t)s * L * 64 + lane;
-    float* co = Cout + (size_t)s * L * 64 + lane;
-    float* uo = Uout + (size_t)s * L * 192 + lane;  // [l][m][lane]
+    float* hob = Hout + (size_t)s * L * 64;
+    float* cob = Cout + (size_t)s * L * 64;
+    float* uob = Uout + (size_t)s * L * 192;  // [l][m][lane]
+    // The recurrence step of scan position sl touches row t = sl (forward lanes) or L-1-sl (reverse lanes): as a byte offset from the
+    // sequence base that is  off0 + sl * dstr  with per-lane constants - one v_mad per access (wave-uniform base + 32-bit offset form)
+    const int dstr = rev ? -256 : 256, off0 = (rev ? (L - 1) * 256 : 0) + lane * 4;
+    const int off0u = (rev ? (L - 1) * 768 : 0) + lane * 4;  // same for the [l][3][64] pre-activation rows
     constexpr float kUnscale = 1.0f / kNegLog2e;
     float c = 0.f;
     const int nch = (L + 31) >> 5;
@@ -572,12 +576,6 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
     for (int ch = 0; ch < nch; ++ch) {
         const int sl0 = ch * 32;
         floatx16 acc[2][3];
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[dd][m][r] = 0.f;  // (bias as initial value costs 64 live VGPRs at the loop top: spills)
         int woff = i * LDW + 32 * kh;
         asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
                                         // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
@@ -587,8 +585,16 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const float4 b0 = ld4(wp + (m * 64) * LDW + 4 * q), b1 = ld4(wp + (m * 64 + 32) * LDW + 4 * q);
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
+                if (q == 0) {  // the chain starts from a zero C operand (an inline constant): no accumulator clearing
+                    floatx16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, z, 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, z, 0, 0, 0);
+                } else {
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
+                }
                 acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, b0.y, acc[0][m], 0, 0, 0);
                 acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, b1.y, acc[1][m], 0, 0, 0);
                 acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, b0.z, acc[0][m], 0, 0, 0);
@@ -598,27 +604,32 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
             }
         }
         if (ch + 1 < nch) load_a(sl0 + 32);
-        // lanes 0-31 keep dir 0, lanes 32-63 take dir 1: each lane hands its partner (lane ^ 32) the half it does not need
-        // (ds_bpermute; hipcc miscompiles a chain of __builtin_amdgcn_permlane32_swap on accumulator elements).  Afterwards
+        // Half exchange: v_permlane32_swap X, Y swaps lanes 32-63 of X with lanes 0-31 of Y.  With X = a dir-0 accumulator register and
+        // Y = the same register of the dir-1 tile, lanes 0-31 end up with (own dir-0 rows, dir-0 rows of lane + 32) and lanes 32-63
+        // with (dir-1 rows of lane - 32, own dir-1 rows): every lane holds all 32 steps of ITS direction, no selects.  Afterwards
         // acc[0][m][r] -> local step rho(r), acc[1][m][r] -> rho(r) + 4,  rho(r) = (r & 3) + 8 (r >> 2).
+        // Inline asm (the builtin on accumulator elements is miscompiled by this hipcc), so the hazards are ours: nothing may move
+        // across the barrier, 20 wait states cover the last MFMA's 16 passes before its result is read, and the swaps only
+        // read MFMA results (no VALU write of an operand within two wait states).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float x0 = acc[0][m][r], y0 = acc[1][m][r];
-                const float got = __shfl_xor(rev ? x0 : y0, 32, 64);
-                acc[0][m][r] = rev ? got : x0;
-                acc[1][m][r] = rev ? y0 : got;
+                float x0 = acc[0][m][r], y0 = acc[1][m][r];
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                acc[0][m][r] = x0;
+                acc[1][m][r] = y0;
             }
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         // recurrence: 4 groups of 8 steps; a group's skip inputs x' (rows just read as A fragments: L1/L2 hits) are fetched one
         // group ahead
         float xa[8], xb[8];
         auto load_x = [&](float(&xv)[8], int g) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int sl = min(sl0 + 8 * g + k, L - 1);
-                xv[k] = hp[(rev ? L - 1 - sl : sl) * 64 + lane];
-            }
+            for (int k = 0; k < 8; ++k) xv[k] = ld1_off(hp, (unsigned)(off0 + min(sl0 + 8 * g + k, L - 1) * dstr));
         };
         auto steps = [&](const float(&xv)[8], int g, auto G) {
             constexpr int gg = decltype(G)::value;
@@ -629,15 +640,16 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                     const int k = 8 * gg + k8;
                     const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
                     const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
-                    const int t = rev ? L - 1 - sl : sl;
+                    const unsigned off = (unsigned)(off0 + sl * dstr);
                     const float x = xv[k8] * scale_x;
                     const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
                     const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
                     c = u0 + (c - u0) * f;
-                    ho[t * 64] = x + (c - x) * rg;
+                    st1_off(hob, off, x + (c - x) * rg);
                     if (SAVE_C) {
-                        co[t * 64] = c;
-                        uo[t * 192] = u0, uo[t * 192 + 64] = u1 * kUnscale, uo[t * 192 + 128] = u2 * kUnscale;
+                        st1_off(cob, off, c);
+                        const unsigned offu = (unsigned)(off0u + sl * (3 * dstr));
+                        st1_off(uob, offu, u0), st1_off(uob, offu + 256, u1 * kUnscale), st1_off(uob, offu + 512, u2 * kUnscale);
                     }
                 }
             }
