@@ -51,7 +51,7 @@ __device__ __forceinline__ void lip_store(const floatx16 (&acc)[1][WN], const Li
 // ------------------------------------------------------------------------------------------------
 template <int KS>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ Wk, LipEpi e, int H, int W,
-                                                            int Cin, int Ho, int Wo, int stride, long long M) {
+                                                            int Cin, int Ho, int Wo, int stride, long long M, long long in_bytes) {
     __shared__ __attribute__((aligned(16))) float As[64 * kLipLds];
     __shared__ __attribute__((aligned(16))) float Bs[128 * kLipLds];
     constexpr int PAD = KS / 2;
@@ -59,9 +59,13 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const float* __restri
     const long long px0 = (long long)blockIdx.x * 128;
     const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
     const int ktot = KS * KS * Cin;
-    // the 8 pixel rows this thread stages: image base offset, top-left input coordinate
-    int iy0[8], ix0[8];
-    long long nb[8];
+    // The 8 pixel rows this thread stages.  Per row, once: the byte offset of its window's top-left element and a KS*KS-bit mask of
+    // the taps that fall inside the image.  Per K step the address is then ONE add (row offset + the step's uniform tap / channel
+    // offset) and the zero padding ONE select: out-of-image taps get an offset past the end of the buffer descriptor, which the
+    // hardware answers with zeros (fp32 MFMA does not overlap with VALU work - per-step address arithmetic is paid in full).
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, (int)min(in_bytes, (long long)0x7fffffff), 0x00020000);
+    int roff[8];
+    unsigned rmask[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         long long px = px0 + r0 + 16 * j;
@@ -69,21 +73,27 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const float* __restri
         if (!ok) px = 0;
         const long long n = px / (Ho * Wo);
         const int rem = (int)(px - n * (Ho * Wo)), oy = rem / Wo, ox = rem - oy * Wo;
-        iy0[j] = ok ? oy * stride - PAD : -(1 << 20);  // out-of-range rows read zeros
-        ix0[j] = ox * stride - PAD;
-        nb[j] = n * H * W;
+        const int iy = oy * stride - PAD, ix = ox * stride - PAD;
+        roff[j] = (int)(((n * H + iy) * W + ix) * Cin + c4) * 4;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            const int y = iy + t / KS, x = ix + t % KS;
+            if (ok && y >= 0 && y < H && x >= 0 && x < W) mk |= 1u << t;
+        }
+        rmask[j] = mk;
     }
     float4 va[4], vb[8];
     auto fetch = [&](int tap, int ci0) {
         const int dy = tap / KS, dx = tap - dy * KS;
+        const int soff = ((dy * W + dx) * Cin + ci0) * 4;  // wave-uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) va[j] = ld4(Wk + (size_t)(co0 + r0 + 16 * j) * ktot + tap * Cin + ci0 + c4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int iy = iy0[j] + dy, ix = ix0[j] + dx;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float4 v = ld4(in + ((nb[j] + (long long)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)) * Cin + ci0 + c4));
-            vb[j] = ok ? v : f4(0, 0, 0, 0);
+            const int off = (rmask[j] >> tap) & 1 ? roff[j] + soff : 0x7ffffff0;
+            const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0));
+            vb[j] = f4(v[0], v[1], v[2], v[3]);
         }
     };
     const int wave = threadIdx.x >> 6, wm = wave & 1, wn = wave >> 1;
@@ -246,14 +256,16 @@ int rtfs_lip_maxpool_fwd(const float* in, float* out, int N, int H, int W, void*
 int rtfs_conv_nhwc_fwd(const float* in, const float* Wk, const float* bias, const float* slope, const float* res, float* out, int N, int H, int W,
                        int Cin, int Cout, int ks, int stride, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin % 64 || Cout % 64 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2)) return RTFS_EINVAL;
+    const long long in_bytes = (long long)N * H * W * Cin * 4;
+    if (in_bytes >= 0x7ffffff0LL) return RTFS_EINVAL;  // 32-bit buffer offsets (2 GB of input activations per call)
     const int pad = ks / 2, Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const long long M = (long long)N * Ho * Wo;
     LipEpi e{bias, slope, res, out, Cout};
     dim3 grid((unsigned)((M + 127) / 128), Cout / 64);
     if (ks == 3)
-        hipLaunchKernelGGL((conv_nhwc_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, in, Wk, e, H, W, Cin, Ho, Wo, stride, M);
+        hipLaunchKernelGGL((conv_nhwc_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, in, Wk, e, H, W, Cin, Ho, Wo, stride, M, in_bytes);
     else
-        hipLaunchKernelGGL((conv_nhwc_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, in, Wk, e, H, W, Cin, Ho, Wo, stride, M);
+        hipLaunchKernelGGL((conv_nhwc_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, in, Wk, e, H, W, Cin, Ho, Wo, stride, M, in_bytes);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
