@@ -312,14 +312,16 @@ int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const 
 }
 
 int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
-    if (B <= 0 || T2 <= 0 || T2 > 512) return RTFS_EINVAL;
+    if (B <= 0 || T2 <= 0 || T2 > 1024) return RTFS_EINVAL;  // the [32][T2] score tile lives in LDS: 1024 keys = 131.6 KB (16.4 s of audio)
     dim3 grid((T2 + 31) / 32, kHeads, B);
     if (T2 <= 128)
         hipLaunchKernelGGL((attn_core_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else if (T2 <= 256)
         hipLaunchKernelGGL((attn_core_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
-    else
+    else if (T2 <= 512)
         hipLaunchKernelGGL((attn_core_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+    else
+        hipLaunchKernelGGL((attn_core_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

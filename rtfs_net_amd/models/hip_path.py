@@ -291,6 +291,9 @@ class HipForward:
         T2 = (T - 2) // 2 + 1
         if T2 < 8:
             raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
+        if T2 > 1024:
+            raise ValueError(f"input too long for the HIP path: {L} samples = {T2} compressed frames, the TF-attention score tile holds 1024 "
+                             "(about 16.4 s at 16 kHz); split longer recordings into segments")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats

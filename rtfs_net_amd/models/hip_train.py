@@ -168,6 +168,8 @@ class HipTrainer:
         T2 = (T - 2) // 2 + 1
         if T2 < 8:
             raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
+        if T2 > 512:
+            raise ValueError(f"training segment too long for the HIP path: {T2} compressed frames, the attention adjoint holds 512 (about 8 s)")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats

@@ -79,3 +79,18 @@ def test_train_mode_runs_under_autograd_and_is_refused_without():
     assert out.requires_grad and out.grad_fn is not None and torch.isfinite(out).all()
     with torch.no_grad(), pytest.raises(NotImplementedError):
         model(mix.cuda(), emb.cuda())
+
+
+def test_long_utterance_and_length_limit():
+    """8.5 s (531 compressed frames: the 1024-key attention tile) against the oracle; past 16.4 s the path refuses loudly."""
+    from oracle.avnet_ref import avnet_forward
+
+    model, sd, cfg = make_model(2, "cuda")
+    L = 136000
+    mix, _, emb = synth.synth_inputs(1, L, 212)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+        ref = avnet_forward(sd, cfg, mix, emb)
+        assert rel(out, ref) < WAVE_TOL
+        with pytest.raises(ValueError):
+            model(torch.zeros(1, 270000, device="cuda"), torch.zeros(1, 512, 420, device="cuda"))
