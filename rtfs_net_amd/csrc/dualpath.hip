@@ -300,10 +300,13 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, cons
 // the padding of a sequence to a multiple of 64 (L = 57: 64 -> 57 rows per sequence, -10.9 % of the MFMAs; L = 118: 128 -> 118,
 // -7.8 %).  A tile then covers up to three sequences: its slab holds, per sequence segment, the segment's rows plus the 7 halo rows
 // (<= 64 + 21 rows), and output row i reads slab row i + 7 g(i) + tap, g = the segment of row i (a per-lane constant).  U0 is
-// [S][L][256] = [S*L][256], so the write-back is one contiguous block of rows.  LDS: the longer slabs are paid for by storing the
-// weight chunk unpadded (64-byte rows, 16-byte slot XOR-swizzled with (row >> 1) & 3: conflict-free for the 8-lane groups of a
-// ds_read_b128) - 79 KB, two workgroups per CU as before.  Otherwise as the second generation: 128 x 256 workgroup tile, persistent,
-// next tile's raw rows fetched under the current tile's k-loop.
+// [S][L][256] = [S*L][256], so the write-back is one contiguous block of rows.
+// Work unit = (tile pair, 128-column half): a workgroup owns a CONTIGUOUS range of units (balanced to one unit), stages the pair's two
+// slabs once (LayerNormalization4D on the way in) and runs the K loop once per column half with a 64 x 64 wave tile - 64 accumulator
+// registers instead of 128, so the fragment reads of a k step are no longer funnelled through one register quad, and the tail of the
+// launch is quantised in half-size units.  BK = 32, weight chunk unpadded (128-byte rows, 16-byte slot XOR-swizzled with row & 7),
+// 78 KB of LDS: two workgroups per CU.  The raw rows of the next pair are fetched into registers under the last K loop of the
+// current one.
 constexpr int kFlatRows = 64 + 21;
 struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
     int r0, s0, l0, n0, n1;  // first flattened row, its (sequence, position); rows of segment 0, 1 (segment 2 = the rest)
@@ -311,10 +314,10 @@ struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
 __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
                                                                  int S, int total_tiles) {
-    constexpr int BK = 16, N = 256;
+    constexpr int BK = 32, N = 256, NP = 128;  // columns per pass
     constexpr int NIT = (2 * kFlatRows * 16 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float slab[2][kFlatRows * kSlabLd];
-    __shared__ __attribute__((aligned(16))) float Bs[2][N * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NP * BK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const float4 g4 = ld4(gamma + (threadIdx.x & 15) * 4), b4 = ld4(beta + (threadIdx.x & 15) * 4);
@@ -330,20 +333,20 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
         t.n1 = min(L, 64 - t.n0);
         return t;
     };
-    // weight chunk: global -> registers -> LDS (row n = 16 floats = four 16-byte slots, slot c stored at c ^ ((n >> 1) & 3))
+    // weight chunk of a pass: global -> registers -> LDS (row n = 32 floats = eight 16-byte slots, slot c stored at c ^ (n & 7))
     float4 breg[4];
-    auto load_b = [&](int k0) {
+    auto load_b = [&](int np, int k0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = threadIdx.x + it * 256, row = idx >> 2, c = idx & 3;
-            breg[it] = ld4(Wt + (size_t)row * 512 + k0 + c * 4);
+            const int idx = threadIdx.x + it * 256, row = idx >> 3, c = idx & 7;
+            breg[it] = ld4(Wt + (size_t)(np * NP + row) * 512 + k0 + c * 4);
         }
     };
     auto store_b = [&](float* B) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = threadIdx.x + it * 256, row = idx >> 2, c = idx & 3;
-            st4(B + row * BK + ((c ^ ((row >> 1) & 3)) << 2), breg[it]);
+            const int idx = threadIdx.x + it * 256, row = idx >> 3, c = idx & 7;
+            st4(B + row * BK + ((c ^ (row & 7)) << 2), breg[it]);
         }
     };
     float4 sraw[NIT];
@@ -395,22 +398,25 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
         }
     };
 
-    int pair = blockIdx.x;
+    // this workgroup's units [u0, u1): unit u = (pair u >> 1, column half u & 1)
     const int npairs = (total_tiles + 1) / 2;
-    load_b(0);
-    fetch_slabs(pair);
-    store_slabs(pair);
+    const long long U = 2LL * npairs;
+    const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+    if (u0 >= u1) return;
+    load_b(u0 & 1, 0);
+    fetch_slabs(u0 >> 1);
+    store_slabs(u0 >> 1);
     store_b(Bs[0]);
     __syncthreads();
 
-    const int swz = (i >> 1) & 3;
-    const int bco0 = (kh ^ swz) << 2, bco1 = ((2 + kh) ^ swz) << 2;  // LDS slot of this lane's k quad in the two halves of a chunk
+    const int sw = i & 7;
     constexpr int NK = 512 / BK;
 #pragma unroll 1
-    while (true) {
-        const int next = pair + gridDim.x;
-        const bool has_next = next < npairs;
-        if (has_next) fetch_slabs(next);
+    for (int u = u0; u < u1; ++u) {
+        const int pair = u >> 1, np = u & 1;
+        const bool has_next = u + 1 < u1;
+        const bool new_pair = has_next && ((u + 1) >> 1) != pair;
+        if (new_pair) fetch_slabs(pair + 1);
         const FlatTile t = tile_of(min(pair * 2 + wm, total_tiles - 1));
         int prow[2];  // slab row of this lane's output row in the wave's two row tiles
 #pragma unroll
@@ -418,24 +424,24 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             const int ri = 32 * m + i;
             prow[m] = ri + 7 * ((ri >= t.n0) + (ri >= t.n0 + t.n1));
         }
-        floatx16 acc[4][2];  // [weight tile][row tile]
+        floatx16 acc[2][2];  // [weight tile][row tile]
         acc_zero(acc);
 #pragma unroll 1
         for (int kc = 0; kc < NK; ++kc) {
             const int cur = kc & 1;
-            if (kc + 1 < NK) load_b((kc + 1) * BK);
+            if (kc + 1 < NK) load_b(np, (kc + 1) * BK);
             const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-            const float* ap = Bs[cur] + (wn * 128 + i) * BK;
+            const float* ap = Bs[cur] + (wn * 64 + i) * BK;
             const float* sp = slab[wm] + kk * kSlabLd + c0 + 4 * kh;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float4 a[4], b[2];
+            for (int q = 0; q < 4; ++q) {
+                float4 a[2], b[2];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) a[n] = ld4(ap + n * 32 * BK + (h ? bco1 : bco0));
+                for (int n = 0; n < 2; ++n) a[n] = ld4(ap + n * 32 * BK + (((2 * q + kh) ^ sw) << 2));
 #pragma unroll
-                for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * h);
+                for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * q);
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].x, b[m].x, acc[n][m], 0, 0, 0);
@@ -447,23 +453,22 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             if (kc + 1 < NK) store_b(Bs[cur ^ 1]);
             __syncthreads();
         }
-        if (has_next) load_b(0);
+        if (has_next) load_b((u + 1) & 1, 0);
         if (pair * 2 + wm < total_tiles) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const long long r = (long long)t.r0 + 32 * m + i;
                 if (r < R) {
-                    float* o = dst + r * N + wn * 128 + 4 * kh;
+                    float* o = dst + r * N + np * NP + wn * 64 + 4 * kh;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n)
+                    for (int n = 0; n < 2; ++n)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) st4(o + n * 32 + 8 * g, acc_group(acc[n][m], g));
                 }
             }
         }
         if (!has_next) break;
-        pair = next;
-        store_slabs(pair);  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
+        if (new_pair) store_slabs(pair + 1);  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
         store_b(Bs[0]);
         __syncthreads();
     }
@@ -699,7 +704,8 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
     static const bool per_seq_tiles = getenv("RTFS_UNFOLD_PER_SEQ") != nullptr;  // second-generation kernel (tiles padded per sequence)
     if (!per_seq_tiles && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
-        hipLaunchKernelGGL(unfold_gemm128f_kernel, dim3(fpairs < resident ? fpairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
+        const int units = 2 * fpairs;  // (tile pair, column half)
+        hipLaunchKernelGGL(unfold_gemm128f_kernel, dim3(units < resident ? units : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
                            Wt, U0, S, ftiles);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
