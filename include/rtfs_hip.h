@@ -94,6 +94,14 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
                    const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt /*[256][64]*/,
                    const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, int B,
                    int T, int T2, void* stream);
+/* rtfs_resid_fwd of block i (with a0) fused with rtfs_proj_fwd of block i+1 (the blocks share their weights, tdanet.py:9-59 / `shared`):
+ * out as above, plus py = Wp . prelu(out*gw+gb) + pbias ([B][T*129][64], pre-gLN) and its gLN partial sums in pstats - the next
+ * block's projection (tdanet.py:108-109) is computed from the output tile while it is still in LDS. */
+int rtfs_resid_proj_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                        const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt,
+                        const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0, float* out,
+                        const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream);
 
 /* ---- a10: CAF, ATTNFusionCell.forward, layers/fusion.py:252-274 --------------------------------------------- */
 int rtfs_caf_video_fwd(const float* v /*[B][512][Tv]*/, const float* att_w, const float* att_b, const float* att_g, const float* att_be,

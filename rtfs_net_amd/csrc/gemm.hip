@@ -120,6 +120,12 @@ struct EpiResidual {
     const float *__restrict__ gw, *__restrict__ gb;
     float slope;
     const float* __restrict__ a0;  // may be null
+    // PROJ variant: the NEXT block's gateway + projection (tdanet.py:108-109, shared weights) computed from the output tile while it
+    // is still in LDS: py = Wp . prelu(out * gw + gb) + pbias (pre-gLN, [B][TF][64]) and its gLN partial sums
+    const float* __restrict__ pw;     // [64][256]
+    const float* __restrict__ pbias;  // [64]
+    float* __restrict__ py;
+    double* pslot;
 };
 
 // S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
@@ -290,12 +296,14 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
 //  * 52 KB of LDS -> 2-3 workgroups per CU overlap one's MFMA phase with the others' memory phases.
 // Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_A0>
+template <bool HAS_A0, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDE = 68;
     constexpr int LDO = 260;
     __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
     __shared__ __attribute__((aligned(16))) float Ot[32 * LDO];  // one 32-pixel half of the output tile, pixel-major
+    __shared__ float pred[8];
+    float ps = 0.f, pq = 0.f;  // PROJ: gLN partial sums of the projection output
     const int b = blockIdx.y;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     pro.init(b);
@@ -376,6 +384,8 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
             float4 sv[8], av[8];
+            float4 wp[16];  // PROJ: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3], t = 0..15
+            const float* wpp = PROJ ? epi.pw + (size_t)(16 * w + (lane & 15)) * 256 + 64 * (lane >> 4) : nullptr;
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -397,8 +407,56 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[it], cgw, cgb), epi.slope - 1.0f);
                 if (HAS_A0) v = v + av[it];
                 if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
+                if (PROJ) {
+                    st4(Ot + r * LDO + cq, prelu4(fma4(v, cgw, cgb), epi.slope));  // the next block's gateway, in place
+                    // two of the 16 projection-weight fragments per iteration, into the registers sv / av just left (L2 latency
+                    // hidden behind the rest of this loop)
+                    wp[2 * it] = ld4(wpp + 8 * it), wp[2 * it + 1] = ld4(wpp + 8 * it + 4);
+                }
+            }
+            if (PROJ) {
+                // projection of the 32 gated pixels now in Ot, as proj_kernel does it: 16x16x4 MFMA, wave w owns output channels
+                // 16w .. 16w+15 for both 16-pixel sub-tiles and the whole K = 256; lane group kk = lane >> 4 takes k = 64kk + s.
+                // The weight fragments (64 VGPRs) are streamed from L2 into the registers the epilogue loads just left.
+                const int j = lane & 15, kk = lane >> 4;
+                __syncthreads();  // Ot holds the gated tile
+                // four independent accumulator chains (2 pixel sub-tiles x even / odd k quads): the 40-cycle dependent latency of
+                // the 32-cycle instruction never shows
+                floatx4 pa[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pa[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+                const float* ap = Ot + j * LDO + 64 * kk;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float4 e0 = ld4(ap + 4 * t), e1 = ld4(ap + 16 * LDO + 4 * t);
+                    const int c = 2 * (t & 1);
+                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e0.x, pa[c], 0, 0, 0);
+                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e1.x, pa[c + 1], 0, 0, 0);
+                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e0.y, pa[c], 0, 0, 0);
+                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e1.y, pa[c + 1], 0, 0, 0);
+                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e0.z, pa[c], 0, 0, 0);
+                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e1.z, pa[c + 1], 0, 0, 0);
+                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e0.w, pa[c], 0, 0, 0);
+                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e1.w, pa[c + 1], 0, 0, 0);
+                }
+                const float4 pb4 = ld4(epi.pbias + 16 * w + 4 * kk);
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int p = m0 + pt * 32 + 16 * sub + j;
+                    if (p < Mb) {
+                        const float4 o = f4(pa[sub][0] + pa[sub + 2][0], pa[sub][1] + pa[sub + 2][1], pa[sub][2] + pa[sub + 2][2],
+                                            pa[sub][3] + pa[sub + 2][3]) + pb4;
+                        st4(epi.py + ((size_t)b * Mb + p) * kH + 16 * w + 4 * kk, o);
+                        ps += o.x + o.y + o.z + o.w;
+                        pq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                    }
+                }
             }
         }
+    }
+    if (PROJ) {
+        __syncthreads();
+        block_stats_commit(ps, pq, pred, epi.pslot, b);
     }
 }
 
@@ -538,7 +596,7 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
     const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
     ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null};
+    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null, nullptr, nullptr, nullptr, nullptr};
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
     // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
     // 64 -> 804; small batches get more, smaller workgroups.
@@ -549,6 +607,29 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
         hipLaunchKernelGGL(resid_kernel<true>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
     else
         hipLaunchKernelGGL(resid_kernel<false>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// rtfs_resid_fwd (with a0) fused with the NEXT block's rtfs_proj_fwd (shared block weights): out as above, plus
+// py = Wp . prelu(out*gw+gb) + pbias ([B][TF][64], pre-gLN) and its gLN partial sums in pstats - the projection reads the output tile
+// from LDS instead of re-reading 1 GB of `out` from HBM.
+int rtfs_resid_proj_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                        const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                        const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                        const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                        const float* a0, float* out, const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2,
+                        void* stream) {
+    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
+    ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
+                    {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0, Wp, pbias, py, pstats};
+    if (B <= 0 || T <= 0 || !a0 || !Wp || !py || !pstats) return RTFS_EINVAL;
+    const int Mb = T * kF, tiles = (Mb + 63) / 64;
+    const long long want = ((long long)tiles * B + 1023) / 1024;
+    const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
+    hipLaunchKernelGGL((resid_kernel<true, true>), dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

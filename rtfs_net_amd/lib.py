@@ -49,6 +49,7 @@ SIGNATURES = {
     "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, P, I, I, P],
     "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
     "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
+    "rtfs_resid_proj_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, P],
     "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
     "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
     "rtfs_mask_fwd": [P, F, P, P, P, P, P, I, I, P],

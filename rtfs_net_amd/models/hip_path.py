@@ -222,13 +222,17 @@ class HipForward:
         lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
 
     # ---- one RTFS block (a5) ----
-    def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None):
+    def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None, y0=None, next_proj=None):
+        """One RTFS block.  `y0`: this block's projection output if the previous block's residual kernel already produced it;
+        `next_proj` = (y0 buffer, statistics slot) of the NEXT block: its gateway + projection are then fused into this block's residual
+        kernel (shared block weights, `a0` present), which saves re-reading the 256-channel output from HBM."""
         dev = s_in.device
         TF = T * F_BINS
         full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
         low = lambda: torch.empty(B * T2 * F2 * H, device=dev)  # noqa: E731
-        y0 = full()
-        lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], y0, st[0], B, TF)
+        if y0 is None:
+            y0 = full()
+            lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], y0, st[0], B, TF)
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         D0 = full()
@@ -273,8 +277,14 @@ class HipForward:
         cl, cg, cgate = full(), low(), low()
         lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
         lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
+        if next_proj is not None and a0_or_none is not None:
+            lib.call("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
+                     cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, bw["pw"], bw["pb"], next_proj[0],
+                     next_proj[1], B, T, T2)
+            return True
         lib.call("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                  cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+        return False
 
     @torch.no_grad()
     def __call__(self, wav: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
@@ -343,9 +353,15 @@ class HipForward:
         if taps is not None:
             taps["block0"], taps["vp"] = x.clone(), v1
             taps["caf_plus_a0" if not last else "caf"] = s.clone()
+        fuse = len(blocks) == 1 and os.environ.get("RTFS_NO_PROJ_FUSION", "0") != "1"  # shared block weights: block i+1's projection = block i's
+        y0_next = None
         for i in range(1, R):
             last = i == R - 1
-            self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2)
+            y0_cur, nxt = y0_next, None
+            if fuse and not last:
+                nxt = (torch.empty(B * TF * H, device=dev), stats[1 + 12 * (i + 1)])
+            fused = self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, y0=y0_cur, next_proj=nxt)
+            y0_next = nxt[0] if fused else None
             s, x = x, s
         # a11: S3 mask; a12: decoder taps + iSTFT
         masked = x

@@ -232,3 +232,20 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     U = torch.full((seqs.shape[0] * L * 256,), float("nan"), device="cuda")
     lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim)
     assert rel(U.view(want.shape), want) < 2e-6
+
+
+def test_resid_proj_fusion_matches_separate_calls():
+    """Blocks 1..R-2 compute the next block's projection inside the residual kernel: same waveform as the separate kernels (the only
+    difference is the summation order of the 256-term projection dot products)."""
+    import os
+
+    model, sd, cfg = make_model(4, "cuda")
+    mix, _, emb = synth.synth_inputs(3, 16000, 25)
+    with torch.no_grad():
+        fused = model(mix.cuda(), emb.cuda())
+        os.environ["RTFS_NO_PROJ_FUSION"] = "1"
+        try:
+            plain = model(mix.cuda(), emb.cuda())
+        finally:
+            del os.environ["RTFS_NO_PROJ_FUSION"]
+    assert rel(fused, plain) < 2e-6 and not torch.equal(fused, plain)
