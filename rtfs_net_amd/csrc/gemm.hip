@@ -359,6 +359,20 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
             }
         }
         __syncthreads();
+        // residual-side operands of the first 32-pixel half: issued BEFORE the MFMA phase so that their HBM latency runs under it
+        // (the kernel is latency-bound once the projection rides in the epilogue)
+        float4 sv[8], av[8];
+        auto load_sv = [&](int pt) {
+            const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
+                sv[it] = ld4_off(s_b, o);
+                if (HAS_A0) av[it] = ld4_off(a0_b, o);
+            }
+        };
+        load_sv(0);
+        __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks these loads below the MFMAs to save registers)
         floatx16 acc[2][2];
         acc_zero(acc);
 #pragma unroll
@@ -383,16 +397,10 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         // one pixel's whole 1 KB row - 8 lines - for s_in, a0 and the store; the per-channel constants sit in registers.
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            float4 sv[8], av[8];
             float4 wp[16];  // PROJ: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3], t = 0..15
             const float* wpp = PROJ ? epi.pw + (size_t)(16 * w + (lane & 15)) * 256 + 64 * (lane >> 4) : nullptr;
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
-                sv[it] = ld4_off(s_b, o);
-                if (HAS_A0) av[it] = ld4_off(a0_b, o);
-            }
+            if (pt == 1) load_sv(1);
             __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
