@@ -11,7 +11,10 @@ timing barrier and the max-over-ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- the dominant kernel, timed live with HIP events on the launch stream during the timed steps
+                  (infer: the layer-0 unfold GEMM; train: the dominant BACKWARD kernel, the layer-0 Toeplitz weight gradient)
   cpu_baseline -- the oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample (N=1 only)
+`value` / `ms_per_step` come from the wall clock around the K timed steps (barrier + synchronize on both sides, max over ranks);
+`ms_per_step_median` is the median of the per-step HIP-event durations of the same K steps.
 """
 from __future__ import annotations
 
@@ -81,11 +84,14 @@ def main():
     ap.add_argument("--lip", action="store_true",
                     help="infer mode: start from 88x88 mouth crops and run the HIP lip encoder (FRCNNVideoModel) inside the timed step "
                          "(core.py:87-89); default: lip embeddings are the input, as BASELINE.json's configs state")
-    ap.add_argument("--roofline-kernel", default="rtfs_dp_unfold_gemm_fwd")
+    ap.add_argument("--roofline-kernel", default=None, help="entry point timed for the roofline object (default: rtfs_dp_unfold_gemm_fwd, "
+                    "or rtfs_wgrad's layer-0 Toeplitz launches in --mode train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.roofline_kernel is None:
+        args.roofline_kernel = "rtfs_dp_unfold_gemm_fwd" if args.mode == "infer" else "rtfs_wgrad"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +116,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
-    from oracle import synth  # synthetic inputs only (shared with the tests); the oracle itself is used for cpu_baseline below
     from rtfs_net_amd import AVNet, lib
+    from rtfs_net_amd import synthetic as synth  # deterministic synthetic weights / inputs (the oracle is only used for cpu_baseline below)
+    from rtfs_net_amd.dist_util import max_over_ranks
 
     L = int(args.seconds * 16000)
     T = 1 + L // 128
@@ -131,8 +138,8 @@ def main():
     if args.lip:
         if args.mode != "infer":
             raise SystemExit("--lip is an inference option (the lip encoder is frozen)")
-        from oracle.lip_ref import lip_inputs
         from rtfs_net_amd.models import videomodels
+        from rtfs_net_amd.synthetic import lip_inputs
 
         lipnet = videomodels.FRCNNVideoModel(print_macs=False)
         lipnet.load_state_dict(synth.synth_state_dict(lipnet.state_dict(), salt=3))
@@ -148,17 +155,31 @@ def main():
     def forward():
         return model(mix, lipnet(crops) if lipnet is not None else emb)
 
+    step_events = []
+
+    def timed(fn):
+        """K steps between barriers; every step additionally bracketed by HIP events on the compute stream (median step time)"""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = fn()
+            e1.record()
+            step_events.append((e0, e1))
+        barrier()
+        return o, time.perf_counter() - t0
+
+    # train mode: the dominant backward kernel is the layer-0 Toeplitz weight gradient (rtfs_wgrad with nshift = 8 taps, 256 output
+    # columns: dW0 = sum over windows of dU0^T . X); its integer arguments are (ldy, ldx, ldw, rows, L, npos, shift0, nshift, N, K, ...)
+    wgrad_l0 = (lambda ints: len(ints) >= 10 and ints[7] == 8 and ints[8] == 256) if args.roofline_kernel == "rtfs_wgrad" else None
+
     if args.mode == "infer":
         with torch.no_grad():
             for _ in range(args.warmup):
                 out = forward()
             barrier()
             lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out = forward()
-            barrier()
-            elapsed = time.perf_counter() - t0
+            out, elapsed = timed(forward)
             prof = lib.profile_end()
     else:
         # training step as in train.py:98-101,135-146 + config yaml:117-120: neg-SNR loss, AdamW(lr 1e-3, wd 0.1), clip 5.0,
@@ -188,19 +209,14 @@ def main():
         for _ in range(args.warmup):
             out = step()
         barrier()
-        lib.profile_begin(args.roofline_kernel)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        lib.profile_begin(args.roofline_kernel, wgrad_l0)
+        out, elapsed = timed(step)
         prof = lib.profile_end()
     assert torch.isfinite(out).all()
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = max_over_ranks(elapsed, dev, dist)
 
     if rank == 0:
         frames = world * args.batch * T * args.steps
@@ -212,6 +228,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_median": median_ms,  # per-step HIP events on rank 0's compute stream
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -238,7 +255,17 @@ def main():
                 roof = {"kernel": "rtfs::unfold_gemm128f_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
                         "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "launches": len(durs), "avg_launch_ms": tot_ms / len(durs),
-                        "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", args)}
+                        "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", args),
+                        "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
+            elif name == "rtfs_wgrad":
+                # dW0[256][512] += dU0[S*L][256]^T . X_unfold[S*L][512]: the same 2*S*L*512*256 flop as the forward layer-0 GEMM
+                fl = dp_gemm_flops(args.batch, T2)
+                tot_ms = sum(prof)
+                tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)
+                roof = {"kernel": "rtfs::toeplitz_wgrad_kernel (rtfs_wgrad, nshift 8: weight gradient of LN4D + unfold + SRU layer-0 GEMM, "
+                                  "fp32 MFMA, all 8 taps per staged row block)",
+                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
             else:
                 km = kernel_models(args.batch, T, T2, Tv).get(name)
                 if km is not None:

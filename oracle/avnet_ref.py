@@ -396,9 +396,11 @@ def avnet_forward(sd: dict, audionet: dict, wav: torch.Tensor, emb: torch.Tensor
     if taps is not None:
         taps["vp"], taps["caf"] = v1, a
     for i in range(1, R):
-        a = tdanet_block(a + a0, ablk, cfg["audio"], training=training)
+        btaps = {} if taps is not None else None
+        a = tdanet_block(a + a0, ablk, cfg["audio"], training=training, taps=btaps)
         if taps is not None:
             taps[f"block{i}"] = a
+            taps.update({f"block{i}.{k}": v for k, v in btaps.items()})
     sep = s3_mask(a, a_emb, root.sub("mask_generator"), cfg["n_src"], cfg["mask_act"])
     if taps is not None:
         taps["masked"] = sep

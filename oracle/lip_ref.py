@@ -61,9 +61,4 @@ def frcnn_forward(sd: dict, x: torch.Tensor, taps: dict | None = None) -> torch.
     return y.view(B, T, -1).transpose(1, 2).contiguous()
 
 
-def lip_inputs(B: int, T: int, H: int = 88, W: int = 88, seed: int = 20240229) -> torch.Tensor:
-    """Synthetic normalised mouth crops: the reference normalises uint8 grey frames with mean 0.421, std 0.165
-    (src/datas/transform.py:151-167) -> values in about [-2.6, 3.5]; uniform over that range, fixed seed."""
-    g = torch.Generator()
-    g.manual_seed(seed + 17 * B + T)
-    return (torch.rand(B, 1, T, H, W, generator=g) - 0.421) / 0.165
+from rtfs_net_amd.synthetic import lip_inputs  # noqa: E402,F401  (generator shared with bench.py; kept importable from here for the fixture scripts)

@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// the C-ABI every .hip file defines a part of: including it here makes a definition that drifts from its declaration fail to compile
+#include "../../include/rtfs_hip.h"
+
 namespace rtfs {
 
 constexpr int kC = 256;   // encoder / bottleneck channels   (config yaml: enc_dec_params.out_chan)
@@ -26,8 +29,7 @@ constexpr float kEps = 1e-5f;  // src/models/layers/normalizations.py:5
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// ---- error codes returned across the C-ABI -------------------------------------------------------
-enum : int { RTFS_OK = 0, RTFS_EINVAL = -1, RTFS_ELAUNCH = -2 };
+// ---- error codes returned across the C-ABI: RTFS_OK / RTFS_EINVAL / RTFS_ELAUNCH (include/rtfs_hip.h) ----
 
 #define RTFS_LAUNCH_CHECK()                         \
     do {                                            \

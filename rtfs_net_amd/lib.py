@@ -113,10 +113,6 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
 def ptr(t):
     """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
     if t is None:
@@ -132,13 +128,15 @@ def ptr_array(tensors):
 
 
 _prof_name = None
+_prof_pred = None
 _prof_events = []
 
 
-def profile_begin(name: str):
-    """Time every launch of ONE entry point with HIP events recorded on the launch stream (bench.py roofline)."""
-    global _prof_name, _prof_events, _prof_labels
-    _prof_name, _prof_events, _prof_labels = name, [], []
+def profile_begin(name: str, pred=None):
+    """Time every launch of ONE entry point with HIP events recorded on the launch stream (bench.py roofline).
+    `pred(int_args)` (optional) narrows that to the launches whose integer arguments (shapes / modes) it accepts."""
+    global _prof_name, _prof_events, _prof_labels, _prof_pred
+    _prof_name, _prof_events, _prof_labels, _prof_pred = name, [], [], pred
 
 
 def profile_end():
@@ -155,27 +153,56 @@ def profile_labels():
 
 
 def call(name: str, *args):
-    """Invoke an entry point; tensors are converted to pointers, the current stream is appended."""
+    """Invoke an entry point; tensors are converted to pointers, the stream is appended.
+
+    The launch goes to the device that OWNS the tensors: every tensor argument must live on the same HIP device, the call runs
+    with that device current (hipGetDevice-keyed library state, csrc/spread.hip) and on torch's current stream OF THAT DEVICE -
+    a model moved with `.to('cuda:1')` works without `torch.cuda.set_device(1)`."""
     conv = []
     keep = []
+    dev = None
     for a in args:
         if isinstance(a, torch.Tensor):
             conv.append(ptr(a))
+            dev = _same_device(name, dev, a)
         elif isinstance(a, (list, tuple)):
+            for t in a:
+                if t is not None:
+                    dev = _same_device(name, dev, t)
             arr = ptr_array(a)
             keep.append(arr)
             conv.append(ctypes.cast(arr, c_void_p))
         else:
             conv.append(a)
-    if name == _prof_name or _prof_name == "*":
+    if dev is None:
+        raise ValueError(f"{name}: no device tensor among the arguments")
+    if dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return _launch(name, conv, args, dev)
+    return _launch(name, conv, args, dev)
+
+
+def _same_device(name, dev, t):
+    if not t.is_cuda:
+        raise ValueError("rtfs HIP kernels need contiguous device tensors")
+    if dev is None:
+        return t.device
+    if t.device != dev:
+        raise ValueError(f"{name}: tensor arguments live on different devices ({dev} and {t.device})")
+    return dev
+
+
+def _launch(name, conv, args, dev):
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if (name == _prof_name and (_prof_pred is None or _prof_pred(tuple(a for a in args if isinstance(a, int))))) or _prof_name == "*":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # torch's current stream == the stream handed to the kernel
-        rc = getattr(load(), name)(*conv, _stream())
+        rc = getattr(load(), name)(*conv, stream)
         e1.record()
         _prof_events.append((e0, e1))
         if _prof_name == "*":  # tools/train_breakdown.py: label = entry point + its integer arguments (shapes / modes)
             _prof_labels.append(name + str(tuple(a for a in args if isinstance(a, int))))
     else:
-        rc = getattr(load(), name)(*conv, _stream())
+        rc = getattr(load(), name)(*conv, stream)
     if rc != 0:
         raise RuntimeError(f"{name} failed with code {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import sys
+import warnings
 
 import torch
 import torch.nn as nn
@@ -116,8 +117,24 @@ class AVNet(nn.Module):
         self.decoder = STFTDecoder(**{k: v for k, v in enc_dec_params.items() if k not in ("in_chan", "n_src")},
                                    in_chan=self.enc_out_chan * n_src, n_src=n_src)
         self._hip = HipForward(self)
+        self._warned_eval_grad = False
+        # any state-dict load (load_state_dict, from_pretrain, load_state_dict_in, Lightning checkpoints) drops the kernel-layout copies
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_hip_cache())
         if self.print_macs:
             self.get_MACs()
+
+    def invalidate_hip_cache(self):
+        """Drop the kernel-layout copies of the weights (transposed / permuted / BatchNorm-folded, models/hip_path.py).  They are
+        rebuilt automatically when a parameter or buffer is replaced or modified in place through autograd-visible ops (optimizer
+        steps, `load_state_dict`, `.to()`); writers that go through `.data` (EMA copy-back, manual weight surgery) bypass the version
+        counters the cache is keyed on and must call this."""
+        self._hip.invalidate()
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.invalidate()
+
+    def train(self, mode: bool = True):
+        self.invalidate_hip_cache()  # eval folds BatchNorm running statistics into the prepared weights, train does not
+        return super().train(mode)
 
     # ---- configuration family check ------------------------------------------------------------
     def _check_family(self):
@@ -155,11 +172,19 @@ class AVNet(nn.Module):
             x = x.reshape(x.shape[0], -1)
         if mouth_embedding is None:
             raise ValueError("RTFS-Net needs the lip embedding tensor [B, 512, Tv]")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return self._forward_autograd(x, mouth_embedding)
-        if self.training:
-            raise NotImplementedError("training-mode forward without autograd is not supported: use torch.no_grad() with model.eval(), or enable grad")
-        return self._hip(x, mouth_embedding)
+        if not x.is_cuda:
+            raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
+        with torch.cuda.device(x.device):  # launches, side streams and scratch follow the tensors' device, not the process default
+            if torch.is_grad_enabled() and (mouth_embedding.requires_grad or any(p.requires_grad for p in self.parameters())):
+                if not self.training and not self._warned_eval_grad:
+                    self._warned_eval_grad = True
+                    warnings.warn("AVNet.forward in eval() mode with autograd enabled takes the TRAINING-STEP path (all activations saved: "
+                                  "tens of GB at batch 32, segments <= 8 s, video block as PyTorch glue). Wrap inference in torch.no_grad().",
+                                  stacklevel=2)
+                return self._forward_autograd(x, mouth_embedding)
+            if self.training:
+                raise NotImplementedError("training-mode forward without autograd is not supported: use torch.no_grad() with model.eval(), or enable grad")
+            return self._hip(x, mouth_embedding)
 
     # names of the parameters whose gradients come from the HIP backward chain (everything but the video-side glue)
     def _hip_param_names(self):
@@ -214,8 +239,15 @@ class AVNet(nn.Module):
     def from_pretrain(pretrained_model_conf_or_path, *args, **kwargs):
         from . import get
 
-        # reference checkpoints (train.py:156-160) carry a torch TorchVersion object in "infos": load like torch 2.1 did
-        conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=False)
+        # reference checkpoints (train.py:156-160) carry a torch TorchVersion object in "infos"; everything else is tensors and plain
+        # containers, so the safe unpickler is enough once that one class is allow-listed.  `unsafe_pickle=True` restores
+        # torch 2.1's behaviour (arbitrary objects) for checkpoints that need it - explicit opt-in only.
+        unsafe = bool(kwargs.pop("unsafe_pickle", False))
+        if unsafe:
+            conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=False)
+        else:
+            with torch.serialization.safe_globals([torch.torch_version.TorchVersion]):
+                conf = torch.load(pretrained_model_conf_or_path, map_location="cpu", weights_only=True)
         model_class = get(conf["model_name"])
         model = model_class(print_macs=False, *args, **kwargs)
         model.load_state_dict(conf["state_dict"])

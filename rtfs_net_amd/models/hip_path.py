@@ -64,8 +64,8 @@ def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
 class PreparedWeights:
     """Kernel-layout copies of the parameters (transposes / permutations done once, re-done when parameters change)."""
 
-    def __init__(self, model, pack_vp=True):
-        self.version = self.fingerprint(model)
+    def __init__(self, model, pack_vp=True, training=False):
+        self.version = self.fingerprint(model, training)
         dev = next(model.parameters()).device
         self.device = dev
         w = {}
@@ -131,8 +131,18 @@ class PreparedWeights:
         self.w = w
 
     @staticmethod
-    def fingerprint(model):
-        return tuple((p.data_ptr(), p._version) for p in list(model.parameters()) + list(model.buffers()))
+    def fingerprint(model, training=False):
+        """(storage, version counter) of everything the prepared copies are derived from.  Inference: every parameter and buffer
+        (BatchNorm running statistics are folded into the CAF / VP weights).  Training step: parameters and the SRU `scale_x`
+        buffers only - batch statistics replace the running ones, which the step itself updates in place (keying on them
+        forced a rebuild, and its device->host sync, between every forward and backward).
+        NOT seen: writes through `.data` / `torch.Tensor.set_` (no version bump): call `model.invalidate_hip_cache()` after them."""
+        tensors = list(model.parameters())
+        if training:
+            tensors += [b for n, b in model.named_buffers() if n.endswith("scale_x")]
+        else:
+            tensors += list(model.buffers())
+        return tuple((p.data_ptr(), p._version) for p in tensors)
 
     @staticmethod
     def _dw(sd, prefix):
@@ -191,11 +201,22 @@ class PreparedWeights:
         return b
 
 
+class _TapView:
+    """write-only view of the tap dict that suffixes every key with '#<block index>' (blocks 1..R-1)"""
+
+    def __init__(self, taps, i):
+        self.taps, self.suffix = taps, f"#{i}"
+
+    def __setitem__(self, key, value):
+        self.taps[key + self.suffix] = value
+
+
 class HipForward:
     def __init__(self, model):
         self.model = model
         self._prep = None
         self.taps = None  # set to a dict to capture stage outputs (tests)
+        self.tap_all_blocks = False  # with `taps`: also capture the stages of blocks 1..R-1 (keys suffixed '#i')
         self._vp_stream = None
 
     def weights(self) -> PreparedWeights:
@@ -203,6 +224,10 @@ class HipForward:
         if self._prep is None or self._prep.version != fp:
             self._prep = PreparedWeights(self.model)
         return self._prep
+
+    def invalidate(self):
+        """drop the kernel-layout weight copies (rebuilt on the next forward)"""
+        self._prep = None
 
     # ---- dual path (a6-a7) ----
     def _dual_path(self, G, d, B, T2, dim):
@@ -360,8 +385,11 @@ class HipForward:
             y0_cur, nxt = y0_next, None
             if fuse and not last:
                 nxt = (torch.empty(B * TF * H, device=dev), stats[1 + 12 * (i + 1)])
-            fused = self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, y0=y0_cur, next_proj=nxt)
+            tap_i = _TapView(taps, i) if (taps is not None and self.tap_all_blocks) else None
+            fused = self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, tap=tap_i, y0=y0_cur, next_proj=nxt)
             y0_next = nxt[0] if fused else None
+            if tap_i is not None:
+                tap_i["block"] = x.clone()
             s, x = x, s
         # a11: S3 mask; a12: decoder taps + iSTFT
         masked = x

@@ -25,7 +25,7 @@ class TrainWeights(PreparedWeights):
     """PreparedWeights + the transposed / re-ordered copies the input-gradient GEMMs need."""
 
     def __init__(self, model):
-        super().__init__(model, pack_vp=False)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
+        super().__init__(model, pack_vp=False, training=True)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
         w = self.w
         w["bn_wT"], w["mask_wT"], w["dec_wT"] = _t(w["bn_w"]), _t(w["mask_w"]), _t(w["dec_w"])
         sd = {k: v.detach() for k, v in model.state_dict().items()}
@@ -74,10 +74,13 @@ class HipTrainer:
         self._prep = None
 
     def weights(self) -> TrainWeights:
-        fp = PreparedWeights.fingerprint(self.model)
+        fp = PreparedWeights.fingerprint(self.model, training=True)
         if self._prep is None or self._prep.version != fp:
             self._prep = TrainWeights(self.model)
         return self._prep
+
+    def invalidate(self):
+        self._prep = None
 
     # ================================================= forward =================================================
     def _dual_path_fwd(self, G, d, B, T2, dim, save):
@@ -174,6 +177,7 @@ class HipTrainer:
         dev = wav.device
         R = m.refinement_module.audio_net.repeats
         c = Ctx()
+        c.pw = pw  # the SAME prepared weights serve forward_b and both backward stages of this step (parameters do not change inside a step)
         c.B, c.L, c.T, c.T2, c.R = B, L, T, T2, R
         c.stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         stats = c.stats
@@ -194,7 +198,7 @@ class HipTrainer:
     def forward_b(self, c, att, rsz):
         """CAF cell, RTFS blocks 1..R-1, S3 mask, decoder, iSTFT -> out [B,1,L]."""
         m = self.model
-        pw = self.weights()
+        pw = c.pw
         w = pw.w
         B, L, T, T2, R = c.B, c.L, c.T, c.T2, c.R
         TF = T * F_BINS
@@ -427,7 +431,7 @@ class HipTrainer:
     def backward_b(self, c, dout):
         """adjoint of forward_b: dout [B,1,L] -> (d x0, d a0 or None, d a_emb, datt, drsz); parameter gradients go to c.gr."""
         m = self.model
-        pw = self.weights()
+        pw = c.pw
         w = pw.w
         B, L, T, T2, R, Tv = c.B, c.L, c.T, c.T2, c.R, c.Tv
         TF = T * F_BINS
@@ -470,7 +474,7 @@ class HipTrainer:
     def backward_a(self, c, dx0, da0, da_emb):
         """adjoint of forward_a.  dx0: gradient of block 0's output (overwritten); da0: running d(a0) sum of the later blocks (updated in
         place) or None; da_emb: gradient that reached a_emb through the S3 mask (updated in place).  -> grads dict in kernel layout."""
-        pw = self.weights()
+        pw = c.pw
         w = pw.w
         B, T, T2, R = c.B, c.T, c.T2, c.R
         TF = T * F_BINS
@@ -645,7 +649,7 @@ class AVNetHipFunction(torch.autograd.Function):
         trainer = ctx.trainer
         with torch.no_grad():
             datt, drsz, gr = trainer.backward(ctx.saved, dout)
-            ref = grads_to_reference(trainer.model, trainer.weights(), gr)
+            ref = grads_to_reference(trainer.model, ctx.saved.pw, gr)
         grads = tuple(ref.get(n) for n in ctx.names)
         ctx.saved = None
         return (None, None, None, datt, drsz) + grads
@@ -678,7 +682,7 @@ class AVNetHipStageA(torch.autograd.Function):
             if da_emb is None:
                 da_emb = torch.zeros(n, device=c.x0.device)
             gr = trainer.backward_a(c, dx0, da0, da_emb)
-            ref = grads_to_reference(trainer.model, trainer.weights(), gr)
+            ref = grads_to_reference(trainer.model, c.pw, gr)
         grads = tuple(ref.get(name) for name in ctx.names)
         c.__dict__.clear()
         ctx.step.c = None

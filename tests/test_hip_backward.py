@@ -25,10 +25,13 @@ def _oracle_grads(sd, cfg, mix, emb, wgt, training):
     return out.detach(), {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
 
 
-@pytest.mark.parametrize("training,B,L,R,Tv", [(False, 2, 4096, 2, 6), (True, 2, 4096, 2, 6), (False, 1, 12100, 1, 19)])
+@pytest.mark.parametrize("training,B,L,R,Tv", [(False, 2, 4096, 2, 6), (True, 2, 4096, 2, 6), (False, 1, 12100, 1, 19), (False, 1, 4096, 3, 6),
+                                               (False, 1, 32000, 2, 50)])
 def test_parameter_gradients(training, B, L, R, Tv):
     """third case: T2 = 47 -> time-path sequences of 40 steps, long enough for the all-taps Toeplitz weight-gradient kernel and the
-    2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1"""
+    2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1.
+    fourth case: R = 3 -> a MIDDLE block, whose adjoint runs rtfs_proj_gateway_bwd with a0_mode 2 (da0 += ds).
+    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3."""
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
