@@ -15,13 +15,13 @@ TOL = 3e-3
 AUDIO_SKIP = ("refinement_module.video_net.",)
 
 
-def _oracle_grads(sd, cfg, mix, emb, wgt, training):
+def _oracle_grads(sd, cfg, mix, emb, wgt, training, dtype=torch.float64):
     from oracle.avnet_ref import avnet_forward
 
     nograd = ("running_mean", "running_var", "scale_x", ".pe")
-    sd64 = {k: (v.double().clone().requires_grad_(not k.endswith(nograd)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    out = avnet_forward(sd64, cfg, mix.double(), emb.double(), training=training)
-    (out * wgt.double()).sum().backward()
+    sd64 = {k: (v.to(dtype).clone().requires_grad_(not k.endswith(nograd)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    out = avnet_forward(sd64, cfg, mix.to(dtype), emb.to(dtype), training=training)
+    (out * wgt.to(dtype)).sum().backward()
     return out.detach(), {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
 
 
@@ -31,7 +31,11 @@ def test_parameter_gradients(training, B, L, R, Tv):
     """third case: T2 = 47 -> time-path sequences of 40 steps, long enough for the all-taps Toeplitz weight-gradient kernel and the
     2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1.
     fourth case: R = 3 -> a MIDDLE block, whose adjoint runs rtfs_proj_gateway_bwd with a0_mode 2 (da0 += ds).
-    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3."""
+    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3.  At
+    that size the float32 problem itself is the limit: with 8.3 M activations per ReLU / PReLU layer a few dozen sit within fp32
+    round-off of the kink, and ANY fp32 evaluation (torch's own autograd of the oracle in float32 included) differs from the
+    float64 gradient by 5e-3 ... 1e-2 on many tensors (4.5e-2 on the gateway slope).  There the bound per tensor is therefore
+    max(3e-3, 1.25 x the error of torch-fp32 autograd of the oracle + 1e-3): as close to the float64 truth as torch's fp32."""
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
@@ -46,6 +50,10 @@ def test_parameter_gradients(training, B, L, R, Tv):
     ref_out, ref = _oracle_grads(sd, cfg, mix, emb, wgt, training)
     assert rel(out.detach(), ref_out) < 1e-3
     scale = max(float(g.norm()) for g in ref.values())
+    fp32_err = {}
+    if L >= 32000:
+        _, g32 = _oracle_grads(sd, cfg, mix, emb, wgt, training, torch.float32)
+        fp32_err = {n: float((g32[n].double() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale) for n in ref}
     checked = 0
     for n, p in model.named_parameters():
         assert p.grad is not None, n
@@ -58,7 +66,10 @@ def test_parameter_gradients(training, B, L, R, Tv):
         # mixed tolerance (as allclose): tensors whose whole gradient is ~1e-4 of the largest one are cancellation residue
         # of fp32 sums (softmax over Tv, BatchNorm) and are held to the absolute floor instead
         err = float((p.grad.double().cpu() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale)
-        assert err < (1e-2 if p.numel() <= 12 else TOL), (n, err)
+        bound = 1e-2 if p.numel() <= 12 else TOL
+        if n in fp32_err:
+            bound = max(bound, 1.25 * fp32_err[n] + 1e-3)
+        assert err < bound, (n, err, fp32_err.get(n))
         checked += 1
     assert checked > 150
 
