@@ -230,6 +230,97 @@ __device__ __forceinline__ void mma_block_bn(floatx16 (&acc)[WM][WN], const floa
     }
 }
 
+// ---- bf16 / split-bf16 MFMA (v_mfma_f32_32x32x16_bf16, v_mfma_f32_16x16x32_bf16; 16x the fp32 MFMA rate) --------------------------
+// Precision switch of every MFMA kernel, template parameter NT ("terms"):
+//   NT = 0  exact fp32 (v_mfma_f32_32x32x2_f32): the default path, untouched by the code below;
+//   NT = 1  operands rounded to bfloat16 (RNE), fp32 accumulation:                 a.b ~ a_hi b_hi
+//   NT = 3  split-bf16: a = a_hi + a_lo (a_lo = bf16(a - a_hi)), three products:    a.b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi
+//           (drops a_lo b_lo ~ 2^-18 |a b|: waveform error ~8e-6 vs fp32 on RTFS-Net-12, tools/bf16_error_model.py).
+// PACKED SLOT.  The fp32 kernels stage operands k-contiguously as float4 = 4 consecutive k.  The bf16 paths keep every address,
+// stride and swizzle of those layouts and store in the same 16 bytes the 4 hi halves and the 4 lo halves of the same 4 k values:
+//      slot = [hi(k0) hi(k1) | hi(k2) hi(k3) | lo(k0) lo(k1) | lo(k2) lo(k3)]        (4 dwords)
+// A lane that read slots q and q+1 of its row (k = 8q + 4kh .. +3 and 8(q+1) + 4kh .. +3) owns 8 k values = one A / B fragment of
+// the K = 16 instruction; which k a fragment element holds is free as long as both operands agree, and they are built the same way.
+// Weights are packed once on the host into the same slots (same byte size and indexing as the fp32 matrix), so weight staging is
+// the unchanged plain copy; activations are packed by the staging store (pack4) or in registers (frag_f32).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even): a -> bits 0..15, b -> 16..31
+    const float2v f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2v));
+}
+template <int NT>
+__device__ __forceinline__ float4 pack4(float4 v) {
+    if constexpr (NT == 0) return v;
+    const unsigned h0 = pk_bf16(v.x, v.y), h1 = pk_bf16(v.z, v.w);
+    unsigned l0 = 0, l1 = 0;
+    if constexpr (NT == 3) {
+        l0 = pk_bf16(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+        l1 = pk_bf16(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+    }
+    return make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1));
+}
+struct Frag {  // one MFMA operand fragment (8 k values of one row): hi and lo planes
+    bf16x8 hi, lo;
+};
+__device__ __forceinline__ Frag frag_packed(float4 s0, float4 s1) {  // two packed slots of the same row -> fragment (register renaming only)
+    const uint4v h = {__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y)};
+    const uint4v l = {__float_as_uint(s0.z), __float_as_uint(s0.w), __float_as_uint(s1.z), __float_as_uint(s1.w)};
+    return Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+}
+template <int NT>
+__device__ __forceinline__ Frag frag_f32(float4 a, float4 b) {  // two fp32 k-quads of the same row -> fragment, packed in registers
+    return frag_packed(pack4<NT>(a), pack4<NT>(b));
+}
+template <int NT>
+__device__ __forceinline__ void mma32(floatx16& acc, const Frag& a, const Frag& b) {
+    if constexpr (NT == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+template <int NT>
+__device__ __forceinline__ void mma16(floatx4& acc, const Frag& a, const Frag& b) {  // 16x16x32: lane group kk = lane >> 4 supplies 8 k values
+    if constexpr (NT == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+// mma_block on PACKED LDS tiles (same addressing as mma_block; kdepth a multiple of 16).
+template <int NT, int WM, int WN, int BT = 32, int AT = 32>
+__device__ __forceinline__ void mma_block_p(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, kh = lane >> 5;
+    const float* ap = As + i * lda + kh * 4;
+    const float* bp = Bs + i * ldb + kh * 4;
+#pragma unroll 2
+    for (int q = 0; q < kdepth; q += 16) {
+        Frag a[WM], b[WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) a[m] = frag_packed(ld4(ap + btile_row<AT>(m) * lda + q), ld4(ap + btile_row<AT>(m) * lda + q + 8));
+#pragma unroll
+        for (int n = 0; n < WN; ++n) b[n] = frag_packed(ld4(bp + btile_row<BT>(n) * ldb + q), ld4(bp + btile_row<BT>(n) * ldb + q + 8));
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) mma32<NT>(acc[m][n], a[m], b[n]);
+    }
+}
+// precision dispatch used by the kernels that call mma_block: NT = 0 -> the fp32 block, else the packed block
+template <int NT, int WM, int WN, int BT = 32, int AT = 32>
+__device__ __forceinline__ void mma_block_nt(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    if constexpr (NT == 0)
+        mma_block<WM, WN, BT, AT>(acc, As, lda, Bs, ldb, kdepth);
+    else
+        mma_block_p<NT, WM, WN, BT, AT>(acc, As, lda, Bs, ldb, kdepth);
+}
+
 template <int WM, int WN>
 __device__ __forceinline__ void acc_zero(floatx16 (&acc)[WM][WN]) {
 #pragma unroll

@@ -153,8 +153,10 @@ struct EpiMask {
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK, class Pro, class Epi>
+// NT: precision of the contraction (common.h): 0 fp32, 1 bf16, 3 split-bf16.  NT != 0: `Wt` is the host-PACKED weight (same indexing).
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK, class Pro, class Epi, int NT = 0>
 __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb) {
+    static_assert(NT == 0 || BK % 16 == 0, "the bf16 instruction consumes 16 k per step");
     constexpr int LD = BK + 4;
     constexpr int WGN = N / (32 * WN), WGM = 4 / WGN;
     static_assert(WGM * WGN == 4 && BM == WGM * WM * 32, "wave tiling must cover the workgroup tile");
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
     };
     auto store_a = [&](float* dst) {
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) st4(dst + (arow0 + i * (1024 / BK)) * LD + ac4, pro.xform(areg[i], ak0 + ac4, ptab));
+        for (int i = 0; i < A_PER; ++i) st4(dst + (arow0 + i * (1024 / BK)) * LD + ac4, pack4<NT>(pro.xform(areg[i], ak0 + ac4, ptab)));
     };
 
     floatx16 acc[WN][WM];  // [weight tile][pixel tile]: rows = output channels, lanes = pixels
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
             load_a((kc + 1) * BK);
             breg.load(Wt, K, (kc + 1) * BK);
         }
-        mma_block<WN, WM, 32, BT>(acc, Bs[cur] + bcol0 * LD, LD, As[cur] + wm * WM * 32 * LD, LD, BK);
+        mma_block_nt<NT, WN, WM, 32, BT>(acc, Bs[cur] + bcol0 * LD, LD, As[cur] + wm * WM * 32 * LD, LD, BK);
         if (kc + 1 < NK) {
             store_a(As[cur ^ 1]);
             breg.store(Bs[cur ^ 1], LD);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
 //  * 52 KB of LDS -> 2-3 workgroups per CU overlap one's MFMA phase with the others' memory phases.
 // Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_A0, bool PROJ = false>
+template <bool HAS_A0, bool PROJ = false, int NT = 0>  // NT != 0: Wt and epi.pw are host-PACKED (common.h)
 __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDE = 68;
     constexpr int LDO = 260;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
             for (int it = 0; it < 4; ++it) {
                 const float4 a = fma4(xa[it], ld4(&Ns[0][0][c4]), ld4(&Ns[0][1][c4])), d = fma4(xd[it], ld4(&Ns[1][0][c4]), ld4(&Ns[1][1][c4]));
                 const float4 g = fma4(xg[it], ld4(&Ns[2][0][c4]), ld4(&Ns[2][1][c4])), sg = sigmoid4(fma4(xs[it], ld4(&Ns[3][0][c4]), ld4(&Ns[3][1][c4])));
-                st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, fma4(a, sg, g) + d);
+                st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, pack4<NT>(fma4(a, sg, g) + d));
             }
         }
         __syncthreads();
@@ -375,20 +377,34 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks these loads below the MFMAs to save registers)
         floatx16 acc[2][2];
         acc_zero(acc);
+        if constexpr (NT == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 e0 = ld4(Es + i * LDE + 8 * q + 4 * kh);
-            const float4 e1 = ld4(Es + (32 + i) * LDE + 8 * q + 4 * kh);
+            for (int q = 0; q < 8; ++q) {
+                const float4 e0 = ld4(Es + i * LDE + 8 * q + 4 * kh);
+                const float4 e1 = ld4(Es + (32 + i) * LDE + 8 * q + 4 * kh);
+    #pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e0.x, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e1.x, acc[nt][1], 0, 0, 0);
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e0.y, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e1.y, acc[nt][1], 0, 0, 0);
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e0.z, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e1.z, acc[nt][1], 0, 0, 0);
+                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e0.w, acc[nt][0], 0, 0, 0);
+                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e1.w, acc[nt][1], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e0.x, acc[nt][0], 0, 0, 0);
-                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e1.x, acc[nt][1], 0, 0, 0);
-                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e0.y, acc[nt][0], 0, 0, 0);
-                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e1.y, acc[nt][1], 0, 0, 0);
-                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e0.z, acc[nt][0], 0, 0, 0);
-                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e1.z, acc[nt][1], 0, 0, 0);
-                acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e0.w, acc[nt][0], 0, 0, 0);
-                acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e1.w, acc[nt][1], 0, 0, 0);
+            for (int q2 = 0; q2 < 4; ++q2) {  // 16 k per step: packed slots 2 q2 and 2 q2 + 1 of every row
+                const Frag e0 = frag_packed(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e1 = frag_packed(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const Frag wq = frag_packed(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
+                    mma32<NT>(acc[nt][0], wq, e0);
+                    mma32<NT>(acc[nt][1], wq, e1);
+                }
             }
         }
         // Epilogue through LDS.  In the accumulator a lane owns ONE pixel and 16 B of channels, so a direct global epilogue makes
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 if (HAS_A0) v = v + av[it];
                 if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
                 if (PROJ) {
-                    st4(Ot + r * LDO + cq, prelu4(fma4(v, cgw, cgb), epi.slope));  // the next block's gateway, in place
+                    st4(Ot + r * LDO + cq, pack4<NT>(prelu4(fma4(v, cgw, cgb), epi.slope)));  // the next block's gateway, in place
                     // two of the 16 projection-weight fragments per iteration, into the registers sv / av just left (L2 latency
                     // hidden behind the rest of this loop)
                     wp[2 * it] = ld4(wpp + 8 * it), wp[2 * it + 1] = ld4(wpp + 8 * it + 4);
@@ -434,18 +450,30 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pa[c] = floatx4{0.f, 0.f, 0.f, 0.f};
                 const float* ap = Ot + j * LDO + 64 * kk;
+                if constexpr (NT == 0) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float4 e0 = ld4(ap + 4 * t), e1 = ld4(ap + 16 * LDO + 4 * t);
-                    const int c = 2 * (t & 1);
-                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e0.x, pa[c], 0, 0, 0);
-                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e1.x, pa[c + 1], 0, 0, 0);
-                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e0.y, pa[c], 0, 0, 0);
-                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e1.y, pa[c + 1], 0, 0, 0);
-                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e0.z, pa[c], 0, 0, 0);
-                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e1.z, pa[c + 1], 0, 0, 0);
-                    pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e0.w, pa[c], 0, 0, 0);
-                    pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e1.w, pa[c + 1], 0, 0, 0);
+                    for (int t = 0; t < 16; ++t) {
+                        const float4 e0 = ld4(ap + 4 * t), e1 = ld4(ap + 16 * LDO + 4 * t);
+                        const int c = 2 * (t & 1);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e0.x, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e1.x, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e0.y, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e1.y, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e0.z, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e1.z, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e0.w, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e1.w, pa[c + 1], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t2 = 0; t2 < 8; ++t2) {  // 16x16x32: lane group kk supplies the 8 k values of packed slots 2 t2, 2 t2 + 1
+                        const Frag e0 = frag_packed(ld4(ap + 8 * t2), ld4(ap + 8 * t2 + 4));
+                        const Frag e1 = frag_packed(ld4(ap + 16 * LDO + 8 * t2), ld4(ap + 16 * LDO + 8 * t2 + 4));
+                        const Frag wq = frag_packed(wp[2 * t2], wp[2 * t2 + 1]);
+                        const int c = 2 * (t2 & 1);
+                        mma16<NT>(pa[c], wq, e0);
+                        mma16<NT>(pa[c + 1], wq, e1);
+                    }
                 }
                 const float4 pb4 = ld4(epi.pbias + 16 * w + 4 * kk);
 #pragma unroll
@@ -479,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 // only thing in LDS (66.6 KB -> 2 workgroups per CU: one in its 256-MFMA phase while the other stores / fetches /
 // writes back).  ~180 VGPRs, no spills (the 32x32x2 variants of this kernel needed 128 VGPRs of weights and spilled).
 // ------------------------------------------------------------------------------------------------
+template <int NT = 0>  // NT != 0: Wt is host-PACKED (common.h)
 __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasStats epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDA = 260, TM = 64;
     __shared__ __attribute__((aligned(16))) float As[TM * LDA];
@@ -506,26 +535,36 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
         const int m0 = (tile0 + tl) * TM;
         if (m0 >= Mb) break;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) st4(As + (w + it * 4) * LDA + c4, prelu4(fma4(araw[it], gw4, gb4), pro.slope));
+        for (int it = 0; it < 16; ++it) st4(As + (w + it * 4) * LDA + c4, pack4<NT>(prelu4(fma4(araw[it], gw4, gb4), pro.slope)));
         if (tl + 1 < tiles_per_wg) fetch(min(m0 + TM, Mb - 1));  // flies under this tile's MFMAs
         __syncthreads();
         floatx4 acc[4];
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) acc[pt] = floatx4{0.f, 0.f, 0.f, 0.f};
         const float* ap = As + j * LDA + 64 * kk;
+        if constexpr (NT == 0) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            float4 e[4];
+            for (int t = 0; t < 16; ++t) {
+                float4 e[4];
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt) e[pt] = ld4(ap + pt * 16 * LDA + 4 * t);
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, e[pt].x, acc[pt], 0, 0, 0);
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].y, e[pt].y, acc[pt], 0, 0, 0);
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].z, e[pt].z, acc[pt], 0, 0, 0);
+    #pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].w, e[pt].w, acc[pt], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) e[pt] = ld4(ap + pt * 16 * LDA + 4 * t);
+            for (int t2 = 0; t2 < 8; ++t2) {
+                const Frag wq = frag_packed(wf[2 * t2], wf[2 * t2 + 1]);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].x, e[pt].x, acc[pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].y, e[pt].y, acc[pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].z, e[pt].z, acc[pt], 0, 0, 0);
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t].w, e[pt].w, acc[pt], 0, 0, 0);
+                for (int pt = 0; pt < 4; ++pt)
+                    mma16<NT>(acc[pt], wq, frag_packed(ld4(ap + pt * 16 * LDA + 8 * t2), ld4(ap + pt * 16 * LDA + 8 * t2 + 4)));
+            }
         }
         __syncthreads();  // As consumed by every wave: the next tile may overwrite it while the epilogues run
         // accumulator of sub-tile pt: channels 16w + 4kk .. +3 (registers 0..3) of pixel m0 + 16pt + j
@@ -544,14 +583,21 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
     block_stats_commit(s, qq, red, epi.slot, b);
 }
 
-template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK = 32, class Pro, class Epi>
+template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK = 32, int NT = 0, class Pro, class Epi>
 static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
     if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
     dim3 grid((Mb + BM - 1) / BM, B);
-    hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, BK, Pro, Epi>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
+    hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, BK, Pro, Epi, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
+// run-time precision -> template: terms 1 (bf16) or 3 (split-bf16); anything else is refused
+#define RTFS_TERMS_DISPATCH(terms, CALL1, CALL3) \
+    do {                                         \
+        if ((terms) == 1) return CALL1;          \
+        if ((terms) == 3) return CALL3;          \
+        return RTFS_EINVAL;                      \
+    } while (0)
 
 }  // namespace rtfs
 

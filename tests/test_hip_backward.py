@@ -31,11 +31,11 @@ def test_parameter_gradients(training, B, L, R, Tv):
     """third case: T2 = 47 -> time-path sequences of 40 steps, long enough for the all-taps Toeplitz weight-gradient kernel and the
     2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1.
     fourth case: R = 3 -> a MIDDLE block, whose adjoint runs rtfs_proj_gateway_bwd with a0_mode 2 (da0 += ds).
-    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3.  At
-    that size the float32 problem itself is the limit: with 8.3 M activations per ReLU / PReLU layer a few dozen sit within fp32
-    round-off of the kink, and ANY fp32 evaluation (torch's own autograd of the oracle in float32 included) differs from the
-    float64 gradient by 5e-3 ... 1e-2 on many tensors (4.5e-2 on the gateway slope).  There the bound per tensor is therefore
-    max(3e-3, 1.25 x the error of torch-fp32 autograd of the oracle + 1e-3): as close to the float64 truth as torch's fp32."""
+    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3.  It runs
+    on input seed 2: with the default seed ONE PReLU activation of the 50-token video branch lies within fp32 round-off of its kink,
+    and every fp32 evaluation that lands on the other side of it than float64 does (this build, and torch's own fp32 autograd of the
+    oracle on some CPUs - tools/grad_vs_fp32.py) is off by 2e-3 ... 4e-2 on ~100 tensors downstream of that one element; seeds 1-3
+    show the all-or-nothing pattern (median error 3e-3 with the flip, 4e-5 ... 1e-4 without).  A property of the function, not of a kernel."""
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
@@ -43,17 +43,13 @@ def test_parameter_gradients(training, B, L, R, Tv):
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
     model.train(training)
-    mix, _, emb = synth.synth_inputs(B, L, Tv)
+    mix, _, emb = synth.synth_inputs(B, L, Tv, seed=2 if L >= 32000 else synth.INPUT_SEED)
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(7))
     out = model(mix.cuda(), emb.cuda())
     (out * wgt.cuda()).sum().backward()
     ref_out, ref = _oracle_grads(sd, cfg, mix, emb, wgt, training)
     assert rel(out.detach(), ref_out) < 1e-3
     scale = max(float(g.norm()) for g in ref.values())
-    fp32_err = {}
-    if L >= 32000:
-        _, g32 = _oracle_grads(sd, cfg, mix, emb, wgt, training, torch.float32)
-        fp32_err = {n: float((g32[n].double() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale) for n in ref}
     checked = 0
     for n, p in model.named_parameters():
         assert p.grad is not None, n
@@ -66,10 +62,7 @@ def test_parameter_gradients(training, B, L, R, Tv):
         # mixed tolerance (as allclose): tensors whose whole gradient is ~1e-4 of the largest one are cancellation residue
         # of fp32 sums (softmax over Tv, BatchNorm) and are held to the absolute floor instead
         err = float((p.grad.double().cpu() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale)
-        bound = 1e-2 if p.numel() <= 12 else TOL
-        if n in fp32_err:
-            bound = max(bound, 1.25 * fp32_err[n] + 1e-3)
-        assert err < bound, (n, err, fp32_err.get(n))
+        assert err < (1e-2 if p.numel() <= 12 else TOL), (n, err)
         checked += 1
     assert checked > 150
 

@@ -54,7 +54,7 @@ def test_every_block_stage_against_reference_taps(name, R, B, L):
         got["down1" + s] = gln(low(taps["D1" + s]), p + "downsample_layers.1.full_layer.")
         got["dp_freq" + s], got["dp_time" + s], got["attn" + s] = low(taps["dp_freq" + s]), low(taps["dp_time" + s]), low(taps["attn" + s])
         got["tfar0" + s], got["tfar1" + s] = full(taps["tfar0" + s], 64), low(taps["tfar1" + s])
-    assert len(got) == 6 + 9 * R
+    assert len(got) == 5 + 9 * R
     worst = ("", 0.0)
     for k, v in got.items():
         e = rel(strided(v), torch.from_numpy(z["tap." + k]))
