@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--layers", type=int, default=6, help="RTFS-Net-R (audio_params.repeats)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="arithmetic of the dense contractions (infer mode): f32 = exact fp32 MFMA (headline); bf16 = operands rounded to bfloat16; "
+                         "bf16x3 = split-bf16, three bf16 MFMAs per product (fp32-level accuracy).  Activations, statistics, recurrence stay fp32")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: separation forward (headline metric); train: forward + backward + AdamW (+ RCCL gradient all-reduce for N>1)")
     ap.add_argument("--lip", action="store_true",
@@ -130,6 +133,10 @@ def main():
     sd = synth.synth_state_dict(model.state_dict())  # random-init weights of the architecture ("data": synthetic)
     model.load_state_dict(sd)
     model = model.to(dev)
+    if args.dtype != "f32":
+        if args.mode != "infer":
+            raise SystemExit("--dtype bf16 / bf16x3 are inference modes (the training step computes in fp32)")
+        model.set_compute_dtype(args.dtype)
     # each rank gets its own shard of the global batch (different seed -> different utterances)
     mix, _, emb = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)
     mix, emb = mix.to(dev), emb.to(dev)
@@ -232,12 +239,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": (f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), " if args.mode == "infer" else
                              f"RTFS-Net-{args.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
-                            + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, fp32, random-init weights",
+                            + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, "
+                            + {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation and activations", "bf16x3": "split-bf16 (3-term) MFMA / fp32 accumulation and activations"}[args.dtype]
+                            + ", random-init weights",
                 "mode": args.mode + ("+lip-encoder" if args.lip else ""),
                 "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
                 "parallelism": f"utterance-sharded x{world}, no data-path collective" + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
@@ -247,7 +256,16 @@ def main():
         roof = None
         if prof:
             name = args.roofline_kernel
-            if name == "rtfs_dp_unfold_gemm_fwd":
+            if name == "rtfs_dp_unfold_gemm_fwd" and args.dtype != "f32":
+                # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
+                by = {4: 4.0 * (args.batch * T2 * F2 * H + args.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (args.batch * T2 * F2 * H + args.batch * F2 * (T2 - 7) * 256)}
+                tot_ms = sum(prof)
+                roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{3 if args.dtype == 'bf16x3' else 1}> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on "
+                                  "v_mfma_f32_32x32x16_bf16)", "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                        "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,
+                        "mfma_tflops_algorithmic": (dp_gemm_flops(args.batch, T2)[4] + dp_gemm_flops(args.batch, T2)[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12}
+            elif name == "rtfs_dp_unfold_gemm_fwd":
                 fl = dp_gemm_flops(args.batch, T2)
                 durs = prof  # launches alternate dim 4 (freq), dim 3 (time)
                 tot_ms = sum(durs)

@@ -220,6 +220,46 @@ int rtfs_lip_avgpool_fwd(const float* in, float* out, int B, int T, int HW, int 
  * or NULL = centre crop (transform.py:96-101); lut [256] = the value map evaluated on the host in float64; P [B][T+4][ch+6][cw+6]. */
 int rtfs_lip_roi_fwd(const unsigned char* roi, const int* crop, const float* lut, float* P, int B, int T, int H, int W, int ch, int cw, void* stream);
 
+/* =====================================================================================================================
+ * bf16 MFMA variants of the inference path (BASELINE config 5: "bf16 with MFMA attention").
+ * Same computation as the fp32 entry point of the same name - activations stay fp32 in HBM, accumulation, norm statistics,
+ * the SRU recurrence, softmax and (i)STFT stay fp32 - but every dense contraction runs on v_mfma_f32_32x32x16_bf16 /
+ * v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate):
+ *     terms = 1   operands rounded to bfloat16                                       (waveform ~4e-3 rel. of fp32, RTFS-Net-12)
+ *     terms = 3   split-bf16, a.b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi (three MFMAs)   (waveform ~8e-6 rel. of fp32)
+ * Weight arguments typed `const void* Wpk` are HOST-PACKED: the fp32 matrix W[n][k] of the fp32 entry point, every group of 4
+ * consecutive k replaced in place by 8 bfloat16 {hi(k0..k3), lo(k0..k3)} (lo = bf16(w - hi); same byte size and indexing;
+ * rtfs_net_amd/models/hip_path.py:pack_bf16).  rtfs_sru_layer_fwd_bf16 takes the plain fp32 weight.
+ * Replaces the same reference lines as the fp32 siblings (attention.py:171-173 for the attention core, rnn_layers.py:146-150, ...).
+ */
+int rtfs_bottleneck_fwd_bf16(const float* a_emb, const double* stats, const float* gamma, const float* beta, const void* Wpk, const float* bias,
+                             float* a0, int B, int TF, int terms, void* stream);
+int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float gslope, const void* Wpk, const float* bias, float* y, double* stats_out,
+                       int B, int TF, int terms, void* stream);
+int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
+                                 void* stream);
+int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, int S, int L,
+                            int terms, void* stream);
+int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream);
+int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
+                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, int terms, void* stream);
+int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, int B, int T2, int terms, void* stream);
+int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
+                           int T2, int terms, void* stream);
+int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                        const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk, const float* bias,
+                        const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, int B, int T, int T2,
+                        int terms, void* stream);
+int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                             const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                             const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk,
+                             const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0, float* out,
+                             const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2, int terms, void* stream);
+int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
+                       int TF, int terms, void* stream);
+int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

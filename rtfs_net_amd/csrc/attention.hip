@@ -20,6 +20,7 @@ constexpr int kQkvN = 96;  // 4 heads x (4 q + 4 k + 16 v) output channels
 // Column order n: [0,16) Q (h*4+e), [16,32) K (h*4+e), [32,96) V (h*16+c).
 // gamma/beta are host-permuted to the output order: gq,gk [4][256], gv [4][1024] (index e*64+f / c*64+f).
 // ------------------------------------------------------------------------------------------------
+template <int NT = 0>  // precision (common.h); NT != 0: Wt host-PACKED
 __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        const float* __restrict__ slope, const float* __restrict__ gq, const float* __restrict__ bq,
                                                        const float* __restrict__ gk, const float* __restrict__ bk, const float* __restrict__ gv,
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
         const int row = idx >> 4, c4 = idx & 15;
         float4 v = ld4(G + ((size_t)tok0 * 64 + min(row, ntok * 64 - 1)) * 64 + c4 * 4);  // clamped: loads stay unconditional and batched
         if (row >= ntok * 64) v = f4(0, 0, 0, 0);
-        st4(As + row * LDA + c4 * 4, v);
+        st4(As + row * LDA + c4 * 4, pack4<NT>(v));
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
 
     floatx16 acc[1][3];
     acc_zero(acc);
-    mma_block<1, 3>(acc, As + w * 32 * LDA, LDA, Bs, LDA, 64);
+    mma_block_nt<NT, 1, 3>(acc, As + w * 32 * LDA, LDA, Bs, LDA, 64);
     __syncthreads();  // every wave is done reading As / Bs before Ys overwrites them
 
 #pragma unroll
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
 //    coalesced 128-byte row segments read directly from global memory -- every V element is fetched once per
 //    workgroup and there is no barrier in this phase either.
 // ------------------------------------------------------------------------------------------------
-template <int MAXKT>
+template <int MAXKT, int PREC = 0>  // PREC = the NT of common.h (0 fp32, 1 bf16, 3 split-bf16); Q, K, V, P are packed in registers
 __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
                                                            float* __restrict__ O, float* __restrict__ LSE, int T2) {
     constexpr int LDS_S = MAXKT * 32 + 4;
@@ -149,13 +150,19 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
         floatx16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if constexpr (PREC == 0) {
 #pragma unroll 8
-        for (int q = 0; q < 32; ++q) {
-            const float4 a = ld4(qrow + 8 * q), kb = ld4(krow + 8 * q);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kb.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kb.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kb.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kb.w, acc, 0, 0, 0);
+            for (int q = 0; q < 32; ++q) {
+                const float4 a = ld4(qrow + 8 * q), kb = ld4(krow + 8 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kb.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kb.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kb.w, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int q2 = 0; q2 < 16; ++q2)
+                mma32<PREC>(acc, frag_f32<PREC>(ld4(qrow + 16 * q2), ld4(qrow + 16 * q2 + 8)), frag_f32<PREC>(ld4(krow + 16 * q2), ld4(krow + 16 * q2 + 8)));
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) Ss[acc_row(r) * LDS_S + kt * 32 + i] = acc[r] * 0.0625f;
@@ -202,22 +209,39 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
         const float* pa = Ss + i * LDS_S + 4 * kh;
-        for (int kq = 0; kq < NT * 4; ++kq) {  // 8 keys per step: this lane's keys are 8kq + 4kh .. +3
-            const float4 p = ld4(pa + 8 * kq);
-            const int key = 8 * kq + 4 * kh;
-            float vb[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float* vr = Vg + (size_t)min(key + r, T2 - 1) * 1024 + n0 + i;  // padded keys carry zero weight
-#pragma unroll
-                for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+        if constexpr (PREC == 0) {
+            for (int kq = 0; kq < NT * 4; ++kq) {  // 8 keys per step: this lane's keys are 8kq + 4kh .. +3
+                const float4 p = ld4(pa + 8 * kq);
+                const int key = 8 * kq + 4 * kh;
+                float vb[4][4];
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* vr = Vg + (size_t)min(key + r, T2 - 1) * 1024 + n0 + i;  // padded keys carry zero weight
+    #pragma unroll
+                    for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+                }
+    #pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, vb[n][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, vb[n][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, vb[n][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, vb[n][3], acc[n], 0, 0, 0);
+                }
             }
+        } else {
+            for (int kq2 = 0; kq2 < NT * 2; ++kq2) {  // 16 keys per step: this lane's keys are 16kq2 + 4kh .. +3 and 16kq2 + 8 + 4kh .. +3
+                const Frag fp = frag_f32<PREC>(ld4(pa + 16 * kq2), ld4(pa + 16 * kq2 + 8));
+                const int key = 16 * kq2 + 4 * kh;
+                float vb[4][8];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, vb[n][0], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, vb[n][1], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, vb[n][2], acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, vb[n][3], acc[n], 0, 0, 0);
+                for (int r = 0; r < 8; ++r) {
+                    const float* vr = Vg + (size_t)min(key + (r & 3) + 2 * (r & 4), T2 - 1) * 1024 + n0 + i;  // padded keys carry zero weight
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    mma32<PREC>(acc[n], fp, frag_f32<PREC>(f4(vb[n][0], vb[n][1], vb[n][2], vb[n][3]), f4(vb[n][4], vb[n][5], vb[n][6], vb[n][7])));
             }
         }
 #pragma unroll
@@ -237,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 // Computes Y^T[co][f] = W[co][c] . X[c][f] so the O layout [c][f] is consumed without a transpose.
 // gamma/beta are host-permuted to [f][c].
 // ------------------------------------------------------------------------------------------------
+template <int NT = 0>  // NT != 0: W host-PACKED
 __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__ O, const float* __restrict__ W, const float* __restrict__ bias,
                                                        float slope, const float* __restrict__ gamma_fc, const float* __restrict__ beta_fc,
                                                        float* __restrict__ G, float* __restrict__ Ypre) {
@@ -260,7 +285,10 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
     __syncthreads();
     floatx16 acc[1][1];
     acc_zero(acc);
-    mma_block_bn<1, 1>(acc, Ws + wm * 32 * LD, LD, Xs + wn * 32, LD, 64);
+    if constexpr (NT == 0)
+        mma_block_bn<1, 1>(acc, Ws + wm * 32 * LD, LD, Xs + wn * 32, LD, 64);
+    else
+        mma_block_bn_p<NT, 1, 1>(acc, Ws + wm * 32 * LD, LD, Xs + wn * 32, LD, 64);
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -298,40 +326,73 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
 
 using namespace rtfs;
 
-extern "C" {
-
-int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
-                      const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2,
-                      void* stream) {
+template <int NT>
+static int attn_qkv_impl(const float* G, const float* Wt, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
+                         const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
     const int BT = B * T2;
-    hipLaunchKernelGGL(attn_qkv_kernel, dim3((BT + 1) / 2), dim3(256), 0, (hipStream_t)stream, G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V,
+    hipLaunchKernelGGL(attn_qkv_kernel<NT>, dim3((BT + 1) / 2), dim3(256), 0, (hipStream_t)stream, G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V,
                        Ypre_or_null, BT, T2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
+template <int NT>
+static int attn_core_impl(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0 || T2 > 1024) return RTFS_EINVAL;  // the [32][T2] score tile lives in LDS: 1024 keys = 131.6 KB (16.4 s of audio)
     dim3 grid((T2 + 31) / 32, kHeads, B);
     if (T2 <= 128)
-        hipLaunchKernelGGL((attn_core_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<4, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else if (T2 <= 256)
-        hipLaunchKernelGGL((attn_core_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<8, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else if (T2 <= 512)
-        hipLaunchKernelGGL((attn_core_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<16, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else
-        hipLaunchKernelGGL((attn_core_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<32, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
-                      float* Ypre_or_null, int B, int T2, void* stream) {
+template <int NT>
+static int attn_out_impl(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
+                         float* Ypre_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(attn_out_kernel, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null);
+    hipLaunchKernelGGL(attn_out_kernel<NT>, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+extern "C" {
+
+int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
+                      const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2,
+                      void* stream) {
+    return attn_qkv_impl<0>(G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream);
+}
+int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
+                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, attn_qkv_impl<1>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, nullptr, B, T2, stream),
+                        attn_qkv_impl<3>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, nullptr, B, T2, stream));
+}
+
+int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
+    return attn_core_impl<0>(Q, K, V, O, LSE_or_null, B, T2, stream);
+}
+// QK^T and PV on v_mfma_f32_32x32x16_bf16 (terms 1) or as three-term split-bf16 products (terms 3); softmax in fp32
+int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, int B, int T2, int terms, void* stream) {
+    RTFS_TERMS_DISPATCH(terms, attn_core_impl<1>(Q, K, V, O, nullptr, B, T2, stream), attn_core_impl<3>(Q, K, V, O, nullptr, B, T2, stream));
+}
+
+int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
+                      float* Ypre_or_null, int B, int T2, void* stream) {
+    return attn_out_impl<0>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream);
+}
+int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
+                           int T2, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, G, nullptr, B, T2, stream),
+                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, nullptr, B, T2, stream));
 }
 
 }  // extern "C"

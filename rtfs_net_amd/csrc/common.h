@@ -37,6 +37,14 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
         if (e_ != hipSuccess) return RTFS_ELAUNCH;  \
     } while (0)
 
+// run-time precision -> template: terms 1 (bf16) or 3 (split-bf16); anything else is refused
+#define RTFS_TERMS_DISPATCH(terms, CALL1, CALL3) \
+    do {                                         \
+        if ((terms) == 1) return CALL1;          \
+        if ((terms) == 3) return CALL3;          \
+        return RTFS_EINVAL;                      \
+    } while (0)
+
 // ---- gLN statistics --------------------------------------------------------------------------------
 // A global layer norm (GroupNorm(1,C), normalizations.py:8-17) needs mean/var over (C,T,F) of one
 // utterance: a grid-wide reduction.  Producers add per-workgroup partial (sum, sum of squares) into a
@@ -283,6 +291,22 @@ __device__ __forceinline__ void mma32(floatx16& acc, const Frag& a, const Frag& 
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
 }
+// first product of an accumulator chain: C = inline-constant zero (no register clearing)
+template <int NT>
+__device__ __forceinline__ floatx16 mma32_first(const Frag& a, const Frag& b) {
+    floatx16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    floatx16 acc;
+    if constexpr (NT == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, z, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, z, 0, 0, 0);
+    }
+    return acc;
+}
 template <int NT>
 __device__ __forceinline__ void mma16(floatx4& acc, const Frag& a, const Frag& b) {  // 16x16x32: lane group kk = lane >> 4 supplies 8 k values
     if constexpr (NT == 3) {
@@ -319,6 +343,30 @@ __device__ __forceinline__ void mma_block_nt(floatx16 (&acc)[WM][WN], const floa
         mma_block<WM, WN, BT, AT>(acc, As, lda, Bs, ldb, kdepth);
     else
         mma_block_p<NT, WM, WN, BT, AT>(acc, As, lda, Bs, ldb, kdepth);
+}
+
+// mma_block_bn with a PACKED A tile (k-contiguous weights) and a plain fp32 n-contiguous B tile (packed in registers)
+template <int NT, int WM, int WN>
+__device__ __forceinline__ void mma_block_bn_p(floatx16 (&acc)[WM][WN], const float* As, int lda, const float* Bs, int ldb, int kdepth) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, kh = lane >> 5;
+    const float* ap = As + i * lda + kh * 4;
+    const float* bp = Bs + (kh * 4) * ldb + i;
+#pragma unroll 2
+    for (int q = 0; q < kdepth; q += 16) {
+        Frag a[WM], b[WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) a[m] = frag_packed(ld4(ap + m * 32 * lda + q), ld4(ap + m * 32 * lda + q + 8));
+#pragma unroll
+        for (int n = 0; n < WN; ++n) {
+            const float* c0 = bp + q * ldb + n * 32;
+            b[n] = frag_f32<NT>(f4(c0[0], c0[ldb], c0[2 * ldb], c0[3 * ldb]), f4(c0[8 * ldb], c0[9 * ldb], c0[10 * ldb], c0[11 * ldb]));
+        }
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int n = 0; n < WN; ++n) mma32<NT>(acc[m][n], a[m], b[n]);
+    }
 }
 
 template <int WM, int WN>

@@ -32,7 +32,7 @@ constexpr int kSlabLd = 68;
 
 // MODE 0: slab = LN4D(G) rows m0..m0+70;  out U0[S][L][256]
 // MODE 1: slab = zero-padded h3 rows (m0-7)..(m0+63);  out G[pos] = acc + bias + G[pos]  (in place)
-template <int N, int WM, int WN, int BK, int MODE>
+template <int N, int WM, int WN, int BK, int MODE, int NT = 0>  // NT != 0 (common.h): Wt host-PACKED, slab packed on store
 __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, float* __restrict__ dst) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
             v = ld4(src + ((size_t)s * map.L + min(max(l, 0), map.L - 1)) * 64 + c4 * 4);  // clamped + select: the slab loads stay batched
             if (!(row < kSlabRows && l >= 0 && l < map.L)) v = f4(0, 0, 0, 0);
         }
-        if (row < kSlabRows) st4(slab + row * kSlabLd + c4 * 4, v);
+        if (row < kSlabRows) st4(slab + row * kSlabLd + c4 * 4, pack4<NT>(v));
     }
     breg.store(Bs[0], LDB);
     __syncthreads();
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
         const int cur = kc & 1;
         if (kc + 1 < NK) breg.load(Wt, 512, (kc + 1) * BK);
         const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-        mma_block<WN, WM>(acc, Bs[cur] + wn * WN * 32 * LDB, LDB, slab + (wm * WM * 32 + kk) * kSlabLd + c0, kSlabLd, BK);
+        mma_block_nt<NT, WN, WM>(acc, Bs[cur] + wn * WN * 32 * LDB, LDB, slab + (wm * WM * 32 + kk) * kSlabLd + c0, kSlabLd, BK);
         if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
         __syncthreads();
     }
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
 // one): G[pos] += sum_{k', j} h3[pos + k' - 7][j] * Wt[c][k'*64 + j] + bias[c].  Against the 64-row toeplitz_gemm_kernel every 64 x 64
 // weight stage now feeds 128 rows (half the weight bytes and barriers per flop) and a wave owns 1 weight tile x 2 row tiles
 // (3 LDS reads per 8 MFMAs instead of 2 per 4).  Slab loads are unconditional (clamped + select).
+template <int NT = 0>
 __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ Wt,
                                                              const float* __restrict__ bias, float* __restrict__ dst, int tiles_per_seq, int total_tiles) {
     constexpr int BK = 64, LDB = BK + 4, N = 64;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const f
         const int l = m0[q] + row - 7;
         float4 v = ld4(src + ((size_t)seq[q] * map.L + min(max(l, 0), map.L - 1)) * 64 + c4);
         if (!(l >= 0 && l < map.L)) v = f4(0, 0, 0, 0);
-        if (idx < 2 * kSlabRows * 16) st4(slab[q] + row * kSlabLd + c4, v);
+        if (idx < 2 * kSlabRows * 16) st4(slab[q] + row * kSlabLd + c4, pack4<NT>(v));
     }
     breg.store(Bs[0], LDB);
     __syncthreads();
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const f
     for (int kc = 0; kc < 8; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < 8) breg.load(Wt, 512, (kc + 1) * BK);
-        mma_block<1, 2>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab[st] + kc * kSlabLd, kSlabLd, BK);
+        mma_block_nt<NT, 1, 2>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab[st] + kc * kSlabLd, kSlabLd, BK);
         if (kc + 1 < 8) breg.store(Bs[cur ^ 1], LDB);
         __syncthreads();
     }
@@ -311,6 +312,7 @@ constexpr int kFlatRows = 64 + 21;
 struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
     int r0, s0, l0, n0, n1;  // first flattened row, its (sequence, position); rows of segment 0, 1 (segment 2 = the rest)
 };
+template <int NT = 0>
 __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
                                                                  int S, int total_tiles) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             for (int o = 8; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o, 64);
             const float rstd = 1.0f / sqrtf(sqs * (1.f / 64.f) + kEps);
             const float4 y = ok ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
-            if (inr) st4(slab[st] + j * kSlabLd + (threadIdx.x & 15) * 4, y);
+            if (inr) st4(slab[st] + j * kSlabLd + (threadIdx.x & 15) * 4, pack4<NT>(y));
         }
     };
 
@@ -433,22 +435,38 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
             const float* ap = Bs[cur] + (wn * 64 + i) * BK;
             const float* sp = slab[wm] + kk * kSlabLd + c0 + 4 * kh;
+            if constexpr (NT == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 a[2], b[2];
+                for (int q = 0; q < 4; ++q) {
+                    float4 a[2], b[2];
+    #pragma unroll
+                    for (int n = 0; n < 2; ++n) a[n] = ld4(ap + n * 32 * BK + (((2 * q + kh) ^ sw) << 2));
+    #pragma unroll
+                    for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * q);
+    #pragma unroll
+                    for (int n = 0; n < 2; ++n)
+    #pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].x, b[m].x, acc[n][m], 0, 0, 0);
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].y, b[m].y, acc[n][m], 0, 0, 0);
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].z, b[m].z, acc[n][m], 0, 0, 0);
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].w, b[m].w, acc[n][m], 0, 0, 0);
+                        }
+                }
+            } else {
 #pragma unroll
-                for (int n = 0; n < 2; ++n) a[n] = ld4(ap + n * 32 * BK + (((2 * q + kh) ^ sw) << 2));
+                for (int q2 = 0; q2 < 2; ++q2) {  // 16 k per step: packed slots (4 q2 + kh) and (4 q2 + 2 + kh) of every row
+                    Frag a[2], b[2];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * q);
+                    for (int n = 0; n < 2; ++n)
+                        a[n] = frag_packed(ld4(ap + n * 32 * BK + (((4 * q2 + kh) ^ sw) << 2)), ld4(ap + n * 32 * BK + (((4 * q2 + 2 + kh) ^ sw) << 2)));
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                    for (int m = 0; m < 2; ++m) b[m] = frag_packed(ld4(sp + prow[m] * kSlabLd + 16 * q2), ld4(sp + prow[m] * kSlabLd + 16 * q2 + 8));
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].x, b[m].x, acc[n][m], 0, 0, 0);
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].y, b[m].y, acc[n][m], 0, 0, 0);
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].z, b[m].z, acc[n][m], 0, 0, 0);
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[n].w, b[m].w, acc[n][m], 0, 0, 0);
-                    }
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) mma32<NT>(acc[n][m], a[n], b[m]);
+                }
             }
             if (kc + 1 < NK) store_b(Bs[cur ^ 1]);
             __syncthreads();
@@ -535,7 +553,7 @@ __global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__
 //   A operand: lane (i, kh) supplies h_prev[t(i)][32kh + s] at MFMA step s (the K order is free as long as A and B agree), i.e.
 //   32 consecutive floats of one row = 8 x 16-byte loads;  B operand: W[(m, d, j=i)][32kh + s] via ds_read_b128.
 // ------------------------------------------------------------------------------------------------
-template <bool SAVE_C>  // training: also stores the cell states and the pre-activations U (the adjoint's inputs)
+template <bool SAVE_C, int NT = 0>  // SAVE_C (training): also stores the cell states and the pre-activations U (the adjoint's inputs); NT: common.h
 __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
                                                            const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
                                                            float* __restrict__ Cout, float* __restrict__ Uout, int S, int L) {
@@ -545,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
     for (int idx = threadIdx.x; idx < 192 * 16; idx += 256) {
         const int n = idx >> 4, q4 = (idx & 15) * 4;
         const float sc = n >= 64 ? kNegLog2e : 1.0f;
-        st4(Ws + n * LDW + q4, ld4(Wt + n * 64 + q4) * sc);
+        st4(Ws + n * LDW + q4, pack4<NT>(ld4(Wt + n * 64 + q4) * sc));  // (Wt is the plain fp32 weight for every NT: packed here, after the scaling)
     }
     __syncthreads();
     const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: bases below live in SGPRs
@@ -585,27 +603,46 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
         asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
                                         // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
         const float* wp = Ws + woff;
+        if constexpr (NT == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const float4 b0 = ld4(wp + (m * 64) * LDW + 4 * q), b1 = ld4(wp + (m * 64 + 32) * LDW + 4 * q);
-                if (q == 0) {  // the chain starts from a zero C operand (an inline constant): no accumulator clearing
-                    floatx16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, z, 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, z, 0, 0, 0);
-                } else {
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
+            for (int q = 0; q < 8; ++q) {
+    #pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const float4 b0 = ld4(wp + (m * 64) * LDW + 4 * q), b1 = ld4(wp + (m * 64 + 32) * LDW + 4 * q);
+                    if (q == 0) {  // the chain starts from a zero C operand (an inline constant): no accumulator clearing
+                        floatx16 z;
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, z, 0, 0, 0);
+                        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, z, 0, 0, 0);
+                    } else {
+                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
+                        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
+                    }
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, b0.y, acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, b1.y, acc[1][m], 0, 0, 0);
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, b0.z, acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, b1.z, acc[1][m], 0, 0, 0);
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, b0.w, acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, b1.w, acc[1][m], 0, 0, 0);
                 }
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, b0.y, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, b1.y, acc[1][m], 0, 0, 0);
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, b0.z, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, b1.z, acc[1][m], 0, 0, 0);
-                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, b0.w, acc[0][m], 0, 0, 0);
-                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, b1.w, acc[1][m], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {  // 16 k per step: this lane's k = 32 kh + 8 p .. + 7 (the fp32 fragments of quads 2p, 2p + 1, packed in registers)
+                const Frag fa0 = frag_f32<NT>(a0[2 * p], a0[2 * p + 1]), fa1 = frag_f32<NT>(a1[2 * p], a1[2 * p + 1]);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const Frag b0 = frag_packed(ld4(wp + (m * 64) * LDW + 8 * p), ld4(wp + (m * 64) * LDW + 8 * p + 4));
+                    const Frag b1 = frag_packed(ld4(wp + (m * 64 + 32) * LDW + 8 * p), ld4(wp + (m * 64 + 32) * LDW + 8 * p + 4));
+                    if (p == 0) {
+                        acc[0][m] = mma32_first<NT>(fa0, b0);
+                        acc[1][m] = mma32_first<NT>(fa1, b1);
+                    } else {
+                        mma32<NT>(acc[0][m], fa0, b0);
+                        mma32<NT>(acc[1][m], fa1, b1);
+                    }
+                }
             }
         }
         if (ch + 1 < nch) load_a(sl0 + 32);
@@ -685,46 +722,68 @@ static SeqMap make_map(int dim, int B, int T2) {
     return m;
 }
 
-extern "C" {
-
-// G: [B][T2][F2][64].  U0: [S][L][256] with S = B*T2 (dim 4) or B*F2 (dim 3), L = npos-7, column = (dir*32+j)*4+m.
-// Wt: [256][512], k index = kk*64 + c.
-int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim,
-                            void* stream) {
+template <int NT>
+static int unfold_gemm_impl(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim, void* stream) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
     const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
-    if (npairs < 256) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
-        hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+    if (npairs < 256 || (NT != 0 && m.L < 32)) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
+        hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0, NT>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
     static const bool per_seq_tiles = getenv("RTFS_UNFOLD_PER_SEQ") != nullptr;  // second-generation kernel (tiles padded per sequence)
-    if (!per_seq_tiles && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
+    if ((NT != 0 || !per_seq_tiles) && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
         const int units = 2 * fpairs;  // (tile pair, column half)
-        hipLaunchKernelGGL(unfold_gemm128f_kernel, dim3(units < resident ? units : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
+        hipLaunchKernelGGL(unfold_gemm128f_kernel<NT>, dim3(units < resident ? units : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
                            Wt, U0, S, ftiles);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
+    if (NT != 0) return RTFS_EINVAL;  // (not reached: the bf16 paths are served by the two kernels above)
     hipLaunchKernelGGL(unfold_gemm128_kernel, dim3(npairs < resident ? npairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0,
                        tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-// H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.
-int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
+template <int NT>
+static int convt_impl(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.npos + 63) / 64, total = S * tps;
-    hipLaunchKernelGGL(convt_gemm2_kernel, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, tps, total);
+    hipLaunchKernelGGL(convt_gemm2_kernel<NT>, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+extern "C" {
+
+// G: [B][T2][F2][64].  U0: [S][L][256] with S = B*T2 (dim 4) or B*F2 (dim 3), L = npos-7, column = (dir*32+j)*4+m.
+// Wt: [256][512], k index = kk*64 + c.
+
+int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim,
+                            void* stream) {
+    return unfold_gemm_impl<0>(G, gamma, beta, Wt, U0, B, T2, dim, stream);
+}
+// bf16 (terms 1) / split-bf16 (terms 3) MFMA; Wpk = host-packed weight (same indexing as Wt)
+int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
+                                 void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, unfold_gemm_impl<1>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<3>(G, gamma, beta, W, U0, B, T2, dim, stream));
+}
+
+// H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.
+int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
+    return convt_impl<0>(H3, Wt, bias, G, B, T2, dim, stream);
+}
+int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, convt_impl<1>(H3, W, bias, G, B, T2, dim, stream), convt_impl<3>(H3, W, bias, G, B, T2, dim, stream));
 }
 
 // km = 4: U [S][L][64][4];  km = 3: U [S][L][3][64] and X [S][L][64].  wc, bias: [2][64] (forget | reset).  H: [S][L][64].
@@ -755,6 +814,19 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
     else
         hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
                            Uout_or_null, S, L);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// inference-only bf16 / split-bf16 variant of rtfs_sru_layer_fwd: Wt is the PLAIN fp32 weight (packed in the kernel after the gate scaling)
+int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, int S, int L, int terms,
+                            void* stream) {
+    if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3)) return RTFS_EINVAL;
+    dim3 grid((S + 3) / 4);
+    if (terms == 1)
+        hipLaunchKernelGGL((sru_layer_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, nullptr, nullptr, S, L);
+    else
+        hipLaunchKernelGGL((sru_layer_kernel<false, 3>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, nullptr, nullptr, S, L);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

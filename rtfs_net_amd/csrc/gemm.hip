@@ -591,42 +591,34 @@ static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
-// run-time precision -> template: terms 1 (bf16) or 3 (split-bf16); anything else is refused
-#define RTFS_TERMS_DISPATCH(terms, CALL1, CALL3) \
-    do {                                         \
-        if ((terms) == 1) return CALL1;          \
-        if ((terms) == 3) return CALL3;          \
-        return RTFS_EINVAL;                      \
-    } while (0)
+
 
 }  // namespace rtfs
 
 using namespace rtfs;
 
-template <int K, int N, int BM, int WM, int WN>
+template <int K, int N, int BM, int WM, int WN, int NT = 0>
 static int rows_gemm(const float* X, const float* Wt, const float* bias, float* Y, int M, int accumulate, hipStream_t st) {
     ProPlain pro{X, K};
     if (bias) {
-        if (accumulate) return launch<K, N, BM, WM, WN, false>(pro, EpiBias<true, true>{Y, bias, N}, Wt, 1, M, st);
-        return launch<K, N, BM, WM, WN, false>(pro, EpiBias<true, false>{Y, bias, N}, Wt, 1, M, st);
+        if (accumulate) return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<true, true>{Y, bias, N}, Wt, 1, M, st);
+        return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<true, false>{Y, bias, N}, Wt, 1, M, st);
     }
-    if (accumulate) return launch<K, N, BM, WM, WN, false>(pro, EpiBias<false, true>{Y, nullptr, N}, Wt, 1, M, st);
-    return launch<K, N, BM, WM, WN, false>(pro, EpiBias<false, false>{Y, nullptr, N}, Wt, 1, M, st);
+    if (accumulate) return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<false, true>{Y, nullptr, N}, Wt, 1, M, st);
+    return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<false, false>{Y, nullptr, N}, Wt, 1, M, st);
 }
 
-extern "C" {
-
-// a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
-int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt,
-                        const float* bias, float* a0, int B, int TF, void* stream) {
+template <int NT>
+static int bottleneck_impl(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt, const float* bias, float* a0,
+                           int B, int TF, hipStream_t st) {
     ProGlnRelu pro{a_emb, stats, 1.0 / ((double)TF * kC), gamma, beta};
     EpiBias<true> epi{a0, bias, kC};
-    return launch<256, 256, 64, 2, 2, false, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+    return launch<256, 256, 64, 2, 2, false, 16, NT>(pro, epi, Wt, B, TF, st);
 }
 
-// y = Wp . prelu(s*gw+gb) + bias (pre-gLN projection output, [B][TF][64]) and its gLN partial sums.
-int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope, const float* Wt, const float* bias, float* y,
-                  double* stats_out, int B, int TF, void* stream) {
+template <int NT>
+static int proj_impl(const float* s, const float* gw, const float* gb, float gslope, const float* Wt, const float* bias, float* y, double* stats_out,
+                     int B, int TF, hipStream_t st) {
     ProGateway pro{s, gw, gb, gslope};
     EpiBiasStats epi{y, bias, kH, stats_out};
     if (B <= 0 || TF <= 0) return RTFS_EINVAL;
@@ -635,9 +627,72 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
     const int tiles = (TF + 63) / 64;
     const long long want = ((long long)tiles * B + 511) / 512;
     const int per = (int)(want < 2 ? 2 : (want > 32 ? 32 : want));
-    hipLaunchKernelGGL(proj_kernel, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, TF, per);
+    hipLaunchKernelGGL(proj_kernel<NT>, dim3((tiles + per - 1) / per, B), dim3(256), 0, st, pro, epi, Wt, TF, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+// shared by rtfs_resid_fwd / rtfs_resid_proj_fwd and their bf16 siblings (Wp == nullptr: no fused projection)
+template <int NT>
+static int resid_impl(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                      const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                      const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt, const float* bias,
+                      const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, const float* Wp,
+                      const float* pbias, float* py, double* pstats, int B, int T, int T2, hipStream_t st) {
+    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
+    ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
+                    {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null, Wp, pbias, py, pstats};
+    if (B <= 0 || T <= 0) return RTFS_EINVAL;
+    if (Wp && (!a0_or_null || !py || !pstats)) return RTFS_EINVAL;
+    // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
+    // 64 -> 804; small batches get more, smaller workgroups.
+    const int Mb = T * kF, tiles = (Mb + 63) / 64;
+    const long long want = ((long long)tiles * B + 1023) / 1024;
+    const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
+    const dim3 grid((tiles + per - 1) / per, B);
+    if (Wp)
+        hipLaunchKernelGGL((resid_kernel<true, true, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    else if (a0_or_null)
+        hipLaunchKernelGGL((resid_kernel<true, false, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    else
+        hipLaunchKernelGGL((resid_kernel<false, false, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+template <int NT>
+static int mask_impl(const float* x, float slope, const float* Wt, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B, int TF,
+                     hipStream_t st) {
+    ProPrelu pro{x, slope};
+    EpiMask epi{masked, bias, a_emb, m_or_null};
+    return launch<256, 256, 64, 2, 2, true, 16, NT>(pro, epi, Wt, B, TF, st);
+}
+
+extern "C" {
+
+// a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
+int rtfs_bottleneck_fwd(const float* a_emb, const double* stats, const float* gamma, const float* beta, const float* Wt,
+                        const float* bias, float* a0, int B, int TF, void* stream) {
+    return bottleneck_impl<0>(a_emb, stats, gamma, beta, Wt, bias, a0, B, TF, (hipStream_t)stream);
+}
+int rtfs_bottleneck_fwd_bf16(const float* a_emb, const double* stats, const float* gamma, const float* beta, const void* Wpk, const float* bias,
+                             float* a0, int B, int TF, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, bottleneck_impl<1>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream),
+                        bottleneck_impl<3>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream));
+}
+
+// y = Wp . prelu(s*gw+gb) + bias (pre-gLN projection output, [B][TF][64]) and its gLN partial sums.
+int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope, const float* Wt, const float* bias, float* y,
+                  double* stats_out, int B, int TF, void* stream) {
+    return proj_impl<0>(s, gw, gb, gslope, Wt, bias, y, stats_out, B, TF, (hipStream_t)stream);
+}
+int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float gslope, const void* Wpk, const float* bias, float* y, double* stats_out,
+                       int B, int TF, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, proj_impl<1>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream),
+                        proj_impl<3>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream));
 }
 
 // out = Wr . expanded + bias + prelu(s*gw+gb) [+ a0]; the four tensors of `expanded` are passed pre-gLN with their stats.
@@ -647,22 +702,21 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
                    const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
                    const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                    const float* a0_or_null, float* out, int B, int T, int T2, void* stream) {
-    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
-    ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
-                    {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null, nullptr, nullptr, nullptr, nullptr};
-    if (B <= 0 || T <= 0) return RTFS_EINVAL;
-    // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
-    // 64 -> 804; small batches get more, smaller workgroups.
-    const int Mb = T * kF, tiles = (Mb + 63) / 64;
-    const long long want = ((long long)tiles * B + 1023) / 1024;
-    const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
-    if (a0_or_null)
-        hipLaunchKernelGGL(resid_kernel<true>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
-    else
-        hipLaunchKernelGGL(resid_kernel<false>, dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
-    RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    return resid_impl<0>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, Wt, bias, s_in,
+                         gw, gb, gslope, a0_or_null, out, nullptr, nullptr, nullptr, nullptr, B, T, T2, (hipStream_t)stream);
+}
+int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                        const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                        const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                        const void* Wpk, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                        const float* a0_or_null, float* out, int B, int T, int T2, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+#define RESID_NT(NTV)                                                                                                                                  \
+    resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
+                    gb, gslope, a0_or_null, out, nullptr, nullptr, nullptr, nullptr, B, T, T2, (hipStream_t)stream)
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3));
+#undef RESID_NT
 }
 
 // rtfs_resid_fwd (with a0) fused with the NEXT block's rtfs_proj_fwd (shared block weights): out as above, plus
@@ -675,25 +729,36 @@ int rtfs_resid_proj_fwd(const float* cl, const double* cl_stats, const float* cl
                         const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                         const float* a0, float* out, const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2,
                         void* stream) {
-    const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
-    ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
-                    {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0, Wp, pbias, py, pstats};
-    if (B <= 0 || T <= 0 || !a0 || !Wp || !py || !pstats) return RTFS_EINVAL;
-    const int Mb = T * kF, tiles = (Mb + 63) / 64;
-    const long long want = ((long long)tiles * B + 1023) / 1024;
-    const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
-    hipLaunchKernelGGL((resid_kernel<true, true>), dim3((tiles + per - 1) / per, B), dim3(256), 0, (hipStream_t)stream, pro, epi, Wt, Mb, per);
-    RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
+    if (!a0 || !Wp || !py || !pstats) return RTFS_EINVAL;
+    return resid_impl<0>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, Wt, bias, s_in,
+                         gw, gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream);
+}
+int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                             const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                             const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                             const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                             const void* Wpk, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                             const float* a0, float* out, const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2,
+                             int terms, void* stream) {
+    if (!a0 || !Wp_pk || !py || !pstats) return RTFS_EINVAL;
+    const float *W = (const float*)Wpk, *Wp = (const float*)Wp_pk;
+#define RESID_NT(NTV)                                                                                                                                  \
+    resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
+                    gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream)
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3));
+#undef RESID_NT
 }
 
 // masked = complex_mul(relu(Wm . prelu(x) + bias), a_emb)   all [B][TF][256]
 int rtfs_mask_fwd(const float* x, float slope, const float* Wt, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
                   int TF, void* stream) {
-    ProPrelu pro{x, slope};
-    EpiMask epi{masked, bias, a_emb, m_or_null};
-    return launch<256, 256, 64, 2, 2, true, 16>(pro, epi, Wt, B, TF, (hipStream_t)stream);
+    return mask_impl<0>(x, slope, Wt, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream);
+}
+int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
+                       int TF, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, mask_impl<1>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream),
+                        mask_impl<3>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream));
 }
 
 // Y[M][N] (= or +=) X[M][K] . Wt[N][K]^T (+ bias), row-major.  Used for the SRU layer 1-3 projections, the decoder taps,
@@ -718,6 +783,15 @@ int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, f
 
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {
     return rtfs_gemm_rows(X, Wt, bias_or_null, Y, M, K, N, 0, stream);
+}
+
+// bf16 / split-bf16 row GEMM of the inference path: the decoder taps (256 -> 32); Wpk = host-packed weight
+int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const float* W = (const float*)Wpk;
+    if (K == 256 && N == 32)
+        RTFS_TERMS_DISPATCH(terms, (rows_gemm<256, 32, 128, 1, 1, 1>(X, W, bias_or_null, Y, M, 0, st)), (rows_gemm<256, 32, 128, 1, 1, 3>(X, W, bias_or_null, Y, M, 0, st)));
+    return RTFS_EINVAL;
 }
 
 }  // extern "C"

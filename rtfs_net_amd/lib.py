@@ -85,6 +85,19 @@ SIGNATURES = {
     "rtfs_caf_bwd_apply": [P] * 8 + [I, I, I, I, P],
     "rtfs_istft_bwd": [P, P, P, I, I, P],
     "rtfs_spec_patches": [P, P, I, I, P],
+    # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
+    "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],
+    "rtfs_proj_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
+    "rtfs_dp_unfold_gemm_fwd_bf16": [P, P, P, P, P, I, I, I, I, P],
+    "rtfs_sru_layer_fwd_bf16": [P, P, P, P, F, P, I, I, I, P],
+    "rtfs_dp_convt_fwd_bf16": [P, P, P, P, I, I, I, I, P],
+    "rtfs_attn_qkv_fwd_bf16": [P] * 13 + [I, I, I, P],
+    "rtfs_attn_core_fwd_bf16": [P, P, P, P, I, I, I, P],
+    "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, I, I, I, P],
+    "rtfs_resid_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, I, P],
+    "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
+    "rtfs_mask_fwd_bf16": [P, F, P, P, P, P, P, I, I, I, P],
+    "rtfs_gemm_rows_fwd_bf16": [P, P, P, P, I, I, I, I, P],
 }
 
 _lib = None
@@ -194,7 +207,7 @@ def _same_device(name, dev, t):
 
 def _launch(name, conv, args, dev):
     stream = torch.cuda.current_stream(dev).cuda_stream
-    if (name == _prof_name and (_prof_pred is None or _prof_pred(tuple(a for a in args if isinstance(a, int))))) or _prof_name == "*":
+    if ((name == _prof_name or name == str(_prof_name) + "_bf16") and (_prof_pred is None or _prof_pred(tuple(a for a in args if isinstance(a, int))))) or _prof_name == "*":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # torch's current stream == the stream handed to the kernel
         rc = getattr(load(), name)(*conv, stream)

@@ -132,6 +132,19 @@ class AVNet(nn.Module):
         if getattr(self, "_trainer", None) is not None:
             self._trainer.invalidate()
 
+    def set_compute_dtype(self, name: str):
+        """Arithmetic of the dense contractions (1x1 convs, SRU input GEMMs, ConvTranspose1d, attention QK^T / PV, decoder taps) of the
+        INFERENCE path: "f32" (default: exact fp32 MFMA), "bf16" (operands rounded to bfloat16, fp32 accumulation: ~4e-3 relative on the
+        waveform) or "bf16x3" (split-bf16, three bf16 MFMAs per product: ~1e-5 relative, inside the 1e-3 parity bound at 16/3 of the fp32
+        MFMA rate).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
+        training step is fp32 only.  (The reference selects precision through Lightning's `precision` flag; its configs use 32.)"""
+        from .hip_path import COMPUTE_DTYPES
+
+        if name not in COMPUTE_DTYPES:
+            raise ValueError(f"compute dtype must be one of {sorted(COMPUTE_DTYPES)}, got {name!r}")
+        self._hip.prec = COMPUTE_DTYPES[name]
+        return self
+
     def train(self, mode: bool = True):
         self.invalidate_hip_cache()  # eval folds BatchNorm running statistics into the prepared weights, train does not
         return super().train(mode)

@@ -25,6 +25,21 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+# compute dtype of the dense contractions (every MFMA kernel): name -> `terms` argument of the *_bf16 entry points (0 = the fp32 entry points)
+COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "bf16x3": 3}
+
+
+def pack_bf16(w: torch.Tensor) -> torch.Tensor:
+    """fp32 weight [N, K] (K % 4 == 0, k contiguous) -> the HOST-PACKED operand of the *_bf16 entry points (include/rtfs_hip.h,
+    csrc/common.h "PACKED SLOT"): every group of 4 consecutive k becomes 8 bfloat16 {hi(k0..k3), lo(k0..k3)}, hi = bf16(w) (round to
+    nearest even), lo = bf16(w - hi).  Same byte size and indexing as the fp32 matrix.  Returned as a bfloat16 tensor [N, K/4, 8]."""
+    w = w.detach().float().contiguous()
+    N, K = w.shape
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    return torch.cat([hi.view(N, K // 4, 4), lo.view(N, K // 4, 4)], -1).contiguous()
+
+
 def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
     """VP block parameters packed in the order of VpOff (csrc/vp.hip), BatchNorm1d folded with its running statistics (eval)."""
     eps = 1e-5
@@ -64,8 +79,9 @@ def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
 class PreparedWeights:
     """Kernel-layout copies of the parameters (transposes / permutations done once, re-done when parameters change)."""
 
-    def __init__(self, model, pack_vp=True, training=False):
+    def __init__(self, model, pack_vp=True, training=False, prec=0):
         self.version = self.fingerprint(model, training)
+        self.prec = prec
         dev = next(model.parameters()).device
         self.device = dev
         w = {}
@@ -128,6 +144,15 @@ class PreparedWeights:
             if w["vp"].numel() != lib.load().rtfs_vp_param_count():
                 raise RuntimeError("VP parameter packing does not match csrc/vp.hip (VpOff)")
             w["vp_pe"] = _f32(sd["refinement_module.video_net.blocks.globalatt.0.MHSA.pos_enc.pe"][0, :64]).to(dev)
+        if prec:  # bf16 / split-bf16 compute: host-packed copies of every MFMA weight (suffix _pk), next to the fp32 ones
+            for k in ("bn_w", "mask_w", "dec_w"):
+                w[k + "_pk"] = pack_bf16(w[k])
+            for b in self.blocks:
+                b["pw_pk"], b["rw_pk"] = pack_bf16(b["pw"]), pack_bf16(b["rw"])
+                for j in (0, 1):
+                    d = b[f"dp{j}"]
+                    d["w0_pk"], d["ct_w_pk"] = pack_bf16(d["w0"]), pack_bf16(d["ct_w"])
+                b["attn"]["w_pk"], b["attn"]["ow_pk"] = pack_bf16(b["attn"]["w"]), pack_bf16(b["attn"]["ow"])
         self.w = w
 
     @staticmethod
@@ -218,12 +243,24 @@ class HipForward:
         self.taps = None  # set to a dict to capture stage outputs (tests)
         self.tap_all_blocks = False  # with `taps`: also capture the stages of blocks 1..R-1 (keys suffixed '#i')
         self._vp_stream = None
+        self.prec = COMPUTE_DTYPES[os.environ.get("RTFS_COMPUTE_DTYPE", "f32")]  # AVNet.set_compute_dtype
 
     def weights(self) -> PreparedWeights:
         fp = PreparedWeights.fingerprint(self.model)
-        if self._prep is None or self._prep.version != fp:
-            self._prep = PreparedWeights(self.model)
+        if self._prep is None or self._prep.version != fp or self._prep.prec != self.prec:
+            self._prep = PreparedWeights(self.model, prec=self.prec)
         return self._prep
+
+    def _mm(self, name, *args):
+        """an entry point whose contraction runs on MFMA: the fp32 one, or its *_bf16 sibling with the `terms` argument"""
+        if self.prec:
+            lib.call(name + "_bf16", *args, self.prec)
+        else:
+            lib.call(name, *args)
+
+    def _wk(self, d, key):
+        """the weight `key` of dict `d` in the form the selected precision's entry point takes (fp32 / host-packed)"""
+        return d[key + "_pk"] if self.prec else d[key]
 
     def invalidate(self):
         """drop the kernel-layout weight copies (rebuilt on the next forward)"""
@@ -235,16 +272,19 @@ class HipForward:
         L = npos - 7
         dev = G.device
         U = torch.empty(S * L * 256, device=dev)
-        lib.call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U, B, T2, dim)
+        self._mm("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], self._wk(d, "w0"), U, B, T2, dim)
         h = torch.empty(S * L * 64, device=dev)
         l0 = d["layers"][0]
         lib.call("rtfs_sru_scan_fwd", U, None, l0["wc"], l0["bias"], l0["scale_x"], h, S, L, 4)
         del U
         for lw in d["layers"][1:]:  # input projection fused into the recurrence
             h2 = torch.empty_like(h)
-            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, None, S, L)
+            if self.prec:
+                lib.call("rtfs_sru_layer_fwd_bf16", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, S, L, self.prec)
+            else:
+                lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, None, S, L)
             h = h2
-        lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
+        self._mm("rtfs_dp_convt_fwd", h, self._wk(d, "ct_w"), d["ct_b"], G, B, T2, dim)
 
     # ---- one RTFS block (a5) ----
     def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None, y0=None, next_proj=None):
@@ -257,7 +297,7 @@ class HipForward:
         low = lambda: torch.empty(B * T2 * F2 * H, device=dev)  # noqa: E731
         if y0 is None:
             y0 = full()
-            lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], y0, st[0], B, TF)
+            self._mm("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], self._wk(bw, "pw"), bw["pb"], y0, st[0], B, TF)
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         D0 = full()
@@ -278,10 +318,15 @@ class HipForward:
         Q = torch.empty(B * 4 * T2 * 256, device=dev)
         K = torch.empty_like(Q)
         V = torch.empty(B * 4 * T2 * 1024, device=dev)
-        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, None, B, T2)
         O = torch.empty(B * T2 * 4096, device=dev)
-        lib.call("rtfs_attn_core_fwd", Q, K, V, O, None, B, T2)
-        lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, None, B, T2)
+        if self.prec:
+            lib.call("rtfs_attn_qkv_fwd_bf16", G, a["w_pk"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, B, T2, self.prec)
+            lib.call("rtfs_attn_core_fwd_bf16", Q, K, V, O, B, T2, self.prec)
+            lib.call("rtfs_attn_out_fwd_bf16", O, a["ow_pk"], a["ob"], a["oslope"], a["og"], a["obe"], G, B, T2, self.prec)
+        else:
+            lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, None, B, T2)
+            lib.call("rtfs_attn_core_fwd", Q, K, V, O, None, B, T2)
+            lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, None, B, T2)
         if tap is not None:
             tap["attn"] = G.clone()
         # TFAR (a5.6)
@@ -303,12 +348,12 @@ class HipForward:
         lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
         lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
         if next_proj is not None and a0_or_none is not None:
-            lib.call("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
-                     cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, bw["pw"], bw["pb"], next_proj[0],
-                     next_proj[1], B, T, T2)
+            self._mm("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
+                     cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, self._wk(bw, "pw"), bw["pb"],
+                     next_proj[0], next_proj[1], B, T, T2)
             return True
-        lib.call("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
-                 cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+        self._mm("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
+                 cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
         return False
 
     @torch.no_grad()
@@ -342,7 +387,7 @@ class HipForward:
         lib.call("rtfs_enc_conv_fwd", spec, w["enc"], a_emb, stats[0], B, T)
         # a2: bottleneck
         a0 = torch.empty_like(a_emb)
-        lib.call("rtfs_bottleneck_fwd", a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], a0, B, TF)
+        self._mm("rtfs_bottleneck_fwd", a_emb, stats[0], w["bn_g"], w["bn_b"], self._wk(w, "bn_w"), w["bn_bias"], a0, B, TF)
         if taps is not None:
             taps["spec"], taps["a_emb"], taps["a0"] = spec, a_emb, a0
 
@@ -393,9 +438,9 @@ class HipForward:
             s, x = x, s
         # a11: S3 mask; a12: decoder taps + iSTFT
         masked = x
-        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], a_emb, masked, None, B, TF)
+        self._mm("rtfs_mask_fwd", s, w["mask_slope"], self._wk(w, "mask_w"), w["mask_b"], a_emb, masked, None, B, TF)
         tapbuf = torch.empty(B * TF * 32, device=dev)
-        lib.call("rtfs_gemm_rows_fwd", masked, w["dec_w"], None, tapbuf, B * TF, 256, 32)
+        self._mm("rtfs_gemm_rows_fwd", masked, self._wk(w, "dec_w"), None, tapbuf, B * TF, 256, 32)
         frames = torch.empty(B * T * 256, device=dev)
         out = torch.empty(B, L, device=dev)
         lib.call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
