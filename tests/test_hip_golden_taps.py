@@ -47,8 +47,8 @@ def test_every_block_stage_against_reference_taps(name, R, B, L):
     got["caf"] = full(taps["caf_plus_a0"], 256) - got["a0"]
     for i in range(R):
         s = "" if i == 0 else f"#{i}"
-        if i > 0:
-            got["block" + s] = full(taps["block" + s], 256)
+        if i > 0:  # the residual kernel of blocks 1..R-2 writes the NEXT block's input, block output + a0 (refinement_module.py:60)
+            got["block" + s] = full(taps["block" + s], 256) - (got["a0"] if i < R - 1 else 0)
         got["projection" + s] = F.prelu(gln(full(taps["y0" + s], 64), p + "projection.full_layer."), sd[p + "projection.full_layer.4.weight"])
         got["down0" + s] = gln(full(taps["D0" + s], 64), p + "downsample_layers.0.full_layer.")
         got["down1" + s] = gln(low(taps["D1" + s]), p + "downsample_layers.1.full_layer.")
