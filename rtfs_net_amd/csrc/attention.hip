@@ -257,6 +257,150 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// core for MORE than 1024 compressed frames (utterances longer than 16.4 s; the reference has no length limit): the keys are walked
+// in blocks of 1024 through the same [32][1024] LDS score tile, in two sweeps - (1) running row maximum / sum of exponentials over
+// all blocks (the online-softmax recurrence), (2) scores recomputed block by block, normalised with the FINAL statistics and
+// accumulated into O = P V (all 8 feature tiles of the wave stay in registers across the blocks; no rescaling of accumulators).
+// QK^T is computed twice (16 of the core's 80 MMAC per key-query pair); inference only (no LSE output).
+// ------------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void attn_core_long_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
+                                                             float* __restrict__ O, int T2) {
+    constexpr int MAXKT = 32, LDS_S = MAXKT * 32 + 4;
+    __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
+    __shared__ float rmax[32], rsum[32];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int q0 = qt * 32;
+    const int NTall = (T2 + 31) / 32, nblk = (NTall + MAXKT - 1) / MAXKT;
+    const size_t headoff = ((size_t)b * kHeads + h) * T2;
+    const float* Qg = Q + headoff * 256;
+    const float* Kg = Kx + headoff * 256;
+    const float* Vg = V + headoff * 1024;
+    const float* qrow = Qg + (size_t)min(q0 + i, T2 - 1) * 256 + 4 * kh;
+
+    auto scores = [&](int kb) {  // scaled scores of key block kb -> Ss[query][key - 1024 kb]
+        const int kt0 = kb * MAXKT, ktn = min(MAXKT, NTall - kt0);
+        for (int kt = w; kt < ktn; kt += 4) {
+            const float* krow = Kg + (size_t)min((kt0 + kt) * 32 + i, T2 - 1) * 256 + 4 * kh;
+            floatx16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (PREC == 0) {
+#pragma unroll 8
+                for (int q = 0; q < 32; ++q) {
+                    const float4 a = ld4(qrow + 8 * q), kb4 = ld4(krow + 8 * q);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, kb4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, kb4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, kb4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, kb4.w, acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll 4
+                for (int q2 = 0; q2 < 16; ++q2)
+                    mma32<PREC>(acc, frag_f32<PREC>(ld4(qrow + 16 * q2), ld4(qrow + 16 * q2 + 8)), frag_f32<PREC>(ld4(krow + 16 * q2), ld4(krow + 16 * q2 + 8)));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ss[acc_row(r) * LDS_S + kt * 32 + i] = acc[r] * 0.0625f;
+        }
+    };
+
+    if (threadIdx.x < 32) rmax[threadIdx.x] = -3.0e38f, rsum[threadIdx.x] = 0.f;
+    // ---- sweep 1: row statistics over all key blocks ----
+    for (int kb = 0; kb < nblk; ++kb) {
+        __syncthreads();  // the statistics / previous block's scores are settled
+        scores(kb);
+        __syncthreads();
+        const int nkey = min(MAXKT * 32, T2 - kb * MAXKT * 32);
+        for (int rr = 0; rr < 8; ++rr) {
+            const int rowi = w * 8 + rr;
+            const float* row = Ss + rowi * LDS_S;
+            float mx = -3.0e38f;
+            for (int col = lane; col < nkey; col += 64) mx = fmaxf(mx, row[col]);
+            mx = wave_max(mx);
+            const float mold = rmax[rowi], mnew = fmaxf(mold, mx);
+            float sum = 0.f;
+            for (int col = lane; col < nkey; col += 64) sum += __expf(row[col] - mnew);
+            sum = wave_sum(sum);
+            if (lane == 0) {
+                rsum[rowi] = rsum[rowi] * __expf(mold - mnew) + sum;
+                rmax[rowi] = mnew;
+            }
+        }
+    }
+    // ---- sweep 2: P = exp(S - max) / sum per block, O += P V ----
+    floatx16 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int kb = 0; kb < nblk; ++kb) {
+        __syncthreads();
+        scores(kb);
+        __syncthreads();
+        const int key0 = kb * MAXKT * 32;
+        const int nkey = min(MAXKT * 32, T2 - key0), ktn = min(MAXKT, NTall - kb * MAXKT);
+        for (int rr = 0; rr < 8; ++rr) {
+            const int rowi = w * 8 + rr;
+            float* row = Ss + rowi * LDS_S;
+            const float mx = rmax[rowi], inv = 1.0f / rsum[rowi];
+            for (int col = lane; col < ktn * 32; col += 64) row[col] = col < nkey ? __expf(row[col] - mx) * inv : 0.f;  // zero weight for the padded keys
+        }
+        __syncthreads();
+        const float* pa = Ss + i * LDS_S + 4 * kh;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int n0 = w * 256 + pass * 128;
+            if constexpr (PREC == 0) {
+                for (int kq = 0; kq < ktn * 4; ++kq) {
+                    const float4 p = ld4(pa + 8 * kq);
+                    const int key = key0 + 8 * kq + 4 * kh;
+                    float vb[4][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float* vr = Vg + (size_t)min(key + r, T2 - 1) * 1024 + n0 + i;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        floatx16& a = acc[pass * 4 + n];
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, vb[n][0], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, vb[n][1], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, vb[n][2], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, vb[n][3], a, 0, 0, 0);
+                    }
+                }
+            } else {
+                for (int kq2 = 0; kq2 < ktn * 2; ++kq2) {
+                    const Frag fp = frag_f32<PREC>(ld4(pa + 16 * kq2), ld4(pa + 16 * kq2 + 8));
+                    const int key = key0 + 16 * kq2 + 4 * kh;
+                    float vb[4][8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float* vr = Vg + (size_t)min(key + (r & 3) + 2 * (r & 4), T2 - 1) * 1024 + n0 + i;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        mma32<PREC>(acc[pass * 4 + n], fp, frag_f32<PREC>(f4(vb[n][0], vb[n][1], vb[n][2], vb[n][3]), f4(vb[n][4], vb[n][5], vb[n][6], vb[n][7])));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = q0 + acc_row(r);
+            const int e = w * 256 + n * 32 + i;  // pass * 128 + (n & 3) * 32 = n * 32
+            const int c = h * 16 + (e >> 6), f = e & 63;
+            if (t < T2) O[(((size_t)b * T2 + t) * 64 + c) * 64 + f] = acc[n][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // out-projection + PReLU + LN4D over (64, F) + residual, one token per workgroup, in place on G.
 // Computes Y^T[co][f] = W[co][c] . X[c][f] so the O layout [c][f] is consumed without a transpose.
 // gamma/beta are host-permuted to [f][c].
@@ -339,8 +483,14 @@ static int attn_qkv_impl(const float* G, const float* Wt, const float* bias, con
 
 template <int NT>
 static int attn_core_impl(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
-    if (B <= 0 || T2 <= 0 || T2 > 1024) return RTFS_EINVAL;  // the [32][T2] score tile lives in LDS: 1024 keys = 131.6 KB (16.4 s of audio)
+    if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
     dim3 grid((T2 + 31) / 32, kHeads, B);
+    if (T2 > 1024) {  // past 16.4 s of audio the [32][T2] score tile no longer fits the LDS: key-blocked two-sweep kernel (inference only)
+        if (LSE_or_null) return RTFS_EINVAL;
+        hipLaunchKernelGGL((attn_core_long_kernel<NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     if (T2 <= 128)
         hipLaunchKernelGGL((attn_core_kernel<4, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
     else if (T2 <= 256)

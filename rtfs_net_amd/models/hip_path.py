@@ -370,10 +370,13 @@ class HipForward:
         T = 1 + L // 128
         T2 = (T - 2) // 2 + 1
         if T2 < 8:
-            raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
-        if T2 > 1024:
-            raise ValueError(f"input too long for the HIP path: {L} samples = {T2} compressed frames, the TF-attention score tile holds 1024 "
-                             "(about 16.4 s at 16 kHz); split longer recordings into segments")
+            # the reference fails here too: rnn_layers.py:141-143 pads to ceil((n - 8) / 1) + 8 = n (no padding for stride 1), and
+            # nn.Unfold((8, 1)) raises on fewer than 8 compressed frames (RuntimeError; tests/test_oracle_golden.py pins that)
+            raise ValueError("input too short: fewer than 8 compressed frames (16 STFT frames, L >= 1920 samples) - the 8-tap unfold of the "
+                             "time-path DualPathRNN has no window, exactly as in the reference (which raises from nn.Unfold)")
+        if T * F_BINS * C * 4 >= 2 ** 31:
+            raise ValueError(f"input too long for the HIP path: {L} samples - one utterance's [T][129][256] fp32 activation must stay below 2 GiB "
+                             "(32-bit offsets inside an utterance): about 130 s at 16 kHz; split longer recordings into segments")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats
