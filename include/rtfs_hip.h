@@ -55,6 +55,13 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
                     const float* const* w /*[16][64]*/, const float* const* bias, float* const* out, double* const* stats_out, int B, int Tin,
                     int Fin, void* stream);
 
+/* the same stride-1 convolutions applied to InjectionMultiSum's mix gLN(loc) * sigmoid(gLN(gate)^) + gLN(glob)^ (layers/fusion.py:59-67; what
+ * rtfs_tfar_mix_fwd writes) without materialising it: loc [B][T][F][64]; gate, glob [B][Tg][Fg][64] (^ = nearest up-sampling); nconv in {1,2} */
+int rtfs_dwconv_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                        const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats,
+                        const float* glob_g, const float* glob_b, int nconv, const float* const* w /*[16][64]*/, const float* const* bias,
+                        float* const* out, double* const* stats_out, int B, int T, int F, int Tg, int Fg, void* stream);
+
 /* ---- a5.4: global pooling, tdanet.py:117-118 ---------------------------------------------------------------- */
 int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* d1, const double* d1_stats,
                   const float* d1_g, const float* d1_b, float* G, int B, int T, int T2, void* stream);

@@ -14,6 +14,21 @@ namespace rtfs {
 
 constexpr int kMaxConv = 4;
 
+struct NormRefLite {
+    const float* x;
+    const double* slot;
+    double inv_n;
+    const float *gamma, *beta;
+};
+
+__device__ __forceinline__ void norm_coef(const NormRefLite& r, int b, int c4, float4& sc, float4& sh) {
+    float mean, rstd;
+    stats_finalize(r.slot, b, r.inv_n, mean, rstd);
+    const float4 g = ld4(r.gamma + c4), be = ld4(r.beta + c4);
+    sc = g * rstd;
+    sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+}
+
 struct DwArgs {
     const float* in;      // [B][Tin][Fin][64]
     const double* slot;   // gLN stats of `in` (mode >= 1)
@@ -26,10 +41,15 @@ struct DwArgs {
     const float* bias[kMaxConv];  // [64] or null
     float* out[kMaxConv];         // [B][Tout][Fout][64]
     double* stats[kMaxConv];      // [B][2]
+    // MODE 3 (stride 1 only): the input is the TFAR mix  gLN(in) * sigmoid(gLN(gate)^) + gLN(glob)^  (InjectionMultiSum, fusion.py:59-67;
+    // ^ = nearest up-sampling from (Tg, Fg)), formed on the way into LDS - the mixed tensor never exists in HBM
+    NormRefLite gate, glob;
+    int Tg, Fg;
 };
 
 // Depth-wise 4x4 convolution, sliding-window form.
-//   MODE 0: raw input; 1: gLN(input); 2: PReLU(gLN(input)).  STRIDE 1: 'same' padding (1 before, 2 after); 2: padding 1.
+//   MODE 0: raw input; 1: gLN(input); 2: PReLU(gLN(input)); 3 (dwconv_s1_kernel only): TFAR mix of three gLN'd tensors.
+//   STRIDE 1: 'same' padding (1 before, 2 after); 2: padding 1.
 //   Zero padding applies to the transformed input (conv_layers.py:104-113): out-of-range taps are masked to 0.
 // Thread = (output time row, channel quad); it walks a frequency segment keeping a 4-column x 4-row register
 // window of the (normalised) input, so every input element is loaded once per overlapping time row (4x for
@@ -149,21 +169,6 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
     }
 }
 
-struct NormRefLite {
-    const float* x;
-    const double* slot;
-    double inv_n;
-    const float *gamma, *beta;
-};
-
-__device__ __forceinline__ void norm_coef(const NormRefLite& r, int b, int c4, float4& sc, float4& sh) {
-    float mean, rstd;
-    stats_finalize(r.slot, b, r.inv_n, mean, rstd);
-    const float4 g = ld4(r.gamma + c4), be = ld4(r.beta + c4);
-    sc = g * rstd;
-    sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
-}
-
 // Stride-1 depth-wise 4x4 convolution, LDS-staged.  The register-window kernel above issues one column's four loads per output
 // step and needs them in that same step, so every step pays a full memory latency (measured: 150-190 us for a 530 MB stream).
 // Here a workgroup stages the (16+3) x (8+3) pixel x 64 channel input block of 16 x 8 outputs with ALL loads in flight at once
@@ -196,6 +201,20 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
         sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
     }
     const float* inb = a.in + (size_t)b * T * F * kH;
+    // MODE 3: gate / glob tensors at (Tg, Fg) and their folded gLN coefficients
+    // (kept in LDS and re-read per staging group: four more float4 of per-channel constants in registers spill the compute phase)
+    __shared__ __attribute__((aligned(16))) float mixc[MODE == 3 ? 4 * 64 : 4];
+    const float *gateb = nullptr, *globb = nullptr;
+    if (MODE == 3) {
+        if (threadIdx.x < 16) {
+            float4 scg, shg, sce, she;
+            norm_coef(a.gate, b, c4, scg, shg);
+            norm_coef(a.glob, b, c4, sce, she);
+            st4(mixc + c4, scg), st4(mixc + 64 + c4, shg), st4(mixc + 128 + c4, sce), st4(mixc + 192 + c4, she);
+        }
+        gateb = a.gate.x + (size_t)b * a.Tg * a.Fg * kH;
+        globb = a.glob.x + (size_t)b * a.Tg * a.Fg * kH;
+    }
     const bool tvalid = to < T;
     float s[NCONV], q[NCONV];
 #pragma unroll
@@ -215,18 +234,61 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
         constexpr int NN = (R * TC * 16 + 255) / 256, NH = (R * 3 * 16 + 255) / 256;
         const bool first = fb == f0;
         float4 vn[NN], vh[NH];
+        int moff = c4;
+        asm volatile("" : "+v"(moff));  // opaque per block: the constants are re-read from LDS instead of living in 16 VGPRs
+        auto xform = [&](float4 x, float4 g, float4 e, int ti, int fi) {
+            if (MODE >= 1) x = fma4(x, sc, sh);
+            if (MODE == 2) x = prelu4(x, a.slope);
+            if (MODE == 3) x = fma4(x, sigmoid4(fma4(g, ld4(mixc + moff), ld4(mixc + 64 + moff))), fma4(e, ld4(mixc + 128 + moff), ld4(mixc + 192 + moff)));
+            if (!(ti >= 0 && ti < T && fi >= 0 && fi < F)) x = f4(0, 0, 0, 0);
+            return x;
+        };
+        // MODE 3 fetches three tensors per element: after the barrier the new columns stream through registers in groups of NG elements
+        // (3 NG loads in flight), each mixed and stored as soon as it arrives - the register file cannot hold all 3 x NN loads
+        constexpr int NG = 4;
+        auto fetch_new = [&](int i0, int i1) {
+            float4 gn[MODE == 3 ? NN : 1], en[MODE == 3 ? NN : 1];
 #pragma unroll
-        for (int i = 0; i < NN; ++i) {  // new columns: block columns 3 .. 10
-            const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
-            const int ti = t0 - 1 + r, fi = fb - 1 + c;
-            vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);  // saddr + 32-bit offset
-        }
+            for (int i = i0; i < i1; ++i) {  // new columns: block columns 3 .. 10
+                const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+                const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
+                vn[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);  // saddr + 32-bit offset
+                if (MODE == 3) {
+                    const unsigned og = (((unsigned)nearest_src(ti, a.Tg, T) * a.Fg + nearest_src(fi, a.Fg, F)) * kH + c4) * 4u;
+                    gn[i] = ld4_off(gateb, og), en[i] = ld4_off(globb, og);
+                }
+            }
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                vn[i] = xform(vn[i], gn[MODE == 3 ? i : 0], en[MODE == 3 ? i : 0], t0 - 1 + r, fb - 1 + c);
+            }
+        };
+        auto store_new = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i) {
+                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                if (idx < R * TC * 16) st4(tile + r * RS + c * 64 + c4, vn[i]);
+            }
+        };
         if (first) {
+            float4 gh[MODE == 3 ? NH : 1], eh[MODE == 3 ? NH : 1];
 #pragma unroll
             for (int i = 0; i < NH; ++i) {  // halo columns 0 .. 2 from memory
                 const int idx = threadIdx.x + i * 256, r = min(idx / 48, R - 1), c = (idx % 48) >> 4;
-                const int ti = t0 - 1 + r, fi = fb - 1 + c;
-                vh[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+                const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
+                vh[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);
+                if (MODE == 3) {
+                    const unsigned og = (((unsigned)nearest_src(ti, a.Tg, T) * a.Fg + nearest_src(fi, a.Fg, F)) * kH + c4) * 4u;
+                    gh[i] = ld4_off(gateb, og), eh[i] = ld4_off(globb, og);
+                }
+            }
+            if (MODE == 3) {  // (modes 0-2 transform after the barrier, below: their loads stay in flight across it)
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    const int idx = threadIdx.x + i * 256, r = idx / 48, c = (idx % 48) >> 4;
+                    vh[i] = xform(vh[i], gh[i], eh[i], t0 - 1 + r, fb - 1 + c);
+                }
             }
         } else {
 #pragma unroll
@@ -235,22 +297,35 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                 vh[i] = ld4(tile + r * RS + (c + TC) * 64 + c4);
             }
         }
-        __syncthreads();  // previous block's window reads are done
-        auto xform = [&](float4 x, int ti, int fi) {
-            if (MODE >= 1) x = fma4(x, sc, sh);
-            if (MODE == 2) x = prelu4(x, a.slope);
-            if (!(ti >= 0 && ti < T && fi >= 0 && fi < F)) x = f4(0, 0, 0, 0);
-            return x;
-        };
+        if (MODE != 3) {
 #pragma unroll
-        for (int i = 0; i < NN; ++i) {
-            const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
-            if (idx < R * TC * 16) st4(tile + r * RS + c * 64 + c4, xform(vn[i], t0 - 1 + r, fb - 1 + c));
+            for (int i = 0; i < NN; ++i) {
+                const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+                const int ti = t0 - 1 + r, fi = fb - 1 + c;
+                vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+            }
+        }
+        __syncthreads();  // previous block's window reads are done
+        if (MODE != 3) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) {
+                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                vn[i] = xform(vn[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c);
+            }
+            store_new(0, NN);
+        } else {
+#pragma unroll
+            for (int i0 = 0; i0 < NN; i0 += NG) {
+                fetch_new(i0, i0 + NG < NN ? i0 + NG : NN);
+                store_new(i0, i0 + NG < NN ? i0 + NG : NN);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
             const int idx = threadIdx.x + i * 256, r = idx / 48, c = (idx % 48) >> 4;
-            if (idx < R * 3 * 16) st4(tile + r * RS + c * 64 + c4, first ? xform(vh[i], t0 - 1 + r, fb - 1 + c) : vh[i]);
+            if (idx < R * 3 * 16)
+                st4(tile + r * RS + c * 64 + c4, (first && MODE != 3) ? xform(vh[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c) : vh[i]);
         }
         __syncthreads();
         // ---- 8 output columns from a sliding window over LDS (column c of the block lives in window slot c & 3)
@@ -485,6 +560,8 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
         a.out[j] = j < nconv ? out[j] : nullptr;
         a.stats[j] = j < nconv ? stats_out[j] : nullptr;
     }
+    a.gate = a.glob = NormRefLite{nullptr, nullptr, 0.0, nullptr, nullptr};
+    a.Tg = a.Fg = 0;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
         if (mode == 0) return launch_dw<1, 0>(a, B, st);
@@ -494,6 +571,30 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
     if (mode == 0) return launch_dw<2, 0>(a, B, st);
     if (mode == 1) return launch_dw<2, 1>(a, B, st);
     return launch_dw<2, 2>(a, B, st);
+}
+
+// The same stride-1 convolutions applied to the TFAR mix  gLN(loc) * sigmoid(gLN(gate)^) + gLN(glob)^  (rtfs_tfar_mix_fwd's output) WITHOUT
+// materialising it: loc [B][T][F][64], gate / glob [B][Tg][Fg][64] (nearest up-sampling), all passed pre-gLN with their statistics.
+int rtfs_dwconv_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                        const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats,
+                        const float* glob_g, const float* glob_b, int nconv, const float* const* w, const float* const* bias, float* const* out,
+                        double* const* stats_out, int B, int T, int F, int Tg, int Fg, void* stream) {
+    if (B <= 0 || (nconv != 1 && nconv != 2) || T <= 0 || F <= 0 || Tg <= 0 || Fg <= 0) return RTFS_EINVAL;
+    DwArgs a;
+    a.in = loc, a.slot = loc_stats, a.inv_n = 1.0 / ((double)T * F * kH), a.gamma = loc_g, a.beta = loc_b, a.slope = 0.f;
+    a.Tin = a.Tout = T, a.Fin = a.Fout = F;
+    a.nconv = nconv;
+    for (int j = 0; j < kMaxConv; ++j) {
+        a.w[j] = j < nconv ? w[j] : nullptr;
+        a.bias[j] = j < nconv ? bias[j] : nullptr;
+        a.out[j] = j < nconv ? out[j] : nullptr;
+        a.stats[j] = j < nconv ? stats_out[j] : nullptr;
+    }
+    const double ng = 1.0 / ((double)Tg * Fg * kH);
+    a.gate = NormRefLite{gate, gate_stats, ng, gate_g, gate_b};
+    a.glob = NormRefLite{glob, glob_stats, ng, glob_g, glob_b};
+    a.Tg = Tg, a.Fg = Fg;
+    return launch_dw<1, 3>(a, B, (hipStream_t)stream);
 }
 
 int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* d1, const double* d1_stats,

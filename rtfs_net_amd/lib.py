@@ -28,6 +28,7 @@ SIGNATURES = {
     "rtfs_bottleneck_fwd": [P, P, P, P, P, P, P, I, I, P],
     "rtfs_proj_fwd": [P, P, P, F, P, P, P, P, I, I, P],
     "rtfs_dwconv_fwd": [P, P, P, P, F, I, I, I, P, P, P, P, I, I, I, P],
+    "rtfs_dwconv_mix_fwd": [P] * 12 + [I, P, P, P, P, I, I, I, I, I, P],
     "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],

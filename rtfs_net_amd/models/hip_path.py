@@ -339,14 +339,24 @@ class HipForward:
         g0, gg0, g1, gg1 = low(), low(), low(), low()
         lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [g0, gg0, g1, gg1],
                  [st[5], st[6], st[7], st[8]], B, T2, F2)
-        F0, F1 = full(), low()
-        lib.call("rtfs_tfar_mix_fwd", l0, st[3], f0l[2], f0l[3], gg0, st[6], f0gate[2], f0gate[3], g0, st[5], f0g[2], f0g[3], F0, B, T, F_BINS, T2, F2)
-        lib.call("rtfs_tfar_mix_fwd", l1, st[4], f1l[2], f1l[3], gg1, st[8], f1gate[2], f1gate[3], g1, st[7], f1g[2], f1g[3], F1, B, T2, F2, T2, F2)
-        if tap is not None:
-            tap["tfar0"], tap["tfar1"] = F0, F1
         cl, cg, cgate = full(), low(), low()
-        lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
-        lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
+        fuse_mix = os.environ.get("RTFS_NO_MIX_FUSION", "0") != "1"
+        if tap is not None or not fuse_mix:  # the mixed tensors themselves (stage taps of the tests; the un-fused A/B path)
+            F0, F1 = full(), low()
+            lib.call("rtfs_tfar_mix_fwd", l0, st[3], f0l[2], f0l[3], gg0, st[6], f0gate[2], f0gate[3], g0, st[5], f0g[2], f0g[3], F0, B, T, F_BINS, T2, F2)
+            lib.call("rtfs_tfar_mix_fwd", l1, st[4], f1l[2], f1l[3], gg1, st[8], f1gate[2], f1gate[3], g1, st[7], f1g[2], f1g[3], F1, B, T2, F2, T2, F2)
+            if tap is not None:
+                tap["tfar0"], tap["tfar1"] = F0, F1
+        if fuse_mix:
+            # concat layer convolutions straight from the un-mixed operands: the TFAR mixes F0 / F1 (fusion.py:59-67) are formed while the
+            # convolution stages its input tile and never reach HBM (-2 x (8.3 + 2.0) MB per utterance and block)
+            lib.call("rtfs_dwconv_mix_fwd", l0, st[3], f0l[2], f0l[3], gg0, st[6], f0gate[2], f0gate[3], g0, st[5], f0g[2], f0g[3], 1, [cl_[0]], [None],
+                     [cl], [st[9]], B, T, F_BINS, T2, F2)
+            lib.call("rtfs_dwconv_mix_fwd", l1, st[4], f1l[2], f1l[3], gg1, st[8], f1gate[2], f1gate[3], g1, st[7], f1g[2], f1g[3], 2,
+                     [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2, T2, F2)
+        else:
+            lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
+            lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
         if next_proj is not None and a0_or_none is not None:
             self._mm("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                      cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, self._wk(bw, "pw"), bw["pb"],

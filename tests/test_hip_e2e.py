@@ -110,3 +110,14 @@ def test_30s_utterance_key_blocked_attention(dtype):
     e = rel(out, ref)
     print(f"30 s, {dtype}: waveform rel L2 vs the oracle = {e:.3e}")
     assert e < WAVE_TOL
+
+
+def test_fused_tfar_mix_convolution_matches_the_unfused_pair(monkeypatch):
+    """rtfs_dwconv_mix_fwd (TFAR mix formed inside the concat-layer convolution's staging) against rtfs_tfar_mix_fwd + rtfs_dwconv_fwd"""
+    model, _, _ = make_model(3, "cuda")
+    mix, _, emb = synth.synth_inputs(2, 16000 + 77, 25)
+    with torch.no_grad():
+        fused = model(mix.cuda(), emb.cuda())
+        monkeypatch.setenv("RTFS_NO_MIX_FUSION", "1")
+        plain = model(mix.cuda(), emb.cuda())
+    assert rel(fused, plain) < 1e-6

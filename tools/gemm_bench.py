@@ -1,0 +1,44 @@
+"""GPU micro-benchmark of the layer-0 unfold GEMM entry point (both dual paths at the bench shape) + an output checksum for A/B runs.
+
+    [RTFS_UNFOLD_PIPE=1] python tools/gemm_bench.py [dtype: f32|bf16|bf16x3] [B] [T2]
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rtfs_net_amd import lib  # noqa: E402
+from rtfs_net_amd.models.hip_path import COMPUTE_DTYPES, pack_bf16  # noqa: E402
+
+
+def main(dtype="f32", B=32, T2=125):
+    prec = COMPUTE_DTYPES[dtype]
+    g = torch.Generator().manual_seed(0)
+    G = torch.randn(B, T2, 64, 64, generator=g).cuda()
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    W = (torch.randn(256, 512, generator=g) * 0.05).cuda()
+    Wk = pack_bf16(W) if prec else W
+    for dim in (4, 3):
+        S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
+        L = npos - 7
+        U = torch.empty(S * L * 256, device="cuda")
+        name = "rtfs_dp_unfold_gemm_fwd" + ("_bf16" if prec else "")
+        args = (G, gamma, beta, Wk, U, B, T2, dim) + ((prec,) if prec else ())
+        for _ in range(3):
+            lib.call(name, *args)
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for a, b in ev:
+            a.record()
+            lib.call(name, *args)
+            b.record()
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in ev)
+        fl = 2.0 * S * L * 512 * 256
+        print(f"{dtype} dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {float(U.double().sum()):.10e} {float(U.double().abs().sum()):.10e}")
+
+
+if __name__ == "__main__":
+    main(*(sys.argv[1:2] or ["f32"]), *[int(a) for a in sys.argv[2:4]])
