@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--roofline-kernel", default=None, help="entry point timed for the roofline object (default: rtfs_dp_unfold_gemm_fwd, "
                     "or rtfs_wgrad's layer-0 Toeplitz launches in --mode train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-line", action="store_true",
+                    help="N = 1 infer runs also measure the training step of the same configuration (BASELINE config 3) in a child process and "
+                         "attach it as `training_step`; this flag skips that (it is skipped together with the CPU baseline as well)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -337,6 +340,23 @@ def main():
                                      "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
             res["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": n, "kind": "port",
                                    "sample": f"oracle/avnet_ref.py, RTFS-Net-{args.layers}, batch 1 x {args.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
+        # ---- the training step of the same configuration (BASELINE config 3), measured by a child `--mode train` run ----
+        if world == 1 and args.mode == "infer" and args.dtype == "f32" and not args.lip and not args.no_train_line and not args.no_cpu_baseline:
+            import subprocess
+
+            del model, mix, emb, out
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--layers",
+                   str(args.layers), "--batch", str(args.batch), "--seconds", str(args.seconds)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                t = json.loads(line[-1]) if (r.returncode == 0 and line) else None
+            except Exception:  # noqa: BLE001  (the headline line must still be printed)
+                t = None
+            res["training_step"] = None if t is None else {
+                "metric": t["metric"], "value": t["value"], "unit": t["unit"], "ms_per_step": t["ms_per_step"], "ms_per_step_median": t["ms_per_step_median"],
+                "steps": t["steps"], "warmup": t["warmup"], "workload": t["config"]["workload"], "roofline": t["roofline"]}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -30,6 +30,10 @@ def test_single_process_line():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(res["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(res["cpu_baseline"])
     assert res["si_sdri_parity"]["abs_diff_db"] <= 0.01  # BASELINE.json metric: "...; SI-SDRi parity" (HIP vs oracle, same utterance)
+    # BASELINE config 3 rides along: the training step of the same configuration, measured by a child `--mode train` run
+    tr = res["training_step"]
+    assert tr is not None and tr["value"] > 0 and tr["ms_per_step"] > 0 and "training step" in tr["workload"]
+    assert tr["roofline"]["bound"] == "mfma" and "wgrad" in tr["roofline"]["kernel"]
 
 
 def test_lip_encoder_in_the_timed_step():
