@@ -137,9 +137,7 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev)
     if args.dtype != "f32":
-        if args.mode != "infer":
-            raise SystemExit("--dtype bf16 / bf16x3 are inference modes (the training step computes in fp32)")
-        model.set_compute_dtype(args.dtype)
+        model.set_compute_dtype(args.dtype)  # inference path and training step alike (MFMA kernels only; everything else stays fp32)
     # each rank gets its own shard of the global batch (different seed -> different utterances)
     mix, _, emb = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)
     mix, emb = mix.to(dev), emb.to(dev)
@@ -283,9 +281,11 @@ def main():
                 fl = dp_gemm_flops(args.batch, T2)
                 tot_ms = sum(prof)
                 tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)
+                bf = args.dtype != "f32"
                 roof = {"kernel": "rtfs::toeplitz_wgrad_kernel (rtfs_wgrad, nshift 8: weight gradient of LN4D + unfold + SRU layer-0 GEMM, "
-                                  "fp32 MFMA, all 8 taps per staged row block)",
-                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                  + ("bf16 MFMA (%s), " % args.dtype if bf else "fp32 MFMA, ") + "all 8 taps per staged row block)",
+                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                        "peak": {"f32": MFMA_F32_PEAK_TF, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype], "unit": "TFLOP/s",
                         "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
             else:
                 km = kernel_models(args.batch, T, T2, Tv).get(name)

@@ -245,14 +245,15 @@ int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float g
                        int B, int TF, int terms, void* stream);
 int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
                                  void* stream);
-int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, int S, int L,
-                            int terms, void* stream);
+int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout,
+                            float* Cout_or_null, float* Uout_or_null, int S, int L, int terms, void* stream);
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream);
 int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
-                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, int terms, void* stream);
-int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, int B, int T2, int terms, void* stream);
-int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
-                           int T2, int terms, void* stream);
+                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2, int terms,
+                           void* stream);
+int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, int terms, void* stream);
+int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
+                           float* Ypre_or_null, int B, int T2, int terms, void* stream);
 int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                         const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                         const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk, const float* bias,
@@ -266,6 +267,17 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
 int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
                        int TF, int terms, void* stream);
 int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream);
+/* bf16 / split-bf16 siblings of the MFMA entry points of the TRAINING step (same arguments + `terms`; fp32 accumulation; weight operands
+ * host-packed, activation / gradient operands packed inside the kernels).  Gradients agree with the fp32 step to ~1e-5 with terms = 3. */
+int rtfs_gemm_rows_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, int terms, void* stream);
+int rtfs_wgrad_bf16(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off,
+                    int nshift, int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, int terms,
+                    void* stream);
+int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float* dx, const float* s, const float* gw, const float* gb, float slope,
+                               float* ds, int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, int terms,
+                               void* stream);
+int rtfs_fold_gemm_bwd_bf16(const float* dU0, const void* Wpk, float* dxn, int B, int T2, int dim, int terms, void* stream);
+int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int B, int T2, int dim, int terms, void* stream);
 
 #ifdef __cplusplus
 }

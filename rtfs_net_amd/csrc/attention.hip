@@ -529,29 +529,30 @@ int rtfs_attn_qkv_fwd(const float* G, const float* Wt, const float* bias, const 
     return attn_qkv_impl<0>(G, Wt, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream);
 }
 int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
-                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, int B, int T2, int terms, void* stream) {
+                           const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2, int terms,
+                           void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, attn_qkv_impl<1>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, nullptr, B, T2, stream),
-                        attn_qkv_impl<3>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, nullptr, B, T2, stream));
+    RTFS_TERMS_DISPATCH(terms, attn_qkv_impl<1>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream),
+                        attn_qkv_impl<3>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream));
 }
 
 int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
     return attn_core_impl<0>(Q, K, V, O, LSE_or_null, B, T2, stream);
 }
 // QK^T and PV on v_mfma_f32_32x32x16_bf16 (terms 1) or as three-term split-bf16 products (terms 3); softmax in fp32
-int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, int B, int T2, int terms, void* stream) {
-    RTFS_TERMS_DISPATCH(terms, attn_core_impl<1>(Q, K, V, O, nullptr, B, T2, stream), attn_core_impl<3>(Q, K, V, O, nullptr, B, T2, stream));
+int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, int terms, void* stream) {
+    RTFS_TERMS_DISPATCH(terms, attn_core_impl<1>(Q, K, V, O, LSE_or_null, B, T2, stream), attn_core_impl<3>(Q, K, V, O, LSE_or_null, B, T2, stream));
 }
 
 int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
                       float* Ypre_or_null, int B, int T2, void* stream) {
     return attn_out_impl<0>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream);
 }
-int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G, int B,
-                           int T2, int terms, void* stream) {
+int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
+                           float* Ypre_or_null, int B, int T2, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, G, nullptr, B, T2, stream),
-                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, nullptr, B, T2, stream));
+    RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream),
+                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream));
 }
 
 }  // extern "C"

@@ -68,7 +68,9 @@ struct WgradArgs {
 // through LDS at the end and the tile leaves with one coalesced fp32 atomic per element.  Global loads of stage i+1 are in
 // flight during the MFMAs of stage i (register prefetch, two LDS stages, one barrier per stage).  1-D grid decoded so that
 // all (shift, tile) workgroups of one row range run back-to-back on ONE XCD: the 8 taps re-read the same rows from that L2.
-template <int NT, int KT, int PRO>
+// P: precision of the contraction (common.h NT: 0 fp32, 1 bf16, 3 split-bf16).  P != 0: the K = 16 instruction is fed the wave's 8 rows by
+// lanes 0-31 (packed in registers from the scalar LDS reads) and zeros by lanes 32-63 - half of its K is padding, still 8/3 of the fp32 rate.
+template <int NT, int KT, int PRO, int P = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int NW = NT * 32, KW = KT * 32, LDY = NW + 4, LDX = KW + 4, CH = 32, STAGE = CH * (LDY + LDX);
     static_assert(NW * LDX <= 2 * STAGE, "reduction buffer aliases the stages");
@@ -153,23 +155,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int rb = r0; rb < r1; rb += CH) {
         const bool more = rb + CH < r1;
         if (more) load(rb + CH);
-        const float* yp = lds + cur * STAGE + (w * 8 + kh * 4) * LDY + i;
-        const float* xp = lds + cur * STAGE + CH * LDY + (w * 8 + kh * 4) * LDX + i;
-        float av[NT][4], bv[KT][4];
-#pragma unroll
-        for (int m = 0; m < NT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) av[m][r] = yp[r * LDY + m * 32];
-#pragma unroll
-        for (int n = 0; n < KT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[n][r] = xp[r * LDX + n * 32];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
+        if constexpr (P == 0) {
+            const float* yp = lds + cur * STAGE + (w * 8 + kh * 4) * LDY + i;
+            const float* xp = lds + cur * STAGE + CH * LDY + (w * 8 + kh * 4) * LDX + i;
+            float av[NT][4], bv[KT][4];
 #pragma unroll
             for (int m = 0; m < NT; ++m)
 #pragma unroll
-                for (int n = 0; n < KT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bv[n][r], acc[m][n], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) av[m][r] = yp[r * LDY + m * 32];
+#pragma unroll
+            for (int n = 0; n < KT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[n][r] = xp[r * LDX + n * 32];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int n = 0; n < KT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bv[n][r], acc[m][n], 0, 0, 0);
+        } else {
+            const float* yp = lds + cur * STAGE + (w * 8) * LDY + i;
+            const float* xp = lds + cur * STAGE + CH * LDY + (w * 8) * LDX + i;
+            const float keep = kh == 0 ? 1.f : 0.f;
+            Frag fa[NT], fb[KT];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = yp[r * LDY + m * 32] * keep;
+                fa[m] = frag_f32<P>(f4(v[0], v[1], v[2], v[3]), f4(v[4], v[5], v[6], v[7]));
+            }
+#pragma unroll
+            for (int n = 0; n < KT; ++n) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = xp[r * LDX + n * 32] * keep;
+                fb[n] = frag_f32<P>(f4(v[0], v[1], v[2], v[3]), f4(v[4], v[5], v[6], v[7]));
+            }
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int n = 0; n < KT; ++n) mma32<P>(acc[m][n], fa[m], fb[n]);
+        }
         if (more) store(lds + (cur ^ 1) * STAGE);
         __syncthreads();
         cur ^= 1;
@@ -217,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // feeds 512 MFMAs: wave w owns taps 2w, 2w+1 (2 x 2 x 2 accumulator tiles), so there is no cross-wave sum either.
 // The row index is the MFMA contraction index, hence uniform per k-step: the slab row of chunk row i is i (+7 once the chunk
 // has crossed into its second segment) + tap.  x_off shifts the window (conv-transpose: -7); rows outside [0, x_seg) are zero.
+template <int P = 0>
 __global__ __launch_bounds__(256, 2) void toeplitz_wgrad_kernel(WgradArgs a) {
     constexpr int LD = 68, CH = 32, XR = CH + 14, STAGE = (CH + XR) * LD;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -298,6 +326,37 @@ __global__ __launch_bounds__(256, 2) void toeplitz_wgrad_kernel(WgradArgs a) {
         const float* Ys = lds + cur * STAGE;
         const float* Xs = Ys + CH * LD;
         const int nAc = s_nA[cur];
+        if constexpr (P != 0) {
+#pragma unroll
+            for (int q = 0; q < CH; q += 16) {  // K = 16 per instruction: lane half kh supplies chunk rows q + 8 kh .. + 7
+                float ya[2][8], xb[2][2][8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = q + kh * 8 + r;
+                    const int srow = row + (row >= nAc ? 7 : 0) + 2 * w;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) ya[m][r] = Ys[row * LD + m * 32 + i];
+#pragma unroll
+                    for (int z = 0; z < 2; ++z)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) xb[z][n][r] = Xs[(srow + z) * LD + n * 32 + i];
+                }
+                Frag fa[2], fb[2][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) fa[m] = frag_f32<P>(f4(ya[m][0], ya[m][1], ya[m][2], ya[m][3]), f4(ya[m][4], ya[m][5], ya[m][6], ya[m][7]));
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        fb[z][n] = frag_f32<P>(f4(xb[z][n][0], xb[z][n][1], xb[z][n][2], xb[z][n][3]), f4(xb[z][n][4], xb[z][n][5], xb[z][n][6], xb[z][n][7]));
+#pragma unroll
+                for (int z = 0; z < 2; ++z)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) mma32<P>(acc[z][m][n], fa[m], fb[z][n]);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < CH; q += 8) {
             float av[2][4], bv[2][2][4];
@@ -349,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void toeplitz_wgrad_kernel(WgradArgs a) {
     }
 }
 
-template <int NT, int KT>
+template <int NT, int KT, int P = 0>
 static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     WgradArgs a = a0;
     const int nblk = ((a.NOUT + NT * 32 - 1) / (NT * 32)) * ((a.KIN + KT * 32 - 1) / (KT * 32)) * a.nshift;
@@ -360,10 +419,10 @@ static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
     const dim3 grid((unsigned)((a.ngroups + 7) / 8 * 8 * nblk));
     switch (pro) {
-        case 0: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 0>), grid, dim3(256), 0, st, a); break;
-        case 1: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 1>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 2>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 3>), grid, dim3(256), 0, st, a); break;
+        case 0: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 0, P>), grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 1, P>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 2, P>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 3, P>), grid, dim3(256), 0, st, a); break;
     }
 }
 
@@ -374,7 +433,7 @@ static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
 // applies the gateway adjoint on the way out:  ds (= or +=) dG*prelu'(u)*gw, the running d(a0) sum, and the three parameter
 // reductions.  dG never exists in HBM: 2 GB less traffic per block than rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd.
 // ACCM: 0 none, 1 acc = ds, 2 acc += ds.   Wt: [256][64] (output channel major, k contiguous).
-template <bool ACCUM, int ACCM>
+template <bool ACCUM, int ACCM, int P = 0>  // P != 0: Wt host-PACKED (common.h)
 __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* __restrict__ dy0, const float* __restrict__ Wt, const float* __restrict__ dx,
                                                                   const float* __restrict__ s_in, const float* __restrict__ gw,
                                                                   const float* __restrict__ gb, float slope, float* __restrict__ ds,
@@ -402,11 +461,24 @@ __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* _
 #pragma unroll
             for (int it = 0; it < 4; ++it) xa[it] = ld4_off(dy0, ((unsigned)min(m0 + (int)(threadIdx.x >> 4) + it * 16, M - 1) * kH + c4) * 4u);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, xa[it]);
+            for (int it = 0; it < 4; ++it) st4(Es + ((threadIdx.x >> 4) + it * 16) * LDE + c4, pack4<P>(xa[it]));
         }
         __syncthreads();
         floatx16 acc[2][2];
         acc_zero(acc);
+        if constexpr (P != 0) {
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const Frag e0 = frag_packed(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e1 = frag_packed(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const Frag wq = frag_packed(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
+                    mma32<P>(acc[nt][0], wq, e0);
+                    mma32<P>(acc[nt][1], wq, e1);
+                }
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float4 e0 = ld4(Es + i * LDE + 8 * q + 4 * kh);
@@ -495,7 +567,7 @@ struct SeqMapB {
 // MODE 3 (fold, unfold-GEMM input gradient): slab = zero-padded dU0 rows (m0-7)..(m0+63), width 256, K = 8*256,
 //         out dxn in G layout (plain store).
 // Weights Wt: [64][K] k-contiguous.  64-row tile, 4 waves as 2x2 of 32x32, weights first (lanes = positions).
-template <int MODE>
+template <int MODE, int P = 0>  // P != 0: Wt host-PACKED, slab packed on store
 __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const float* __restrict__ src, const float* __restrict__ Wt, float* __restrict__ dst) {
     constexpr int SW = MODE == 2 ? 64 : 256, LDSL = SW + 4, K = 8 * SW, BK = 64, LDB = BK + 4;
     constexpr int ROWS = 71;
@@ -518,7 +590,7 @@ __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const fl
             const int l = m0 + row - 7;
             if (l >= 0 && l < map.L) v = ld4(src + ((size_t)s * map.L + l) * 256 + c4);
         }
-        st4(slab + row * LDSL + c4, v);
+        st4(slab + row * LDSL + c4, pack4<P>(v));
     }
     breg.store(Bs[0], LDB);
     __syncthreads();
@@ -530,7 +602,7 @@ __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const fl
         const int cur = kc & 1;
         if (kc + 1 < NK) breg.load(Wt, K, (kc + 1) * BK);
         const int k0 = kc * BK, kk = k0 / SW, c0 = k0 % SW;
-        mma_block<1, 1>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab + (wm * 32 + kk) * LDSL + c0, LDSL, BK);
+        mma_block_nt<P, 1, 1>(acc, Bs[cur] + wn * 32 * LDB, LDB, slab + (wm * 32 + kk) * LDSL + c0, LDSL, BK);
         if (kc + 1 < NK) breg.store(Bs[cur ^ 1], LDB);
         __syncthreads();
     }
@@ -552,7 +624,7 @@ __global__ __launch_bounds__(256) void toeplitz_bwd_kernel(SeqMapB map, const fl
 // MFMA pipe idles through every slab load).  Here the 256 columns are walked in four 64-wide chunks: slab chunk (64*NP+7) x 64 and the
 // 64x64 weight stages fit 2-3 workgroups per CU, the next slab chunk / weight stage travel through registers under the MFMAs.
 // Workgroup tile = 64*NP positions x 64 channels, 4 waves as (channel half) x (position half), weights first (lanes = positions).
-template <int NP>
+template <int NP, int P = 0>  // P != 0: Wt host-PACKED, slab packed on store
 __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void fold_gemm_bwd_kernel(SeqMapB map, const float* __restrict__ dU0, const float* __restrict__ Wt,
                                                                float* __restrict__ dst) {
     constexpr int TP = 64 * NP, ROWS = TP + 7, LDSL = 68, LDB = 68, SQ = ROWS * 16, SPT = (SQ + 255) / 256;
@@ -577,7 +649,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void fold_gemm_bwd_kernel(Seq
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
             const int idx = threadIdx.x + i * 256, row = idx >> 4, c4 = (idx & 15) * 4;
-            if (idx < SQ) st4(slab + row * LDSL + c4, sreg[i]);
+            if (idx < SQ) st4(slab + row * LDSL + c4, pack4<P>(sreg[i]));
         }
     };
     ChunkRegs<64, 64> breg;
@@ -596,7 +668,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void fold_gemm_bwd_kernel(Seq
         for (int kp = 0; kp < 8; ++kp) {
             const bool last = nc == 3 && kp == 7;
             if (!last) breg.load(Wt, 2048, (kp == 7 ? 0 : kp + 1) * 256 + (kp == 7 ? nc + 1 : nc) * 64);
-            mma_block<1, NP>(acc, Bs[cur] + wm * 32 * LDB, LDB, slab + (wn * 32 * NP + kp) * LDSL, LDSL, 64);
+            mma_block_nt<P, 1, NP>(acc, Bs[cur] + wm * 32 * LDB, LDB, slab + (wn * 32 * NP + kp) * LDSL, LDSL, 64);
             if (kp == 7 && nc + 1 < 4) {
                 __syncthreads();  // every wave is done with this slab chunk
                 store_slab();
@@ -621,27 +693,10 @@ __global__ __launch_bounds__(256, NP == 1 ? 3 : 2) void fold_gemm_bwd_kernel(Seq
 
 using namespace rtfs;
 
-static SeqMapB make_map(int dim, int T2) {
-    SeqMapB m;
-    if (dim == 4) {
-        m.seq_div = 1, m.stride_hi = (long long)kF2 * kH, m.stride_lo = 0, m.pos_stride = kH, m.npos = kF2;
-    } else {
-        m.seq_div = kF2, m.stride_hi = (long long)T2 * kF2 * kH, m.stride_lo = kH, m.pos_stride = (long long)kF2 * kH, m.npos = T2;
-    }
-    m.L = m.npos - 7;
-    return m;
-}
-
-extern "C" {
-
-// dW[n][z*KIN + k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r, z)][k] for the shifts z = 0..nshift-1;
-// r = seq*seg_len + l, xrow = seq*x_seg + l + x_off + z (zero row if outside its segment).  nshift = 1 for the plain maps; the
-// unfold / conv-transpose Toeplitz weight gradients are ONE launch with nshift = 8.
-// dbias (optional): dbias[n] += sum_r dY[r][n].
-// pro: 0 plain; 1 X' = prelu(X*p0+p1, slope) (gateway); 2 X' = prelu(X, slope); 3 X' = relu(gLN(X)) with stats slot / p0=gamma,p1=beta,
-// rows_per_b rows per utterance (inv_n = 1/(rows_per_b*KIN)).  NOUT, KIN multiples of 32.
-int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off, int nshift,
-               int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
+template <int P>
+static int wgrad_impl(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off,
+                      int nshift, int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b,
+                      void* stream) {
     if (M <= 0 || M >= (1ll << 31) || (NOUT & 31) || (KIN & 31) || pro < 0 || pro > 3 || nshift < 1) return RTFS_EINVAL;
     WgradArgs a;
     a.dY = dY, a.ldy = ldy, a.X = X, a.ldx = ldx, a.dW = dW, a.ldw = ldw, a.dbias = dbias, a.M = (int)M;
@@ -655,27 +710,27 @@ int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int
         long long rpw = ((long long)a.M * nblk / 1024 + 31) / 32 * 32;
         a.rows_per_wg = (int)(rpw < 512 ? 512 : rpw);
         a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
-        hipLaunchKernelGGL(toeplitz_wgrad_kernel, dim3((unsigned)((a.ngroups + 7) / 8 * 8 * nblk)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(toeplitz_wgrad_kernel<P>, dim3((unsigned)((a.ngroups + 7) / 8 * 8 * nblk)), dim3(256), 0, st, a);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
-    if (NOUT >= 128 && NOUT % 128 == 0) wgrad_launch<4, 2>(a, pro, st);
-    else if (KIN >= 128) wgrad_launch<2, 4>(a, pro, st);
-    else wgrad_launch<2, 2>(a, pro, st);
+    if (NOUT >= 128 && NOUT % 128 == 0) wgrad_launch<4, 2, P>(a, pro, st);
+    else if (KIN >= 128) wgrad_launch<2, 4, P>(a, pro, st);
+    else wgrad_launch<2, 2, P>(a, pro, st);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-// ds (= or +=) gateway adjoint of (dx + dy0 . Wp); see proj_gateway_bwd_kernel.  rows * 1 KB must stay below 4 GB (32-bit byte offsets).
-int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
-                          int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
+template <int P>
+static int proj_gateway_bwd_impl(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                                 int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
     if (rows <= 0 || rows * 1024 >= (1ll << 32) || acc_mode < 0 || acc_mode > 2 || (acc_mode && (!acc || accumulate))) return RTFS_EINVAL;
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
     const int M = (int)rows, tiles = (M + 63) / 64, per = 16;
     const dim3 grid((tiles + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
-#define PGB(A, MODE) hipLaunchKernelGGL((proj_gateway_bwd_kernel<A, MODE>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per)
+#define PGB(A, MODE) hipLaunchKernelGGL((proj_gateway_bwd_kernel<A, MODE, P>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per)
     if (accumulate) PGB(true, 0);
     else if (acc_mode == 0) PGB(false, 0);
     else if (acc_mode == 1) PGB(false, 1);
@@ -685,27 +740,89 @@ int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, c
     return spread_finish(scr, SpreadOut{{dgw, dgb, dslope}, {kC, kC, 1}}, st);
 }
 
-// dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]
-int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int T2, int dim, void* stream) {
+static SeqMapB make_map(int dim, int T2) {
+    SeqMapB m;
+    if (dim == 4) {
+        m.seq_div = 1, m.stride_hi = (long long)kF2 * kH, m.stride_lo = 0, m.pos_stride = kH, m.npos = kF2;
+    } else {
+        m.seq_div = kF2, m.stride_hi = (long long)T2 * kF2 * kH, m.stride_lo = kH, m.pos_stride = (long long)kF2 * kH, m.npos = T2;
+    }
+    m.L = m.npos - 7;
+    return m;
+}
+
+template <int P>
+static int fold_impl(const float* dU0, const float* Wt, float* dxn, int B, int T2, int dim, void* stream) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMapB m = make_map(dim, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     if (m.npos > 64)
-        hipLaunchKernelGGL(fold_gemm_bwd_kernel<2>, dim3((m.npos + 127) / 128, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
+        hipLaunchKernelGGL((fold_gemm_bwd_kernel<2, P>), dim3((m.npos + 127) / 128, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
     else
-        hipLaunchKernelGGL(fold_gemm_bwd_kernel<1>, dim3((m.npos + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
+        hipLaunchKernelGGL((fold_gemm_bwd_kernel<1, P>), dim3((m.npos + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dU0, Wt, dxn);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
-// dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
-int rtfs_convt_bwd_input(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
+template <int P>
+static int convt_bwd_impl(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMapB m = make_map(dim, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
-    hipLaunchKernelGGL(toeplitz_bwd_kernel<2>, dim3((m.L + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dG, Wt, dH3);
+    hipLaunchKernelGGL((toeplitz_bwd_kernel<2, P>), dim3((m.L + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dG, Wt, dH3);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+extern "C" {
+
+// dW[n][z*KIN + k] (row stride ldw) += sum_r dY[r][n] * X'[xrow(r, z)][k] for the shifts z = 0..nshift-1;
+// r = seq*seg_len + l, xrow = seq*x_seg + l + x_off + z (zero row if outside its segment).  nshift = 1 for the plain maps; the
+// unfold / conv-transpose Toeplitz weight gradients are ONE launch with nshift = 8.
+// dbias (optional): dbias[n] += sum_r dY[r][n].
+// pro: 0 plain; 1 X' = prelu(X*p0+p1, slope) (gateway); 2 X' = prelu(X, slope); 3 X' = relu(gLN(X)) with stats slot / p0=gamma,p1=beta,
+// rows_per_b rows per utterance (inv_n = 1/(rows_per_b*KIN)).  NOUT, KIN multiples of 32.
+int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off, int nshift,
+               int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream) {
+    return wgrad_impl<0>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream);
+}
+// bf16 (terms 1) / split-bf16 (terms 3) products with fp32 accumulation; both operands are activations / gradients, packed inside the kernel
+int rtfs_wgrad_bf16(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off,
+                    int nshift, int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, int terms,
+                    void* stream) {
+    RTFS_TERMS_DISPATCH(terms, wgrad_impl<1>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream),
+                        wgrad_impl<3>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream));
+}
+
+// ds (= or +=) gateway adjoint of (dx + dy0 . Wp); see proj_gateway_bwd_kernel.  rows * 1 KB must stay below 4 GB (32-bit byte offsets).
+int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                          int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
+    return proj_gateway_bwd_impl<0>(dy0, WpT, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream);
+}
+int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float* dx, const float* s, const float* gw, const float* gb, float slope,
+                               float* ds, int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, int terms,
+                               void* stream) {
+    const float* W = (const float*)WpT_pk;
+    RTFS_TERMS_DISPATCH(terms, proj_gateway_bwd_impl<1>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream),
+                        proj_gateway_bwd_impl<3>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream));
+}
+
+// dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]
+int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int T2, int dim, void* stream) {
+    return fold_impl<0>(dU0, Wt, dxn, B, T2, dim, stream);
+}
+int rtfs_fold_gemm_bwd_bf16(const float* dU0, const void* Wpk, float* dxn, int B, int T2, int dim, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, fold_impl<1>(dU0, W, dxn, B, T2, dim, stream), fold_impl<3>(dU0, W, dxn, B, T2, dim, stream));
+}
+
+// dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
+int rtfs_convt_bwd_input(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
+    return convt_bwd_impl<0>(dG, Wt, dH3, B, T2, dim, stream);
+}
+int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int B, int T2, int dim, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, convt_bwd_impl<1>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<3>(dG, W, dH3, B, T2, dim, stream));
 }
 
 }  // extern "C"

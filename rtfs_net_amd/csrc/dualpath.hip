@@ -818,15 +818,19 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
     return RTFS_OK;
 }
 
-// inference-only bf16 / split-bf16 variant of rtfs_sru_layer_fwd: Wt is the PLAIN fp32 weight (packed in the kernel after the gate scaling)
-int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, int S, int L, int terms,
-                            void* stream) {
-    if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3)) return RTFS_EINVAL;
+// bf16 / split-bf16 variant of rtfs_sru_layer_fwd: Wt is the PLAIN fp32 weight (packed in the kernel after the gate scaling)
+int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
+                            float* Uout_or_null, int S, int L, int terms, void* stream) {
+    if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3) || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
     dim3 grid((S + 3) / 4);
-    if (terms == 1)
-        hipLaunchKernelGGL((sru_layer_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, nullptr, nullptr, S, L);
-    else
-        hipLaunchKernelGGL((sru_layer_kernel<false, 3>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, nullptr, nullptr, S, L);
+    hipStream_t st = (hipStream_t)stream;
+#define SRU_L(SAVE, NTV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV>), grid, dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
+    if (Cout_or_null) {
+        if (terms == 1) SRU_L(true, 1); else SRU_L(true, 3);
+    } else {
+        if (terms == 1) SRU_L(false, 1); else SRU_L(false, 3);
+    }
+#undef SRU_L
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

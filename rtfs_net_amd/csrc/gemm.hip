@@ -785,13 +785,28 @@ int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_nul
     return rtfs_gemm_rows(X, Wt, bias_or_null, Y, M, K, N, 0, stream);
 }
 
-// bf16 / split-bf16 row GEMM of the inference path: the decoder taps (256 -> 32); Wpk = host-packed weight
-int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream) {
+// bf16 / split-bf16 row GEMMs (Wpk = host-packed weight [N][K]): every shape of rtfs_gemm_rows
+int rtfs_gemm_rows_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, int terms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const float* W = (const float*)Wpk;
-    if (K == 256 && N == 32)
-        RTFS_TERMS_DISPATCH(terms, (rows_gemm<256, 32, 128, 1, 1, 1>(X, W, bias_or_null, Y, M, 0, st)), (rows_gemm<256, 32, 128, 1, 1, 3>(X, W, bias_or_null, Y, M, 0, st)));
+#define RG(KK, NN, BM, WM, WN)  \
+    if (K == KK && N == NN)     \
+        RTFS_TERMS_DISPATCH(terms, (rows_gemm<KK, NN, BM, WM, WN, 1>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 3>(X, W, bias_or_null, Y, M, accumulate, st)));
+    RG(64, 192, 64, 1, 3)
+    RG(256, 32, 128, 1, 1)
+    RG(192, 64, 128, 2, 1)
+    RG(256, 64, 128, 2, 1)
+    RG(64, 256, 64, 2, 2)
+    RG(32, 256, 64, 2, 2)
+    RG(256, 256, 64, 2, 2)
+    RG(64, 64, 128, 2, 1)
+    RG(64, 96, 128, 1, 3)
+    RG(96, 64, 128, 2, 1)
+#undef RG
     return RTFS_EINVAL;
+}
+int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream) {
+    return rtfs_gemm_rows_bf16(X, Wpk, bias_or_null, Y, M, K, N, 0, terms, stream);
 }
 
 }  // extern "C"

@@ -90,15 +90,20 @@ SIGNATURES = {
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_proj_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
     "rtfs_dp_unfold_gemm_fwd_bf16": [P, P, P, P, P, I, I, I, I, P],
-    "rtfs_sru_layer_fwd_bf16": [P, P, P, P, F, P, I, I, I, P],
+    "rtfs_sru_layer_fwd_bf16": [P, P, P, P, F, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd_bf16": [P, P, P, P, I, I, I, I, P],
-    "rtfs_attn_qkv_fwd_bf16": [P] * 13 + [I, I, I, P],
-    "rtfs_attn_core_fwd_bf16": [P, P, P, P, I, I, I, P],
-    "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, I, I, I, P],
+    "rtfs_attn_qkv_fwd_bf16": [P] * 14 + [I, I, I, P],
+    "rtfs_attn_core_fwd_bf16": [P, P, P, P, P, I, I, I, P],
+    "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
     "rtfs_resid_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, I, P],
     "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
     "rtfs_mask_fwd_bf16": [P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_gemm_rows_fwd_bf16": [P, P, P, P, I, I, I, I, P],
+    "rtfs_gemm_rows_bf16": [P, P, P, P, I, I, I, I, I, P],
+    "rtfs_wgrad_bf16": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, I, P],
+    "rtfs_proj_gateway_bwd_bf16": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, I, P],
+    "rtfs_fold_gemm_bwd_bf16": [P, P, P, I, I, I, I, P],
+    "rtfs_convt_bwd_input_bf16": [P, P, P, I, I, I, I, P],
 }
 
 _lib = None

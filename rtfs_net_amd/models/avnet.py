@@ -137,12 +137,17 @@ class AVNet(nn.Module):
         INFERENCE path: "f32" (default: exact fp32 MFMA), "bf16" (operands rounded to bfloat16, fp32 accumulation: ~4e-3 relative on the
         waveform) or "bf16x3" (split-bf16, three bf16 MFMAs per product: ~1e-5 relative, inside the 1e-3 parity bound at 16/3 of the fp32
         MFMA rate).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
-        training step is fp32 only.  (The reference selects precision through Lightning's `precision` flag; its configs use 32.)"""
+        training step follows the same switch: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain on the bf16
+        pipe with fp32 accumulation (the attention-core adjoint and everything element-wise stay fp32).
+        (The reference selects precision through Lightning's `precision` flag; its configs use 32.)"""
         from .hip_path import COMPUTE_DTYPES
 
         if name not in COMPUTE_DTYPES:
             raise ValueError(f"compute dtype must be one of {sorted(COMPUTE_DTYPES)}, got {name!r}")
         self._hip.prec = COMPUTE_DTYPES[name]
+        self._compute_prec = COMPUTE_DTYPES[name]
+        if getattr(self, "_trainer", None) is not None:
+            self._trainer.prec = self._compute_prec
         return self
 
     def train(self, mode: bool = True):
@@ -215,6 +220,7 @@ class AVNet(nn.Module):
             raise NotImplementedError("the HIP backward accumulates into ONE shared RTFS block (audio_params.shared: true)")
         if getattr(self, "_trainer", None) is None:
             self._trainer = HipTrainer(self)
+            self._trainer.prec = getattr(self, "_compute_prec", self._hip.prec)
         rm = self.refinement_module
         # the video branch (~150 tiny PyTorch launches in train mode) runs on a side stream underneath the encoder / first RTFS block
         # of the HIP function, which waits for it right before the CAF cell; autograd runs its backward on that stream as well

@@ -279,10 +279,7 @@ class HipForward:
         del U
         for lw in d["layers"][1:]:  # input projection fused into the recurrence
             h2 = torch.empty_like(h)
-            if self.prec:
-                lib.call("rtfs_sru_layer_fwd_bf16", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, S, L, self.prec)
-            else:
-                lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, None, S, L)
+            self._mm("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, None, None, S, L)  # (plain fp32 weight in every mode)
             h = h2
         self._mm("rtfs_dp_convt_fwd", h, self._wk(d, "ct_w"), d["ct_b"], G, B, T2, dim)
 
@@ -319,14 +316,9 @@ class HipForward:
         K = torch.empty_like(Q)
         V = torch.empty(B * 4 * T2 * 1024, device=dev)
         O = torch.empty(B * T2 * 4096, device=dev)
-        if self.prec:
-            lib.call("rtfs_attn_qkv_fwd_bf16", G, a["w_pk"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, B, T2, self.prec)
-            lib.call("rtfs_attn_core_fwd_bf16", Q, K, V, O, B, T2, self.prec)
-            lib.call("rtfs_attn_out_fwd_bf16", O, a["ow_pk"], a["ob"], a["oslope"], a["og"], a["obe"], G, B, T2, self.prec)
-        else:
-            lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, None, B, T2)
-            lib.call("rtfs_attn_core_fwd", Q, K, V, O, None, B, T2)
-            lib.call("rtfs_attn_out_fwd", O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, None, B, T2)
+        self._mm("rtfs_attn_qkv_fwd", G, self._wk(a, "w"), a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], Q, K, V, None, B, T2)
+        self._mm("rtfs_attn_core_fwd", Q, K, V, O, None, B, T2)
+        self._mm("rtfs_attn_out_fwd", O, self._wk(a, "ow"), a["ob"], a["oslope"], a["og"], a["obe"], G, None, B, T2)
         if tap is not None:
             tap["attn"] = G.clone()
         # TFAR (a5.6)

@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from .. import lib
-from .hip_path import C, F2, F_BINS, H, PreparedWeights, _f32
+from .hip_path import C, COMPUTE_DTYPES, F2, F_BINS, H, PreparedWeights, _f32, pack_bf16
 
 
 def _t(x):
@@ -24,8 +24,9 @@ def _t(x):
 class TrainWeights(PreparedWeights):
     """PreparedWeights + the transposed / re-ordered copies the input-gradient GEMMs need."""
 
-    def __init__(self, model):
+    def __init__(self, model, prec=0):
         super().__init__(model, pack_vp=False, training=True)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
+        self.prec = prec
         w = self.w
         w["bn_wT"], w["mask_wT"], w["dec_wT"] = _t(w["bn_w"]), _t(w["mask_w"]), _t(w["dec_w"])
         sd = {k: v.detach() for k, v in model.state_dict().items()}
@@ -49,6 +50,22 @@ class TrainWeights(PreparedWeights):
             q = f"{caf}{tag}_embed.full_layer."
             w[f"caf_{tag}_dw"] = _f32(sd[q + "2.weight"].reshape(C))
             w[f"caf_{tag}_g"], w[f"caf_{tag}_be"] = _f32(sd[q + "3.weight"]), _f32(sd[q + "3.bias"])
+        if prec:  # bf16 / split-bf16 step: every weight that is ONLY an MFMA operand is replaced by its host-packed form (hip_path.pack_bf16);
+            # the SRU layer 1-3 weights `w` stay fp32 (packed inside rtfs_sru_layer_fwd_bf16 after the gate scaling)
+            for k in ("bn_w", "mask_w", "dec_w", "bn_wT", "mask_wT", "dec_wT"):
+                w[k] = pack_bf16(w[k])
+            for b in self.blocks:
+                for k in ("pw", "rw", "pwT", "rwT"):
+                    b[k] = pack_bf16(b[k])
+                for j in (0, 1):
+                    d = b[f"dp{j}"]
+                    for k in ("w0", "ct_w", "fold_w", "ctbi_w"):
+                        d[k] = pack_bf16(d[k])
+                    for lw in d["layers"][1:]:
+                        lw["wT"] = pack_bf16(lw["wT"])
+                a = b["attn"]
+                for k in ("w", "ow", "wT", "owT"):
+                    a[k] = pack_bf16(a[k])
 
 
 class Ctx:
@@ -68,16 +85,31 @@ def _acc(gr, key, n, dev):
     return t
 
 
+# entry points whose contraction runs on MFMA and that have a *_bf16 sibling (include/rtfs_hip.h); everything else is fp32 in every mode
+_MFMA_ENTRY_POINTS = frozenset((
+    "rtfs_bottleneck_fwd", "rtfs_proj_fwd", "rtfs_dp_unfold_gemm_fwd", "rtfs_sru_layer_fwd", "rtfs_dp_convt_fwd", "rtfs_attn_qkv_fwd", "rtfs_attn_core_fwd",
+    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_fold_gemm_bwd",
+    "rtfs_convt_bwd_input"))
+
+
 class HipTrainer:
     def __init__(self, model):
         self.model = model
         self._prep = None
+        self.prec = 0  # AVNet.set_compute_dtype: 0 fp32, 1 bf16, 3 split-bf16 products in every MFMA kernel of the step
 
     def weights(self) -> TrainWeights:
         fp = PreparedWeights.fingerprint(self.model, training=True)
-        if self._prep is None or self._prep.version != fp:
-            self._prep = TrainWeights(self.model)
+        if self._prep is None or self._prep.version != fp or self._prep.prec != self.prec:
+            self._prep = TrainWeights(self.model, self.prec)
         return self._prep
+
+    def _call(self, name, *args):
+        """lib.call, routed to the *_bf16 sibling (extra `terms` argument) for the MFMA entry points when a bf16 mode is selected"""
+        if self.prec and name in _MFMA_ENTRY_POINTS:
+            lib.call(name + "_bf16", *args, self.prec)
+        else:
+            lib.call(name, *args)
 
     def invalidate(self):
         self._prep = None
@@ -90,19 +122,19 @@ class HipTrainer:
         save.G_in = G.clone()
         save.U, save.h, save.c = [], [], []
         U0 = torch.empty(S * L * 256, device=dev)
-        lib.call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim)
+        self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim)
         h = torch.empty(S * L * 64, device=dev)
         c = torch.empty_like(h)
         l0 = d["layers"][0]
-        lib.call("rtfs_sru_scan_train_fwd", U0, None, l0["wc"], l0["bias"], l0["scale_x"], h, c, S, L, 4)
+        self._call("rtfs_sru_scan_train_fwd", U0, None, l0["wc"], l0["bias"], l0["scale_x"], h, c, S, L, 4)
         save.U.append(U0), save.h.append(h), save.c.append(c)
         for lw in d["layers"][1:]:
             U = torch.empty(S * L * 192, device=dev)
             h2, c2 = torch.empty_like(h), torch.empty_like(h)
-            lib.call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, c2, U, S, L)  # projection fused, U / c saved
+            self._call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, c2, U, S, L)  # projection fused, U / c saved
             save.U.append(U), save.h.append(h2), save.c.append(c2)
             h = h2
-        lib.call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
+        self._call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
 
     def _block_fwd(self, s_in, out, a0_or_none, bw, st, B, T, T2):
         dev = s_in.device
@@ -112,14 +144,14 @@ class HipTrainer:
         k = Ctx()
         k.s_in, k.st, k.has_a0 = s_in, st, a0_or_none is not None
         k.y0 = full()
-        lib.call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], k.y0, st[0], B, TF)
+        self._call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], k.y0, st[0], B, TF)
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         k.D0, k.D1 = full(), low()
-        lib.call("rtfs_dwconv_fwd", k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [k.D0], [st[1]], B, T, F_BINS)
-        lib.call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [k.D1], [st[2]], B, T, F_BINS)
+        self._call("rtfs_dwconv_fwd", k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [k.D0], [st[1]], B, T, F_BINS)
+        self._call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [k.D1], [st[2]], B, T, F_BINS)
         G = low()
-        lib.call("rtfs_pool_fwd", k.D0, st[1], d0g, d0be, k.D1, st[2], d1g, d1be, G, B, T, T2)
+        self._call("rtfs_pool_fwd", k.D0, st[1], d0g, d0be, k.D1, st[2], d1g, d1be, G, B, T, T2)
         k.dp = [Ctx(), Ctx()]
         self._dual_path_fwd(G, bw["dp0"], B, T2, 4, k.dp[0])
         self._dual_path_fwd(G, bw["dp1"], B, T2, 3, k.dp[1])
@@ -129,29 +161,29 @@ class HipTrainer:
         k.K = torch.empty_like(k.Q)
         k.V = torch.empty(B * 4 * T2 * 1024, device=dev)
         k.Ypre96 = torch.empty(B * T2 * 64 * 96, device=dev)
-        lib.call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], k.Q, k.K, k.V, k.Ypre96, B, T2)
+        self._call("rtfs_attn_qkv_fwd", G, a["w"], a["bias"], a["slope"], a["gq"], a["bq"], a["gk"], a["bk"], a["gv"], a["bv"], k.Q, k.K, k.V, k.Ypre96, B, T2)
         k.O = torch.empty(B * T2 * 4096, device=dev)
         k.LSE = torch.empty(B * 4 * T2, device=dev)
-        lib.call("rtfs_attn_core_fwd", k.Q, k.K, k.V, k.O, k.LSE, B, T2)
+        self._call("rtfs_attn_core_fwd", k.Q, k.K, k.V, k.O, k.LSE, B, T2)
         k.Ypre_o = torch.empty(B * T2 * 4096, device=dev)
-        lib.call("rtfs_attn_out_fwd", k.O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, k.Ypre_o, B, T2)
+        self._call("rtfs_attn_out_fwd", k.O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, k.Ypre_o, B, T2)
         k.G3 = G
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
         k.l0, k.l1 = full(), low()
-        lib.call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [k.l0], [st[3]], B, T, F_BINS)
-        lib.call("rtfs_dwconv_fwd", k.D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [k.l1], [st[4]], B, T2, F2)
+        self._call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [k.l0], [st[3]], B, T, F_BINS)
+        self._call("rtfs_dwconv_fwd", k.D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [k.l1], [st[4]], B, T2, F2)
         k.g0, k.gg0, k.g1, k.gg1 = low(), low(), low(), low()
-        lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [k.g0, k.gg0, k.g1, k.gg1],
+        self._call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [k.g0, k.gg0, k.g1, k.gg1],
                  [st[5], st[6], st[7], st[8]], B, T2, F2)
         k.F0, k.F1 = full(), low()
-        lib.call("rtfs_tfar_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], k.F0, B, T, F_BINS, T2, F2)
-        lib.call("rtfs_tfar_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], k.F1, B, T2, F2, T2, F2)
+        self._call("rtfs_tfar_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], k.F0, B, T, F_BINS, T2, F2)
+        self._call("rtfs_tfar_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], k.F1, B, T2, F2, T2, F2)
         k.cl, k.cg, k.cgate = full(), low(), low()
-        lib.call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
-        lib.call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
-        lib.call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
+        self._call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
+        self._call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
+        self._call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
                  cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
         return k
 
@@ -182,11 +214,11 @@ class HipTrainer:
         c.stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         stats = c.stats
         c.spec = torch.empty(B * TF * 2, device=dev)
-        lib.call("rtfs_stft_fwd", wav, c.spec, B, L)
+        self._call("rtfs_stft_fwd", wav, c.spec, B, L)
         c.a_emb = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_enc_conv_fwd", c.spec, w["enc"], c.a_emb, stats[0], B, T)
+        self._call("rtfs_enc_conv_fwd", c.spec, w["enc"], c.a_emb, stats[0], B, T)
         c.a0 = torch.empty_like(c.a_emb)
-        lib.call("rtfs_bottleneck_fwd", c.a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], c.a0, B, TF)
+        self._call("rtfs_bottleneck_fwd", c.a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], c.a0, B, TF)
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         c.blk = []
@@ -215,7 +247,7 @@ class HipTrainer:
         c.caf = self._caf_coeffs(x, w, B * TF, m.training)
         s = torch.empty_like(c.a_emb)
         last = R == 1
-        lib.call("rtfs_caf_fuse_fwd", x, c.caf["ks"], c.caf["kb"], c.caf["vs"], c.caf["vb"], c.att, c.rsz, None if last else c.a0, s, B, T, c.Tv)
+        self._call("rtfs_caf_fuse_fwd", x, c.caf["ks"], c.caf["kb"], c.caf["vs"], c.caf["vb"], c.att, c.rsz, None if last else c.a0, s, B, T, c.Tv)
         for i in range(1, R):
             last = i == R - 1
             nxt = torch.empty_like(c.a_emb)
@@ -224,12 +256,12 @@ class HipTrainer:
         c.refined = s
         c.masked = torch.empty_like(c.a_emb)
         c.m = torch.empty_like(c.a_emb)
-        lib.call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], c.a_emb, c.masked, c.m, B, TF)
+        self._call("rtfs_mask_fwd", s, w["mask_slope"], w["mask_w"], w["mask_b"], c.a_emb, c.masked, c.m, B, TF)
         tapbuf = torch.empty(B * TF * 32, device=dev)
-        lib.call("rtfs_gemm_rows", c.masked, w["dec_w"], None, tapbuf, B * TF, 256, 32, 0)
+        self._call("rtfs_gemm_rows", c.masked, w["dec_w"], None, tapbuf, B * TF, 256, 32, 0)
         frames = torch.empty(B * T * 256, device=dev)
         out = torch.empty(B, L, device=dev)
-        lib.call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
+        self._call("rtfs_istft_fwd", tapbuf, frames, out, B, L)
         return out.view(B, 1, L)
 
     def _caf_coeffs(self, x, w, rows, training):
@@ -239,7 +271,7 @@ class HipTrainer:
         out = {"training": training}
         if training:
             sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
-            lib.call("rtfs_chan_stats", x, sums[0], sums[1], rows)
+            self._call("rtfs_chan_stats", x, sums[0], sums[1], rows)
             n = float(rows)
             out["sync"] = (torch.distributed.is_available() and torch.distributed.is_initialized()
                            and isinstance(cell.key_embed.full_layer[3], torch.nn.SyncBatchNorm))  # train.py:145 sync_batchnorm=True
@@ -270,17 +302,17 @@ class HipTrainer:
         dev = dN.device
         red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         dg, db = _acc(gr, key + ".g", Cc, dev), _acc(gr, key + ".b", Cc, dev)
-        lib.call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
-        lib.call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
+        self._call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
+        self._call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
     def _dw_bwd(self, dOut, conv, inp, in_st, in_g, in_b, in_slope, mode, stride, dIn, accumulate, gr, key, B, Tin, Fin, has_bias):
         """depth-wise conv adjoint: input gradient (w.r.t. the transformed input) and tap/bias gradients."""
         dev = dOut.device
         dW = _acc(gr, key + ".w", 16 * 64, dev)
         dbias = _acc(gr, key + ".bias", 64, dev) if has_bias else None
-        lib.call("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
+        self._call("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
         if dIn is not None:
-            lib.call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
+            self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
 
     def _dual_path_bwd(self, dG, d, sv, B, T2, dim, gr, key):
         """dG: gradient w.r.t. the stage output (G layout), updated IN PLACE to the gradient w.r.t. the stage input."""
@@ -290,32 +322,32 @@ class HipTrainer:
         g = lambda name, n: _acc(gr, f"{key}.{name}", n, dev)  # noqa: E731
         # ConvTranspose1d + bias + residual
         dG_seq = torch.empty(S * npos * 64, device=dev)
-        lib.call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
+        self._call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
         dct = g("ct_w", 64 * 512)
-        lib.call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
-        lib.call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
+        self._call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
         # SRU layers 3..1
         for l in (3, 2, 1):
             lw = d["layers"][l]
             dU = torch.empty(S * L * 192, device=dev)
             dx = torch.empty(S * L * 64, device=dev)
-            lib.call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
+            self._call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
                      S, L, 3)
-            lib.call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
-            lib.call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
+            self._call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
+            self._call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
             dh = dx
         l0 = d["layers"][0]
         dU0 = torch.empty(S * L * 256, device=dev)
-        lib.call("rtfs_sru_scan_bwd", sv.U[0], None, sv.c[0], l0["wc"], l0["bias"], l0["scale_x"], dh, dU0, None, g("l0.wc", 128), g("l0.bias", 128), S, L, 4)
+        self._call("rtfs_sru_scan_bwd", sv.U[0], None, sv.c[0], l0["wc"], l0["bias"], l0["scale_x"], dh, dU0, None, g("l0.wc", 128), g("l0.bias", 128), S, L, 4)
         # layer-0 GEMM: weight gradient over the Toeplitz windows, input gradient by folding
         xn_seq = torch.empty(S * npos * 64, device=dev)
-        lib.call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
+        self._call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
         dw0 = g("w0", 256 * 512)
-        lib.call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
         dxn = torch.empty(B * T2 * F2 * 64, device=dev)
-        lib.call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
-        lib.call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
+        self._call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
+        self._call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
 
     def _attn_bwd(self, dG, a, k, B, T2, gr, key):
         """dG: gradient w.r.t. the attention output, updated in place to the gradient w.r.t. its input."""
@@ -324,22 +356,22 @@ class HipTrainer:
         ntok = B * T2
         rows = ntok * 64
         dYo = torch.empty(rows * 64, device=dev)
-        lib.call("rtfs_attn_out_norm_bwd", dG, k.Ypre_o, a["oslope"], a["og"], dYo, g("og", 4096), g("obe", 4096), g("oslope", 1), ntok)
+        self._call("rtfs_attn_out_norm_bwd", dG, k.Ypre_o, a["oslope"], a["og"], dYo, g("og", 4096), g("obe", 4096), g("oslope", 1), ntok)
         Ocl = torch.empty(rows * 64, device=dev)
-        lib.call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
-        lib.call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, g("ob", 64), rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
+        self._call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, g("ob", 64), rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
         dOcl = torch.empty(rows * 64, device=dev)
-        lib.call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
+        self._call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
         dO = torch.empty(rows * 64, device=dev)
-        lib.call("rtfs_transpose_tok", dOcl, dO, ntok)  # back to the O layout [c][f]
+        self._call("rtfs_transpose_tok", dOcl, dO, ntok)  # back to the O layout [c][f]
         dQ, dK, dV = torch.empty_like(k.Q), torch.empty_like(k.K), torch.empty_like(k.V)
         Dws = torch.empty(B * 4 * T2, device=dev)
-        lib.call("rtfs_attn_core_bwd", k.Q, k.K, k.V, k.O, dO, k.LSE, Dws, dQ, dK, dV, B, T2)
+        self._call("rtfs_attn_core_bwd", k.Q, k.K, k.V, k.O, dO, k.LSE, Dws, dQ, dK, dV, B, T2)
         dY96 = torch.empty(rows * 96, device=dev)
-        lib.call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
+        self._call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
                  g("bk", 1024), g("gv", 4096), g("bv", 4096), g("slope", 12), B, T2)
-        lib.call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
-        lib.call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
+        self._call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
     def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode):
         """dx: gradient w.r.t. the block output [B,TF,256] (overwritten).  Returns ds (gradient w.r.t. the block input).
@@ -358,13 +390,13 @@ class HipTrainer:
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
         # residual_conv: bias, weight (needs `expanded`), input gradient
         E = full()
-        lib.call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
-        lib.call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
+        self._call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
-        lib.call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
+        self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as a copy of dE
         dN_cl, dN_cgate, dN_cg = full(), low(), low()
-        lib.call("rtfs_mix_bwd", dE, k.cl, st[9], cl_[2], cl_[3], k.cgate, st[11], cgate_[2], cgate_[3], dN_cl, dN_cgate, dN_cg, B, T, F_BINS, T2, F2)
+        self._call("rtfs_mix_bwd", dE, k.cl, st[9], cl_[2], cl_[3], k.cgate, st[11], cgate_[2], cgate_[3], dN_cl, dN_cgate, dN_cg, B, T, F_BINS, T2, F2)
         dN_D0 = dE.clone()
         # concat layer: gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
@@ -377,9 +409,9 @@ class HipTrainer:
         self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, "blk.cgate", B, T2, F2, False)
         # fusion layers' mixes
         dN_l0, dN_gg0, dN_g0 = full(), low(), low()
-        lib.call("rtfs_mix_bwd", dF0, k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], dN_l0, dN_gg0, dN_g0, B, T, F_BINS, T2, F2)
+        self._call("rtfs_mix_bwd", dF0, k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], dN_l0, dN_gg0, dN_g0, B, T, F_BINS, T2, F2)
         dN_l1, dN_gg1, dN_g1 = low(), low(), low()
-        lib.call("rtfs_mix_bwd", dF1, k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], dN_l1, dN_gg1, dN_g1, B, T2, F2, T2, F2)
+        self._call("rtfs_mix_bwd", dF1, k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], dN_l1, dN_gg1, dN_g1, B, T2, F2, T2, F2)
         dl0, dl1 = full(), low()
         self._gln_bwd(dN_l0, k.l0, st[3], f0l[2], f0l[3], dl0, False, gr, "blk.f0l", B, TF)
         self._gln_bwd(dN_l1, k.l1, st[4], f1l[2], f1l[3], dl1, False, gr, "blk.f1l", B, lo)
@@ -399,8 +431,8 @@ class HipTrainer:
         self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, "blk.dp1")
         self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, "blk.dp0")
         # pooled = avgpool(D0n) + D1n
-        lib.call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
-        lib.call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
+        self._call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
+        self._call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
         # downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
         dD1 = low()
         self._gln_bwd(dN_D1, k.D1, st[2], d1g, d1be, dD1, False, gr, "blk.d1", B, lo)
@@ -412,14 +444,14 @@ class HipTrainer:
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
-        lib.call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
+        self._call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
         # d(gateway out) = dx (residual path) + dy0 . Wp, formed inside the gateway adjoint
         if a0_mode >= 3:
-            lib.call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0,
+            self._call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0,
                      g("gw", C), g("gb", C), g("gslope", 1), B * TF)
             return da0
         ds = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C),
+        self._call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C),
                  g("gslope", 1), B * TF)
         return ds
 
@@ -442,19 +474,19 @@ class HipTrainer:
         # iSTFT + decoder taps
         dspec = torch.empty(B * TF * 2, device=dev)
         dtaps = torch.empty(B * TF * 32, device=dev)
-        lib.call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
-        lib.call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
+        self._call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
         dmasked = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
+        self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
         # S3 mask
         da_emb = _zeros(B * TF * C, dev)
         dz = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
-        lib.call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
+        self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
+        self._call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dpre = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
+        self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
-        lib.call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
+        self._call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
         # RTFS blocks R-1 .. 1, CAF, block 0
         da0 = torch.empty(B * TF * C, device=dev)  # running sum of the gradients of every block input (each is `... + a0`)
         blocks = pw.blocks
@@ -465,10 +497,10 @@ class HipTrainer:
         datt, drsz = _zeros(B * Tv * C, dev), _zeros(B * Tv * C, dev)
         Rr = _zeros(4 * C, dev)
         cf = c.caf
-        lib.call("rtfs_caf_bwd_reduce", dx, c.x0, cf["ks"], cf["kb"], cf["vs"], cf["vb"], c.att, c.rsz, datt, drsz, Rr, B, T, Tv)
+        self._call("rtfs_caf_bwd_reduce", dx, c.x0, cf["ks"], cf["kb"], cf["vs"], cf["vb"], c.att, c.rsz, datt, drsz, Rr, B, T, Tv)
         coef = self._caf_bwd_coeffs(cf, w, Rr.view(4, C), gr, m)
         dx0 = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
+        self._call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
         return dx0, (da0 if R > 1 else None), da_emb, datt.view(B, Tv, C), drsz.view(B, Tv, C)
 
     def backward_a(self, c, dx0, da0, da_emb):
@@ -486,14 +518,14 @@ class HipTrainer:
             da0 = torch.empty(B * TF * C, device=dev)
         self._block_bwd(dx0, c.blk[0], blocks[0], B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
-        lib.call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
+        self._call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
-        lib.call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
+        self._call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
         self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
-        lib.call("rtfs_spec_patches", c.spec, patches, B, T)
-        lib.call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
+        self._call("rtfs_spec_patches", c.spec, patches, B, T)
+        self._call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
         return gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):

@@ -28,6 +28,17 @@ def _oracle_grads(sd, cfg, mix, emb, wgt, training, dtype=torch.float64):
 @pytest.mark.parametrize("training,B,L,R,Tv", [(False, 2, 4096, 2, 6), (True, 2, 4096, 2, 6), (False, 1, 12100, 1, 19), (False, 1, 4096, 3, 6),
                                                (False, 1, 32000, 2, 50)])
 def test_parameter_gradients(training, B, L, R, Tv):
+    _check_parameter_gradients(training, B, L, R, Tv, "f32")
+
+
+@pytest.mark.parametrize("training,B,L,R,Tv", [(True, 2, 4096, 2, 6), (False, 1, 4096, 3, 6), (False, 1, 32000, 2, 50)])
+def test_parameter_gradients_split_bf16_step(training, B, L, R, Tv):
+    """the same check with `set_compute_dtype("bf16x3")`: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain as
+    three-term split-bf16 products on the bf16 MFMA pipe (fp32 accumulation) - same tolerance as the fp32 step"""
+    _check_parameter_gradients(training, B, L, R, Tv, "bf16x3")
+
+
+def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     """third case: T2 = 47 -> time-path sequences of 40 steps, long enough for the all-taps Toeplitz weight-gradient kernel and the
     2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1.
     fourth case: R = 3 -> a MIDDLE block, whose adjoint runs rtfs_proj_gateway_bwd with a0_mode 2 (da0 += ds).
@@ -43,6 +54,7 @@ def test_parameter_gradients(training, B, L, R, Tv):
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
     model.train(training)
+    model.set_compute_dtype(dtype)
     mix, _, emb = synth.synth_inputs(B, L, Tv, seed=2 if L >= 32000 else synth.INPUT_SEED)
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(7))
     out = model(mix.cuda(), emb.cuda())
