@@ -76,12 +76,34 @@ def _zeros(n, dev, dtype=torch.float32):
     return torch.zeros(n, device=dev, dtype=dtype)
 
 
+class _ZeroPool:
+    """Zero-initialised scratch of one training step, carved from ONE pre-zeroed slab per dtype: the ~260 parameter-gradient accumulators
+    and gLN adjoint reduction slots of a step otherwise cost one fill launch each (1578 FillFunctor launches per 6 steps in
+    profiles/r02_c_train_kernel_stats.txt).  Slices are 128-byte aligned; a slab that runs out is replaced by a fresh one."""
+
+    def __init__(self, dev, n_f32=2_200_000, n_f64=65_536):
+        self.dev, self.size = dev, {torch.float32: n_f32, torch.float64: n_f64}
+        self.slab, self.used = {}, {}
+
+    def take(self, n, dtype=torch.float32):
+        per = 128 // (4 if dtype == torch.float32 else 8)
+        n_al = (n + per - 1) // per * per
+        if dtype not in self.slab or self.used[dtype] + n_al > self.slab[dtype].numel():
+            self.slab[dtype] = torch.zeros(max(self.size[dtype], n_al), dtype=dtype, device=self.dev)
+            self.used[dtype] = 0
+        o = self.used[dtype]
+        self.used[dtype] = o + n_al
+        return self.slab[dtype][o:o + n]
+
+
 def _acc(gr, key, n, dev):
-    """gradient accumulator `key` of the step, zero-filled on FIRST use only (the earlier dict-default idiom built - and filled - its
-    default tensor on every call: 768 fill launches per step)"""
+    """gradient accumulator `key` of the step, zero on FIRST use (a slice of the step's pre-zeroed pool, see _ZeroPool)"""
     t = gr.get(key)
     if t is None:
-        t = gr[key] = torch.zeros(n, device=dev)
+        pool = gr.get("_pool")
+        if pool is None:
+            pool = gr["_pool"] = _ZeroPool(dev)
+        t = gr[key] = pool.take(n)
     return t
 
 
@@ -300,8 +322,8 @@ class HipTrainer:
     def _gln_bwd(self, dN, X, st, gamma, beta, dX, accumulate, gr, key, B, rows, Cc=H, act=0, slope=0.0, dslope=None):
         """dN: gradient w.r.t. (act of) the normalised tensor; X: pre-norm; result dX (= or +=); gamma/beta grads into gr[key]."""
         dev = dN.device
-        red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         dg, db = _acc(gr, key + ".g", Cc, dev), _acc(gr, key + ".b", Cc, dev)
+        red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
         self._call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         self._call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
