@@ -110,7 +110,7 @@ def _acc(gr, key, n, dev):
 # entry points whose contraction runs on MFMA and that have a *_bf16 sibling (include/rtfs_hip.h); everything else is fp32 in every mode
 _MFMA_ENTRY_POINTS = frozenset((
     "rtfs_bottleneck_fwd", "rtfs_proj_fwd", "rtfs_dp_unfold_gemm_fwd", "rtfs_sru_layer_fwd", "rtfs_dp_convt_fwd", "rtfs_attn_qkv_fwd", "rtfs_attn_core_fwd",
-    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_fold_gemm_bwd",
+    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_resid_proj_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_fold_gemm_bwd",
     "rtfs_convt_bwd_input"))
 
 
@@ -158,15 +158,20 @@ class HipTrainer:
             h = h2
         self._call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
 
-    def _block_fwd(self, s_in, out, a0_or_none, bw, st, B, T, T2):
+    def _block_fwd(self, s_in, out, a0_or_none, bw, st, B, T, T2, y0=None, next_proj=None):
+        """`y0`: this block's projection output when the previous block's residual kernel already produced it; `next_proj` = (y0 buffer,
+        statistics slot) of the NEXT block: its gateway + projection then ride in this block's residual kernel (rtfs_resid_proj_fwd,
+        shared block weights) - as in the inference path (hip_path.HipForward._block)"""
         dev = s_in.device
         TF = T * F_BINS
         full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
         low = lambda: torch.empty(B * T2 * F2 * H, device=dev)  # noqa: E731
         k = Ctx()
         k.s_in, k.st, k.has_a0 = s_in, st, a0_or_none is not None
-        k.y0 = full()
-        self._call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], k.y0, st[0], B, TF)
+        k.y0 = y0
+        if y0 is None:
+            k.y0 = full()
+            self._call("rtfs_proj_fwd", s_in, bw["gw"], bw["gb"], bw["gslope"], bw["pw"], bw["pb"], k.y0, st[0], B, TF)
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         k.D0, k.D1 = full(), low()
@@ -205,8 +210,15 @@ class HipTrainer:
         k.cl, k.cg, k.cgate = full(), low(), low()
         self._call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
         self._call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
-        self._call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
-                 cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+        if next_proj is not None and a0_or_none is not None:
+            self._call("rtfs_resid_proj_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
+                       cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, bw["pw"], bw["pb"], next_proj[0], next_proj[1],
+                       B, T, T2)
+            k.fused_next = True
+        else:
+            self._call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
+                       cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
+            k.fused_next = False
         return k
 
     def forward(self, wav, att, rsz):
@@ -270,10 +282,15 @@ class HipTrainer:
         s = torch.empty_like(c.a_emb)
         last = R == 1
         self._call("rtfs_caf_fuse_fwd", x, c.caf["ks"], c.caf["kb"], c.caf["vs"], c.caf["vb"], c.att, c.rsz, None if last else c.a0, s, B, T, c.Tv)
+        fuse = len(blocks) == 1  # shared block weights: block i+1's gateway / projection weights are block i's
+        y0_next = None
         for i in range(1, R):
             last = i == R - 1
             nxt = torch.empty_like(c.a_emb)
-            c.blk.append(self._block_fwd(s, nxt, None if last else c.a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2))
+            np_ = (torch.empty(B * TF * H, device=dev), stats[1 + 12 * (i + 1)]) if (fuse and not last) else None
+            blk = self._block_fwd(s, nxt, None if last else c.a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, y0=y0_next, next_proj=np_)
+            y0_next = np_[0] if blk.fused_next else None
+            c.blk.append(blk)
             s = nxt
         c.refined = s
         c.masked = torch.empty_like(c.a_emb)
