@@ -13,7 +13,10 @@ from __future__ import annotations
 
 import torch
 
-from .. import lib
+try:
+    from .. import lib
+except ImportError:  # a relocated copy of this sub-package (train.py:95 copies src/models into the experiment directory and test.py:33-36
+    from rtfs_net_amd import lib  # imports it as <exp>.models): the binding is taken from the installed package
 from .hip_path import C, COMPUTE_DTYPES, F2, F_BINS, H, PreparedWeights, _f32, pack_bf16
 
 

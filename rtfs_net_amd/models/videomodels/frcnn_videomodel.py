@@ -15,7 +15,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import lib
+try:
+    from ... import lib
+except ImportError:  # relocated copy of the models sub-package (train.py:95 / test.py:33-36): binding from the installed package
+    from rtfs_net_amd import lib
 
 
 def _act(relu_type: str, planes: int) -> nn.Module:

@@ -14,7 +14,10 @@ import random
 import numpy as np
 import torch
 
-from ... import lib
+try:
+    from ... import lib
+except ImportError:  # relocated copy of the models sub-package (train.py:95 / test.py:33-36): binding from the installed package
+    from rtfs_net_amd import lib
 
 
 class MouthROI:

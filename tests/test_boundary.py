@@ -148,3 +148,28 @@ def test_ctypes_signatures_match_header():
                 raise AssertionError(f"{name}: cannot classify '{a}'")
         got = [kind[t] for t in lib.SIGNATURES[name]]
         assert got == want, (name, "".join(got), "".join(want))
+
+
+def test_models_subpackage_is_relocatable(tmp_path):
+    """train.py:95 copies `src/models` into the experiment directory and test.py:33-36 imports it back as `<exp>.models`
+    (a plain directory import, no parent package around it): a copy of rtfs_net_amd/models must import and build the model there."""
+    import copy
+    import importlib
+    import shutil
+    import sys
+
+    from rtfs_net_amd import synthetic
+
+    exp = tmp_path / "exp_relocated"
+    shutil.copytree(os.path.join(ROOT, "rtfs_net_amd", "models"), exp / "models", ignore=shutil.ignore_patterns("__pycache__"))
+    sys.path.append(str(tmp_path))
+    try:
+        mod = importlib.import_module("exp_relocated.models")
+        vm = importlib.import_module("exp_relocated.models.videomodels")
+        assert mod.AVNet.__module__.startswith("exp_relocated.models") and hasattr(vm, "FRCNNVideoModel")
+        model = mod.AVNet(print_macs=False, **copy.deepcopy(synthetic.rtfs_audionet(2)))
+        assert sum(p.numel() for p in model.parameters()) == 740210
+    finally:
+        sys.path.remove(str(tmp_path))
+        for k in [k for k in sys.modules if k.startswith("exp_relocated")]:
+            del sys.modules[k]
