@@ -340,23 +340,32 @@ def main():
                                      "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
             res["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": n, "kind": "port",
                                    "sample": f"oracle/avnet_ref.py, RTFS-Net-{args.layers}, batch 1 x {args.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
-        # ---- the training step of the same configuration (BASELINE config 3), measured by a child `--mode train` run ----
+        # ---- riders of the default N = 1 line, each measured by a child run of this script on the same configuration:
+        #   training_step   BASELINE config 3 (`--mode train`, fp32)
+        #   split_bf16      the same separation forward with `--dtype bf16x3` (bf16 MFMA pipe, three-term products, waveform within 1e-5 of fp32)
         if world == 1 and args.mode == "infer" and args.dtype == "f32" and not args.lip and not args.no_train_line and not args.no_cpu_baseline:
             import subprocess
 
             del model, mix, emb, out
             torch.cuda.empty_cache()
-            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--layers",
-                   str(args.layers), "--batch", str(args.batch), "--seconds", str(args.seconds)]
-            try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                t = json.loads(line[-1]) if (r.returncode == 0 and line) else None
-            except Exception:  # noqa: BLE001  (the headline line must still be printed)
-                t = None
-            res["training_step"] = None if t is None else {
-                "metric": t["metric"], "value": t["value"], "unit": t["unit"], "ms_per_step": t["ms_per_step"], "ms_per_step_median": t["ms_per_step_median"],
-                "steps": t["steps"], "warmup": t["warmup"], "workload": t["config"]["workload"], "roofline": t["roofline"]}
+            common = ["--no-cpu-baseline", "--layers", str(args.layers), "--batch", str(args.batch), "--seconds", str(args.seconds)]
+
+            def child(extra):
+                try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True, text=True, timeout=600)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    return json.loads(line[-1]) if (r.returncode == 0 and line) else None
+                except Exception:  # noqa: BLE001  (the headline line must still be printed)
+                    return None
+
+            def brief(t):
+                return None if t is None else {
+                    "metric": t["metric"], "value": t["value"], "unit": t["unit"], "dtype": t["dtype"], "ms_per_step": t["ms_per_step"],
+                    "ms_per_step_median": t["ms_per_step_median"], "steps": t["steps"], "warmup": t["warmup"], "workload": t["config"]["workload"],
+                    "roofline": t["roofline"]}
+
+            res["training_step"] = brief(child(["--mode", "train", "--steps", "6", "--warmup", "2"]))
+            res["split_bf16"] = brief(child(["--dtype", "bf16x3", "--steps", str(args.steps), "--warmup", str(args.warmup)]))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

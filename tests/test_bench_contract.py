@@ -34,6 +34,8 @@ def test_single_process_line():
     tr = res["training_step"]
     assert tr is not None and tr["value"] > 0 and tr["ms_per_step"] > 0 and "training step" in tr["workload"]
     assert tr["roofline"]["bound"] == "mfma" and "wgrad" in tr["roofline"]["kernel"]
+    sb = res["split_bf16"]
+    assert sb is not None and sb["dtype"] == "bf16x3" and sb["value"] > 0
 
 
 def test_lip_encoder_in_the_timed_step():
