@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--layers", type=int, default=6, help="RTFS-Net-R (audio_params.repeats)")
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=2.0)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3", "bf16x6"], default="f32",
                     help="arithmetic of the dense contractions (infer mode): f32 = exact fp32 MFMA (headline); bf16 = operands rounded to bfloat16; "
                          "bf16x3 = split-bf16, three bf16 MFMAs per product (fp32-level accuracy).  Activations, statistics, recurrence stay fp32")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
@@ -246,7 +246,8 @@ def main():
                 "workload": (f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), " if args.mode == "infer" else
                              f"RTFS-Net-{args.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
                             + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, "
-                            + {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation and activations", "bf16x3": "split-bf16 (3-term) MFMA / fp32 accumulation and activations"}[args.dtype]
+                            + {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation and activations", "bf16x3": "split-bf16 (3-term) MFMA / fp32 accumulation and activations",
+                               "bf16x6": "fp32 operands split into three bf16 values (6-term products on the bf16 MFMA pipe) / fp32 accumulation and activations"}[args.dtype]
                             + ", random-init weights",
                 "mode": args.mode + ("+lip-encoder" if args.lip else ""),
                 "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
@@ -261,7 +262,7 @@ def main():
                 # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
                 by = {4: 4.0 * (args.batch * T2 * F2 * H + args.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (args.batch * T2 * F2 * H + args.batch * F2 * (T2 - 7) * 256)}
                 tot_ms = sum(prof)
-                roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{3 if args.dtype == 'bf16x3' else 1}> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on "
+                roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{ {'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}[args.dtype] }> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on "
                                   "v_mfma_f32_32x32x16_bf16)", "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                         "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,
@@ -285,7 +286,7 @@ def main():
                 roof = {"kernel": "rtfs::toeplitz_wgrad_kernel (rtfs_wgrad, nshift 8: weight gradient of LN4D + unfold + SRU layer-0 GEMM, "
                                   + ("bf16 MFMA (%s), " % args.dtype if bf else "fp32 MFMA, ") + "all 8 taps per staged row block)",
                         "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
-                        "peak": {"f32": MFMA_F32_PEAK_TF, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype], "unit": "TFLOP/s",
+                        "peak": {"f32": MFMA_F32_PEAK_TF, "bf16": 2500.0, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.dtype], "unit": "TFLOP/s",
                         "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
             else:
                 km = kernel_models(args.batch, T, T2, Tv).get(name)

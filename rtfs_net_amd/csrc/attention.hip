@@ -533,7 +533,8 @@ int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, c
                            void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, attn_qkv_impl<1>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream),
-                        attn_qkv_impl<3>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream));
+                        attn_qkv_impl<3>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream),
+                        attn_qkv_impl<6>(G, W, bias, slope, gq, bq, gk, bk, gv, bv, Q, K, V, Ypre_or_null, B, T2, stream));
 }
 
 int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
@@ -541,7 +542,7 @@ int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O,
 }
 // QK^T and PV on v_mfma_f32_32x32x16_bf16 (terms 1) or as three-term split-bf16 products (terms 3); softmax in fp32
 int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, int terms, void* stream) {
-    RTFS_TERMS_DISPATCH(terms, attn_core_impl<1>(Q, K, V, O, LSE_or_null, B, T2, stream), attn_core_impl<3>(Q, K, V, O, LSE_or_null, B, T2, stream));
+    RTFS_TERMS_DISPATCH(terms, attn_core_impl<1>(Q, K, V, O, LSE_or_null, B, T2, stream), attn_core_impl<3>(Q, K, V, O, LSE_or_null, B, T2, stream), attn_core_impl<6>(Q, K, V, O, LSE_or_null, B, T2, stream));
 }
 
 int rtfs_attn_out_fwd(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
@@ -552,7 +553,8 @@ int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, f
                            float* Ypre_or_null, int B, int T2, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream),
-                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream));
+                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream),
+                        attn_out_impl<6>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream));
 }
 
 }  // extern "C"

@@ -469,11 +469,11 @@ __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* _
         if constexpr (P != 0) {
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {
-                const Frag e0 = frag_packed(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
-                const Frag e1 = frag_packed(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e0 = frag_lds<P>(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e1 = frag_lds<P>(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const Frag wq = frag_packed(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
+                    const Frag wq = frag_lds<P>(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
                     mma32<P>(acc[nt][0], wq, e0);
                     mma32<P>(acc[nt][1], wq, e1);
                 }
@@ -791,7 +791,8 @@ int rtfs_wgrad_bf16(const float* dY, int ldy, const float* X, int ldx, float* dW
                     int nshift, int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, int terms,
                     void* stream) {
     RTFS_TERMS_DISPATCH(terms, wgrad_impl<1>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream),
-                        wgrad_impl<3>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream));
+                        wgrad_impl<3>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream),
+                        wgrad_impl<6>(dY, ldy, X, ldx, dW, ldw, dbias, M, seg_len, x_seg, x_off, nshift, NOUT, KIN, pro, p0, p1, slope, stats, rows_per_b, stream));
 }
 
 // ds (= or +=) gateway adjoint of (dx + dy0 . Wp); see proj_gateway_bwd_kernel.  rows * 1 KB must stay below 4 GB (32-bit byte offsets).
@@ -804,7 +805,8 @@ int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float
                                void* stream) {
     const float* W = (const float*)WpT_pk;
     RTFS_TERMS_DISPATCH(terms, proj_gateway_bwd_impl<1>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream),
-                        proj_gateway_bwd_impl<3>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream));
+                        proj_gateway_bwd_impl<3>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream),
+                        proj_gateway_bwd_impl<6>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream));
 }
 
 // dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]
@@ -813,7 +815,7 @@ int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int
 }
 int rtfs_fold_gemm_bwd_bf16(const float* dU0, const void* Wpk, float* dxn, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, fold_impl<1>(dU0, W, dxn, B, T2, dim, stream), fold_impl<3>(dU0, W, dxn, B, T2, dim, stream));
+    RTFS_TERMS_DISPATCH(terms, fold_impl<1>(dU0, W, dxn, B, T2, dim, stream), fold_impl<3>(dU0, W, dxn, B, T2, dim, stream), fold_impl<6>(dU0, W, dxn, B, T2, dim, stream));
 }
 
 // dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
@@ -822,7 +824,7 @@ int rtfs_convt_bwd_input(const float* dG, const float* Wt, float* dH3, int B, in
 }
 int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, convt_bwd_impl<1>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<3>(dG, W, dH3, B, T2, dim, stream));
+    RTFS_TERMS_DISPATCH(terms, convt_bwd_impl<1>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<3>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<6>(dG, W, dH3, B, T2, dim, stream));
 }
 
 }  // extern "C"

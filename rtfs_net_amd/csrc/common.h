@@ -37,12 +37,13 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
         if (e_ != hipSuccess) return RTFS_ELAUNCH;  \
     } while (0)
 
-// run-time precision -> template: terms 1 (bf16) or 3 (split-bf16); anything else is refused
-#define RTFS_TERMS_DISPATCH(terms, CALL1, CALL3) \
-    do {                                         \
-        if ((terms) == 1) return CALL1;          \
-        if ((terms) == 3) return CALL3;          \
-        return RTFS_EINVAL;                      \
+// run-time precision -> template: terms 1 (bf16), 3 (split-bf16) or 6 (fp32-equivalent three-way split); anything else is refused
+#define RTFS_TERMS_DISPATCH(terms, CALL1, CALL3, CALL6) \
+    do {                                                \
+        if ((terms) == 1) return CALL1;                 \
+        if ((terms) == 3) return CALL3;                 \
+        if ((terms) == 6) return CALL6;                 \
+        return RTFS_EINVAL;                             \
     } while (0)
 
 // ---- gLN statistics --------------------------------------------------------------------------------
@@ -244,6 +245,10 @@ __device__ __forceinline__ void mma_block_bn(floatx16 (&acc)[WM][WN], const floa
 //   NT = 1  operands rounded to bfloat16 (RNE), fp32 accumulation:                 a.b ~ a_hi b_hi
 //   NT = 3  split-bf16: a = a_hi + a_lo (a_lo = bf16(a - a_hi)), three products:    a.b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi
 //           (drops a_lo b_lo ~ 2^-18 |a b|: waveform error ~8e-6 vs fp32 on RTFS-Net-12, tools/bf16_error_model.py).
+//   NT = 6  fp32-equivalent: a = a_hi + a_mid + a_lo carries all 24 mantissa bits of the fp32 operand in three bfloat16 values; the six
+//           products hh, hm, mh, hl, lh, mm are accumulated in fp32, the dropped ml, lm, ll terms are <= 2^-23 |a b| - the size of ONE fp32
+//           rounding.  6 x 32 cycles per K = 16 against 8 x 64 on the fp32 pipe: 2.7x its rate at its accuracy (not bit-identical to it).
+//           Operands stay plain fp32 in HBM and LDS (three planes do not fit the 16-byte slot below) and are split in registers.
 // PACKED SLOT.  The fp32 kernels stage operands k-contiguously as float4 = 4 consecutive k.  The bf16 paths keep every address,
 // stride and swizzle of those layouts and store in the same 16 bytes the 4 hi halves and the 4 lo halves of the same 4 k values:
 //      slot = [hi(k0) hi(k1) | hi(k2) hi(k3) | lo(k0) lo(k1) | lo(k2) lo(k3)]        (4 dwords)
@@ -262,7 +267,7 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf1
 }
 template <int NT>
 __device__ __forceinline__ float4 pack4(float4 v) {
-    if constexpr (NT == 0) return v;
+    if constexpr (NT == 0 || NT == 6) return v;  // NT = 6 keeps fp32 tiles and splits in registers (frag_lds)
     const unsigned h0 = pk_bf16(v.x, v.y), h1 = pk_bf16(v.z, v.w);
     unsigned l0 = 0, l1 = 0;
     if constexpr (NT == 3) {
@@ -271,20 +276,48 @@ __device__ __forceinline__ float4 pack4(float4 v) {
     }
     return make_float4(__uint_as_float(h0), __uint_as_float(h1), __uint_as_float(l0), __uint_as_float(l1));
 }
-struct Frag {  // one MFMA operand fragment (8 k values of one row): hi and lo planes
-    bf16x8 hi, lo;
+struct Frag {  // one MFMA operand fragment (8 k values of one row): hi and lo planes (+ mid for the three-way split, NT = 6)
+    bf16x8 hi, lo, mid;
 };
 __device__ __forceinline__ Frag frag_packed(float4 s0, float4 s1) {  // two packed slots of the same row -> fragment (register renaming only)
     const uint4v h = {__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y)};
     const uint4v l = {__float_as_uint(s0.z), __float_as_uint(s0.w), __float_as_uint(s1.z), __float_as_uint(s1.w)};
-    return Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+    return Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l), __builtin_bit_cast(bf16x8, l)};
+}
+// three-way split of 8 fp32 values: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (the residues are exact in fp32)
+__device__ __forceinline__ Frag frag_split3(float4 a, float4 b) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint4v h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned hj = pk_bf16(v[2 * j], v[2 * j + 1]);
+        const float r0 = v[2 * j] - __uint_as_float(hj << 16), r1 = v[2 * j + 1] - __uint_as_float(hj & 0xffff0000u);
+        const unsigned mj = pk_bf16(r0, r1);
+        const unsigned lj = pk_bf16(r0 - __uint_as_float(mj << 16), r1 - __uint_as_float(mj & 0xffff0000u));
+        h[j] = hj, m[j] = mj, l[j] = lj;
+    }
+    return Frag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l), __builtin_bit_cast(bf16x8, m)};
 }
 template <int NT>
 __device__ __forceinline__ Frag frag_f32(float4 a, float4 b) {  // two fp32 k-quads of the same row -> fragment, packed in registers
+    if constexpr (NT == 6) return frag_split3(a, b);
     return frag_packed(pack4<NT>(a), pack4<NT>(b));
+}
+// fragment from two 16-byte LDS / register slots of the kernel's operand tile: packed slots for NT = 1, 3; plain fp32 k-quads for NT = 6
+template <int NT>
+__device__ __forceinline__ Frag frag_lds(float4 s0, float4 s1) {
+    if constexpr (NT == 6) return frag_split3(s0, s1);
+    return frag_packed(s0, s1);
 }
 template <int NT>
 __device__ __forceinline__ void mma32(floatx16& acc, const Frag& a, const Frag& b) {
+    if constexpr (NT == 6) {  // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+    }
     if constexpr (NT == 3) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
@@ -298,7 +331,14 @@ __device__ __forceinline__ floatx16 mma32_first(const Frag& a, const Frag& b) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     floatx16 acc;
-    if constexpr (NT == 3) {
+    if constexpr (NT == 6) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, z, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+    } else if constexpr (NT == 3) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, z, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
@@ -309,6 +349,13 @@ __device__ __forceinline__ floatx16 mma32_first(const Frag& a, const Frag& b) {
 }
 template <int NT>
 __device__ __forceinline__ void mma16(floatx4& acc, const Frag& a, const Frag& b) {  // 16x16x32: lane group kk = lane >> 4 supplies 8 k values
+    if constexpr (NT == 6) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.hi, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.mid, acc, 0, 0, 0);
+    }
     if constexpr (NT == 3) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
@@ -327,9 +374,9 @@ __device__ __forceinline__ void mma_block_p(floatx16 (&acc)[WM][WN], const float
     for (int q = 0; q < kdepth; q += 16) {
         Frag a[WM], b[WN];
 #pragma unroll
-        for (int m = 0; m < WM; ++m) a[m] = frag_packed(ld4(ap + btile_row<AT>(m) * lda + q), ld4(ap + btile_row<AT>(m) * lda + q + 8));
+        for (int m = 0; m < WM; ++m) a[m] = frag_lds<NT>(ld4(ap + btile_row<AT>(m) * lda + q), ld4(ap + btile_row<AT>(m) * lda + q + 8));
 #pragma unroll
-        for (int n = 0; n < WN; ++n) b[n] = frag_packed(ld4(bp + btile_row<BT>(n) * ldb + q), ld4(bp + btile_row<BT>(n) * ldb + q + 8));
+        for (int n = 0; n < WN; ++n) b[n] = frag_lds<NT>(ld4(bp + btile_row<BT>(n) * ldb + q), ld4(bp + btile_row<BT>(n) * ldb + q + 8));
 #pragma unroll
         for (int m = 0; m < WM; ++m)
 #pragma unroll
@@ -356,7 +403,7 @@ __device__ __forceinline__ void mma_block_bn_p(floatx16 (&acc)[WM][WN], const fl
     for (int q = 0; q < kdepth; q += 16) {
         Frag a[WM], b[WN];
 #pragma unroll
-        for (int m = 0; m < WM; ++m) a[m] = frag_packed(ld4(ap + m * 32 * lda + q), ld4(ap + m * 32 * lda + q + 8));
+        for (int m = 0; m < WM; ++m) a[m] = frag_lds<NT>(ld4(ap + m * 32 * lda + q), ld4(ap + m * 32 * lda + q + 8));
 #pragma unroll
         for (int n = 0; n < WN; ++n) {
             const float* c0 = bp + q * ldb + n * 32;

@@ -459,9 +459,9 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
                     Frag a[2], b[2];
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        a[n] = frag_packed(ld4(ap + n * 32 * BK + (((4 * q2 + kh) ^ sw) << 2)), ld4(ap + n * 32 * BK + (((4 * q2 + 2 + kh) ^ sw) << 2)));
+                        a[n] = frag_lds<NT>(ld4(ap + n * 32 * BK + (((4 * q2 + kh) ^ sw) << 2)), ld4(ap + n * 32 * BK + (((4 * q2 + 2 + kh) ^ sw) << 2)));
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) b[m] = frag_packed(ld4(sp + prow[m] * kSlabLd + 16 * q2), ld4(sp + prow[m] * kSlabLd + 16 * q2 + 8));
+                    for (int m = 0; m < 2; ++m) b[m] = frag_lds<NT>(ld4(sp + prow[m] * kSlabLd + 16 * q2), ld4(sp + prow[m] * kSlabLd + 16 * q2 + 8));
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -633,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
                 const Frag fa0 = frag_f32<NT>(a0[2 * p], a0[2 * p + 1]), fa1 = frag_f32<NT>(a1[2 * p], a1[2 * p + 1]);
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    const Frag b0 = frag_packed(ld4(wp + (m * 64) * LDW + 8 * p), ld4(wp + (m * 64) * LDW + 8 * p + 4));
-                    const Frag b1 = frag_packed(ld4(wp + (m * 64 + 32) * LDW + 8 * p), ld4(wp + (m * 64 + 32) * LDW + 8 * p + 4));
+                    const Frag b0 = frag_lds<NT>(ld4(wp + (m * 64) * LDW + 8 * p), ld4(wp + (m * 64) * LDW + 8 * p + 4));
+                    const Frag b1 = frag_lds<NT>(ld4(wp + (m * 64 + 32) * LDW + 8 * p), ld4(wp + (m * 64 + 32) * LDW + 8 * p + 4));
                     if (p == 0) {
                         acc[0][m] = mma32_first<NT>(fa0, b0);
                         acc[1][m] = mma32_first<NT>(fa1, b1);
@@ -774,7 +774,7 @@ int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* bet
 int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
                                  void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, unfold_gemm_impl<1>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<3>(G, gamma, beta, W, U0, B, T2, dim, stream));
+    RTFS_TERMS_DISPATCH(terms, unfold_gemm_impl<1>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<3>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<6>(G, gamma, beta, W, U0, B, T2, dim, stream));
 }
 
 // H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.
@@ -783,7 +783,7 @@ int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float
 }
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, convt_impl<1>(H3, W, bias, G, B, T2, dim, stream), convt_impl<3>(H3, W, bias, G, B, T2, dim, stream));
+    RTFS_TERMS_DISPATCH(terms, convt_impl<1>(H3, W, bias, G, B, T2, dim, stream), convt_impl<3>(H3, W, bias, G, B, T2, dim, stream), convt_impl<6>(H3, W, bias, G, B, T2, dim, stream));
 }
 
 // km = 4: U [S][L][64][4];  km = 3: U [S][L][3][64] and X [S][L][64].  wc, bias: [2][64] (forget | reset).  H: [S][L][64].
@@ -821,14 +821,14 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
 // bf16 / split-bf16 variant of rtfs_sru_layer_fwd: Wt is the PLAIN fp32 weight (packed in the kernel after the gate scaling)
 int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                             float* Uout_or_null, int S, int L, int terms, void* stream) {
-    if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3) || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
+    if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3 && terms != 6) || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
     dim3 grid((S + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
 #define SRU_L(SAVE, NTV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV>), grid, dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
     if (Cout_or_null) {
-        if (terms == 1) SRU_L(true, 1); else SRU_L(true, 3);
+        if (terms == 1) SRU_L(true, 1); else if (terms == 3) SRU_L(true, 3); else SRU_L(true, 6);
     } else {
-        if (terms == 1) SRU_L(false, 1); else SRU_L(false, 3);
+        if (terms == 1) SRU_L(false, 1); else if (terms == 3) SRU_L(false, 3); else SRU_L(false, 6);
     }
 #undef SRU_L
     RTFS_LAUNCH_CHECK();

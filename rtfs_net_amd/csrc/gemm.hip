@@ -397,11 +397,11 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         } else {
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {  // 16 k per step: packed slots 2 q2 and 2 q2 + 1 of every row
-                const Frag e0 = frag_packed(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
-                const Frag e1 = frag_packed(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e0 = frag_lds<NT>(ld4(Es + i * LDE + 16 * q2 + 4 * kh), ld4(Es + i * LDE + 16 * q2 + 8 + 4 * kh));
+                const Frag e1 = frag_lds<NT>(ld4(Es + (32 + i) * LDE + 16 * q2 + 4 * kh), ld4(Es + (32 + i) * LDE + 16 * q2 + 8 + 4 * kh));
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const Frag wq = frag_packed(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
+                    const Frag wq = frag_lds<NT>(wf[nt][2 * q2], wf[nt][2 * q2 + 1]);
                     mma32<NT>(acc[nt][0], wq, e0);
                     mma32<NT>(acc[nt][1], wq, e1);
                 }
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 } else {
 #pragma unroll
                     for (int t2 = 0; t2 < 8; ++t2) {  // 16x16x32: lane group kk supplies the 8 k values of packed slots 2 t2, 2 t2 + 1
-                        const Frag e0 = frag_packed(ld4(ap + 8 * t2), ld4(ap + 8 * t2 + 4));
-                        const Frag e1 = frag_packed(ld4(ap + 16 * LDO + 8 * t2), ld4(ap + 16 * LDO + 8 * t2 + 4));
-                        const Frag wq = frag_packed(wp[2 * t2], wp[2 * t2 + 1]);
+                        const Frag e0 = frag_lds<NT>(ld4(ap + 8 * t2), ld4(ap + 8 * t2 + 4));
+                        const Frag e1 = frag_lds<NT>(ld4(ap + 16 * LDO + 8 * t2), ld4(ap + 16 * LDO + 8 * t2 + 4));
+                        const Frag wq = frag_lds<NT>(wp[2 * t2], wp[2 * t2 + 1]);
                         const int c = 2 * (t2 & 1);
                         mma16<NT>(pa[c], wq, e0);
                         mma16<NT>(pa[c + 1], wq, e1);
@@ -560,10 +560,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
         } else {
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
-                const Frag wq = frag_packed(wf[2 * t2], wf[2 * t2 + 1]);
+                const Frag wq = frag_lds<NT>(wf[2 * t2], wf[2 * t2 + 1]);
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt)
-                    mma16<NT>(acc[pt], wq, frag_packed(ld4(ap + pt * 16 * LDA + 8 * t2), ld4(ap + pt * 16 * LDA + 8 * t2 + 4)));
+                    mma16<NT>(acc[pt], wq, frag_lds<NT>(ld4(ap + pt * 16 * LDA + 8 * t2), ld4(ap + pt * 16 * LDA + 8 * t2 + 4)));
             }
         }
         __syncthreads();  // As consumed by every wave: the next tile may overwrite it while the epilogues run
@@ -680,7 +680,8 @@ int rtfs_bottleneck_fwd_bf16(const float* a_emb, const double* stats, const floa
                              float* a0, int B, int TF, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, bottleneck_impl<1>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream),
-                        bottleneck_impl<3>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream));
+                        bottleneck_impl<3>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream),
+                        bottleneck_impl<6>(a_emb, stats, gamma, beta, W, bias, a0, B, TF, (hipStream_t)stream));
 }
 
 // y = Wp . prelu(s*gw+gb) + bias (pre-gLN projection output, [B][TF][64]) and its gLN partial sums.
@@ -692,7 +693,8 @@ int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float g
                        int B, int TF, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, proj_impl<1>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream),
-                        proj_impl<3>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream));
+                        proj_impl<3>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream),
+                        proj_impl<6>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream));
 }
 
 // out = Wr . expanded + bias + prelu(s*gw+gb) [+ a0]; the four tensors of `expanded` are passed pre-gLN with their stats.
@@ -715,7 +717,7 @@ int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
                     gb, gslope, a0_or_null, out, nullptr, nullptr, nullptr, nullptr, B, T, T2, (hipStream_t)stream)
-    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3));
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(6));
 #undef RESID_NT
 }
 
@@ -745,7 +747,7 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
                     gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream)
-    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3));
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(6));
 #undef RESID_NT
 }
 
@@ -758,7 +760,8 @@ int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float
                        int TF, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, mask_impl<1>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream),
-                        mask_impl<3>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream));
+                        mask_impl<3>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream),
+                        mask_impl<6>(x, slope, W, bias, a_emb, masked, m_or_null, B, TF, (hipStream_t)stream));
 }
 
 // Y[M][N] (= or +=) X[M][K] . Wt[N][K]^T (+ bias), row-major.  Used for the SRU layer 1-3 projections, the decoder taps,
@@ -791,7 +794,7 @@ int rtfs_gemm_rows_bf16(const float* X, const void* Wpk, const float* bias_or_nu
     const float* W = (const float*)Wpk;
 #define RG(KK, NN, BM, WM, WN)  \
     if (K == KK && N == NN)     \
-        RTFS_TERMS_DISPATCH(terms, (rows_gemm<KK, NN, BM, WM, WN, 1>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 3>(X, W, bias_or_null, Y, M, accumulate, st)));
+        RTFS_TERMS_DISPATCH(terms, (rows_gemm<KK, NN, BM, WM, WN, 1>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 3>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 6>(X, W, bias_or_null, Y, M, accumulate, st)));
     RG(64, 192, 64, 1, 3)
     RG(256, 32, 128, 1, 1)
     RG(192, 64, 128, 2, 1)

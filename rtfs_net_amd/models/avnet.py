@@ -135,8 +135,9 @@ class AVNet(nn.Module):
     def set_compute_dtype(self, name: str):
         """Arithmetic of the dense contractions (1x1 convs, SRU input GEMMs, ConvTranspose1d, attention QK^T / PV, decoder taps) of the
         INFERENCE path: "f32" (default: exact fp32 MFMA), "bf16" (operands rounded to bfloat16, fp32 accumulation: ~4e-3 relative on the
-        waveform) or "bf16x3" (split-bf16, three bf16 MFMAs per product: ~1e-5 relative, inside the 1e-3 parity bound at 16/3 of the fp32
-        MFMA rate).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
+        waveform), "bf16x3" (split-bf16, three bf16 MFMAs per product: ~1e-5 relative, inside the 1e-3 parity bound at 16/3 of the fp32
+        MFMA rate) or "bf16x6" (each fp32 operand split into three bfloat16 values = its full 24-bit mantissa, six bf16 MFMAs per product:
+        fp32-level accuracy, not bit-identical, at 8/3 of the fp32 MFMA rate).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
         training step follows the same switch: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain on the bf16
         pipe with fp32 accumulation (the attention-core adjoint and everything element-wise stay fp32).
         (The reference selects precision through Lightning's `precision` flag; its configs use 32.)"""

@@ -29,7 +29,8 @@ def _f32(t):
 
 
 # compute dtype of the dense contractions (every MFMA kernel): name -> `terms` argument of the *_bf16 entry points (0 = the fp32 entry points)
-COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "bf16x3": 3}
+COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+PACKED_WEIGHT_MODES = (1, 3)  # modes whose *_bf16 entry points take host-packed weights; bf16x6 splits plain fp32 operands in registers
 
 
 def pack_bf16(w: torch.Tensor) -> torch.Tensor:
@@ -147,7 +148,7 @@ class PreparedWeights:
             if w["vp"].numel() != lib.load().rtfs_vp_param_count():
                 raise RuntimeError("VP parameter packing does not match csrc/vp.hip (VpOff)")
             w["vp_pe"] = _f32(sd["refinement_module.video_net.blocks.globalatt.0.MHSA.pos_enc.pe"][0, :64]).to(dev)
-        if prec:  # bf16 / split-bf16 compute: host-packed copies of every MFMA weight (suffix _pk), next to the fp32 ones
+        if prec in PACKED_WEIGHT_MODES:  # bf16 / split-bf16 compute: host-packed copies of every MFMA weight (suffix _pk), next to the fp32 ones
             for k in ("bn_w", "mask_w", "dec_w"):
                 w[k + "_pk"] = pack_bf16(w[k])
             for b in self.blocks:
@@ -263,7 +264,7 @@ class HipForward:
 
     def _wk(self, d, key):
         """the weight `key` of dict `d` in the form the selected precision's entry point takes (fp32 / host-packed)"""
-        return d[key + "_pk"] if self.prec else d[key]
+        return d[key + "_pk"] if self.prec in PACKED_WEIGHT_MODES else d[key]
 
     def invalidate(self):
         """drop the kernel-layout weight copies (rebuilt on the next forward)"""

@@ -17,7 +17,7 @@ try:
     from .. import lib
 except ImportError:  # a relocated copy of this sub-package (train.py:95 copies src/models into the experiment directory and test.py:33-36
     from rtfs_net_amd import lib  # imports it as <exp>.models): the binding is taken from the installed package
-from .hip_path import C, COMPUTE_DTYPES, F2, F_BINS, H, PreparedWeights, _f32, pack_bf16
+from .hip_path import C, F2, F_BINS, H, PACKED_WEIGHT_MODES, PreparedWeights, _f32, pack_bf16
 
 
 def _t(x):
@@ -53,7 +53,7 @@ class TrainWeights(PreparedWeights):
             q = f"{caf}{tag}_embed.full_layer."
             w[f"caf_{tag}_dw"] = _f32(sd[q + "2.weight"].reshape(C))
             w[f"caf_{tag}_g"], w[f"caf_{tag}_be"] = _f32(sd[q + "3.weight"]), _f32(sd[q + "3.bias"])
-        if prec:  # bf16 / split-bf16 step: every weight that is ONLY an MFMA operand is replaced by its host-packed form (hip_path.pack_bf16);
+        if prec in PACKED_WEIGHT_MODES:  # bf16 / split-bf16 step: every weight that is ONLY an MFMA operand is replaced by its host-packed form (hip_path.pack_bf16);
             # the SRU layer 1-3 weights `w` stay fp32 (packed inside rtfs_sru_layer_fwd_bf16 after the gate scaling)
             for k in ("bn_w", "mask_w", "dec_w", "bn_wT", "mask_wT", "dec_wT"):
                 w[k] = pack_bf16(w[k])
