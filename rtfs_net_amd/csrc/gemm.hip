@@ -689,12 +689,14 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
                   double* stats_out, int B, int TF, void* stream) {
     return proj_impl<0>(s, gw, gb, gslope, Wt, bias, y, stats_out, B, TF, (hipStream_t)stream);
 }
+// (terms = 6 runs the fp32 kernel: the projection / residual kernels are bound by their 256-channel streams, and splitting operands in registers
+// costs them more VALU than the fp32 MFMAs it replaces - measured 546 vs 372 us and 1126 vs 1056 us; both are fp32-accurate)
 int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float gslope, const void* Wpk, const float* bias, float* y, double* stats_out,
                        int B, int TF, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, proj_impl<1>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream),
                         proj_impl<3>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream),
-                        proj_impl<6>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream));
+                        proj_impl<0>(s, gw, gb, gslope, W, bias, y, stats_out, B, TF, (hipStream_t)stream));
 }
 
 // out = Wr . expanded + bias + prelu(s*gw+gb) [+ a0]; the four tensors of `expanded` are passed pre-gLN with their stats.
@@ -717,7 +719,7 @@ int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
                     gb, gslope, a0_or_null, out, nullptr, nullptr, nullptr, nullptr, B, T, T2, (hipStream_t)stream)
-    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(6));
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
 #undef RESID_NT
 }
 
@@ -747,7 +749,7 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
                     gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream)
-    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(6));
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
 #undef RESID_NT
 }
 

@@ -19,7 +19,7 @@ def main(dtype="f32", B=32, T2=125):
     G = torch.randn(B, T2, 64, 64, generator=g).cuda()
     gamma, beta = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
     W = (torch.randn(256, 512, generator=g) * 0.05).cuda()
-    Wk = pack_bf16(W) if prec else W
+    Wk = pack_bf16(W) if prec in (1, 3) else W
     for dim in (4, 3):
         S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
         L = npos - 7
