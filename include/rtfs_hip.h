@@ -234,6 +234,8 @@ int rtfs_lip_roi_fwd(const unsigned char* roi, const int* crop, const float* lut
  * v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate):
  *     terms = 1   operands rounded to bfloat16                                       (waveform ~4e-3 rel. of fp32, RTFS-Net-12)
  *     terms = 3   split-bf16, a.b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi (three MFMAs)   (waveform ~8e-6 rel. of fp32)
+ *     terms = 6   a = a_hi + a_mid + a_lo (three bf16 = the whole fp32 mantissa), six MFMAs (waveform ~7e-7: fp32-equivalent).  Weight arguments are
+ *                 then the PLAIN fp32 matrices of the fp32 entry point (operands are split in registers), not host-packed ones
  * Weight arguments typed `const void* Wpk` are HOST-PACKED: the fp32 matrix W[n][k] of the fp32 entry point, every group of 4
  * consecutive k replaced in place by 8 bfloat16 {hi(k0..k3), lo(k0..k3)} (lo = bf16(w - hi); same byte size and indexing;
  * rtfs_net_amd/models/hip_path.py:pack_bf16).  rtfs_sru_layer_fwd_bf16 takes the plain fp32 weight.
