@@ -403,7 +403,18 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
     // this workgroup's units [u0, u1): unit u = (pair u >> 1, column half u & 1)
     const int npairs = (total_tiles + 1) / 2;
     const long long U = 2LL * npairs;
-    const int u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+    // Balanced over CUs, not over workgroups: the grid is two resident workgroups per CU, and workgroups b and b + gridDim.x / 2 are dispatched to
+    // the same CU in practice (a placement assumption that only affects speed).  The units are first split evenly over the gridDim.x / 2 CU slots and
+    // each slot's share is then halved - with 7.375 units per workgroup (time path at B = 32) the busiest CU carries 15 units instead of 16.
+    int u0, u1;
+    if ((gridDim.x & 1) == 0) {
+        const int half = gridDim.x >> 1, c = blockIdx.x % half, which = blockIdx.x / half;
+        const int c0 = (int)(U * c / half), c1 = (int)(U * (c + 1) / half), first = (c1 - c0 + 1) >> 1;
+        u0 = which == 0 ? c0 : c0 + first;
+        u1 = which == 0 ? c0 + first : c1;
+    } else {
+        u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
+    }
     if (u0 >= u1) return;
     load_b(u0 & 1, 0);
     fetch_slabs(u0 >> 1);

@@ -86,6 +86,18 @@ SIGNATURES = {
     "rtfs_caf_bwd_apply": [P] * 8 + [I, I, I, I, P],
     "rtfs_istft_bwd": [P, P, P, I, I, P],
     "rtfs_spec_patches": [P, P, I, I, P],
+    # ---- VP block training step (csrc/vp_train.hip) ----
+    "rtfs_vp_gate_proj_fwd": [P, P, P, F, P, P, P, P, P, I, I, P],
+    "rtfs_vp_dwconv_fwd": [P, P, P, P, F, I, F, P, P, P, P, P, P, P, I, I, I, I, P],
+    "rtfs_vp_pool_fwd": [P, P, P, P, I, I, I, I, F, F, F, F, P, I, I, P],
+    "rtfs_vp_mix_fwd": [P, P, P, P, F, P, P, P, P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
+    "rtfs_vp_resid_fwd": [P, P, P, P, P, I, I, P],
+    "rtfs_vp_resid_bwd": [P, P, P, P, P, P, I, I, P],
+    "rtfs_vp_mix_bwd": [P, P, P, P, P, F, P, P, P, P, F, P, P, P, P, I, I, I, P],
+    "rtfs_vp_bn_bwd_reduce": [P, P, P, P, P, F, P, I, I, P],
+    "rtfs_vp_dwconv_bwd": [P, P, P, P, P, F, P, F, I, P, P, P, P, F, I, F, P, P, P, P, I, P, I, I, I, I, P],
+    "rtfs_vp_pool_bwd": [P, P, I, I, I, I, I, I, P],
+    "rtfs_vp_gate_proj_bwd": [P, P, P, P, P, F, P, F, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_proj_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],

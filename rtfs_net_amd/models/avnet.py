@@ -9,6 +9,7 @@ string->class factories do for unknown names).
 from __future__ import annotations
 
 import copy
+import os
 import sys
 import warnings
 
@@ -210,6 +211,15 @@ class AVNet(nn.Module):
         skip = ("refinement_module.video_net.", ".attention_embed.", ".resize.")
         return tuple(n for n, _ in self.named_parameters() if not any(s in n for s in skip))
 
+    def _vp_trainer(self, vb):
+        """HIP training step of the video block, if it is the RTFS-Net family's (else None: PyTorch glue)"""
+        from .vp_train import VPTrainer, supported
+
+        tr = getattr(self, "_vp_tr", None)
+        if tr is None or tr.vb is not vb or tr.bns[0] is not vb.projection.full_layer[3]:  # (SyncBatchNorm conversion replaces the BatchNorm modules)
+            self._vp_tr = tr = VPTrainer(vb) if supported(vb) else None
+        return tr
+
     def _forward_autograd(self, x, mouth_embedding):
         """Training step: VP block + CAF video projections in torch autograd (glue); the audio branch is ONE
         autograd.Function whose forward and backward are HIP kernel chains (models/hip_train.py)."""
@@ -231,7 +241,15 @@ class AVNet(nn.Module):
         side = self._glue_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            v1 = rm.video_net.get_block(0)(self.video_bottleneck(mouth_embedding.to(torch.float32)))
+            vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
+            vb = rm.video_net.get_block(0)
+            if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
+                # convolution / BatchNorm chain of the VP block on HIP kernels, GlobalAttention in between as PyTorch glue (models/vp_train.py)
+                from .vp_train import vp_block_train
+
+                v1 = vp_block_train(self._vp_tr, vin)
+            else:
+                v1 = vb(vin)
             cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm
             B = v1.shape[0]
             att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)  # layers/fusion.py:262-264
