@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void vp_gate_proj_fwd_kernel(const float* __re
     const float* xb = x + (size_t)b * TVIN * T;
     float* rb = r + (size_t)b * TVIN * T;
     float s = 0.f, q = 0.f;
-    for (int t0 = 0; t0 < T; t0 += 16) {
+    {   // grid (B, ceil(T / 16)): one 16-step tile per workgroup
+        const int t0 = blockIdx.y * 16;
         const int nt = min(16, T - t0);
         for (int idx = threadIdx.x; idx < TVIN * 16; idx += 256) {
             const int k = idx >> 4, tt = idx & 15;
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(256) void vp_resid_fwd_kernel(const float* __restri
     const int b = blockIdx.x;
     for (int idx = threadIdx.x; idx < TVH * T; idx += 256) et[idx] = e[(size_t)b * TVH * T + idx];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < TVIN * T; idx += 256) {
+    for (int il = threadIdx.x; il < 64 * T; il += 256) {  // grid (B, 8): output channels 64 y .. 64 y + 63
+        const int idx = blockIdx.y * 64 * T + il;
         const int co = idx / T, t = idx - co * T;
         float acc = br[co];
         const float* wr = Wr + (size_t)co * TVH;
@@ -185,31 +187,33 @@ __global__ __launch_bounds__(256) void vp_resid_fwd_kernel(const float* __restri
 // adjoint of vp_resid_fwd w.r.t. e and the weights:  de = Wr^T . dout,  dWr += dout . e^T,  dbr += sum_t dout   (dr = dout is read by vp_gate_proj_bwd)
 __global__ __launch_bounds__(256) void vp_resid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ e, const float* __restrict__ Wr,
                                                            float* __restrict__ de, float* __restrict__ dWr, float* __restrict__ dbr, int T) {
+    // grid (B, 8): workgroup (b, y) owns the 64 output channels co = 64 y .. 64 y + 63 of utterance b; de (zeroed by the caller) collects the 8 partial
+    // sums over co with atomics
     __shared__ float et[TVH * 104];
-    const int b = blockIdx.x;
-    const float* db = dout + (size_t)b * TVIN * T;
-    for (int idx = threadIdx.x; idx < TVH * T; idx += 256) et[idx] = e[(size_t)b * TVH * T + idx];
+    __shared__ float ds[TVH * 104];  // dout rows of this channel group [64][T]
+    const int b = blockIdx.x, co0 = blockIdx.y * 64;
+    const float* db = dout + ((size_t)b * TVIN + co0) * T;
+    for (int idx = threadIdx.x; idx < TVH * T; idx += 256) et[idx] = e[(size_t)b * TVH * T + idx], ds[idx] = db[idx];
     __syncthreads();
-    // dWr[co][k] += sum_t dout[co][t] e[k][t]: thread = (k = tid & 63, co phase)
-    {
+    {  // dWr[co][k] += sum_t dout[co][t] e[k][t]: thread = (k = tid & 63, co phase)
         const int k = threadIdx.x & 63;
-        for (int co = threadIdx.x >> 6; co < TVIN; co += 4) {
+        for (int cl = threadIdx.x >> 6; cl < 64; cl += 4) {
             float acc = 0.f;
-            for (int t = 0; t < T; ++t) acc = fmaf(db[(size_t)co * T + t], et[k * T + t], acc);
-            atomicAdd(dWr + (size_t)co * TVH + k, acc);
+            for (int t = 0; t < T; ++t) acc = fmaf(ds[cl * T + t], et[k * T + t], acc);
+            atomicAdd(dWr + (size_t)(co0 + cl) * TVH + k, acc);
         }
     }
-    for (int co = threadIdx.x; co < TVIN; co += 256) {
+    if (threadIdx.x < 64) {
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += db[(size_t)co * T + t];
-        atomicAdd(dbr + co, acc);
+        for (int t = 0; t < T; ++t) acc += ds[threadIdx.x * T + t];
+        atomicAdd(dbr + co0 + threadIdx.x, acc);
     }
-    // de[k][t] = sum_co Wr[co][k] dout[co][t]
+    // de[k][t] += sum_{co in group} Wr[co][k] dout[co][t]
     for (int idx = threadIdx.x; idx < TVH * T; idx += 256) {
         const int k = idx / T, t = idx - k * T;
         float acc = 0.f;
-        for (int co = 0; co < TVIN; ++co) acc = fmaf(Wr[(size_t)co * TVH + k], db[(size_t)co * T + t], acc);
-        de[(size_t)b * TVH * T + idx] = acc;
+        for (int cl = 0; cl < 64; ++cl) acc = fmaf(Wr[(size_t)(co0 + cl) * TVH + k], ds[cl * T + t], acc);
+        atomicAdd(de + (size_t)b * TVH * T + idx, acc);
     }
 }
 
@@ -369,26 +373,29 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
             dys[c * T + t] = d;
             sb += d;
         }
+        if (blockIdx.y != 0) sb = 0.f;      // dbp once per utterance
         phase_reduce_atomic(sb, red, dbp);  // (also the barrier that publishes dys)
     }
-    const float* rb = r + (size_t)b * TVIN * T;
-    const float* xb = x + (size_t)b * TVIN * T;
-    const float* db = dout + (size_t)b * TVIN * T;
+    // grid (B, 8): workgroup (b, y) owns the 64 input channels k = 64 y .. 64 y + 63 (every workgroup re-derives dy; only y == 0 adds dbp)
+    const int k0 = blockIdx.y * 64;
+    const float* rb = r + ((size_t)b * TVIN + k0) * T;
+    const float* xb = x + ((size_t)b * TVIN + k0) * T;
+    const float* db = dout + ((size_t)b * TVIN + k0) * T;
     // dWp[c][k] += sum_t dy[c][t] r[k][t]
-    for (int k = ph; k < TVIN; k += 4) {
+    for (int kl = ph; kl < 64; kl += 4) {
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc = fmaf(dys[c * T + t], rb[(size_t)k * T + t], acc);
-        atomicAdd(dWp + (size_t)c * TVIN + k, acc);
+        for (int t = 0; t < T; ++t) acc = fmaf(dys[c * T + t], rb[(size_t)kl * T + t], acc);
+        atomicAdd(dWp + (size_t)c * TVIN + k0 + kl, acc);
     }
-    // per input channel k: dr, gateway adjoint
-    float gsl = 0.f;
-    for (int k = threadIdx.x; k < TVIN; k += 256) {
+    // per input channel k = k0 + (tid & 63), time phase: dr, gateway adjoint
+    float gsl = 0.f, aw = 0.f, ab = 0.f;
+    {
+        const int k = k0 + c;
         const float gwk = gw[k], gbk = gb[k];
-        float aw = 0.f, ab = 0.f;
-        for (int t = 0; t < T; ++t) {
-            float dr = db[(size_t)k * T + t];
+        for (int t = ph; t < T; t += 4) {
+            float dr = db[(size_t)c * T + t];
             for (int cc = 0; cc < TVH; ++cc) dr = fmaf(Wp[(size_t)cc * TVIN + k], dys[cc * T + t], dr);
-            const float xv = xb[(size_t)k * T + t], u = fmaf(xv, gwk, gbk);
+            const float xv = xb[(size_t)c * T + t], u = fmaf(xv, gwk, gbk);
             float du = dr;
             if (u <= 0.f) {
                 gsl = fmaf(dr, u, gsl);
@@ -396,11 +403,11 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
             }
             aw = fmaf(du, xv, aw);
             ab += du;
-            dx[(size_t)b * TVIN * T + (size_t)k * T + t] = du * gwk;
+            dx[((size_t)b * TVIN + k) * T + t] = du * gwk;
         }
-        atomicAdd(dgw + k, aw);
-        atomicAdd(dgb + k, ab);
     }
+    phase_reduce_atomic(aw, red, dgw + k0);
+    phase_reduce_atomic(ab, red, dgb + k0);
     gsl = wave_sum(gsl);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gsl;
@@ -422,7 +429,7 @@ extern "C" {
 int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, float gslope, const float* Wp, const float* bp, float* r, float* y, float* stats,
                           int B, int T, void* stream) {
     VP_CHECK(B > 0 && T > 0);
-    hipLaunchKernelGGL(vp_gate_proj_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, gw, gb, gslope, Wp, bp, r, y, stats, T);
+    hipLaunchKernelGGL(vp_gate_proj_fwd_kernel, dim3(B, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, gw, gb, gslope, Wp, bp, r, y, stats, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -463,14 +470,15 @@ int rtfs_vp_mix_fwd(const float* loc, const float* loc_stats, const float* loc_g
 
 int rtfs_vp_resid_fwd(const float* e, const float* Wr, const float* br, const float* r, float* out, int B, int T, void* stream) {
     VP_CHECK(B > 0 && T > 0 && T <= 104);
-    hipLaunchKernelGGL(vp_resid_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, e, Wr, br, r, out, T);
+    hipLaunchKernelGGL(vp_resid_fwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, e, Wr, br, r, out, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
 int rtfs_vp_resid_bwd(const float* dout, const float* e, const float* Wr, float* de, float* dWr, float* dbr, int B, int T, void* stream) {
     VP_CHECK(B > 0 && T > 0 && T <= 104);
-    hipLaunchKernelGGL(vp_resid_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dout, e, Wr, de, dWr, dbr, T);
+    if (hipMemsetAsync(de, 0, (size_t)B * TVH * T * sizeof(float), (hipStream_t)stream) != hipSuccess) return RTFS_ELAUNCH;
+    hipLaunchKernelGGL(vp_resid_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dout, e, Wr, de, dWr, dbr, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -520,7 +528,7 @@ int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const float* y_sta
                           const float* gb, float gslope, const float* Wp, float* dWp, float* dbp, float* dgw, float* dgb, float* dgslope, float* dx, int B,
                           int T, void* stream) {
     VP_CHECK(B > 0 && T > 0 && T <= 104);
-    hipLaunchKernelGGL(vp_gate_proj_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dyhat, y, mk_bn(y_stats, y_gamma, y_beta, y_inv_n), sums,
+    hipLaunchKernelGGL(vp_gate_proj_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dyhat, y, mk_bn(y_stats, y_gamma, y_beta, y_inv_n), sums,
                        inv_n_all, batch_stats, dout, x, r, gw, gb, gslope, Wp, dWp, dbp, dgw, dgb, dgslope, dx, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
