@@ -247,7 +247,9 @@ class AVNet(nn.Module):
                 # convolution / BatchNorm chain of the VP block on HIP kernels, GlobalAttention in between as PyTorch glue (models/vp_train.py)
                 from .vp_train import vp_block_train
 
-                v1 = vp_block_train(self._vp_tr, vin)
+                sc = self._trainer.weights()._scal  # every scalar of the model, one transfer per optimizer step
+                q = "refinement_module.video_net.blocks." if rm.video_net.shared else "refinement_module.video_net.blocks.0."
+                v1 = vp_block_train(self._vp_tr, vin, (sc[q + "gateway.full_layer.4.weight"], sc[q + "projection.full_layer.4.weight"]))
             else:
                 v1 = vb(vin)
             cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm

@@ -68,7 +68,7 @@ class VPTrainer:
         if st.sync:
             torch.distributed.all_reduce(t)
 
-    def _prepare(self, x):
+    def _prepare(self, x, slopes=None):
         vb = self.vb
         st = _Step()
         st.B, st.T = x.shape[0], x.shape[-1]
@@ -83,9 +83,11 @@ class VPTrainer:
             torch.distributed.all_reduce(nb)
             st.Bn = float(nb.item())
         st.stats = torch.zeros(NS, 2, 64, device=dev)
-        # one host transfer for the scalar PReLU slopes
-        sl = torch.cat([vb.gateway.full_layer[4].weight.detach().reshape(1), vb.projection.full_layer[4].weight.detach().reshape(1)]).tolist()
-        st.gslope, st.pslope = sl
+        # the two scalar PReLU slopes are kernel arguments: taken from the caller (AVNet reads every scalar of the model in ONE transfer per
+        # optimizer step, hip_path.PreparedWeights) - fetching them here would be a host synchronisation in the middle of the step
+        if slopes is None:
+            slopes = torch.cat([vb.gateway.full_layer[4].weight.detach().reshape(1), vb.projection.full_layer[4].weight.detach().reshape(1)]).tolist()
+        st.gslope, st.pslope = slopes
         if not st.train:  # running statistics as slots: sum = mean n, sum of squares = (var + mean^2) n with n = 1
             with torch.no_grad():
                 rm = torch.stack([b.running_mean.float() for b in self.bns])
@@ -121,10 +123,10 @@ class VPTrainer:
         return o0, o1
 
     # ---- forward ----------------------------------------------------------------------------------------------------------
-    def forward_a(self, x):
+    def forward_a(self, x, slopes=None):
         vb = self.vb
         x = x.detach().float().contiguous()
-        st = self._prepare(x)
+        st = self._prepare(x, slopes)
         dev, B, T = x.device, st.B, st.T
         st.x = x
         st.r = torch.empty(B, 512, T, device=dev)
@@ -343,7 +345,7 @@ class VPStageA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trainer, holder, x, *params):
         with torch.no_grad():
-            g, st = trainer.forward_a(x)
+            g, st = trainer.forward_a(x, holder.slopes)
         holder.st = st
         ctx.trainer, ctx.holder = trainer, holder
         return g
@@ -379,11 +381,14 @@ class VPStageB(torch.autograd.Function):
 
 class _Holder:
     st = None
+    slopes = None
 
 
-def vp_block_train(trainer: VPTrainer, x: torch.Tensor) -> torch.Tensor:
-    """the VP block of one training step: HIP stage A -> GlobalAttention (PyTorch) -> HIP stage B"""
+def vp_block_train(trainer: VPTrainer, x: torch.Tensor, slopes=None) -> torch.Tensor:
+    """the VP block of one training step: HIP stage A -> GlobalAttention (PyTorch) -> HIP stage B.
+    slopes: (gateway PReLU slope, projection PReLU slope) as Python floats if the caller already has them on the host."""
     holder = _Holder()
+    holder.slopes = slopes
     g = VPStageA.apply(trainer, holder, x, *trainer.params_a())
     g2 = trainer.vb.globalatt(g)
     return VPStageB.apply(trainer, holder, g2, *trainer.params_b())
