@@ -51,33 +51,32 @@ __device__ __forceinline__ void phase_reduce_atomic(float v, float* lds /*256*/,
 __global__ __launch_bounds__(256) void vp_gate_proj_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gw, const float* __restrict__ gb,
                                                                float gslope, const float* __restrict__ Wp, const float* __restrict__ bp,
                                                                float* __restrict__ r, float* __restrict__ y, float* __restrict__ stats, int T) {
+    // grid (B, ceil(T / 4)): one 4-step tile per workgroup - 9 KB of LDS, so that these side-stream kernels fit next to the resident workgroups of
+    // the audio branch (a 32 KB tile made every launch wait for a CU to drain: the video chain then ran SLOWER than the PyTorch glue it replaces)
     __shared__ float red[256];
-    __shared__ float rt[TVIN * 16];  // r tile [512][16 time steps]
+    __shared__ float rt[TVIN * 4];  // r tile [512][4 time steps]
     const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const float* xb = x + (size_t)b * TVIN * T;
     float* rb = r + (size_t)b * TVIN * T;
+    const int t0 = blockIdx.y * 4, nt = min(4, T - t0);
+    for (int idx = threadIdx.x; idx < TVIN * 4; idx += 256) {
+        const int k = idx >> 2, tt = idx & 3;
+        float v = 0.f;
+        if (tt < nt) {
+            v = prelu(fmaf(xb[(size_t)k * T + t0 + tt], gw[k], gb[k]), gslope);
+            rb[(size_t)k * T + t0 + tt] = v;
+        }
+        rt[idx] = v;
+    }
+    __syncthreads();
     float s = 0.f, q = 0.f;
-    {   // grid (B, ceil(T / 16)): one 16-step tile per workgroup
-        const int t0 = blockIdx.y * 16;
-        const int nt = min(16, T - t0);
-        for (int idx = threadIdx.x; idx < TVIN * 16; idx += 256) {
-            const int k = idx >> 4, tt = idx & 15;
-            float v = 0.f;
-            if (tt < nt) {
-                v = prelu(fmaf(xb[(size_t)k * T + t0 + tt], gw[k], gb[k]), gslope);
-                rb[(size_t)k * T + t0 + tt] = v;
-            }
-            rt[idx] = v;
-        }
-        __syncthreads();
-        for (int tt = ph; tt < nt; tt += 4) {
-            float acc = bp[c];
-            const float* wr = Wp + (size_t)c * TVIN;
-            for (int k = 0; k < TVIN; ++k) acc = fmaf(wr[k], rt[k * 16 + tt], acc);
-            y[((size_t)b * TVH + c) * T + t0 + tt] = acc;
-            s += acc, q = fmaf(acc, acc, q);
-        }
-        __syncthreads();
+    if (ph < nt) {  // thread = (output channel c, time step ph of the tile)
+        float acc = bp[c];
+        const float* wr = Wp + (size_t)c * TVIN;
+#pragma unroll 8
+        for (int k = 0; k < TVIN; ++k) acc = fmaf(wr[k], rt[k * 4 + ph], acc);
+        y[((size_t)b * TVH + c) * T + t0 + ph] = acc;
+        s = acc, q = acc * acc;
     }
     phase_reduce_atomic(s, red, stats);
     phase_reduce_atomic(q, red, stats + TVH);
@@ -168,17 +167,16 @@ __global__ __launch_bounds__(256) void vp_mix_fwd_kernel(const float* __restrict
 // residual conv 64 -> 512 + bias + gateway residual:  out = Wr . e + br + r
 __global__ __launch_bounds__(256) void vp_resid_fwd_kernel(const float* __restrict__ e, const float* __restrict__ Wr, const float* __restrict__ br,
                                                            const float* __restrict__ r, float* __restrict__ out, int T) {
-    __shared__ float et[TVH * 104];
+    // grid (B, 8): output channels 64 y .. 64 y + 63; no LDS tile (see vp_gate_proj_fwd_kernel): e is read from L1 / L2
     const int b = blockIdx.x;
-    for (int idx = threadIdx.x; idx < TVH * T; idx += 256) et[idx] = e[(size_t)b * TVH * T + idx];
-    __syncthreads();
-    for (int il = threadIdx.x; il < 64 * T; il += 256) {  // grid (B, 8): output channels 64 y .. 64 y + 63
+    const float* eb = e + (size_t)b * TVH * T;
+    for (int il = threadIdx.x; il < 64 * T; il += 256) {
         const int idx = blockIdx.y * 64 * T + il;
         const int co = idx / T, t = idx - co * T;
         float acc = br[co];
         const float* wr = Wr + (size_t)co * TVH;
 #pragma unroll 8
-        for (int k = 0; k < TVH; ++k) acc = fmaf(wr[k], et[k * T + t], acc);
+        for (int k = 0; k < TVH; ++k) acc = fmaf(wr[k], eb[k * T + t], acc);
         out[(size_t)b * TVIN * T + idx] = acc + r[(size_t)b * TVIN * T + idx];
     }
 }
@@ -188,31 +186,28 @@ __global__ __launch_bounds__(256) void vp_resid_fwd_kernel(const float* __restri
 __global__ __launch_bounds__(256) void vp_resid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ e, const float* __restrict__ Wr,
                                                            float* __restrict__ de, float* __restrict__ dWr, float* __restrict__ dbr, int T) {
     // grid (B, 8): workgroup (b, y) owns the 64 output channels co = 64 y .. 64 y + 63 of utterance b; de (zeroed by the caller) collects the 8 partial
-    // sums over co with atomics
-    __shared__ float et[TVH * 104];
-    __shared__ float ds[TVH * 104];  // dout rows of this channel group [64][T]
+    // sums over co with atomics.  Operands are read from L1 / L2 (no LDS tiles: see vp_gate_proj_fwd_kernel).
     const int b = blockIdx.x, co0 = blockIdx.y * 64;
     const float* db = dout + ((size_t)b * TVIN + co0) * T;
-    for (int idx = threadIdx.x; idx < TVH * T; idx += 256) et[idx] = e[(size_t)b * TVH * T + idx], ds[idx] = db[idx];
-    __syncthreads();
+    const float* eb = e + (size_t)b * TVH * T;
     {  // dWr[co][k] += sum_t dout[co][t] e[k][t]: thread = (k = tid & 63, co phase)
         const int k = threadIdx.x & 63;
         for (int cl = threadIdx.x >> 6; cl < 64; cl += 4) {
             float acc = 0.f;
-            for (int t = 0; t < T; ++t) acc = fmaf(ds[cl * T + t], et[k * T + t], acc);
+            for (int t = 0; t < T; ++t) acc = fmaf(db[cl * T + t], eb[k * T + t], acc);
             atomicAdd(dWr + (size_t)(co0 + cl) * TVH + k, acc);
         }
     }
     if (threadIdx.x < 64) {
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += ds[threadIdx.x * T + t];
+        for (int t = 0; t < T; ++t) acc += db[threadIdx.x * T + t];
         atomicAdd(dbr + co0 + threadIdx.x, acc);
     }
     // de[k][t] += sum_{co in group} Wr[co][k] dout[co][t]
     for (int idx = threadIdx.x; idx < TVH * T; idx += 256) {
         const int k = idx / T, t = idx - k * T;
         float acc = 0.f;
-        for (int cl = 0; cl < 64; ++cl) acc = fmaf(Wr[(size_t)(co0 + cl) * TVH + k], ds[cl * T + t], acc);
+        for (int cl = 0; cl < 64; ++cl) acc = fmaf(Wr[(size_t)(co0 + cl) * TVH + k], db[cl * T + t], acc);
         atomicAdd(de + (size_t)b * TVH * T + idx, acc);
     }
 }
@@ -275,7 +270,6 @@ __global__ __launch_bounds__(256) void vp_dwconv_bwd_kernel(const float* __restr
                                                             float* __restrict__ dbias, float* __restrict__ dsrc, int accumulate,
                                                             float* __restrict__ dslope, int Tin, int Tout, int stride) {
     __shared__ float red[256];
-    __shared__ float dxs[TVH * 104];
     const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
     float omean, orstd, osc, osh, imean, irstd, isc, ish;
     vbn_coef(obn, c, omean, orstd, osc, osh);
@@ -290,22 +284,23 @@ __global__ __launch_bounds__(256) void vp_dwconv_bwd_kernel(const float* __restr
         if (in_act == 1) v = prelu(v, in_slope);
         return v;
     };
-    for (int t = ph; t < Tout; t += 4) {
+    auto dxat = [&](int t) {  // BatchNorm adjoint on read (recomputed for each of the <= 3 uses: no LDS tile, see vp_gate_proj_fwd_kernel)
         const float xh = (raw[oo + t] - omean) * orstd;
-        const float dx = osc * (dyhat[oo + t] - m1 - xh * m2);
-        dxs[c * Tout + t] = dx;
+        return osc * (dyhat[oo + t] - m1 - xh * m2);
+    };
+    for (int t = ph; t < Tout; t += 4) {
+        const float dx = dxat(t);
         const int p = t * stride - 1;
         gw0 = fmaf(dx, ld(p), gw0), gw1 = fmaf(dx, ld(p + 1), gw1), gw2 = fmaf(dx, ld(p + 2), gw2);
         gb += dx;
     }
-    __syncthreads();
     if (dsrc) {
         for (int p = ph; p < Tin; p += 4) {
             float du = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int tn = p + 1 - k;
-                if (tn >= 0 && tn % stride == 0 && tn / stride < Tout) du = fmaf(k == 0 ? w0 : (k == 1 ? w1 : w2), dxs[c * Tout + tn / stride], du);
+                if (tn >= 0 && tn % stride == 0 && tn / stride < Tout) du = fmaf(k == 0 ? w0 : (k == 1 ? w1 : w2), dxat(tn / stride), du);
             }
             if (in_act == 1) {
                 const float y = fmaf(src[oi + p], isc, ish);
@@ -359,42 +354,47 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
                                                                const float* __restrict__ gb, float gslope, const float* __restrict__ Wp,
                                                                float* __restrict__ dWp, float* __restrict__ dbp, float* __restrict__ dgw,
                                                                float* __restrict__ dgb, float* __restrict__ dgslope, float* __restrict__ dx, int T) {
-    __shared__ float dys[TVH * 104];
+    // grid (B, 8): workgroup (b, y) owns the 64 input channels k = 64 y .. 64 y + 63 and walks the time axis in chunks of 16 (dy chunk = 4 KB of LDS;
+    // every workgroup re-derives dy, only y == 0 adds dbp)
+    constexpr int CT = 16;
+    __shared__ float dys[TVH * CT];
     __shared__ float red[256];
-    const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    {
-        float mean, rstd, sc, sh;
-        vbn_coef(ybn, c, mean, rstd, sc, sh);
-        const float m1 = batch_stats ? sums[c] * inv_n_all : 0.f, m2 = batch_stats ? sums[TVH + c] * inv_n_all : 0.f;
-        float sb = 0.f;
-        for (int t = ph; t < T; t += 4) {
-            const size_t o = ((size_t)b * TVH + c) * T + t;
-            const float d = sc * (dyhat[o] - m1 - (y[o] - mean) * rstd * m2);
-            dys[c * T + t] = d;
-            sb += d;
-        }
-        if (blockIdx.y != 0) sb = 0.f;      // dbp once per utterance
-        phase_reduce_atomic(sb, red, dbp);  // (also the barrier that publishes dys)
-    }
-    // grid (B, 8): workgroup (b, y) owns the 64 input channels k = 64 y .. 64 y + 63 (every workgroup re-derives dy; only y == 0 adds dbp)
-    const int k0 = blockIdx.y * 64;
+    const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6, k0 = blockIdx.y * 64;
+    float mean, rstd, sc, sh;
+    vbn_coef(ybn, c, mean, rstd, sc, sh);
+    const float m1 = batch_stats ? sums[c] * inv_n_all : 0.f, m2 = batch_stats ? sums[TVH + c] * inv_n_all : 0.f;
     const float* rb = r + ((size_t)b * TVIN + k0) * T;
     const float* xb = x + ((size_t)b * TVIN + k0) * T;
     const float* db = dout + ((size_t)b * TVIN + k0) * T;
-    // dWp[c][k] += sum_t dy[c][t] r[k][t]
-    for (int kl = ph; kl < 64; kl += 4) {
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc = fmaf(dys[c * T + t], rb[(size_t)kl * T + t], acc);
-        atomicAdd(dWp + (size_t)c * TVIN + k0 + kl, acc);
-    }
-    // per input channel k = k0 + (tid & 63), time phase: dr, gateway adjoint
-    float gsl = 0.f, aw = 0.f, ab = 0.f;
-    {
-        const int k = k0 + c;
-        const float gwk = gw[k], gbk = gb[k];
-        for (int t = ph; t < T; t += 4) {
+    const int k = k0 + c;
+    const float gwk = gw[k], gbk = gb[k];
+    float sb = 0.f, gsl = 0.f, aw = 0.f, ab = 0.f;
+    float wacc[16];  // dWp[c][k0 + ph + 4 j], j = 0..15
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wacc[j] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += CT) {
+        const int nt = min(CT, T - t0);
+        __syncthreads();  // previous chunk consumed
+        for (int tt = ph; tt < nt; tt += 4) {
+            const size_t o = ((size_t)b * TVH + c) * T + t0 + tt;
+            const float d = sc * (dyhat[o] - m1 - (y[o] - mean) * rstd * m2);
+            dys[c * CT + tt] = d;
+            sb += d;
+        }
+        __syncthreads();
+        // dWp[c][k] += sum_t dy[c][t] r[k][t]
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float* rr = rb + (size_t)(ph + 4 * j) * T + t0;
+            float acc = 0.f;
+            for (int tt = 0; tt < nt; ++tt) acc = fmaf(dys[c * CT + tt], rr[tt], acc);
+            wacc[j] += acc;
+        }
+        // input channel k = k0 + c, time steps ph, ph + 4, ...: dr = Wp^T dy + dout, gateway adjoint
+        for (int tt = ph; tt < nt; tt += 4) {
+            const int t = t0 + tt;
             float dr = db[(size_t)c * T + t];
-            for (int cc = 0; cc < TVH; ++cc) dr = fmaf(Wp[(size_t)cc * TVIN + k], dys[cc * T + t], dr);
+            for (int cc = 0; cc < TVH; ++cc) dr = fmaf(Wp[(size_t)cc * TVIN + k], dys[cc * CT + tt], dr);
             const float xv = xb[(size_t)c * T + t], u = fmaf(xv, gwk, gbk);
             float du = dr;
             if (u <= 0.f) {
@@ -406,6 +406,11 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
             dx[((size_t)b * TVIN + k) * T + t] = du * gwk;
         }
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) atomicAdd(dWp + (size_t)c * TVIN + k0 + ph + 4 * j, wacc[j]);
+    if (blockIdx.y != 0) sb = 0.f;  // dbp once per utterance
+    __syncthreads();
+    phase_reduce_atomic(sb, red, dbp);
     phase_reduce_atomic(aw, red, dgw + k0);
     phase_reduce_atomic(ab, red, dgb + k0);
     gsl = wave_sum(gsl);
@@ -429,7 +434,7 @@ extern "C" {
 int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, float gslope, const float* Wp, const float* bp, float* r, float* y, float* stats,
                           int B, int T, void* stream) {
     VP_CHECK(B > 0 && T > 0);
-    hipLaunchKernelGGL(vp_gate_proj_fwd_kernel, dim3(B, (T + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, gw, gb, gslope, Wp, bp, r, y, stats, T);
+    hipLaunchKernelGGL(vp_gate_proj_fwd_kernel, dim3(B, (T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gw, gb, gslope, Wp, bp, r, y, stats, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -238,7 +238,7 @@ class AVNet(nn.Module):
         cur = torch.cuda.current_stream()
         if getattr(self, "_glue_stream", None) is None or self._glue_stream.device != x.device:
             self._glue_stream = torch.cuda.Stream(device=x.device)
-        side = self._glue_stream
+        side = self._glue_stream if os.environ.get("RTFS_VP_NO_SIDE", "0") != "1" else cur
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
