@@ -57,6 +57,7 @@ class VPTrainer:
     def __init__(self, vb):
         self.vb = vb
         self.bns = _bn_modules(vb)
+        self._ncache = {}
 
     # ---- helpers ----------------------------------------------------------------------------------------------------------
     def _sync(self):
@@ -77,11 +78,9 @@ class VPTrainer:
         st.train = vb.training
         st.sync = self._sync()
         dev = x.device
-        st.Bn = float(st.B)
-        if st.sync:  # utterances behind the statistics = all ranks'
-            nb = torch.tensor([st.B], dtype=torch.float32, device=dev)
-            torch.distributed.all_reduce(nb)
-            st.Bn = float(nb.item())
+        # utterances behind the statistics: all ranks' under SyncBatchNorm.  Equal per-rank batches are assumed (what DistributedSampler delivers);
+        # summing the counts with a collective + .item() would put a host synchronisation in the middle of every step
+        st.Bn = float(st.B * (torch.distributed.get_world_size() if st.sync else 1))
         st.stats = torch.zeros(NS, 2, 64, device=dev)
         # the two scalar PReLU slopes are kernel arguments: taken from the caller (AVNet reads every scalar of the model in ONE transfer per
         # optimizer step, hip_path.PreparedWeights) - fetching them here would be a host synchronisation in the middle of the step
@@ -193,7 +192,10 @@ class VPTrainer:
     def _update_running(self, st):
         """BatchNorm running statistics (momentum, unbiased variance) of all 26 layers with a handful of launches"""
         with torch.no_grad():
-            n = torch.tensor([st.Bn * T for T in self._slot_lengths(st)], device=st.stats.device).view(NS, 1)
+            key = (st.Bn, st.T, str(st.stats.device))
+            n = self._ncache.get(key)
+            if n is None:  # (built once per shape: a host -> device copy of a Python list is a blocking transfer)
+                n = self._ncache[key] = torch.tensor([st.Bn * T for T in self._slot_lengths(st)], device=st.stats.device).view(NS, 1)
             mean = st.stats[:, 0] / n
             var = (st.stats[:, 1] / n - mean * mean).clamp_min(0) * (n / (n - 1).clamp_min(1))
             mom = self.bns[0].momentum if self.bns[0].momentum is not None else 0.1
