@@ -233,13 +233,21 @@ class AVNet(nn.Module):
             self._trainer = HipTrainer(self)
             self._trainer.prec = getattr(self, "_compute_prec", self._hip.prec)
         rm = self.refinement_module
-        # the video branch (~150 tiny PyTorch launches in train mode) runs on a side stream underneath the encoder / first RTFS block
-        # of the HIP function, which waits for it right before the CAF cell; autograd runs its backward on that stream as well
+        # The video branch runs on a side stream underneath the encoder / first RTFS block of the HIP function, which waits for it right before the
+        # CAF cell; autograd runs its backward on that stream as well.  HOST order matters too: each step starts with an idle GPU (the weight
+        # preparation reads the scalars of the model back), so the audio stage A is enqueued FIRST - the GPU has work at once - and the video
+        # branch's launches (2-3 ms of host time) after it; the side stream only waits for the inputs (an event recorded before stage A), not for
+        # stage A's kernels.
         cur = torch.cuda.current_stream()
         if getattr(self, "_glue_stream", None) is None or self._glue_stream.device != x.device:
             self._glue_stream = torch.cuda.Stream(device=x.device)
         side = self._glue_stream if os.environ.get("RTFS_VP_NO_SIDE", "0") != "1" else cur
-        side.wait_stream(cur)
+        inputs_ready = cur.record_event()
+        names = self._hip_param_names()
+        params = dict(self.named_parameters())
+        step = StepCtx()
+        x0, a0, a_emb = AVNetHipStageA.apply(self._trainer, names, step, x.to(torch.float32), *[params[n] for n in names])
+        side.wait_event(inputs_ready)
         with torch.cuda.stream(side):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
             vb = rm.video_net.get_block(0)
@@ -260,10 +268,6 @@ class AVNet(nn.Module):
         att.record_stream(cur)
         rsz.record_stream(cur)
         self._trainer.video_stream = side
-        names = self._hip_param_names()
-        params = dict(self.named_parameters())
-        step = StepCtx()
-        x0, a0, a_emb = AVNetHipStageA.apply(self._trainer, names, step, x.to(torch.float32), *[params[n] for n in names])
         return AVNetHipStageB.apply(self._trainer, step, x0, a0, a_emb, att, rsz)
 
     # ---- BaseAVModel API (TDAVNet/base_av_model.py) ---------------------------------------------
