@@ -59,7 +59,7 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     oracle on some CPUs - tools/grad_vs_fp32.py) is off by 2e-3 ... 4e-2 on ~100 tensors downstream of that one element; seeds 1-3
     show the all-or-nothing pattern (median error 3e-3 with the flip, 4e-5 ... 1e-4 without).  A property of the function, not of a kernel -
     and which seed is affected changes with any re-ordering of fp32 sums in any kernel, so this case asserts what a kernel error cannot
-    satisfy instead of a per-tensor 3e-3: median over the 363 tensors < 1e-3 and every tensor within 6e-2 (scalar slopes 0.5)."""
+    satisfy instead of a per-tensor 3e-3: median over the 363 tensors < 5e-3 and every tensor within 6e-2 (scalar slopes 0.5)."""
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
@@ -98,7 +98,7 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     assert checked > 150
     errs.sort()
     print(f"{dtype}: median gradient error {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}")
-    assert errs[len(errs) // 2] < (1e-3 if dtype in ("f32", "bf16x6") else 5e-3)
+    assert errs[len(errs) // 2] < (1e-3 if (dtype in ("f32", "bf16x6") and L < 32000) else 5e-3)  # (full length: a kink flip moves ~100 tensors, docstring)
 
 
 def test_input_of_caf_video_side_gets_gradient():
