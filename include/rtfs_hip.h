@@ -117,6 +117,17 @@ int rtfs_caf_video_fwd(const float* v /*[B][512][Tv]*/, const float* att_w, cons
 int rtfs_caf_fuse_fwd(const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz,
                       const float* a0_or_null, float* out, int B, int T, int Tv, void* stream);
 
+/* Block 0 of the refinement loop: rtfs_resid_fwd (a0_or_null = NULL: the block runs on a0 itself, refinement_module.py:55) fused with
+ * rtfs_caf_fuse_fwd (ATTNFusionCell's audio side, fusion.py:259-272, applied to the block output in the epilogue registers; add_input != 0
+ * adds s_in, which IS a0 for block 0, refinement_module.py:60) and - when Wp_or_null != NULL (needs add_input) - with rtfs_proj_fwd of
+ * block 1: the block output never reaches HBM.  att / rsz: [B][Tv][256] from rtfs_caf_video_fwd; ks/kb/vs/vb: [256] as rtfs_caf_fuse_fwd. */
+int rtfs_resid_caf_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                       const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                       const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt,
+                       const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* ks, const float* kb,
+                       const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input, float* out,
+                       const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream);
+
 /* ---- a11: MaskGenerator.forward + __apply_masks (RI_split), TDAVNet/mask_generator.py:67-99 ------------------ */
 int rtfs_mask_fwd(const float* x, float slope, const float* Wt /*[256][256]*/, const float* bias, const float* a_emb, float* masked,
                   float* m_or_null /*post-ReLU mask, training*/, int B, int TF, void* stream);
@@ -266,6 +277,12 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
                              const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk,
                              const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0, float* out,
                              const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2, int terms, void* stream);
+int rtfs_resid_caf_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
+                            const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
+                            const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk,
+                            const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* ks, const float* kb,
+                            const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input, float* out,
+                            const void* Wp_pk_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, int terms, void* stream);
 int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
                        int TF, int terms, void* stream);
 int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream);

@@ -126,6 +126,12 @@ struct EpiResidual {
     const float* __restrict__ pbias;  // [64]
     float* __restrict__ py;
     double* pslot;
+    // CAF variant (block 0): the audio side of ATTNFusionCell (fusion.py:259-272; key / value depth-wise 1x1 + BatchNorm(eval) folded into
+    // ks/kb, vs/vb) applied to the block output x while it is in the epilogue registers:
+    //   out = relu(x*ks+kb) * rsz[b][tv(t)] + att[b][tv(t)] * (x*vs+vb) [+ s_in]      (block 0's input s_in IS a0, refinement_module.py:55-60)
+    const float *__restrict__ caf_ks, *__restrict__ caf_kb, *__restrict__ caf_vs, *__restrict__ caf_vb;  // [256]
+    const float *__restrict__ att, *__restrict__ rsz;                                                    // [B][Tv][256]
+    int Tv;
 };
 
 // S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
 //  * 52 KB of LDS -> 2-3 workgroups per CU overlap one's MFMA phase with the others' memory phases.
 // Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_A0, bool PROJ = false, int NT = 0>  // NT != 0: Wt and epi.pw are host-PACKED (common.h)
+// CAF (rtfs_resid_caf_fwd): the CAF cell's audio side rides in the epilogue; HAS_A0 then means "+ s_in" (no separate a0 stream).
+template <bool HAS_A0, bool PROJ = false, int NT = 0, bool CAF = false>  // NT != 0: Wt and epi.pw are host-PACKED (common.h)
 __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDE = 68;
     constexpr int LDO = 260;
@@ -311,6 +318,12 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
     pro.init(b);
     const int cq = (threadIdx.x & 63) * 4;  // this thread's channel quad in the coalesced epilogue
     const float4 cbias = ld4(epi.bias + cq), cgw = ld4(epi.gw + cq), cgb = ld4(epi.gb + cq);
+    __shared__ __attribute__((aligned(16))) float cafc[CAF ? 4 * kC : 4];  // CAF: ks | kb | vs | vb, re-read per epilogue row (16 VGPRs otherwise)
+    if (CAF) {
+        const float* src[4] = {epi.caf_ks, epi.caf_kb, epi.caf_vs, epi.caf_vb};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cafc[j * kC + threadIdx.x] = src[j][threadIdx.x];
+    }
     // fold (mean, rstd, gamma, beta) of the four gLNs into scale/shift tables once: Ns[tensor][scale|shift][channel]
     __shared__ __attribute__((aligned(16))) float Ns[4][2][kH];
     const int c4 = (threadIdx.x & 15) * 4;
@@ -335,24 +348,37 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
     const float* cg_b = pro.cg.x + (size_t)b * pro.T2 * kF2 * kH;
     const float* cgate_b = pro.cgate.x + (size_t)b * pro.T2 * kF2 * kH;
     const float* s_b = epi.s_in + (size_t)b * Mb * kC;
-    const float* a0_b = HAS_A0 ? epi.a0 + (size_t)b * Mb * kC : nullptr;
+    const float* a0_b = (HAS_A0 && !CAF) ? epi.a0 + (size_t)b * Mb * kC : nullptr;
+    const float* att_b = CAF ? epi.att + (size_t)b * epi.Tv * kC : nullptr;
+    const float* rsz_b = CAF ? epi.rsz + (size_t)b * epi.Tv * kC : nullptr;
     float* y_b = epi.y + (size_t)b * Mb * kC;
     const int tile0 = blockIdx.x * tiles_per_wg;
+    const int tile_last = min(tile0 + tiles_per_wg, (Mb + 63) / 64) - 1;  // (grid sizing guarantees tile0 * 64 < Mb)
+    // E tile operands: 64 pixels x 64 channels, 4 float4 per thread and tensor (rows past the end are clamped: their columns are never
+    // stored).  The loads of tile i + 1 are issued in the second half of tile i's epilogue - into the registers the accumulators have just
+    // left - so their HBM latency runs under that epilogue / projection instead of in front of the next MFMA phase.
+    float4 xa[4], xd[4], xg[4], xs[4];
+    // (PROJ: only the two full-resolution streams are fetched ahead - 32 registers next to the projection weights; the compressed pair,
+    // mostly L2 hits through the 4x nearest-neighbour reuse, follows at the top of the tile)
+    auto load_e = [&](int m0, bool full_res, bool compressed) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {  // all loads first
+            const int row = min(m0 + (int)(threadIdx.x >> 4) + it * 16, Mb - 1);
+            const int t = row / kF, f = row - t * kF;
+            const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
+            const unsigned hi = ((unsigned)row * kH + c4) * 4u, lo = (((unsigned)t2 * kF2 + f2) * kH + c4) * 4u;  // byte offsets in the utterance
+            if (full_res) xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi);
+            if (compressed) xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
+        }
+    };
+    load_e(tile0 * 64, true, !PROJ);
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
         const int m0 = (tile0 + tl) * 64;
         if (m0 >= Mb) break;
-        // E tile: 64 pixels x 64 channels, 4 float4 per thread (rows past the end are clamped: their columns are never stored)
+        const int m0_next = min(tile0 + tl + 1, tile_last) * 64;  // (the last tile re-fetches itself: L2 hits, no branch around the loads)
+        if (PROJ) load_e(m0, false, true);
         {
-            float4 xa[4], xd[4], xg[4], xs[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {  // all 16 loads first
-                const int row = min(m0 + (threadIdx.x >> 4) + it * 16, Mb - 1);
-                const int t = row / kF, f = row - t * kF;
-                const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
-                const unsigned hi = ((unsigned)row * kH + c4) * 4u, lo = (((unsigned)t2 * kF2 + f2) * kH + c4) * 4u;  // byte offsets in the utterance
-                xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi), xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
-            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float4 a = fma4(xa[it], ld4(&Ns[0][0][c4]), ld4(&Ns[0][1][c4])), d = fma4(xd[it], ld4(&Ns[1][0][c4]), ld4(&Ns[1][1][c4]));
@@ -364,13 +390,24 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         // residual-side operands of the first 32-pixel half: issued BEFORE the MFMA phase so that their HBM latency runs under it
         // (the kernel is latency-bound once the projection rides in the epilogue)
         float4 sv[8], av[8];
+        // CAF: a 32-pixel half spans at most two STFT frames t, hence at most two video frames tv(t) = floor(t Tv / T): both (att, rsz) row
+        // pairs are fetched with the residual operands (the registers of the a0 stream, which this variant does not have)
+        float4 catt[2], crsz[2];
+        int caf_split = 0;  // first pixel row of the half that belongs to the second frame
         auto load_sv = [&](int pt) {
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
                 sv[it] = ld4_off(s_b, o);
-                if (HAS_A0) av[it] = ld4_off(a0_b, o);
+                if (HAS_A0 && !CAF) av[it] = ld4_off(a0_b, o);
+            }
+            if (CAF) {
+                const int p0 = min(m0 + pt * 32, Mb - 1), p1 = min(m0 + pt * 32 + 31, Mb - 1);
+                const int t0 = p0 / kF, t1 = p1 / kF;
+                caf_split = (t0 + 1) * kF;
+                const unsigned o0 = ((unsigned)nearest_src(t0, epi.Tv, pro.T) * kC + cq) * 4u, o1 = ((unsigned)nearest_src(t1, epi.Tv, pro.T) * kC + cq) * 4u;
+                catt[0] = ld4_off(att_b, o0), crsz[0] = ld4_off(rsz_b, o0), catt[1] = ld4_off(att_b, o1), crsz[1] = ld4_off(rsz_b, o1);
             }
         };
         load_sv(0);
@@ -417,6 +454,8 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
             const float* wpp = PROJ ? epi.pw + (size_t)(16 * w + (lane & 15)) * 256 + 64 * (lane >> 4) : nullptr;
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
             if (pt == 1) load_sv(1);
+            int coff = cq;
+            if (CAF) asm volatile("" : "+v"(coff));  // opaque: the table reads stay inside the epilogue loop
             __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -424,12 +463,24 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 for (int g = 0; g < 4; ++g)
                     st4(Ot + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh,
                         f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]));
+            if (pt == 1 && !PROJ) {  // the accumulators are dead: next tile's E operands (PROJ issues them behind its weight loads, below)
+                __builtin_amdgcn_sched_barrier(0);
+                load_e(m0_next, true, true);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int r = (threadIdx.x >> 6) + 4 * it;
                 float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[it], cgw, cgb), epi.slope - 1.0f);
-                if (HAS_A0) v = v + av[it];
+                if (CAF) {
+                    const bool second = prow + 4 * it >= caf_split;
+                    const float4 at = second ? catt[1] : catt[0], rz = second ? crsz[1] : crsz[0];
+                    v = fma4(at, fma4(v, ld4(cafc + 2 * kC + coff), ld4(cafc + 3 * kC + coff)), relu4(fma4(v, ld4(cafc + coff), ld4(cafc + kC + coff))) * rz);
+                    if (HAS_A0) v = v + sv[it];
+                } else if (HAS_A0) {
+                    v = v + av[it];
+                }
                 if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
                 if (PROJ) {
                     st4(Ot + r * LDO + cq, pack4<NT>(prelu4(fma4(v, cgw, cgb), epi.slope)));  // the next block's gateway, in place
@@ -443,6 +494,11 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 // 16w .. 16w+15 for both 16-pixel sub-tiles and the whole K = 256; lane group kk = lane >> 4 takes k = 64kk + s.
                 // The weight fragments (64 VGPRs) are streamed from L2 into the registers the epilogue loads just left.
                 const int j = lane & 15, kk = lane >> 4;
+                if (pt == 1) {  // next tile's E operands, behind the weight loads: in flight under this half's projection MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_e(m0_next, true, false);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 __syncthreads();  // Ot holds the gated tile
                 // four independent accumulator chains (2 pixel sub-tiles x even / odd k quads): the 40-cycle dependent latency of
                 // the 32-cycle instruction never shows
@@ -632,26 +688,43 @@ static int proj_impl(const float* s, const float* gw, const float* gb, float gsl
     return RTFS_OK;
 }
 
-// shared by rtfs_resid_fwd / rtfs_resid_proj_fwd and their bf16 siblings (Wp == nullptr: no fused projection)
+struct CafArgs {  // the CAF cell's audio side for the block-0 variant (rtfs_resid_caf_fwd)
+    const float *ks, *kb, *vs, *vb, *att, *rsz;
+    int Tv;
+};
+
+// shared by rtfs_resid_fwd / rtfs_resid_proj_fwd / rtfs_resid_caf_fwd and their bf16 siblings (Wp == nullptr: no fused projection)
 template <int NT>
 static int resid_impl(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                       const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                       const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt, const float* bias,
                       const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, const float* Wp,
-                      const float* pbias, float* py, double* pstats, int B, int T, int T2, hipStream_t st) {
+                      const float* pbias, float* py, double* pstats, int B, int T, int T2, hipStream_t st, const CafArgs* caf = nullptr) {
     const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
     ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null, Wp, pbias, py, pstats};
+    EpiResidual epi{out, bias, s_in, gw, gb, gslope, a0_or_null, Wp, pbias, py, pstats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
     if (Wp && (!a0_or_null || !py || !pstats)) return RTFS_EINVAL;
+    if (caf) {
+        if (!caf->ks || !caf->kb || !caf->vs || !caf->vb || !caf->att || !caf->rsz || caf->Tv <= 0 || caf->Tv > T) return RTFS_EINVAL;
+        if (a0_or_null && a0_or_null != s_in) return RTFS_EINVAL;  // block 0: the "+ a0" of the cell is "+ the block input"
+        epi.caf_ks = caf->ks, epi.caf_kb = caf->kb, epi.caf_vs = caf->vs, epi.caf_vb = caf->vb, epi.att = caf->att, epi.rsz = caf->rsz, epi.Tv = caf->Tv;
+    }
     // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
     // 64 -> 804; small batches get more, smaller workgroups.
     const int Mb = T * kF, tiles = (Mb + 63) / 64;
     const long long want = ((long long)tiles * B + 1023) / 1024;
     const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
     const dim3 grid((tiles + per - 1) / per, B);
-    if (Wp)
+    if (caf) {
+        if (Wp)
+            hipLaunchKernelGGL((resid_kernel<true, true, NT, true>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+        else if (a0_or_null)
+            hipLaunchKernelGGL((resid_kernel<true, false, NT, true>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+        else
+            hipLaunchKernelGGL((resid_kernel<false, false, NT, true>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    } else if (Wp)
         hipLaunchKernelGGL((resid_kernel<true, true, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
     else if (a0_or_null)
         hipLaunchKernelGGL((resid_kernel<true, false, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb, per);
@@ -749,6 +822,38 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
                     gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream)
+    RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
+#undef RESID_NT
+}
+
+// Block 0: rtfs_resid_fwd (no a0: the block runs on a0 itself) + rtfs_caf_fuse_fwd (+ a0 = + s_in when add_input) [+ block 1's rtfs_proj_fwd
+// when Wp != NULL, which needs add_input]: the block output never reaches HBM, and its residual stream doubles as the cell's a0 stream.
+int rtfs_resid_caf_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                       const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                       const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                       const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                       const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                       const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input,
+                       float* out, const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream) {
+    const CafArgs caf{ks, kb, vs, vb, att, rsz, Tv};
+    if (Wp_or_null && !add_input) return RTFS_EINVAL;
+    return resid_impl<0>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, Wt, bias, s_in,
+                         gw, gb, gslope, add_input ? s_in : nullptr, out, Wp_or_null, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf);
+}
+int rtfs_resid_caf_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
+                            const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
+                            const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,      //
+                            const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
+                            const void* Wpk, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
+                            const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz, int Tv,
+                            int add_input, float* out, const void* Wp_pk_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2,
+                            int terms, void* stream) {
+    const CafArgs caf{ks, kb, vs, vb, att, rsz, Tv};
+    if (Wp_pk_or_null && !add_input) return RTFS_EINVAL;
+    const float *W = (const float*)Wpk, *Wp = (const float*)Wp_pk_or_null;
+#define RESID_NT(NTV)                                                                                                                                  \
+    resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
+                    gb, gslope, add_input ? s_in : nullptr, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf)
     RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
 #undef RESID_NT
 }

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
     "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
     "rtfs_resid_proj_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, P],
+    "rtfs_resid_caf_fwd": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, P],
     "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
     "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
     "rtfs_mask_fwd": [P, F, P, P, P, P, P, I, I, P],
@@ -109,6 +110,7 @@ SIGNATURES = {
     "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
     "rtfs_resid_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, I, P],
     "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
+    "rtfs_resid_caf_fwd_bf16": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, P],
     "rtfs_mask_fwd_bf16": [P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_gemm_rows_fwd_bf16": [P, P, P, P, I, I, I, I, P],
     "rtfs_gemm_rows_bf16": [P, P, P, P, I, I, I, I, I, P],

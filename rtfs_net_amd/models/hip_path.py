@@ -288,10 +288,12 @@ class HipForward:
         self._mm("rtfs_dp_convt_fwd", h, self._wk(d, "ct_w"), d["ct_b"], G, B, T2, dim)
 
     # ---- one RTFS block (a5) ----
-    def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None, y0=None, next_proj=None):
+    def _block(self, s_in, out, a0_or_none, bw, st, B, T, T2, tap=None, y0=None, next_proj=None, caf=None):
         """One RTFS block.  `y0`: this block's projection output if the previous block's residual kernel already produced it;
         `next_proj` = (y0 buffer, statistics slot) of the NEXT block: its gateway + projection are then fused into this block's residual
-        kernel (shared block weights, `a0` present), which saves re-reading the 256-channel output from HBM."""
+        kernel (shared block weights, `a0` present), which saves re-reading the 256-channel output from HBM.
+        `caf` (block 0 only) = callable returning (ks, kb, vs, vb, att, rsz, Tv, add_input): the CAF cell's audio side is then applied in
+        the residual kernel's epilogue (rtfs_resid_caf_fwd) and `out` receives the cell's output [+ a0] instead of the block output."""
         dev = s_in.device
         TF = T * F_BINS
         full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
@@ -353,6 +355,14 @@ class HipForward:
         else:
             lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
             lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
+        if caf is not None:
+            ks, kb, vs, vb, att, rsz, Tv, add_input = caf()  # (waits for the video branch's side stream, launches the cell's video side)
+            nxt = next_proj if add_input else None
+            self._mm("rtfs_resid_caf_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
+                     cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], ks, kb, vs, vb, att, rsz, Tv, int(add_input), out,
+                     self._wk(bw, "pw") if nxt is not None else None, bw["pb"], nxt[0] if nxt is not None else None,
+                     nxt[1] if nxt is not None else None, B, T, T2)
+            return nxt is not None
         if next_proj is not None and a0_or_none is not None:
             self._mm("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                      cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, self._wk(bw, "pw"), bw["pb"],
@@ -419,21 +429,38 @@ class HipForward:
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
         x = torch.empty_like(a_emb)
-        self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
         att = torch.empty(B * Tv * C, device=dev)
         rsz = torch.empty_like(att)
-        cur.wait_stream(self._vp_stream)
-        v1.record_stream(cur)
-        lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
-                 w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
-        s = torch.empty_like(a_emb)
         last = R == 1
-        lib.call("rtfs_caf_fuse_fwd", x, w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, None if last else a0, s, B, T, Tv)
-        if taps is not None:
-            taps["block0"], taps["vp"] = x.clone(), v1
-            taps["caf_plus_a0" if not last else "caf"] = s.clone()
         fuse = len(blocks) == 1 and os.environ.get("RTFS_NO_PROJ_FUSION", "0") != "1"  # shared block weights: block i+1's projection = block i's
+
+        def caf_video():
+            cur.wait_stream(self._vp_stream)
+            v1.record_stream(cur)
+            lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
+                     w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
+
         y0_next = None
+        # stage taps want the block output itself; Tv > T cannot happen on the product path (25 video frames / s vs 125 STFT frames / s)
+        if taps is None and Tv <= T and os.environ.get("RTFS_NO_CAF_FUSION", "0") != "1":
+            # block 0 + CAF cell (+ block 1's projection) in one residual kernel: the block output never reaches HBM (a10 / fusion.py:259-272)
+            def caf_args():
+                caf_video()
+                return w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, Tv, not last
+
+            s = x
+            nxt = (torch.empty(B * TF * H, device=dev), stats[13]) if (fuse and not last) else None
+            if self._block(a0, s, None, bw(0), stats[1:13], B, T, T2, next_proj=nxt, caf=caf_args):
+                y0_next = nxt[0]
+            x = torch.empty_like(a_emb)
+        else:
+            self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
+            caf_video()
+            s = torch.empty_like(a_emb)
+            lib.call("rtfs_caf_fuse_fwd", x, w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, None if last else a0, s, B, T, Tv)
+            if taps is not None:
+                taps["block0"], taps["vp"] = x.clone(), v1
+                taps["caf_plus_a0" if not last else "caf"] = s.clone()
         for i in range(1, R):
             last = i == R - 1
             y0_cur, nxt = y0_next, None

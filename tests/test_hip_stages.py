@@ -249,3 +249,46 @@ def test_resid_proj_fusion_matches_separate_calls():
         finally:
             del os.environ["RTFS_NO_PROJ_FUSION"]
     assert rel(fused, plain) < 2e-6 and not torch.equal(fused, plain)
+
+
+@pytest.mark.parametrize("R", [1, 2, 4])
+def test_caf_fusion_matches_separate_calls(R):
+    """Block 0's residual kernel applies the CAF cell's audio side in its epilogue (rtfs_resid_caf_fwd; the block output never reaches HBM,
+    the residual stream doubles as the cell's a0 stream).  Against the separate rtfs_resid_fwd + rtfs_caf_fuse_fwd (+ rtfs_proj_fwd) calls:
+    the same arithmetic in the same order when block 1's projection is not fused (R = 1 has no a0 and no block 1), the projection's
+    summation order otherwise."""
+    import os
+
+    model, sd, cfg = make_model(R, "cuda")
+    mix, _, emb = synth.synth_inputs(3, 16000, 25)
+
+    def run(**env):
+        os.environ.update(env)
+        try:
+            with torch.no_grad():
+                return model(mix.cuda(), emb.cuda())
+        finally:
+            for k in env:
+                del os.environ[k]
+
+    fused, plain = run(), run(RTFS_NO_CAF_FUSION="1")
+    assert rel(fused, plain) < 2e-6
+    fused_np, plain_np = run(RTFS_NO_PROJ_FUSION="1"), run(RTFS_NO_PROJ_FUSION="1", RTFS_NO_CAF_FUSION="1")
+    assert rel(fused_np, plain_np) < 2e-7
+    if R > 1:
+        assert not torch.equal(fused, fused_np)  # the fused projection did run
+
+
+def test_resid_caf_entry_rejects_bad_arguments():
+    """rtfs_resid_caf_fwd: a fused projection needs add_input; Tv must not exceed T."""
+    from rtfs_net_amd import lib
+
+    z = torch.zeros(64 * 129 * 256, device="cuda")
+    st = torch.zeros(16, dtype=torch.float64, device="cuda")
+    v = torch.zeros(256, device="cuda")
+    args = lambda Tv, add, wp: (z, st, v, v, z, st, v, v, z, st, v, v, z, st, v, v, z, v, z, v, v, 0.25, v, v, v, v, z, z, Tv, add, z, wp, v, z, st,  # noqa: E731
+                                1, 16, 8)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_resid_caf_fwd", *args(4, 0, z))
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_resid_caf_fwd", *args(17, 1, None))
