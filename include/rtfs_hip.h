@@ -90,6 +90,14 @@ int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O,
 int rtfs_attn_out_fwd(const float* O, const float* W /*[64][64] out,in*/, const float* bias, float slope, const float* gamma_fc, const float* beta_fc,
                       float* G /*in place*/, float* Ypre_or_null /*[B*T2][64 f][64 co], training*/, int B, int T2, void* stream);
 
+/* The three readers of gLN(D0) in one pass: rtfs_dwconv_fwd(mode 1, stride 1, w1 -> out1: fusion_layers[0].local_embedding, fusion.py:25-52),
+ * rtfs_dwconv_fwd(mode 1, stride 2, w2 + bias2 -> out2: downsample_layers[1], tdanet.py:112-114) and the adaptive_avg_pool2d(gLN(D0)) term of
+ * rtfs_pool_fwd (tdanet.py:117-118) -> pooled [B][T2][64][64]; rtfs_pool_add_fwd finishes G = pooled + gLN(D1).  T2 = (T - 2) / 2 + 1. */
+int rtfs_dwconv_trio_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* w1, float* out1, double* stats1,
+                         const float* w2, const float* bias2, float* out2, double* stats2, float* pooled, int B, int T, int T2, void* stream);
+int rtfs_pool_add_fwd(const float* pooled, const float* d1, const double* d1_stats, const float* d1_g, const float* d1_b, float* G, int B, int T2,
+                      void* stream);
+
 /* ---- a5.6: TFAR, InjectionMultiSum.forward, layers/fusion.py:54-69 ------------------------------------------ */
 int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
                       const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats,

@@ -353,31 +353,26 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
     const float* rsz_b = CAF ? epi.rsz + (size_t)b * epi.Tv * kC : nullptr;
     float* y_b = epi.y + (size_t)b * Mb * kC;
     const int tile0 = blockIdx.x * tiles_per_wg;
-    const int tile_last = min(tile0 + tiles_per_wg, (Mb + 63) / 64) - 1;  // (grid sizing guarantees tile0 * 64 < Mb)
     // E tile operands: 64 pixels x 64 channels, 4 float4 per thread and tensor (rows past the end are clamped: their columns are never
-    // stored).  The loads of tile i + 1 are issued in the second half of tile i's epilogue - into the registers the accumulators have just
-    // left - so their HBM latency runs under that epilogue / projection instead of in front of the next MFMA phase.
+    // stored).  (Measured, round 2: issuing tile i + 1's loads in the second half of tile i's epilogue - into the registers the
+    // accumulators have just left - made every variant SLOWER: 1065 -> 1163 us with the fused projection, 563 -> 576 us without; the
+    // co-resident workgroup already covers this latency and the early loads only delay the epilogue's own operands.)
     float4 xa[4], xd[4], xg[4], xs[4];
-    // (PROJ: only the two full-resolution streams are fetched ahead - 32 registers next to the projection weights; the compressed pair,
-    // mostly L2 hits through the 4x nearest-neighbour reuse, follows at the top of the tile)
-    auto load_e = [&](int m0, bool full_res, bool compressed) {
+    auto load_e = [&](int m0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {  // all loads first
+        for (int it = 0; it < 4; ++it) {  // all 16 loads first
             const int row = min(m0 + (int)(threadIdx.x >> 4) + it * 16, Mb - 1);
             const int t = row / kF, f = row - t * kF;
             const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
             const unsigned hi = ((unsigned)row * kH + c4) * 4u, lo = (((unsigned)t2 * kF2 + f2) * kH + c4) * 4u;  // byte offsets in the utterance
-            if (full_res) xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi);
-            if (compressed) xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
+            xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi), xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
         }
     };
-    load_e(tile0 * 64, true, !PROJ);
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
         const int m0 = (tile0 + tl) * 64;
         if (m0 >= Mb) break;
-        const int m0_next = min(tile0 + tl + 1, tile_last) * 64;  // (the last tile re-fetches itself: L2 hits, no branch around the loads)
-        if (PROJ) load_e(m0, false, true);
+        load_e(m0);
         {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -463,11 +458,6 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 for (int g = 0; g < 4; ++g)
                     st4(Ot + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh,
                         f4(acc[nt][pt][4 * g], acc[nt][pt][4 * g + 1], acc[nt][pt][4 * g + 2], acc[nt][pt][4 * g + 3]));
-            if (pt == 1 && !PROJ) {  // the accumulators are dead: next tile's E operands (PROJ issues them behind its weight loads, below)
-                __builtin_amdgcn_sched_barrier(0);
-                load_e(m0_next, true, true);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -494,11 +484,6 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 // 16w .. 16w+15 for both 16-pixel sub-tiles and the whole K = 256; lane group kk = lane >> 4 takes k = 64kk + s.
                 // The weight fragments (64 VGPRs) are streamed from L2 into the registers the epilogue loads just left.
                 const int j = lane & 15, kk = lane >> 4;
-                if (pt == 1) {  // next tile's E operands, behind the weight loads: in flight under this half's projection MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_e(m0_next, true, false);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 __syncthreads();  // Ot holds the gated tile
                 // four independent accumulator chains (2 pixel sub-tiles x even / odd k quads): the 40-cycle dependent latency of
                 // the 32-cycle instruction never shows

@@ -375,6 +375,189 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
     }
 }
 
+// The three readers of gLN(D0) in one pass (tdanet.py:112-118, fusion.py:25-52 of fusion_layers[0]): the stride-1 'same' convolution that
+// makes the TFAR local embedding l0, the stride-2 convolution that makes the next pyramid level D1, and the adaptive average pooling of
+// gLN(D0) onto D1's grid.  Staging is dwconv_s1_kernel<1, 1>'s (16 x 8 outputs from a (16+3) x (8+3) pixel LDS tile, gLN and the zero padding
+// applied once on the way in); after the sliding-window pass a second pass reads the SAME tile: the 8 x 4 stride-2 outputs whose 4 x 4 windows
+// (rows 2 t2 - 1 .. 2 t2 + 2, columns 2 f2 - 1 .. 2 f2 + 2: padding 1 = the tile's zeros) and pooling windows (rows 2 t2 .. 2 t2 + nt - 1,
+// nt = 3 for odd T and 2 for even T; columns 2 f2 .. 2 f2 + 2 for 129 -> 64 bins) lie inside it because tiles start on even rows / columns.
+// D0 is read once (1.19x with the t halo) instead of three times (stride-2 kernel 2x through L1, pooling 1x, stride-1 1.19x).
+struct TrioArgs {
+    const float* in;     // [B][T][129][64]
+    const double* slot;  // gLN statistics of `in`
+    double inv_n;
+    const float *gamma, *beta;
+    int T, T2;
+    const float* w1;  // stride 1, no bias
+    float* out1;      // [B][T][129][64]
+    double* stats1;
+    const float *w2, *bias2;  // stride 2
+    float* out2;              // [B][T2][64][64]
+    double* stats2;
+    float* pooled;  // [B][T2][64][64]
+};
+
+__global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fseg) {
+    constexpr int TR = 16, TC = 8, R = TR + 3, CB = TC + 3;
+    constexpr int RS = CB * 64;
+    __shared__ __attribute__((aligned(16))) float tile[R * RS];
+    __shared__ __attribute__((aligned(16))) float ws[2][16 * 64];
+    __shared__ float red[8];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * 256; i += 256) {
+        const int j = i >> 8, o = (i & 255) * 4;
+        st4(&ws[j][o], ld4((j ? a.w2 : a.w1) + o));
+    }
+    const int c4 = (threadIdx.x & 15) * 4, tr = threadIdx.x >> 4;
+    const int T = a.T, T2 = a.T2;
+    constexpr int F = kF;
+    const int t0 = blockIdx.x * TR, to = t0 + tr;
+    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    float4 sc, sh;
+    {
+        float mean, rstd;
+        stats_finalize(a.slot, b, a.inv_n, mean, rstd);
+        const float4 g = ld4(a.gamma + c4), be = ld4(a.beta + c4);
+        sc = g * rstd;
+        sh = f4(be.x - mean * sc.x, be.y - mean * sc.y, be.z - mean * sc.z, be.w - mean * sc.w);
+    }
+    const float* inb = a.in + (size_t)b * T * F * kH;
+    const bool tvalid = to < T;
+    float s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f;
+    __syncthreads();
+    const float4 bias2 = ld4(a.bias2 + c4);
+    const size_t orow = (((size_t)b * T + (tvalid ? to : 0)) * F) * kH + c4;
+    // second pass: this thread's stride-2 outputs (lt, 2 lp) and (lt, 2 lp + 1) of the tile
+    const int lt = tr >> 1, lp = tr & 1;
+    const int t2 = (t0 >> 1) + lt;
+    const bool t2valid = t2 < T2;
+    const float mt3 = (T & 1) ? 1.f : 0.f;                    // pooling window rows: 2 t2 .. 2 t2 + 1 (+ 2 t2 + 2 for odd T)
+    const float pinv = 1.0f / (((T & 1) ? 3.f : 2.f) * 3.f);  // x 3 columns
+    const size_t orow2 = (((size_t)b * T2 + (t2valid ? t2 : 0)) * kF2) * kH + c4;
+
+#pragma unroll 1
+    for (int fb = f0; fb < f1; fb += TC) {
+        constexpr int NN = (R * TC * 16 + 255) / 256, NH = (R * 3 * 16 + 255) / 256;
+        const bool first = fb == f0;
+        float4 vn[NN], vh[NH];
+        auto xform = [&](float4 x, int ti, int fi) {
+            x = fma4(x, sc, sh);
+            if (!(ti >= 0 && ti < T && fi >= 0 && fi < F)) x = f4(0, 0, 0, 0);
+            return x;
+        };
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {  // halo columns 0 .. 2 from memory
+                const int idx = threadIdx.x + i * 256, r = min(idx / 48, R - 1), c = (idx % 48) >> 4;
+                const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
+                vh[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {  // ... or from the previous block's columns 8 .. 10 (already transformed / zero-padded)
+                const int idx = threadIdx.x + i * 256, r = min(idx / 48, R - 1), c = (idx % 48) >> 4;
+                vh[i] = ld4(tile + r * RS + (c + TC) * 64 + c4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NN; ++i) {
+            const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+            const int ti = t0 - 1 + r, fi = fb - 1 + c;
+            vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+        }
+        __syncthreads();  // previous block's window reads are done
+#pragma unroll
+        for (int i = 0; i < NN; ++i) {
+            const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+            if (idx < R * TC * 16) st4(tile + r * RS + c * 64 + c4, xform(vn[i], t0 - 1 + r, fb - 1 + c));
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int idx = threadIdx.x + i * 256, r = idx / 48, c = (idx % 48) >> 4;
+            if (idx < R * 3 * 16) st4(tile + r * RS + c * 64 + c4, first ? xform(vh[i], t0 - 1 + r, fb - 1 + c) : vh[i]);
+        }
+        __syncthreads();
+        // ---- pass 1: 8 stride-1 output columns from a sliding window over LDS (column c of the block lives in window slot c & 3)
+        {
+            const float* trow = tile + tr * RS + c4;
+            float4 win[4][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) win[c][r] = ld4(trow + r * RS + c * 64);
+#pragma unroll 1
+            for (int jb = 0; jb < TC; jb += 4) {
+                int woff = c4;
+                asm volatile("" : "+v"(woff));  // taps re-read from LDS per group of 4 columns (hoisted they pin 64 VGPRs)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = jb + jj;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) win[(jj + 3) & 3][r] = ld4(trow + r * RS + (j + 3) * 64);
+                    float4 acc = f4(0, 0, 0, 0);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                        for (int df = 0; df < 4; ++df) acc = fma4(ld4(&ws[0][(dt * 4 + df) * 64 + woff]), win[(jj + df) & 3][dt], acc);
+                    const int fo = fb + j;
+                    if (tvalid && fo < f1) {
+                        st4(a.out1 + orow + (size_t)fo * kH, acc);
+                        s1 += acc.x + acc.y + acc.z + acc.w;
+                        q1 += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                    }
+                }
+            }
+        }
+        // ---- pass 2: stride-2 convolution + pooling at (t2, f2), f2 = fb / 2 + 2 lp + {0, 1}: tile rows 2 lt .. 2 lt + 3, columns 4 lp .. 4 lp + 5
+        {
+            int woff = c4;
+            asm volatile("" : "+v"(woff));
+            const float* base = tile + (2 * lt) * RS + (4 * lp) * 64 + c4;
+#pragma unroll 1
+            for (int o = 0; o < 2; ++o) {  // (rolled: one 4 x 4 window of registers at a time)
+                float4 x[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[c][r] = ld4(base + r * RS + (2 * o + c) * 64);
+                float4 acc = bias2;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) acc = fma4(ld4(&ws[1][(dt * 4 + df) * 64 + woff]), x[df][dt], acc);
+                // pooling window: rows dt = 1, 2 (, 3), columns df = 1, 2, 3 of the same 4 x 4 window
+                float4 rs[3];
+#pragma unroll
+                for (int dt = 1; dt < 4; ++dt) rs[dt - 1] = x[1][dt] + x[2][dt] + x[3][dt];
+                const float4 pool = (rs[0] + rs[1] + rs[2] * mt3) * pinv;
+                const int f2 = (fb >> 1) + 2 * lp + o;
+                if (t2valid && f2 < kF2 && 2 * f2 < f1) {
+                    st4(a.out2 + orow2 + (size_t)f2 * kH, acc);
+                    st4(a.pooled + orow2 + (size_t)f2 * kH, pool);
+                    s2 += acc.x + acc.y + acc.z + acc.w;
+                    q2 += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    block_stats_commit(s1, q1, red, a.stats1, b);
+    __syncthreads();
+    block_stats_commit(s2, q2, red, a.stats2, b);
+}
+
+// G = pooled + gLN(D1)  (the second half of rtfs_pool_fwd when dwconv_trio_kernel has produced the pooled term)
+__global__ __launch_bounds__(256) void pool_add_kernel(const float* __restrict__ pooled, NormRefLite d1, float* __restrict__ G, int n_pix) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= n_pix) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    float4 sc1, sh1;
+    norm_coef(d1, b, c4, sc1, sh1);
+    const size_t o = ((size_t)b * n_pix + p) * kH + c4;
+    st4(G + o, ld4(pooled + o) + fma4(ld4(d1.x + o), sc1, sh1));
+}
+
 // G = adaptive_avg_pool2d(gLN(D0p) -> (T2,F2)) + gLN(D1p); window [floor(i*in/out), ceil((i+1)*in/out)).
 __global__ __launch_bounds__(256) void pool_kernel(NormRefLite d0, NormRefLite d1, float* __restrict__ G, int T, int T2) {
     const int b = blockIdx.y;
@@ -603,6 +786,27 @@ int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, co
     NormRefLite r0{d0, d0_stats, 1.0 / ((double)T * kF * kH), d0_g, d0_b};
     NormRefLite r1{d1, d1_stats, 1.0 / ((double)T2 * kF2 * kH), d1_g, d1_b};
     hipLaunchKernelGGL(pool_kernel, dim3((T2 * kF2 + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, r0, r1, G, T, T2);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// rtfs_dwconv_fwd(D0, mode 1, stride 1, w1) + rtfs_dwconv_fwd(D0, mode 1, stride 2, w2 + bias2) + the pooling half of rtfs_pool_fwd in ONE pass
+// over D0 [B][T][129][64] (dwconv_trio_kernel); rtfs_pool_add_fwd then finishes G = pooled + gLN(D1).  T2 must be (T - 2) / 2 + 1.
+int rtfs_dwconv_trio_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* w1, float* out1, double* stats1,
+                         const float* w2, const float* bias2, float* out2, double* stats2, float* pooled, int B, int T, int T2, void* stream) {
+    if (B <= 0 || T < 2 || T2 != (T - 2) / 2 + 1 || !bias2) return RTFS_EINVAL;
+    TrioArgs a{d0, d0_stats, 1.0 / ((double)T * kF * kH), d0_g, d0_b, T, T2, w1, out1, stats1, w2, bias2, out2, stats2, pooled};
+    const int nseg = 4, fseg = (((kF + nseg - 1) / nseg) + 7) / 8 * 8;
+    hipLaunchKernelGGL(dwconv_trio_kernel, dim3((T + 15) / 16, B, (kF + fseg - 1) / fseg), dim3(256), 0, (hipStream_t)stream, a, fseg);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_pool_add_fwd(const float* pooled, const float* d1, const double* d1_stats, const float* d1_g, const float* d1_b, float* G, int B, int T2,
+                      void* stream) {
+    if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
+    NormRefLite r1{d1, d1_stats, 1.0 / ((double)T2 * kF2 * kH), d1_g, d1_b};
+    hipLaunchKernelGGL(pool_add_kernel, dim3((T2 * kF2 + 15) / 16, B), dim3(256), 0, (hipStream_t)stream, pooled, r1, G, T2 * kF2);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -306,9 +306,18 @@ class HipForward:
         D0 = full()
         lib.call("rtfs_dwconv_fwd", y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [D0], [st[1]], B, T, F_BINS)
         D1 = low()
-        lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [D1], [st[2]], B, T, F_BINS)
         G = low()
-        lib.call("rtfs_pool_fwd", D0, st[1], d0g, d0be, D1, st[2], d1g, d1be, G, B, T, T2)
+        f0l = bw["fusion_layers.0.local_embedding"]
+        l0 = None
+        if os.environ.get("RTFS_NO_TRIO_FUSION", "0") != "1":
+            # the three readers of gLN(D0) - D1's stride-2 conv, the pooling, fusion_layers[0]'s local embedding - in one pass over D0
+            l0, pooled = full(), low()
+            lib.call("rtfs_dwconv_trio_fwd", D0, st[1], d0g, d0be, f0l[0], l0, st[3], d1w, d1b, D1, st[2], pooled, B, T, T2)
+            lib.call("rtfs_pool_add_fwd", pooled, D1, st[2], d1g, d1be, G, B, T2)
+            del pooled
+        else:
+            lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [D1], [st[2]], B, T, F_BINS)
+            lib.call("rtfs_pool_fwd", D0, st[1], d0g, d0be, D1, st[2], d1g, d1be, G, B, T, T2)
         if tap is not None:
             tap["y0"], tap["D0"], tap["D1"], tap["pooled"] = y0, D0, D1, G.clone()
         self._dual_path(G, bw["dp0"], B, T2, 4)
@@ -328,11 +337,13 @@ class HipForward:
         if tap is not None:
             tap["attn"] = G.clone()
         # TFAR (a5.6)
-        f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
+        f0g, f0gate = bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
-        l0, l1 = full(), low()
-        lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [l0], [st[3]], B, T, F_BINS)
+        l1 = low()
+        if l0 is None:
+            l0 = full()
+            lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [l0], [st[3]], B, T, F_BINS)
         lib.call("rtfs_dwconv_fwd", D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [l1], [st[4]], B, T2, F2)
         g0, gg0, g1, gg1 = low(), low(), low(), low()
         lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [g0, gg0, g1, gg1],

@@ -292,3 +292,53 @@ def test_resid_caf_entry_rejects_bad_arguments():
         lib.call("rtfs_resid_caf_fwd", *args(4, 0, z))
     with pytest.raises(RuntimeError):
         lib.call("rtfs_resid_caf_fwd", *args(17, 1, None))
+
+
+@pytest.mark.parametrize("B,L", [(3, 16000), (2, 32000), (2, 12100), (1, 2048)])
+def test_trio_fusion_matches_separate_calls(B, L):
+    """rtfs_dwconv_trio_fwd + rtfs_pool_add_fwd (one pass over D0 for D1's stride-2 convolution, the pooling and fusion_layers[0]'s local
+    embedding) against the three separate kernels: even and odd frame counts (2- and 3-row pooling windows), ragged tiles, end to end."""
+    import os
+
+    model, sd, cfg = make_model(2, "cuda")
+    mix, _, emb = synth.synth_inputs(B, L, max(8, L // 640))
+    with torch.no_grad():
+        fused = model(mix.cuda(), emb.cuda())
+        os.environ["RTFS_NO_TRIO_FUSION"] = "1"
+        try:
+            plain = model(mix.cuda(), emb.cuda())
+        finally:
+            del os.environ["RTFS_NO_TRIO_FUSION"]
+    assert rel(fused, plain) < 2e-6
+
+
+@pytest.mark.parametrize("B,T", [(2, 251), (3, 126), (1, 17), (2, 95)])
+def test_trio_entry_against_separate_entries(B, T):
+    """The entry points in isolation: every output tensor and both statistics slots."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(7 * B + T)
+    T2 = (T - 2) // 2 + 1
+    dev = "cuda"
+    D0 = torch.randn(B, T, 129, 64, generator=g).to(dev)
+    gam, bet = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+    g1, b1 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.1).to(dev)
+    w1, w2, bias2 = (torch.randn(16, 64, generator=g) * 0.2).to(dev), (torch.randn(16, 64, generator=g) * 0.2).to(dev), torch.randn(64, generator=g).to(dev)
+    st0 = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
+    st0[:, 0] = D0.double().sum((1, 2, 3))
+    st0[:, 1] = (D0.double() ** 2).sum((1, 2, 3))
+    full = lambda: torch.full((B * T * 129 * 64,), float("nan"), device=dev)  # noqa: E731
+    low = lambda: torch.full((B * T2 * 64 * 64,), float("nan"), device=dev)  # noqa: E731
+    sts = lambda: torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)  # noqa: E731
+    l0a, D1a, Ga, s1a, s2a = full(), low(), low(), sts(), sts()
+    lib.call("rtfs_dwconv_fwd", D0, st0, gam, bet, 0.0, 1, 1, 1, [w1], [None], [l0a], [s1a], B, T, 129)
+    lib.call("rtfs_dwconv_fwd", D0, st0, gam, bet, 0.0, 1, 2, 1, [w2], [bias2], [D1a], [s2a], B, T, 129)
+    lib.call("rtfs_pool_fwd", D0, st0, gam, bet, D1a, s2a, g1, b1, Ga, B, T, T2)
+    l0b, D1b, P, Gb, s1b, s2b = full(), low(), low(), low(), sts(), sts()
+    lib.call("rtfs_dwconv_trio_fwd", D0, st0, gam, bet, w1, l0b, s1b, w2, bias2, D1b, s2b, P, B, T, T2)
+    lib.call("rtfs_pool_add_fwd", P, D1b, s2b, g1, b1, Gb, B, T2)
+    assert torch.equal(l0a, l0b) and torch.equal(D1a, D1b)
+    assert rel(Gb, Ga) < 1e-6 and not torch.isnan(Gb).any()
+    assert rel(s1b[:, :2], s1a[:, :2]) < 1e-6 and rel(s2b[:, :2], s2a[:, :2]) < 1e-6
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_dwconv_trio_fwd", D0, st0, gam, bet, w1, l0b, s1b, w2, bias2, D1b, s2b, P, B, T, T2 + 1)
