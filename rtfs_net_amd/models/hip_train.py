@@ -179,9 +179,13 @@ class HipTrainer:
         d1w, d1b, d1g, d1be = bw["d1"]
         k.D0, k.D1 = full(), low()
         self._call("rtfs_dwconv_fwd", k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, 1, [d0w], [d0b], [k.D0], [st[1]], B, T, F_BINS)
-        self._call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [k.D1], [st[2]], B, T, F_BINS)
         G = low()
-        self._call("rtfs_pool_fwd", k.D0, st[1], d0g, d0be, k.D1, st[2], d1g, d1be, G, B, T, T2)
+        # D1's stride-2 convolution, the pooling and fusion_layers[0]'s local embedding in one pass over D0 (as in hip_path.HipForward._block)
+        k.l0, pooled = full(), low()
+        self._call("rtfs_dwconv_trio_fwd", k.D0, st[1], d0g, d0be, bw["fusion_layers.0.local_embedding"][0], k.l0, st[3], d1w, d1b, k.D1, st[2], pooled,
+                   B, T, T2)
+        self._call("rtfs_pool_add_fwd", pooled, k.D1, st[2], d1g, d1be, G, B, T2)
+        del pooled
         k.dp = [Ctx(), Ctx()]
         self._dual_path_fwd(G, bw["dp0"], B, T2, 4, k.dp[0])
         self._dual_path_fwd(G, bw["dp1"], B, T2, 3, k.dp[1])
@@ -201,8 +205,7 @@ class HipTrainer:
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
-        k.l0, k.l1 = full(), low()
-        self._call("rtfs_dwconv_fwd", k.D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [k.l0], [st[3]], B, T, F_BINS)
+        k.l1 = low()
         self._call("rtfs_dwconv_fwd", k.D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [k.l1], [st[4]], B, T2, F2)
         k.g0, k.gg0, k.g1, k.gg1 = low(), low(), low(), low()
         self._call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [k.g0, k.gg0, k.g1, k.gg1],
