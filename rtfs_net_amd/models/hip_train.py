@@ -439,10 +439,10 @@ class HipTrainer:
         self._call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
         self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
-        # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as a copy of dE
+        # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
         dN_cl, dN_cgate, dN_cg = full(), low(), low()
         self._call("rtfs_mix_bwd", dE, k.cl, st[9], cl_[2], cl_[3], k.cgate, st[11], cgate_[2], cgate_[3], dN_cl, dN_cgate, dN_cg, B, T, F_BINS, T2, F2)
-        dN_D0 = dE.clone()
+        dN_D0 = dE
         # concat layer: gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
         self._gln_bwd(dN_cl, k.cl, st[9], cl_[2], cl_[3], dcl, False, gr, "blk.cl", B, TF)
