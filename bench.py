@@ -344,6 +344,7 @@ def main():
         # ---- riders of the default N = 1 line, each measured by a child run of this script on the same configuration:
         #   training_step   BASELINE config 3 (`--mode train`, fp32)
         #   split_bf16      the same separation forward with `--dtype bf16x3` (bf16 MFMA pipe, three-term products, waveform within 1e-5 of fp32)
+        #   training_step_split_bf16   the training step with `--dtype bf16x3` (forward and adjoint GEMMs as three-term split-bf16 products)
         if world == 1 and args.mode == "infer" and args.dtype == "f32" and not args.lip and not args.no_train_line and not args.no_cpu_baseline:
             import subprocess
 
@@ -367,6 +368,7 @@ def main():
 
             res["training_step"] = brief(child(["--mode", "train", "--steps", "6", "--warmup", "2"]))
             res["split_bf16"] = brief(child(["--dtype", "bf16x3", "--steps", str(args.steps), "--warmup", str(args.warmup)]))
+            res["training_step_split_bf16"] = brief(child(["--mode", "train", "--dtype", "bf16x3", "--steps", "6", "--warmup", "2"]))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -36,6 +36,8 @@ def test_single_process_line():
     assert tr["roofline"]["bound"] == "mfma" and "wgrad" in tr["roofline"]["kernel"]
     sb = res["split_bf16"]
     assert sb is not None and sb["dtype"] == "bf16x3" and sb["value"] > 0
+    tb = res["training_step_split_bf16"]
+    assert tb is not None and tb["dtype"] == "bf16x3" and tb["value"] > 0 and "training step" in tb["workload"]
 
 
 def test_lip_encoder_in_the_timed_step():
