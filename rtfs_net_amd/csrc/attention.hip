@@ -61,37 +61,45 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
     mma_block_nt<NT, 1, 3>(acc, As + w * 32 * LDA, LDA, Bs, LDA, 64);
     __syncthreads();  // every wave is done reading As / Bs before Ys overwrites them
 
+    // post-PReLU tile into LDS, and the LN4D statistics over (c, F) per token and module straight from the accumulators: a wave owns 32
+    // frequency bins of ONE token, a lane 16 of them for one output column per column tile; the 12 groups of a token are runs of 4 (Q, K)
+    // or 16 (V) consecutive columns = lanes.  Sum and sum of squares per lane, xor-shuffles inside the run and across the two lane halves,
+    // one partial per (wave, group) through LDS.  (The first version walked the LDS tile group by group, two passes of dependent 4-byte
+    // reads, 6 groups per wave: 6.6 us of latency chain per workgroup.)
+    __shared__ float part[4][12][2];
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+    for (int n = 0; n < 3; ++n) {
+        const int col = n * 32 + (lane & 31);
+        const float cb = bias[col], cs = slope[col];
+        float s = 0.f, q = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = w * 32 + acc_row(r), col = n * 32 + (lane & 31);
-            const float pre = acc[0][n][r] + bias[col];
+            const int row = w * 32 + acc_row(r);
+            const float pre = acc[0][n][r] + cb;
             if (Ypre && row < ntok * 64) Ypre[((size_t)tok0 * 64 + row) * kQkvN + col] = pre;  // training: pre-activation for the adjoint
-            Ys[row * LDY + col] = prelu(pre, slope[col]);
+            const float y = prelu(pre, cs);
+            Ys[row * LDY + col] = y;
+            s += y;
+            q = fmaf(y, y, q);
         }
+        const int run = n == 0 ? 4 : 16;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+            if (o < run) s += __shfl_xor(s, o, 64), q += __shfl_xor(q, o, 64);
+        s += __shfl_xor(s, 32, 64), q += __shfl_xor(q, 32, 64);
+        if (lane < 32 && (lane & (run - 1)) == 0) {
+            const int g = n == 0 ? (lane >> 2) : 8 + 2 * (n - 1) + (lane >> 4);
+            part[w][g][0] = s, part[w][g][1] = q;
+        }
+    }
     __syncthreads();
-
-    // LN4D statistics over (c, F) per token per module: 24 groups, 6 per wave, two-pass.
-    for (int gi = 0; gi < 6; ++gi) {
-        const int g24 = w * 6 + gi;
-        const int tok = g24 / 12, g = g24 % 12;
-        const int col0 = g < 8 ? g * 4 : 32 + (g - 8) * 16;
-        const int sh = g < 8 ? 2 : 4, ncol = 1 << sh;  // 4 or 16 columns: shifts, not a runtime integer division per element
-        const int cnt = 64 * ncol;
-        float s = 0.f;
-        for (int i = lane; i < cnt; i += 64) s += Ys[(tok * 64 + (i >> sh)) * LDY + col0 + (i & (ncol - 1))];
-        const float mean = wave_sum(s) / cnt;
-        float q = 0.f;
-        for (int i = lane; i < cnt; i += 64) {
-            const float d = Ys[(tok * 64 + (i >> sh)) * LDY + col0 + (i & (ncol - 1))] - mean;
-            q = fmaf(d, d, q);
-        }
-        q = wave_sum(q);
-        if (lane == 0) {
-            st[g24][0] = mean;
-            st[g24][1] = 1.0f / sqrtf(q / cnt + kEps);
-        }
+    if (threadIdx.x < 24) {
+        const int tok = threadIdx.x / 12, g = threadIdx.x % 12;
+        const float cnt = g < 8 ? 256.f : 1024.f;
+        const float mean = (part[2 * tok][g][0] + part[2 * tok + 1][g][0]) / cnt;
+        const float var = fmaxf((part[2 * tok][g][1] + part[2 * tok + 1][g][1]) / cnt - mean * mean, 0.f);
+        st[threadIdx.x][0] = mean;
+        st[threadIdx.x][1] = 1.0f / sqrtf(var + kEps);
     }
     __syncthreads();
 
