@@ -451,6 +451,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
     else
         mma_block_bn_p<NT, 1, 1>(acc, Ws + wm * 32 * LD, LD, Xs + wn * 32, LD, 64);
     float s = 0.f;
+    float yv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = wm * 32 + acc_row(r), f = wn * 32 + (lane & 31);
@@ -458,16 +459,18 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
         if (Ypre) Ypre[tok * 4096 + f * 64 + co] = pre;  // training: pre-activation, channels-last [f][co]
         const float y = prelu(pre, slope);
         Ys[co * LDY + f] = y;
+        yv[r] = y;
         s += y;
     }
-    // mean
+    // mean, then the centred sum of squares from the values still in registers (two-pass, no LDS walk)
     s = wave_sum(s);
     if (lane == 0) red[w] = s;
     __syncthreads();
     const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.f / 4096.f);
     float q = 0.f;
-    for (int i = threadIdx.x; i < 4096; i += 256) {
-        const float d = Ys[(i >> 6) * LDY + (i & 63)] - mean;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float d = yv[r] - mean;
         q = fmaf(d, d, q);
     }
     q = wave_sum(q);
@@ -475,11 +478,15 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) * (1.f / 4096.f) + kEps);
     float* g = G + tok * 4096;
+    // residual update in 16-byte pieces: a thread owns 4 consecutive channels of one frequency bin (gamma / beta / G are [f][c])
 #pragma unroll
-    for (int i = threadIdx.x; i < 4096; i += 256) {
+    for (int it = 0; it < 4; ++it) {
+        const int i = (threadIdx.x + it * 256) * 4;
         const int f = i >> 6, c = i & 63;
-        const float y = (Ys[c * LDY + f] - mean) * rstd;
-        g[i] = fmaf(y, gamma_fc[i], beta_fc[i]) + g[i];
+        const float4 y = f4(Ys[c * LDY + f], Ys[(c + 1) * LDY + f], Ys[(c + 2) * LDY + f], Ys[(c + 3) * LDY + f]);
+        const float4 ga = ld4(gamma_fc + i), be = ld4(beta_fc + i), g0 = ld4(g + i);
+        st4(g + i, f4(fmaf((y.x - mean) * rstd, ga.x, be.x) + g0.x, fmaf((y.y - mean) * rstd, ga.y, be.y) + g0.y, fmaf((y.z - mean) * rstd, ga.z, be.z) + g0.z,
+                      fmaf((y.w - mean) * rstd, ga.w, be.w) + g0.w));
     }
 }
 

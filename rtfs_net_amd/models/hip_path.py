@@ -428,6 +428,8 @@ class HipForward:
         cur = torch.cuda.current_stream()
         self._vp_stream.wait_stream(cur)
         Tv = emb.shape[-1]
+        att = torch.empty(B * Tv * C, device=dev)  # (allocated on the main stream: its allocator owns them, the side stream only fills them)
+        rsz = torch.empty_like(att)
         with torch.cuda.stream(self._vp_stream):
             vin = m.video_bottleneck(emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
             if w["vp"] is not None and 8 <= Tv <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
@@ -435,21 +437,20 @@ class HipForward:
                 lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
             else:  # other video_params / lengths: PyTorch-ROCm glue (models/modules.py)
                 v1 = m.refinement_module.video_net.get_block(0)(vin).contiguous()
+            # the CAF cell's video side (one workgroup per utterance, 64 us) rides on the side stream as well
+            lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
+                     w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
 
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
         x = torch.empty_like(a_emb)
-        att = torch.empty(B * Tv * C, device=dev)
-        rsz = torch.empty_like(att)
         last = R == 1
         fuse = len(blocks) == 1 and os.environ.get("RTFS_NO_PROJ_FUSION", "0") != "1"  # shared block weights: block i+1's projection = block i's
 
-        def caf_video():
+        def caf_video():  # join the side stream: att / rsz (and v1 for the taps) are ready past this point
             cur.wait_stream(self._vp_stream)
             v1.record_stream(cur)
-            lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
-                     w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
 
         y0_next = None
         # stage taps want the block output itself; Tv > T cannot happen on the product path (25 video frames / s vs 125 STFT frames / s)
