@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Where do the small device copies of one inference forward come from?  (torch.profiler, python stacks of every Memcpy / copy_ op)"""
+"""What else runs in one inference forward besides the rtfs_* kernels?  torch.profiler: every aten op and every device activity that is not
+an rtfs kernel, with counts (the small `__amd_rocclr_copyBuffer` launches of the kernel trace show up here with their origin)."""
 import copy
 import sys
 
@@ -26,9 +27,10 @@ with torch.no_grad():
 rows = {}
 for e in prof.events():
     n = e.name
-    if "emcpy" in n or n in ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_"):
-        st = [s for s in (e.stack or []) if "rtfs_net_amd" in s]
-        key = (n, st[0] if st else "?")
-        rows[key] = rows.get(key, 0) + 1
-for (n, s), c in sorted(rows.items(), key=lambda kv: -kv[1]):
-    print(f"{c:4d}  {n:28s} {s}")
+    if n.startswith("void rtfs::") or n.startswith("rtfs::"):
+        continue
+    st = [s for s in (e.stack or []) if "rtfs_net_amd" in s]
+    key = (str(e.device_type).split(".")[-1], n[:60], st[0][-70:] if st else "")
+    rows[key] = rows.get(key, 0) + 1
+for (d, n, s), c in sorted(rows.items(), key=lambda kv: -kv[1])[:40]:
+    print(f"{c:4d}  {d:5s} {n:60s} {s}")
