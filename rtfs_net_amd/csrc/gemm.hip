@@ -11,6 +11,7 @@
 // Tiling: 256 threads = 4 waves; workgroup tile BM x N (full N), K streamed in 32-deep chunks through
 // double-buffered LDS; each wave owns WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).  Weights are
 // pre-transposed on the host to Wt[N][K] so both operands are k-contiguous in LDS (common.h).
+#include <cstdlib>
 #include "common.h"
 
 namespace rtfs {
@@ -305,8 +306,17 @@ __global__ __launch_bounds__(256, (WM * WN >= 8 ? 2 : 1)) void pixel_gemm_kernel
 // Each workgroup walks `tiles_per_wg` consecutive 64-pixel tiles of one utterance.
 // ------------------------------------------------------------------------------------------------
 // CAF (rtfs_resid_caf_fwd): the CAF cell's audio side rides in the epilogue; HAS_A0 then means "+ s_in" (no separate a0 stream).
-template <bool HAS_A0, bool PROJ = false, int NT = 0, bool CAF = false>  // NT != 0: Wt and epi.pw are host-PACKED (common.h)
-__global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+// DEEP: ONE workgroup per CU with the whole 512-entry register file (256 VGPR + 256 AGPR per lane): the projection weights stay resident
+// next to the residual-conv weights, both 32-pixel halves' residual operands are fetched before the MFMA phase and the next tile's E
+// operands right after it - every load is issued a full phase before its first use, so a tile costs its arithmetic (fp32 MFMA + the
+// VALU it does not overlap with) instead of arithmetic + three exposed load -> use latencies that two co-resident workgroups only
+// partly cover for each other.  Per element the same arithmetic in the same order as the two-workgroup form (the fp32
+// partial sums of the projection's gLN statistics cover 4x more tiles per workgroup: 1e-7-level differences downstream).
+// DEEP = 1: both halves' residual operands are fetched at the top of their tile; DEEP = 2: each half's register set is re-filled for the NEXT tile as
+// soon as its epilogue has consumed it (reads in flight through every phase).  Measured at B = 32 (us, normal / 1 / 2): residual + projection 1053 / 1047 / 956,
+// CAF + projection 1037 / 980 / 1051, plain 555 / 545 / 623 - the launcher picks per variant.
+template <bool HAS_A0, bool PROJ = false, int NT = 0, bool CAF = false, int DEEP = 0>  // NT != 0: Wt and epi.pw are host-PACKED (common.h)
+__global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LDE = 68;
     constexpr int LDO = 260;
     __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
@@ -368,11 +378,48 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
             xa[it] = ld4_off(cl_b, hi), xd[it] = ld4_off(d0_b, hi), xg[it] = ld4_off(cg_b, lo), xs[it] = ld4_off(cgate_b, lo);
         }
     };
+    // DEEP: projection weights resident: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3], t = 0..15
+    float4 wpr[(DEEP && PROJ) ? 16 : 1];
+    if constexpr (DEEP && PROJ) {
+        const float* wpp0 = epi.pw + (size_t)(16 * w + (lane & 15)) * 256 + 64 * (lane >> 4);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wpr[t] = ld4(wpp0 + 4 * t);
+    }
+    constexpr int NH = DEEP ? 2 : 1;  // register sets of residual operands: DEEP keeps one per 32-pixel half, each re-filled for the NEXT tile as soon as
+                                      // its half's epilogue has consumed it - some 64 KB of reads are in flight per CU through every phase of a tile
+    float4 sv[NH][8], av[NH][8];
+    // CAF: a 32-pixel half spans at most two STFT frames t, hence at most two video frames tv(t) = floor(t Tv / T): both (att, rsz) row
+    // pairs are fetched with the residual operands (the registers of the a0 stream, which this variant does not have)
+    float4 catt[NH][2], crsz[NH][2];
+    int caf_split[NH];  // first pixel row of the half that belongs to the second frame
+    auto load_sv = [&](int m0, int pt) {
+        const int hs = DEEP ? pt : 0;
+        const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
+            sv[hs][it] = ld4_off(s_b, o);
+            if (HAS_A0 && !CAF) av[hs][it] = ld4_off(a0_b, o);
+        }
+        if (CAF) {
+            const int p0 = min(m0 + pt * 32, Mb - 1), p1 = min(m0 + pt * 32 + 31, Mb - 1);
+            const int t0 = p0 / kF, t1 = p1 / kF;
+            caf_split[hs] = (t0 + 1) * kF;
+            const unsigned o0 = ((unsigned)nearest_src(t0, epi.Tv, pro.T) * kC + cq) * 4u, o1 = ((unsigned)nearest_src(t1, epi.Tv, pro.T) * kC + cq) * 4u;
+            catt[hs][0] = ld4_off(att_b, o0), crsz[hs][0] = ld4_off(rsz_b, o0), catt[hs][1] = ld4_off(att_b, o1), crsz[hs][1] = ld4_off(rsz_b, o1);
+        }
+    };
+    const int tile_last = min(tile0 + tiles_per_wg, (Mb + 63) / 64) - 1;
+    if constexpr (DEEP != 0) load_e(tile0 * 64);
+    if constexpr (DEEP == 2) {
+        load_sv(tile0 * 64, 0);
+        load_sv(tile0 * 64, 1);
+    }
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
         const int m0 = (tile0 + tl) * 64;
         if (m0 >= Mb) break;
-        load_e(m0);
+        if constexpr (!DEEP) load_e(m0);
         {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -384,29 +431,11 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
         __syncthreads();
         // residual-side operands of the first 32-pixel half: issued BEFORE the MFMA phase so that their HBM latency runs under it
         // (the kernel is latency-bound once the projection rides in the epilogue)
-        float4 sv[8], av[8];
-        // CAF: a 32-pixel half spans at most two STFT frames t, hence at most two video frames tv(t) = floor(t Tv / T): both (att, rsz) row
-        // pairs are fetched with the residual operands (the registers of the a0 stream, which this variant does not have)
-        float4 catt[2], crsz[2];
-        int caf_split = 0;  // first pixel row of the half that belongs to the second frame
-        auto load_sv = [&](int pt) {
-            const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const unsigned o = ((unsigned)min(prow + 4 * it, Mb - 1) * kC + cq) * 4u;
-                sv[it] = ld4_off(s_b, o);
-                if (HAS_A0 && !CAF) av[it] = ld4_off(a0_b, o);
-            }
-            if (CAF) {
-                const int p0 = min(m0 + pt * 32, Mb - 1), p1 = min(m0 + pt * 32 + 31, Mb - 1);
-                const int t0 = p0 / kF, t1 = p1 / kF;
-                caf_split = (t0 + 1) * kF;
-                const unsigned o0 = ((unsigned)nearest_src(t0, epi.Tv, pro.T) * kC + cq) * 4u, o1 = ((unsigned)nearest_src(t1, epi.Tv, pro.T) * kC + cq) * 4u;
-                catt[0] = ld4_off(att_b, o0), crsz[0] = ld4_off(rsz_b, o0), catt[1] = ld4_off(att_b, o1), crsz[1] = ld4_off(rsz_b, o1);
-            }
-        };
-        load_sv(0);
-        __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks these loads below the MFMAs to save registers)
+        if constexpr (DEEP != 2) {
+            load_sv(m0, 0);
+            if constexpr (DEEP == 1) load_sv(m0, 1);
+            __builtin_amdgcn_sched_barrier(0);  // (left alone, hipcc sinks these loads below the MFMAs to save registers)
+        }
         floatx16 acc[2][2];
         acc_zero(acc);
         if constexpr (NT == 0) {
@@ -439,16 +468,24 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
                 }
             }
         }
+        const int m0_next = min(tile0 + tl + 1, tile_last) * 64;  // (the last tile re-fetches itself: L2 hits, no branch around the loads)
+        if constexpr (DEEP) {  // next tile's E operands
+            __builtin_amdgcn_sched_barrier(0);
+            load_e(m0_next);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // Epilogue through LDS.  In the accumulator a lane owns ONE pixel and 16 B of channels, so a direct global epilogue makes
         // every b128 access touch 32 pixel rows x 32 B (measured: 50 L1 tag accesses per wave-instruction, TA 60 % busy, the
         // kernel issue-stalled behind it).  Transposed through LDS, thread = (channel quad, pixel row): one wave-instruction is
         // one pixel's whole 1 KB row - 8 lines - for s_in, a0 and the store; the per-channel constants sit in registers.
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            float4 wp[16];  // PROJ: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3], t = 0..15
+            float4 wps[DEEP ? 1 : 16];  // PROJ: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3], t = 0..15 (streamed per half unless DEEP)
             const float* wpp = PROJ ? epi.pw + (size_t)(16 * w + (lane & 15)) * 256 + 64 * (lane >> 4) : nullptr;
             const int prow = m0 + pt * 32 + (threadIdx.x >> 6);
-            if (pt == 1) load_sv(1);
+            constexpr int hs_ = 0;
+            const int hs = DEEP ? pt : hs_;
+            if (!DEEP && pt == 1) load_sv(m0, 1);
             int coff = cq;
             if (CAF) asm volatile("" : "+v"(coff));  // opaque: the table reads stay inside the epilogue loop
             __syncthreads();  // pt = 0: every wave is done with Es / pt = 1: Ot of the previous half has been read
@@ -462,22 +499,27 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int r = (threadIdx.x >> 6) + 4 * it;
-                float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[it], cgw, cgb), epi.slope - 1.0f);
+                float4 v = ld4(Ot + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[hs][it], cgw, cgb), epi.slope - 1.0f);
                 if (CAF) {
-                    const bool second = prow + 4 * it >= caf_split;
-                    const float4 at = second ? catt[1] : catt[0], rz = second ? crsz[1] : crsz[0];
+                    const bool second = prow + 4 * it >= caf_split[hs];
+                    const float4 at = second ? catt[hs][1] : catt[hs][0], rz = second ? crsz[hs][1] : crsz[hs][0];
                     v = fma4(at, fma4(v, ld4(cafc + 2 * kC + coff), ld4(cafc + 3 * kC + coff)), relu4(fma4(v, ld4(cafc + coff), ld4(cafc + kC + coff))) * rz);
-                    if (HAS_A0) v = v + sv[it];
+                    if (HAS_A0) v = v + sv[hs][it];
                 } else if (HAS_A0) {
-                    v = v + av[it];
+                    v = v + av[hs][it];
                 }
                 if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
                 if (PROJ) {
                     st4(Ot + r * LDO + cq, pack4<NT>(prelu4(fma4(v, cgw, cgb), epi.slope)));  // the next block's gateway, in place
                     // two of the 16 projection-weight fragments per iteration, into the registers sv / av just left (L2 latency
                     // hidden behind the rest of this loop)
-                    wp[2 * it] = ld4(wpp + 8 * it), wp[2 * it + 1] = ld4(wpp + 8 * it + 4);
+                    if constexpr (!DEEP) wps[2 * it] = ld4(wpp + 8 * it), wps[2 * it + 1] = ld4(wpp + 8 * it + 4);
                 }
+            }
+            if constexpr (DEEP == 2) {  // this half's register set is free: the same half of the NEXT tile, in flight under the projection / the other half
+                __builtin_amdgcn_sched_barrier(0);
+                load_sv(m0_next, pt);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (PROJ) {
                 // projection of the 32 gated pixels now in Ot, as proj_kernel does it: 16x16x4 MFMA, wave w owns output channels
@@ -491,26 +533,30 @@ __global__ __launch_bounds__(256, 2) void resid_kernel(ProExpanded pro, EpiResid
 #pragma unroll
                 for (int c = 0; c < 4; ++c) pa[c] = floatx4{0.f, 0.f, 0.f, 0.f};
                 const float* ap = Ot + j * LDO + 64 * kk;
+                auto wp = [&](int t) -> const float4& {
+                    if constexpr (DEEP) return wpr[t];
+                    else return wps[t];
+                };
                 if constexpr (NT == 0) {
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
                         const float4 e0 = ld4(ap + 4 * t), e1 = ld4(ap + 16 * LDO + 4 * t);
                         const int c = 2 * (t & 1);
-                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e0.x, pa[c], 0, 0, 0);
-                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].x, e1.x, pa[c + 1], 0, 0, 0);
-                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e0.y, pa[c], 0, 0, 0);
-                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].y, e1.y, pa[c + 1], 0, 0, 0);
-                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e0.z, pa[c], 0, 0, 0);
-                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].z, e1.z, pa[c + 1], 0, 0, 0);
-                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e0.w, pa[c], 0, 0, 0);
-                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[t].w, e1.w, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).x, e0.x, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).x, e1.x, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).y, e0.y, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).y, e1.y, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).z, e0.z, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).z, e1.z, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).w, e0.w, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp(t).w, e1.w, pa[c + 1], 0, 0, 0);
                     }
                 } else {
 #pragma unroll
                     for (int t2 = 0; t2 < 8; ++t2) {  // 16x16x32: lane group kk supplies the 8 k values of packed slots 2 t2, 2 t2 + 1
                         const Frag e0 = frag_lds<NT>(ld4(ap + 8 * t2), ld4(ap + 8 * t2 + 4));
                         const Frag e1 = frag_lds<NT>(ld4(ap + 16 * LDO + 8 * t2), ld4(ap + 16 * LDO + 8 * t2 + 4));
-                        const Frag wq = frag_lds<NT>(wp[2 * t2], wp[2 * t2 + 1]);
+                        const Frag wq = frag_lds<NT>(wp(2 * t2), wp(2 * t2 + 1));
                         const int c = 2 * (t2 & 1);
                         mma16<NT>(pa[c], wq, e0);
                         mma16<NT>(pa[c + 1], wq, e1);
@@ -699,6 +745,21 @@ static int resid_impl(const float* cl, const double* cl_stats, const float* cl_g
     // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
     // 64 -> 804; small batches get more, smaller workgroups.
     const int Mb = T * kF, tiles = (Mb + 63) / 64;
+    // one workgroup per CU with the whole register file for the two projection-carrying variants at large batch (resid_kernel, DEEP);
+    // RTFS_RESID_DEEP=0 keeps the two-workgroup form for A/B
+    const char* deep_env = getenv("RTFS_RESID_DEEP");  // (read per call: the A/B test flips it inside one process)
+    const bool deep_off = deep_env != nullptr && deep_env[0] == '0';
+    if (Wp && !deep_off && (long long)tiles * B >= 2048) {
+        const long long wantd = ((long long)tiles * B + 255) / 256;
+        const int perd = (int)(wantd > 128 ? 128 : wantd);
+        const dim3 gridd((tiles + perd - 1) / perd, B);
+        if (caf)
+            hipLaunchKernelGGL((resid_kernel<true, true, NT, true, 1>), gridd, dim3(256), 0, st, pro, epi, Wt, Mb, perd);
+        else
+            hipLaunchKernelGGL((resid_kernel<true, true, NT, false, 2>), gridd, dim3(256), 0, st, pro, epi, Wt, Mb, perd);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     const long long want = ((long long)tiles * B + 1023) / 1024;
     const int per = (int)(want < 2 ? 2 : (want > 16 ? 16 : want));
     const dim3 grid((tiles + per - 1) / per, B);

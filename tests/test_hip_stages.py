@@ -342,3 +342,22 @@ def test_trio_entry_against_separate_entries(B, T):
     assert rel(s1b[:, :2], s1a[:, :2]) < 1e-6 and rel(s2b[:, :2], s2a[:, :2]) < 1e-6
     with pytest.raises(RuntimeError):
         lib.call("rtfs_dwconv_trio_fwd", D0, st0, gam, bet, w1, l0b, s1b, w2, bias2, D1b, s2b, P, B, T, T2 + 1)
+
+
+def test_resid_one_workgroup_per_cu_form_matches():
+    """At large batch the projection-carrying residual kernels run as ONE workgroup per CU with the whole register file (resident
+    projection weights, every load a phase ahead; gemm.hip resid_kernel DEEP): per element the same arithmetic in the same order as the
+    two-workgroup form that small batches and RTFS_RESID_DEEP=0 take; a workgroup owns 4x more tiles, so the fp32 partial sums behind the
+    projection's gLN statistics group differently (1e-7 level)."""
+    import os
+
+    model, sd, cfg = make_model(3, "cuda")
+    mix, _, emb = synth.synth_inputs(10, 16000, 25)  # 254 tiles x 10 utterances >= 2048: the large-batch form
+    with torch.no_grad():
+        deep = model(mix.cuda(), emb.cuda())
+        os.environ["RTFS_RESID_DEEP"] = "0"
+        try:
+            plain = model(mix.cuda(), emb.cuda())
+        finally:
+            del os.environ["RTFS_RESID_DEEP"]
+    assert rel(deep, plain) < 1e-6
