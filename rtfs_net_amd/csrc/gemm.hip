@@ -364,9 +364,10 @@ __global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded 
     float* y_b = epi.y + (size_t)b * Mb * kC;
     const int tile0 = blockIdx.x * tiles_per_wg;
     // E tile operands: 64 pixels x 64 channels, 4 float4 per thread and tensor (rows past the end are clamped: their columns are never
-    // stored).  (Measured, round 2: issuing tile i + 1's loads in the second half of tile i's epilogue - into the registers the
-    // accumulators have just left - made every variant SLOWER: 1065 -> 1163 us with the fused projection, 563 -> 576 us without; the
-    // co-resident workgroup already covers this latency and the early loads only delay the epilogue's own operands.)
+    // stored).  (Measured, round 2, in the two-workgroup form: issuing tile i + 1's loads in the second half of tile i's epilogue - into
+    // the registers the accumulators have just left - made every variant SLOWER: 1065 -> 1163 us with the fused projection, 563 -> 576 us
+    // without; single early loads only queue in front of the epilogue's own operands.  The DEEP form, with the register file to keep a whole
+    // tile's operands in flight, does prefetch them - see the template comment.)
     float4 xa[4], xd[4], xg[4], xs[4];
     auto load_e = [&](int m0) {
 #pragma unroll
