@@ -33,34 +33,44 @@ __global__ __launch_bounds__(256) void sru_scan_train_kernel(const float* __rest
     float* h = Hout + (size_t)s * L * 64 + lane;
     float* cs = Cout + (size_t)s * L * 64 + lane;
     float c = 0.f;
-#pragma unroll 1
-    for (int t0 = 0; t0 < L; t0 += UNR) {
-        float u0[UNR], u1[UNR], u2[UNR], xp[UNR];
+    // two register sets: batch i + 1 is fetched before the recurrence of batch i (as in sru_scan_kernel, dualpath.hip)
+    float va[UNR][4], vb[UNR][4];
+    auto load = [&](int t0, float (&v)[UNR][4]) {
 #pragma unroll
         for (int i = 0; i < UNR; ++i) {
             const int t = min(t0 + i, L - 1);
             const int l = rev ? L - 1 - t : t;
             if (KM == 4) {
-                const float4 v = ld4(u + (size_t)l * 256);
-                u0[i] = v.x, u1[i] = v.y, u2[i] = v.z, xp[i] = v.w;
+                const float4 q = ld4(u + (size_t)l * 256);
+                v[i][0] = q.x, v[i][1] = q.y, v[i][2] = q.z, v[i][3] = q.w;
             } else {
                 const float* p = u + (size_t)l * 192;
-                u0[i] = p[0], u1[i] = p[64], u2[i] = p[128];
-                xp[i] = x[(size_t)l * 64] * scale_x;
+                v[i][0] = p[0], v[i][1] = p[64], v[i][2] = p[128];
+                v[i][3] = x[(size_t)l * 64] * scale_x;
             }
         }
+    };
+    auto run = [&](int t0, const float (&v)[UNR][4]) {
 #pragma unroll
         for (int i = 0; i < UNR; ++i) {
             const int t = t0 + i;
             if (t < L) {
                 const int l = rev ? L - 1 - t : t;
-                const float f = sigmoidf_fast(u1[i] + bf + wf * c);
-                const float r = sigmoidf_fast(u2[i] + br + wr * c);
-                c = u0[i] + (c - u0[i]) * f;
+                const float f = sigmoidf_fast(v[i][1] + bf + wf * c);
+                const float r = sigmoidf_fast(v[i][2] + br + wr * c);
+                c = v[i][0] + (c - v[i][0]) * f;
                 cs[(size_t)l * 64] = c;
-                h[(size_t)l * 64] = xp[i] + (c - xp[i]) * r;
+                h[(size_t)l * 64] = v[i][3] + (c - v[i][3]) * r;
             }
         }
+    };
+    load(0, va);
+#pragma unroll 1
+    for (int t0 = 0; t0 < L; t0 += 2 * UNR) {
+        load(t0 + UNR, vb);
+        run(t0, va);
+        load(t0 + 2 * UNR, va);
+        run(t0 + UNR, vb);
     }
 }
 
