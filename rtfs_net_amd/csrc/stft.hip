@@ -138,17 +138,27 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float* __restri
     float2* Bf = buf[w][1];
     const float* tp = taps + (size_t)b * T * kF * 32;
     for (int k = lane; k < kF; k += 64) {
+        // the 18 taps of a bin: all loads first, addresses clamped and the out-of-range taps masked afterwards (a load under a branch is
+        // waited for before the next one issues: 18 serial L2 latencies per bin in the first version)
+        float vr[9], vi[9];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const int tt = t - kt + 1, ff = k - kf + 1;
+                const float* p = tp + ((size_t)min(max(tt, 0), T - 1) * kF + min(max(ff, 0), kF - 1)) * 32 + kt * 3 + kf;
+                vr[kt * 3 + kf] = p[0];
+                vi[kt * 3 + kf] = p[9];
+            }
         float re = 0.f, im = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
             for (int kf = 0; kf < 3; ++kf) {
                 const int tt = t - kt + 1, ff = k - kf + 1;
-                if (tt >= 0 && tt < T && ff >= 0 && ff < kF) {
-                    const float* p = tp + ((size_t)tt * kF + ff) * 32 + kt * 3 + kf;
-                    re += p[0];
-                    im += p[9];
-                }
+                const bool ok = tt >= 0 && tt < T && ff >= 0 && ff < kF;
+                re += ok ? vr[kt * 3 + kf] : 0.f;  // (same summation order as before: bit-identical)
+                im += ok ? vi[kt * 3 + kf] : 0.f;
             }
         if (k == 0 || k == 128) im = 0.f;  // C2R ignores the imaginary part of DC and Nyquist
         A[k] = make_float2(re, im);
