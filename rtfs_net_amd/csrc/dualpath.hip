@@ -149,6 +149,16 @@ __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const f
         if (idx < 2 * kSlabRows * 16) st4(slab[q] + row * kSlabLd + c4, pack4<NT>(v));
     }
     breg.store(Bs[0], LDB);
+    // the residual rows this lane will add to (G, in place) are fetched here, clamped and unconditional, so that their latency runs under
+    // the 8 k-chunks instead of in front of the stores
+    const size_t sbase = map.base(seq[st]);
+    float4 res[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = min(m0[st] + m * 32 + (lane & 31), map.npos - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) res[m][g] = ld4(dst + sbase + (size_t)row * map.pos_stride + wn * 32 + 8 * g + 4 * (lane >> 5));
+    }
     __syncthreads();
     floatx16 acc[1][2];
     acc_zero(acc);
@@ -161,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const f
         __syncthreads();
     }
     if ((int)blockIdx.x * 2 + st < total_tiles) {
-        const size_t sbase = map.base(seq[st]);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int row = m0[st] + m * 32 + (lane & 31);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void convt_gemm2_kernel(SeqMap map, const f
                 for (int g = 0; g < 4; ++g) {
                     const int col = wn * 32 + 8 * g + 4 * (lane >> 5);
                     float* o = dst + sbase + (size_t)row * map.pos_stride + col;
-                    st4(o, acc_group(acc[0][m], g) + ld4(bias + col) + ld4(o));
+                    st4(o, acc_group(acc[0][m], g) + ld4(bias + col) + res[m][g]);
                 }
             }
         }
