@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const float* __restrict__ wav
 
 // a_emb[b][t][f][c] = sum_{ci,dt,df} W[c][ci][dt][df] * spec[b][t+dt-1][f+df-1][ci]; Wp: [18][256], tap = ci*9+dt*3+df.
 // grid: (ceil(T*F/64), B); each wave walks 16 pixels, each lane owns 4 output channels.
+constexpr int kEncTiles = 4;
 __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__ spec, const float* __restrict__ Wp, float* __restrict__ a_emb,
                                                        double* __restrict__ stats, int T) {
     // The 3x3 neighbourhood of pixel p = t*F + f is p + {-F,0,F} + {-1,0,1} in the flattened [T][F] spectrogram, so the 64 pixels of a
@@ -94,13 +95,18 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 18; ++i) wr[i] = ld4(Wp + i * 256 + lane * 4);
     const float2* sp = reinterpret_cast<const float2*>(spec) + (size_t)b * TF;
-    const int p0 = blockIdx.x * 64;
+    float s = 0.f, q = 0.f;
+    // kEncTiles 64-pixel tiles per workgroup: the 18 weight vectors, the launch and the two statistics atomics are paid once per 256 pixels
+#pragma unroll 1
+    for (int tile = 0; tile < kEncTiles; ++tile) {
+    const int p0 = (blockIdx.x * kEncTiles + tile) * 64;
+    if (p0 >= TF) break;
+    if (tile) __syncthreads();  // the previous tile's taps have been read
     for (int i = threadIdx.x; i < NS; i += 256) {
         const int p = p0 - HALO + i;
         sps[i] = (p >= 0 && p < TF) ? sp[p] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    float s = 0.f, q = 0.f;
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int p = p0 + w * 16 + i;
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(const float* __restrict__
             s += acc.x + acc.y + acc.z + acc.w;
             q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
         }
+    }
     }
     block_stats_commit(s, q, red, stats, b);
 }
@@ -213,7 +220,7 @@ int rtfs_stft_fwd(const float* wav, float* spec, int B, int L, void* stream) {
 
 int rtfs_enc_conv_fwd(const float* spec, const float* Wp, float* a_emb, double* stats, int B, int T, void* stream) {
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(enc_conv_kernel, dim3((T * kF + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, spec, Wp, a_emb, stats, T);
+    hipLaunchKernelGGL(enc_conv_kernel, dim3((T * kF + 64 * kEncTiles - 1) / (64 * kEncTiles), B), dim3(256), 0, (hipStream_t)stream, spec, Wp, a_emb, stats, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
