@@ -4,15 +4,19 @@
     python bench.py [--gpus N --steps K --warmup W] [--layers 6 --batch 32 --seconds 2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under torch.distributed.run (N ranks on
+this node, rendezvous on 127.0.0.1), so both launch forms work.
+
 A "step" = one pass of the hot path (AVNet.forward: STFT -> RTFS blocks -> CAF -> S3 mask -> iSTFT) over one
 batch of synthetic 16 kHz mixtures + lip embeddings already resident in HBM.  Utterances are independent, so N
-GPUs = N shards of the global batch with NO data-path collective ("scaling": "weak"); the only collectives are the
-timing barrier and the max-over-ranks of the elapsed time.
+GPUs = N contiguous shards of the global batch (rtfs_net_amd.dist_util.shard_bounds) with NO data-path collective
+("scaling": "weak"); the only collectives are the timing barrier, the max-over-ranks of the elapsed time and the sum of the frames.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     -- the dominant kernel, timed live with HIP events on the launch stream during the timed steps
                   (infer: the layer-0 unfold GEMM; train: the dominant BACKWARD kernel, the layer-0 Toeplitz weight gradient)
   cpu_baseline -- the oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample (N=1 only)
+and, on the default N = 1 line, riders for the other BASELINE.json configurations (see RIDERS below).
 `value` / `ms_per_step` come from the wall clock around the K timed steps (barrier + synchronize on both sides, max over ranks);
 `ms_per_step_median` is the median of the per-step HIP-event durations of the same K steps.
 """
@@ -22,8 +26,10 @@ import argparse
 import copy
 import json
 import os
+import socket
 import sys
 import time
+from types import SimpleNamespace
 
 import torch
 
@@ -33,8 +39,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 F_BINS, F2, C, H = 129, 64, 256, 64
+DTYPE_TEXT = {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation and activations",
+              "bf16x3": "split-bf16 (3-term) MFMA / fp32 accumulation and activations",
+              "bf16x6": "fp32 operands split into three bf16 values (6-term products on the bf16 MFMA pipe) / fp32 accumulation and activations"}
 
 
 def kernel_models(B, T, T2, Tv):
@@ -42,23 +52,23 @@ def kernel_models(B, T, T2, Tv):
     bytes = stage-boundary tensors read once + written once (fp32); flops = 2 * MACs."""
     TF, lo = T * F_BINS, T2 * F2
     full_c, full_h, low_h = 4.0 * B * TF * C, 4.0 * B * TF * H, 4.0 * B * lo * H
-    m = {
+    return {
         "rtfs_bottleneck_fwd": ("mfma", 2.0 * B * TF * C * C),
         "rtfs_mask_fwd": ("mfma", 2.0 * B * TF * C * C),
         "rtfs_proj_fwd": ("hbm", full_c + full_h),
         "rtfs_resid_fwd": ("hbm", 2 * full_h + 2 * low_h + 3 * full_c),  # cl, d0, cg, cgate, s_in, a0 -> out
+        "rtfs_resid_proj_fwd": ("hbm", 3 * full_h + 2 * low_h + 3 * full_c),  # + the next block's projection output
         "rtfs_caf_fuse_fwd": ("hbm", 3 * full_c),
         "rtfs_enc_conv_fwd": ("hbm", full_c + 4.0 * B * TF * 2),
     }
-    return m
 
 
-def pmc_traffic(kernel_substr, args):
+def pmc_traffic(kernel_substr, a):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (profiles/pmc_traffic.json, written by
     tools/pmc_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command line with the
     gfx950 read correction of MI355X_MICROARCH.md).  Only valid for the default workload; otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path) or (args.layers, args.batch, args.seconds) != (6, 32, 2.0):
+    if not os.path.exists(path) or (a.layers, a.batch, a.seconds, a.dtype, a.mode) != (6, 32, 2.0, "f32", "infer"):
         return None
     for k, v in json.load(open(path)).items():
         if kernel_substr in k:
@@ -69,6 +79,263 @@ def pmc_traffic(kernel_substr, args):
 def dp_gemm_flops(B, T2):
     """per-launch flops of rtfs_dp_unfold_gemm_fwd: freq (dim 4) and time (dim 3) launches differ"""
     return {4: 2.0 * B * T2 * (F2 - 7) * 512 * 256, 3: 2.0 * B * F2 * (T2 - 7) * 512 * 256}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def measure(a, rank, world, local_rank, dist, one_gpu):
+    """One measurement of configuration `a` (layers, batch, seconds, dtype, mode, lip, steps, warmup, roofline_kernel) -> (result dict or
+    None on ranks > 0, handles for the CPU-baseline leg).  Inputs resident in HBM before the timed region; K steps between barriers."""
+    from rtfs_net_amd import AVNet, lib
+    from rtfs_net_amd import synthetic as synth  # deterministic synthetic weights / inputs (the oracle is only used for cpu_baseline)
+    from rtfs_net_amd.dist_util import max_over_ranks, shard_bounds, sum_over_ranks
+
+    dev = torch.device("cuda", local_rank)
+    L = int(a.seconds * 16000)
+    T = 1 + L // 128
+    T2 = (T - 2) // 2 + 1
+    Tv = int(25 * a.seconds)
+    cfg = synth.rtfs_audionet(a.layers)
+    torch.manual_seed(1234)
+    model = AVNet(print_macs=False, **copy.deepcopy(cfg)).eval()
+    sd = synth.synth_state_dict(model.state_dict())  # random-init weights of the architecture ("data": synthetic)
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    if a.dtype != "f32":
+        model.set_compute_dtype(a.dtype)  # inference path and training step alike (MFMA kernels only; everything else stays fp32)
+    # the GLOBAL batch of world x batch utterances, sharded contiguously: this rank owns [lo, hi)
+    lo, hi = shard_bounds(world * a.batch, rank, world)
+    gmix, gtgt, gemb = synth.synth_inputs(world * a.batch, L, Tv, seed=synth.INPUT_SEED)
+    mix, emb, target = gmix[lo:hi].contiguous().to(dev), gemb[lo:hi].contiguous().to(dev), gtgt[lo:hi].contiguous().to(dev)
+    del gmix, gtgt, gemb
+
+    lipnet = crops = None
+    if a.lip:
+        if a.mode != "infer":
+            raise SystemExit("--lip is an inference option (the lip encoder is frozen)")
+        from rtfs_net_amd.models import videomodels
+        from rtfs_net_amd.synthetic import lip_inputs
+
+        lipnet = videomodels.FRCNNVideoModel(print_macs=False)
+        lipnet.load_state_dict(synth.synth_state_dict(lipnet.state_dict(), salt=3))
+        lipnet = lipnet.to(dev)
+        lipnet.eval()
+        crops = lip_inputs(hi - lo, Tv, seed=synth.INPUT_SEED + rank).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def forward():
+        return model(mix, lipnet(crops) if lipnet is not None else emb)
+
+    step_events = []
+
+    def timed(fn):
+        """K steps between barriers; every step additionally bracketed by HIP events on the compute stream (median step time)"""
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = fn()
+            e1.record()
+            step_events.append((e0, e1))
+        barrier()
+        return o, time.perf_counter() - t0
+
+    # train mode: the dominant backward kernel is the layer-0 Toeplitz weight gradient (rtfs_wgrad with nshift = 8 taps, 256 output
+    # columns: dW0 = sum over windows of dU0^T . X); its integer arguments are (ldy, ldx, ldw, rows, L, npos, shift0, nshift, N, K, ...)
+    kern = a.roofline_kernel or ("rtfs_dp_unfold_gemm_fwd" if a.mode == "infer" else "rtfs_wgrad")
+    wgrad_l0 = (lambda ints: len(ints) >= 10 and ints[7] == 8 and ints[8] == 256) if kern == "rtfs_wgrad" else None
+
+    if a.mode == "infer":
+        with torch.no_grad():
+            for _ in range(a.warmup):
+                out = forward()
+            barrier()
+            lib.profile_begin(kern)  # HIP events around that entry point's launches only
+            out, elapsed = timed(forward)
+            prof = lib.profile_end()
+    else:
+        # training step as in train.py:98-101,135-146 + config yaml:117-120: neg-SNR loss, AdamW(lr 1e-3, wd 0.1), clip 5.0,
+        # DDP gradient all-reduce (one 2.96 MB bucket) and SyncBatchNorm over RCCL when N > 1
+        model.train()
+        net = model
+        if dist is not None:
+            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+
+        from rtfs_net_amd.losses import PITLossWrapper, pairwise_neg_snr
+
+        loss_fn = PITLossWrapper(pairwise_neg_snr, pit_from="pw_mtx")  # train.py:98-101; HIP loss head (csrc/loss.hip)
+        target = target.unsqueeze(1)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            est = net(mix, emb)
+            loss = loss_fn(est, target)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            return est.detach()
+
+        for _ in range(a.warmup):
+            out = step()
+        barrier()
+        lib.profile_begin(kern, wgrad_l0)
+        out, elapsed = timed(step)
+        prof = lib.profile_end()
+    assert torch.isfinite(out).all()
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in step_events)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+
+    elapsed = max_over_ranks(elapsed, dev, dist)
+    frames = sum_over_ranks(float((hi - lo) * T * a.steps), dev, dist)  # the units ALL ranks processed
+    handles = SimpleNamespace(model=model, sd=sd, cfg=cfg, L=L, T=T, Tv=Tv, dev=dev)
+    if rank != 0:
+        return None, handles
+    res = {
+        "metric": "separated STFT frames/sec" if a.mode == "infer" else "trained STFT frames/sec (fwd+bwd+optimizer)",
+        "value": frames / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "ms_per_step_median": median_ms,  # per-step HIP events on rank 0's compute stream
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": a.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": (f"RTFS-Net-{a.layers} separation forward (AVNet.forward, eval), " if a.mode == "infer" else
+                         f"RTFS-Net-{a.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
+                        + f"{a.seconds:g} s @16 kHz, batch {a.batch} per GPU, " + DTYPE_TEXT[a.dtype] + ", random-init weights",
+            "mode": a.mode + ("+lip-encoder" if a.lip else ""),
+            "global_batch": world * a.batch, "frames_per_utt": T, "utt_per_s": world * a.batch * a.steps / elapsed,
+            "parallelism": f"utterance-sharded x{world} (contiguous shards of one global batch), no data-path collective"
+                           + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
+        },
+    }
+    # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
+    roof = None
+    if prof:
+        terms = {"bf16": 1, "bf16x3": 3, "bf16x6": 6}.get(a.dtype, 0)
+        fl = dp_gemm_flops(a.batch, T2)
+        tot_ms = sum(prof)
+        if kern == "rtfs_dp_unfold_gemm_fwd" and terms:
+            # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
+            by = {4: 4.0 * (a.batch * T2 * F2 * H + a.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (a.batch * T2 * F2 * H + a.batch * F2 * (T2 - 7) * 256)}
+            roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{terms}> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on v_mfma_f32_32x32x16_bf16)",
+                    "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,
+                    "mfma_tflops_algorithmic": (fl[4] + fl[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12}
+        elif kern == "rtfs_dp_unfold_gemm_fwd":
+            tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)  # launches alternate dim 4 (freq), dim 3 (time)
+            roof = {"kernel": "rtfs::unfold_gemm128f_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
+                    "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
+                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", a),
+                    "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
+        elif kern == "rtfs_wgrad":
+            # dW0[256][512] += dU0[S*L][256]^T . X_unfold[S*L][512]: the same 2*S*L*512*256 flop as the forward layer-0 GEMM
+            tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)
+            roof = {"kernel": "rtfs::toeplitz_wgrad_kernel (rtfs_wgrad, nshift 8: weight gradient of LN4D + unfold + SRU layer-0 GEMM, "
+                              + ("bf16 MFMA (%s), " % a.dtype if terms else "fp32 MFMA, ") + "all 8 taps per staged row block)",
+                    "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                    "peak": MFMA_BF16_PEAK_TF / terms if terms else MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
+        else:
+            km = kernel_models(a.batch, T, T2, Tv).get(kern)
+            if km is not None:
+                bound, amount = km
+                avg_ms = tot_ms / len(prof)
+                if bound == "hbm":
+                    roof = {"kernel": kern, "bound": "hbm", "achieved": amount / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+                else:
+                    roof = {"kernel": kern, "bound": "mfma", "achieved": amount / (avg_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
+                roof.update(launches=len(prof), avg_launch_ms=avg_ms, traffic=None)
+        if roof:
+            roof["frac"] = roof["achieved"] / roof["peak"]
+    res["roofline"] = roof
+    return res, handles
+
+
+def cpu_baseline(res, h, a):
+    """the oracle on the host cores, bounded sample + SI-SDRi parity of the HIP estimate (rank 0, N = 1 only)"""
+    from oracle.avnet_ref import avnet_forward
+    from rtfs_net_amd import synthetic as synth
+    from rtfs_net_amd.metrics import separation_metrics
+
+    cmix, ctgt, cemb = synth.synth_inputs(1, h.L, h.Tv)
+    # the many small ops of this model do not scale to every host core: probe a few thread counts (one run each,
+    # which also warms up) and time the fastest one
+    best_n, best_t = torch.get_num_threads(), float("inf")
+    with torch.no_grad():
+        for cand in sorted({8, 16, 32, torch.get_num_threads()}):
+            if cand > torch.get_num_threads() and cand > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(cand)
+            avnet_forward(h.sd, h.cfg, cmix, cemb)
+            t1 = time.perf_counter()
+            avnet_forward(h.sd, h.cfg, cmix, cemb)
+            dt1 = time.perf_counter() - t1
+            if dt1 < best_t:
+                best_n, best_t = cand, dt1
+    torch.set_num_threads(best_n)
+    n = best_n
+    with torch.no_grad():
+        runs, t0 = 0, time.perf_counter()
+        while runs < 10 and (time.perf_counter() - t0) < a.cpu_budget_s:
+            avnet_forward(h.sd, h.cfg, cmix, cemb)
+            runs += 1
+        dt = (time.perf_counter() - t0) / runs
+    # SI-SDRi parity (BASELINE.json metric): improvement over the mixture of the HIP estimate vs the oracle's, same utterance
+    with torch.no_grad():
+        c_or = avnet_forward(h.sd, h.cfg, cmix, cemb)
+        c_hip = h.model.eval()(cmix.to(h.dev), cemb.to(h.dev))
+    tgt = ctgt.to(h.dev)
+    m_hip = separation_metrics(cmix[0].to(h.dev), tgt, c_hip[0])
+    m_or = separation_metrics(cmix[0].to(h.dev), tgt, c_or[0].to(h.dev))
+    res["si_sdri_parity"] = {"hip_db": m_hip["si-snr_i"], "oracle_db": m_or["si-snr_i"], "abs_diff_db": abs(m_hip["si-snr_i"] - m_or["si-snr_i"]),
+                             "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
+    res["cpu_baseline"] = {"value": h.T / dt, "unit": "frames/s", "cores": n, "kind": "port",
+                           "sample": f"oracle/avnet_ref.py, RTFS-Net-{a.layers}, batch 1 x {a.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
+
+
+def brief(t):
+    return None if t is None else {
+        "metric": t["metric"], "value": t["value"], "unit": t["unit"], "dtype": t["dtype"], "ms_per_step": t["ms_per_step"],
+        "ms_per_step_median": t["ms_per_step_median"], "steps": t["steps"], "warmup": t["warmup"], "workload": t["config"]["workload"],
+        "roofline": t["roofline"]}
+
+
+# Riders of the default N = 1 line (the other configurations of BASELINE.json on the same build):
+#   in this process, one after the other (inference):
+#     config2            RTFS-Net-4, batch 16, 2 s, fp32 forward                              (BASELINE config 2)
+#     config5_bf16x3     RTFS-Net-12, batch 16, 4 s, split-bf16 forward                       (BASELINE config 5 shape, the mode that holds 1e-3)
+#     config5_bf16       the same with plain bf16 operands                                    (what config 5 literally names; 4e-3 on the waveform)
+#     latency_b1         RTFS-Net-6, batch 1, 2 s, fp32: ms per utterance - comparable with the reference's published 64.7 ms (BASELINE.md §1)
+#     split_bf16         the headline workload with --dtype bf16x3
+#   in child processes (the training step holds ~60 GB of activations):
+#     training_step / training_step_split_bf16    BASELINE config 3 (`--mode train`), fp32 and bf16x3
+INFER_RIDERS = [
+    ("config2", dict(layers=4, batch=16, seconds=2.0, dtype="f32", steps=10, warmup=2)),
+    ("config5_bf16x3", dict(layers=12, batch=16, seconds=4.0, dtype="bf16x3", steps=6, warmup=2)),
+    ("config5_bf16", dict(layers=12, batch=16, seconds=4.0, dtype="bf16", steps=6, warmup=2)),
+    ("latency_b1", dict(layers=6, batch=1, seconds=2.0, dtype="f32", steps=30, warmup=5)),
+    ("split_bf16", dict(layers=None, batch=None, seconds=None, dtype="bf16x3", steps=None, warmup=None)),
+]
 
 
 def main():
@@ -90,14 +357,17 @@ def main():
     ap.add_argument("--roofline-kernel", default=None, help="entry point timed for the roofline object (default: rtfs_dp_unfold_gemm_fwd, "
                     "or rtfs_wgrad's layer-0 Toeplitz launches in --mode train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-line", action="store_true",
-                    help="N = 1 infer runs also measure the training step of the same configuration (BASELINE config 3) in a child process and "
-                         "attach it as `training_step`; this flag skips that (it is skipped together with the CPU baseline as well)")
+    ap.add_argument("--no-train-line", action="store_true", help="skip the riders of the default N = 1 line (they are skipped together with the CPU baseline as well)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
-    if args.roofline_kernel is None:
-        args.roofline_kernel = "rtfs_dp_unfold_gemm_fwd" if args.mode == "infer" else "rtfs_wgrad"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher the driver would have used (one rank per GPU of this node, RCCL over xGMI)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,7 +381,6 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -120,236 +389,34 @@ def main():
         if one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
-    from rtfs_net_amd import AVNet, lib
-    from rtfs_net_amd import synthetic as synth  # deterministic synthetic weights / inputs (the oracle is only used for cpu_baseline below)
-    from rtfs_net_amd.dist_util import max_over_ranks
-
-    L = int(args.seconds * 16000)
-    T = 1 + L // 128
-    T2 = (T - 2) // 2 + 1
-    Tv = int(25 * args.seconds)
-    cfg = synth.rtfs_audionet(args.layers)
-    torch.manual_seed(1234)
-    model = AVNet(print_macs=False, **copy.deepcopy(cfg)).eval()
-    sd = synth.synth_state_dict(model.state_dict())  # random-init weights of the architecture ("data": synthetic)
-    model.load_state_dict(sd)
-    model = model.to(dev)
-    if args.dtype != "f32":
-        model.set_compute_dtype(args.dtype)  # inference path and training step alike (MFMA kernels only; everything else stays fp32)
-    # each rank gets its own shard of the global batch (different seed -> different utterances)
-    mix, _, emb = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)
-    mix, emb = mix.to(dev), emb.to(dev)
-
-    lipnet = crops = None
-    if args.lip:
-        if args.mode != "infer":
-            raise SystemExit("--lip is an inference option (the lip encoder is frozen)")
-        from rtfs_net_amd.models import videomodels
-        from rtfs_net_amd.synthetic import lip_inputs
-
-        lipnet = videomodels.FRCNNVideoModel(print_macs=False)
-        lipnet.load_state_dict(synth.synth_state_dict(lipnet.state_dict(), salt=3))
-        lipnet = lipnet.to(dev)
-        lipnet.eval()
-        crops = lip_inputs(args.batch, Tv, seed=synth.INPUT_SEED + rank).to(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def forward():
-        return model(mix, lipnet(crops) if lipnet is not None else emb)
-
-    step_events = []
-
-    def timed(fn):
-        """K steps between barriers; every step additionally bracketed by HIP events on the compute stream (median step time)"""
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            o = fn()
-            e1.record()
-            step_events.append((e0, e1))
-        barrier()
-        return o, time.perf_counter() - t0
-
-    # train mode: the dominant backward kernel is the layer-0 Toeplitz weight gradient (rtfs_wgrad with nshift = 8 taps, 256 output
-    # columns: dW0 = sum over windows of dU0^T . X); its integer arguments are (ldy, ldx, ldw, rows, L, npos, shift0, nshift, N, K, ...)
-    wgrad_l0 = (lambda ints: len(ints) >= 10 and ints[7] == 8 and ints[8] == 256) if args.roofline_kernel == "rtfs_wgrad" else None
-
-    if args.mode == "infer":
-        with torch.no_grad():
-            for _ in range(args.warmup):
-                out = forward()
-            barrier()
-            lib.profile_begin(args.roofline_kernel)  # HIP events around that entry point's launches only
-            out, elapsed = timed(forward)
-            prof = lib.profile_end()
-    else:
-        # training step as in train.py:98-101,135-146 + config yaml:117-120: neg-SNR loss, AdamW(lr 1e-3, wd 0.1), clip 5.0,
-        # DDP gradient all-reduce (one 2.96 MB bucket) and SyncBatchNorm over RCCL when N > 1
-        model.train()
-        target = synth.synth_inputs(args.batch, L, Tv, seed=synth.INPUT_SEED + rank)[1].to(dev)
-        net = model
-        if dist is not None:
-            net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-            net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
-
-        from rtfs_net_amd.losses import PITLossWrapper, pairwise_neg_snr
-
-        loss_fn = PITLossWrapper(pairwise_neg_snr, pit_from="pw_mtx")  # train.py:98-101; HIP loss head (csrc/loss.hip)
-        target = target.unsqueeze(1)
-
-        def step():
-            opt.zero_grad(set_to_none=True)
-            est = net(mix, emb)
-            loss = loss_fn(est, target)
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
-            opt.step()
-            return est.detach()
-
-        for _ in range(args.warmup):
-            out = step()
-        barrier()
-        lib.profile_begin(args.roofline_kernel, wgrad_l0)
-        out, elapsed = timed(step)
-        prof = lib.profile_end()
-    assert torch.isfinite(out).all()
-    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
-    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-
-    elapsed = max_over_ranks(elapsed, dev, dist)
-
+    res, h = measure(args, rank, world, local_rank, dist, one_gpu)
     if rank == 0:
-        frames = world * args.batch * T * args.steps
-        res = {
-            "metric": "separated STFT frames/sec" if args.mode == "infer" else "trained STFT frames/sec (fwd+bwd+optimizer)",
-            "value": frames / elapsed,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_per_step_median": median_ms,  # per-step HIP events on rank 0's compute stream
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": (f"RTFS-Net-{args.layers} separation forward (AVNet.forward, eval), " if args.mode == "infer" else
-                             f"RTFS-Net-{args.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
-                            + f"{args.seconds:g} s @16 kHz, batch {args.batch} per GPU, "
-                            + {"f32": "fp32", "bf16": "bf16 MFMA operands / fp32 accumulation and activations", "bf16x3": "split-bf16 (3-term) MFMA / fp32 accumulation and activations",
-                               "bf16x6": "fp32 operands split into three bf16 values (6-term products on the bf16 MFMA pipe) / fp32 accumulation and activations"}[args.dtype]
-                            + ", random-init weights",
-                "mode": args.mode + ("+lip-encoder" if args.lip else ""),
-                "global_batch": world * args.batch, "frames_per_utt": T, "utt_per_s": world * args.batch * args.steps / elapsed,
-                "parallelism": f"utterance-sharded x{world}, no data-path collective" + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
-            },
-        }
-        # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
-        roof = None
-        if prof:
-            name = args.roofline_kernel
-            if name == "rtfs_dp_unfold_gemm_fwd" and args.dtype != "f32":
-                # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
-                by = {4: 4.0 * (args.batch * T2 * F2 * H + args.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (args.batch * T2 * F2 * H + args.batch * F2 * (T2 - 7) * 256)}
-                tot_ms = sum(prof)
-                roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{ {'bf16': 1, 'bf16x3': 3, 'bf16x6': 6}[args.dtype] }> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on "
-                                  "v_mfma_f32_32x32x16_bf16)", "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
-                        "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,
-                        "mfma_tflops_algorithmic": (dp_gemm_flops(args.batch, T2)[4] + dp_gemm_flops(args.batch, T2)[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12}
-            elif name == "rtfs_dp_unfold_gemm_fwd":
-                fl = dp_gemm_flops(args.batch, T2)
-                durs = prof  # launches alternate dim 4 (freq), dim 3 (time)
-                tot_ms = sum(durs)
-                tot_fl = (fl[4] + fl[3]) * (len(durs) // 2)
-                roof = {"kernel": "rtfs::unfold_gemm128f_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
-                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "launches": len(durs), "avg_launch_ms": tot_ms / len(durs),
-                        "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", args),
-                        "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
-            elif name == "rtfs_wgrad":
-                # dW0[256][512] += dU0[S*L][256]^T . X_unfold[S*L][512]: the same 2*S*L*512*256 flop as the forward layer-0 GEMM
-                fl = dp_gemm_flops(args.batch, T2)
-                tot_ms = sum(prof)
-                tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)
-                bf = args.dtype != "f32"
-                roof = {"kernel": "rtfs::toeplitz_wgrad_kernel (rtfs_wgrad, nshift 8: weight gradient of LN4D + unfold + SRU layer-0 GEMM, "
-                                  + ("bf16 MFMA (%s), " % args.dtype if bf else "fp32 MFMA, ") + "all 8 taps per staged row block)",
-                        "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
-                        "peak": {"f32": MFMA_F32_PEAK_TF, "bf16": 2500.0, "bf16x3": 2500.0 / 3, "bf16x6": 2500.0 / 6}[args.dtype], "unit": "TFLOP/s",
-                        "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
-            else:
-                km = kernel_models(args.batch, T, T2, Tv).get(name)
-                if km is not None:
-                    bound, amount = km
-                    avg_ms = sum(prof) / len(prof)
-                    if bound == "hbm":
-                        roof = {"kernel": name, "bound": "hbm", "achieved": amount / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-                    else:
-                        roof = {"kernel": name, "bound": "mfma", "achieved": amount / (avg_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s"}
-                    roof.update(launches=len(prof), avg_launch_ms=avg_ms, traffic=None)
-            if roof:
-                roof["frac"] = roof["achieved"] / roof["peak"]
-        res["roofline"] = roof
-        # ---- CPU baseline: the oracle on the host cores, bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.avnet_ref import avnet_forward
-
-            cmix, _, cemb = synth.synth_inputs(1, L, Tv)
-            # the many small ops of this model do not scale to every host core: probe a few thread counts (one run each,
-            # which also warms up) and time the fastest one
-            best_n, best_t = torch.get_num_threads(), float("inf")
-            with torch.no_grad():
-                for cand in sorted({8, 16, 32, torch.get_num_threads()}):
-                    if cand > torch.get_num_threads() and cand > (os.cpu_count() or 1):
-                        continue
-                    torch.set_num_threads(cand)
-                    avnet_forward(sd, cfg, cmix, cemb)
-                    t1 = time.perf_counter()
-                    avnet_forward(sd, cfg, cmix, cemb)
-                    dt1 = time.perf_counter() - t1
-                    if dt1 < best_t:
-                        best_n, best_t = cand, dt1
-            torch.set_num_threads(best_n)
-            n = best_n
-            with torch.no_grad():
-                runs, t0 = 0, time.perf_counter()
-                while runs < 10 and (time.perf_counter() - t0) < args.cpu_budget_s:
-                    avnet_forward(sd, cfg, cmix, cemb)
-                    runs += 1
-                dt = (time.perf_counter() - t0) / runs
-            # SI-SDRi parity (BASELINE.json metric): improvement over the mixture of the HIP estimate vs the oracle's, same utterance
-            with torch.no_grad():
-                c_or = avnet_forward(sd, cfg, cmix, cemb)
-                c_hip = model(cmix.to(dev), cemb.to(dev))
-            from rtfs_net_amd.metrics import separation_metrics
-
-            tgt = synth.synth_inputs(1, L, Tv)[1].to(dev)
-            m_hip = separation_metrics(cmix[0].to(dev), tgt, c_hip[0])
-            m_or = separation_metrics(cmix[0].to(dev), tgt, c_or[0].to(dev))
-            res["si_sdri_parity"] = {"hip_db": m_hip["si-snr_i"], "oracle_db": m_or["si-snr_i"], "abs_diff_db": abs(m_hip["si-snr_i"] - m_or["si-snr_i"]),
-                                     "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
-            res["cpu_baseline"] = {"value": T / dt, "unit": "frames/s", "cores": n, "kind": "port",
-                                   "sample": f"oracle/avnet_ref.py, RTFS-Net-{args.layers}, batch 1 x {args.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
-        # ---- riders of the default N = 1 line, each measured by a child run of this script on the same configuration:
-        #   training_step   BASELINE config 3 (`--mode train`, fp32)
-        #   split_bf16      the same separation forward with `--dtype bf16x3` (bf16 MFMA pipe, three-term products, waveform within 1e-5 of fp32)
-        #   training_step_split_bf16   the training step with `--dtype bf16x3` (forward and adjoint GEMMs as three-term split-bf16 products)
+            cpu_baseline(res, h, args)
         if world == 1 and args.mode == "infer" and args.dtype == "f32" and not args.lip and not args.no_train_line and not args.no_cpu_baseline:
             import subprocess
 
-            del model, mix, emb, out
+            del h
             torch.cuda.empty_cache()
+            for name, over in INFER_RIDERS:
+                ra = copy.copy(args)
+                for k, v in over.items():
+                    if v is not None:
+                        setattr(ra, k, v)
+                ra.roofline_kernel = None
+                try:
+                    r, hh = measure(ra, 0, 1, local_rank, None, False)
+                    res[name] = brief(r)
+                    if name == "latency_b1" and r is not None:
+                        res[name]["ms_per_utterance"] = r["ms_per_step_median"]
+                        res[name]["reference_published_ms"] = 64.7  # docs/main_table.png (RTFS-Net-6, one 2 s utterance, hardware not stated): context only
+                    del hh
+                except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                    res[name] = None
+                    print(f"rider {name} failed: {type(e).__name__}: {e}", file=sys.stderr)
+                torch.cuda.empty_cache()
             common = ["--no-cpu-baseline", "--layers", str(args.layers), "--batch", str(args.batch), "--seconds", str(args.seconds)]
 
             def child(extra):
@@ -357,18 +424,12 @@ def main():
                     r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True, text=True, timeout=600)
                     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                     return json.loads(line[-1]) if (r.returncode == 0 and line) else None
-                except Exception:  # noqa: BLE001  (the headline line must still be printed)
+                except Exception:  # noqa: BLE001
                     return None
 
-            def brief(t):
-                return None if t is None else {
-                    "metric": t["metric"], "value": t["value"], "unit": t["unit"], "dtype": t["dtype"], "ms_per_step": t["ms_per_step"],
-                    "ms_per_step_median": t["ms_per_step_median"], "steps": t["steps"], "warmup": t["warmup"], "workload": t["config"]["workload"],
-                    "roofline": t["roofline"]}
-
-            res["training_step"] = brief(child(["--mode", "train", "--steps", "6", "--warmup", "2"]))
-            res["split_bf16"] = brief(child(["--dtype", "bf16x3", "--steps", str(args.steps), "--warmup", str(args.warmup)]))
-            res["training_step_split_bf16"] = brief(child(["--mode", "train", "--dtype", "bf16x3", "--steps", "6", "--warmup", "2"]))
+            nt = str(max(2, min(20, args.steps)))
+            res["training_step"] = brief(child(["--mode", "train", "--steps", nt, "--warmup", "3"]))
+            res["training_step_split_bf16"] = brief(child(["--mode", "train", "--dtype", "bf16x3", "--steps", nt, "--warmup", "3"]))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -68,8 +68,9 @@ int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, co
 
 /* ---- a6-a7: DualPathRNN.forward, layers/rnn_layers.py:136-162; sru.SRU (external, oracle/sru_ref.py) --------- */
 /* dim 4: sequences along F (one per (b,t2)); dim 3: along T (one per (b,f2)).  S sequences of L = npos-7 windows. */
+/* variant: 0 = the library's choice (tiles cut from the flattened (sequence, window) row index), 1 = tiles padded per sequence (A/B; same bits) */
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, float* U0, int B, int T2, int dim,
-                            void* stream);
+                            int variant, void* stream);
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
                       void* stream);
 /* SRU layers 1-3 with the input projection U = Hprev . W fused into the recurrence (U never reaches HBM): Wt [192][64], row = m*64 + dir*32 + j;
@@ -111,12 +112,15 @@ int rtfs_resid_fwd(const float* cl, const double* cl_stats, const float* cl_g, c
                    int T, int T2, void* stream);
 /* rtfs_resid_fwd of block i (with a0) fused with rtfs_proj_fwd of block i+1 (the blocks share their weights, tdanet.py:9-59 / `shared`):
  * out as above, plus py = Wp . prelu(out*gw+gb) + pbias ([B][T*129][64], pre-gLN) and its gLN partial sums in pstats - the next
- * block's projection (tdanet.py:108-109) is computed from the output tile while it is still in LDS. */
+ * block's projection (tdanet.py:108-109) is computed from the output tile while it is still in LDS.
+ * variant (also rtfs_resid_caf_fwd): kernel form at large batch (>= 2048 64-pixel tiles), same result up to the grouping of the fp32 partial sums
+ * behind pstats.  0 = the library's choice; 1 = two 4-wave workgroups per CU; 2 = one 4-wave workgroup per CU with the whole register file;
+ * 3 = one 8-wave workgroup per CU, MFMA waves + memory / element-wise waves (csrc/gemm.hip resid_ws_kernel).  Anything else: RTFS_EINVAL. */
 int rtfs_resid_proj_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                         const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                         const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt,
                         const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0, float* out,
-                        const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream);
+                        const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2, int variant, void* stream);
 
 /* ---- a10: CAF, ATTNFusionCell.forward, layers/fusion.py:252-274 --------------------------------------------- */
 int rtfs_caf_video_fwd(const float* v /*[B][512][Tv]*/, const float* att_w, const float* att_b, const float* att_g, const float* att_be,
@@ -134,7 +138,7 @@ int rtfs_resid_caf_fwd(const float* cl, const double* cl_stats, const float* cl_
                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt,
                        const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* ks, const float* kb,
                        const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input, float* out,
-                       const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream);
+                       const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, int variant, void* stream);
 
 /* ---- a11: MaskGenerator.forward + __apply_masks (RI_split), TDAVNet/mask_generator.py:67-99 ------------------ */
 int rtfs_mask_fwd(const float* x, float slope, const float* Wt /*[256][256]*/, const float* bias, const float* a_emb, float* masked,
@@ -264,8 +268,8 @@ int rtfs_bottleneck_fwd_bf16(const float* a_emb, const double* stats, const floa
                              float* a0, int B, int TF, int terms, void* stream);
 int rtfs_proj_fwd_bf16(const float* s, const float* gw, const float* gb, float gslope, const void* Wpk, const float* bias, float* y, double* stats_out,
                        int B, int TF, int terms, void* stream);
-int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
-                                 void* stream);
+int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int variant,
+                                 int terms, void* stream);
 int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout,
                             float* Cout_or_null, float* Uout_or_null, int S, int L, int terms, void* stream);
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream);
@@ -284,13 +288,15 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
                              const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                              const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk,
                              const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* a0, float* out,
-                             const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2, int terms, void* stream);
+                             const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2, int variant, int terms,
+                             void* stream);
 int rtfs_resid_caf_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                             const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                             const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk,
                             const float* bias, const float* s_in, const float* gw, const float* gb, float gslope, const float* ks, const float* kb,
                             const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input, float* out,
-                            const void* Wp_pk_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, int terms, void* stream);
+                            const void* Wp_pk_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, int variant, int terms,
+                            void* stream);
 int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float* bias, const float* a_emb, float* masked, float* m_or_null, int B,
                        int TF, int terms, void* stream);
 int rtfs_gemm_rows_fwd_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int terms, void* stream);

@@ -75,9 +75,14 @@ def _norm(x, p: P, kind, training=False):
     raise ValueError(f"unsupported norm {kind}")
 
 
+ACT_PROBE = None  # tests only: callable(x, kind) that sees the input of every PReLU / ReLU (tests/util.py: kink margins of the gradient checks)
+
+
 def _act(x, p: P | None, kind):
     if kind is None:
         return x
+    if ACT_PROBE is not None and kind in ("PReLU", "ReLU"):
+        ACT_PROBE(x, kind)
     if kind == "PReLU":
         return F.prelu(x, p["weight"])
     if kind == "ReLU":

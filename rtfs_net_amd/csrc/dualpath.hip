@@ -318,6 +318,12 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128_kernel(SeqMap map, cons
 // 78 KB of LDS: two workgroups per CU.  The raw rows of the next pair are fetched into registers under the last K loop of the
 // current one.
 constexpr int kFlatRows = 64 + 21;
+// Bank-conflict-free segment jumps (round 3): consecutive output rows of a wave read consecutive slab rows, 17 sixteen-byte slots apart, so
+// eight / sixteen neighbouring lanes hit distinct slot residues - except across a sequence boundary, where the slab row jumps by the 7 halo
+// rows and two lanes of the group met in one bank (PMC, round 2: 28 % of this kernel's LDS cycles were conflict cycles).  Segment g of a
+// slab is therefore stored 9 g slots further on: the jump becomes 7 x 17 + 9 = 128 slots = 0 (mod 16) and the residues continue as if the
+// rows were consecutive.  Costs 288 bytes of LDS per slab and one per-lane constant.
+constexpr int kSegSkew = 36;  // floats (= 9 slots) per segment index
 struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
     int r0, s0, l0, n0, n1;  // first flattened row, its (sequence, position); rows of segment 0, 1 (segment 2 = the rest)
 };
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
                                                                  int S, int total_tiles) {
     constexpr int BK = 32, N = 256, NP = 128;  // columns per pass
     constexpr int NIT = (2 * kFlatRows * 16 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float slab[2][kFlatRows * kSlabLd];
+    __shared__ __attribute__((aligned(16))) float slab[2][kFlatRows * kSlabLd + 2 * kSegSkew];
     __shared__ __attribute__((aligned(16))) float Bs[2][NP * BK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
@@ -362,9 +368,9 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
     };
     float4 sraw[NIT];
     // slab row j of a tile -> (sequence, position, valid)
-    auto slab_row = [&](const FlatTile& t, int j, int& sq, int& pos) {
+    auto slab_row = [&](const FlatTile& t, int j, int& sq, int& pos, int& g) {
         const int e0 = t.n0 + 7, e1 = e0 + t.n1 + 7, n2 = 64 - t.n0 - t.n1;
-        const int g = (j >= e0) + (j >= e1);
+        g = (j >= e0) + (j >= e1);
         const int jj = j - (g == 0 ? 0 : (g == 1 ? e0 : e1));
         const int ng = g == 0 ? t.n0 : (g == 1 ? t.n1 : n2);
         sq = t.s0 + g;
@@ -378,8 +384,8 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             const int idx = threadIdx.x + it * 256;
             const int st = idx >= kFlatRows * 16 ? 1 : 0;
             const int j = min((idx - st * kFlatRows * 16) >> 4, kFlatRows - 1);
-            int sq, pos;
-            slab_row(t[st], j, sq, pos);
+            int sq, pos, g;
+            slab_row(t[st], j, sq, pos, g);
             sraw[it] = ld4(src + map.base(min(sq, S - 1)) + (size_t)min(pos, map.npos - 1) * map.pos_stride + (threadIdx.x & 15) * 4);
         }
     };
@@ -392,8 +398,8 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             const int st = idx >= kFlatRows * 16 ? 1 : 0;
             const int j = (idx - st * kFlatRows * 16) >> 4;
             const bool inr = idx < 2 * kFlatRows * 16;
-            int sq, pos;
-            const bool ok = slab_row(t[st], min(j, kFlatRows - 1), sq, pos) && inr;
+            int sq, pos, g;
+            const bool ok = slab_row(t[st], min(j, kFlatRows - 1), sq, pos, g) && inr;
             const float4 v = sraw[it];
             float sum = v.x + v.y + v.z + v.w;
 #pragma unroll
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             for (int o = 8; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o, 64);
             const float rstd = 1.0f / sqrtf(sqs * (1.f / 64.f) + kEps);
             const float4 y = ok ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
-            if (inr) st4(slab[st] + j * kSlabLd + (threadIdx.x & 15) * 4, pack4<NT>(y));
+            if (inr) st4(slab[st] + j * kSlabLd + g * kSegSkew + (threadIdx.x & 15) * 4, pack4<NT>(y));
         }
     };
 
@@ -440,11 +446,11 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
         const bool new_pair = has_next && ((u + 1) >> 1) != pair;
         if (new_pair) fetch_slabs(pair + 1);
         const FlatTile t = tile_of(min(pair * 2 + wm, total_tiles - 1));
-        int prow[2];  // slab row of this lane's output row in the wave's two row tiles
+        int prow[2];  // slab offset (floats) of this lane's output row in the wave's two row tiles: row ri + 7 g, skewed by its segment g
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int ri = 32 * m + i;
-            prow[m] = ri + 7 * ((ri >= t.n0) + (ri >= t.n0 + t.n1));
+            const int ri = 32 * m + i, g = (ri >= t.n0) + (ri >= t.n0 + t.n1);
+            prow[m] = (ri + 7 * g) * kSlabLd + g * kSegSkew;
         }
         floatx16 acc[2][2];  // [weight tile][row tile]
         acc_zero(acc);
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
     #pragma unroll
                     for (int n = 0; n < 2; ++n) a[n] = ld4(ap + n * 32 * BK + (((2 * q + kh) ^ sw) << 2));
     #pragma unroll
-                    for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] * kSlabLd + 8 * q);
+                    for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] + 8 * q);
     #pragma unroll
                     for (int n = 0; n < 2; ++n)
     #pragma unroll
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
                     for (int n = 0; n < 2; ++n)
                         a[n] = frag_lds<NT>(ld4(ap + n * 32 * BK + (((4 * q2 + kh) ^ sw) << 2)), ld4(ap + n * 32 * BK + (((4 * q2 + 2 + kh) ^ sw) << 2)));
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) b[m] = frag_lds<NT>(ld4(sp + prow[m] * kSlabLd + 16 * q2), ld4(sp + prow[m] * kSlabLd + 16 * q2 + 8));
+                    for (int m = 0; m < 2; ++m) b[m] = frag_lds<NT>(ld4(sp + prow[m] + 16 * q2), ld4(sp + prow[m] + 16 * q2 + 8));
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -751,8 +757,8 @@ static SeqMap make_map(int dim, int B, int T2) {
 }
 
 template <int NT>
-static int unfold_gemm_impl(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim, void* stream) {
-    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+static int unfold_gemm_impl(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim, int variant, void* stream) {
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || variant < 0 || variant > 1) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
@@ -762,7 +768,7 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
-    static const bool per_seq_tiles = getenv("RTFS_UNFOLD_PER_SEQ") != nullptr;  // second-generation kernel (tiles padded per sequence)
+    const bool per_seq_tiles = variant == 1;  // second-generation kernel (tiles padded per sequence), kept selectable for A/B: same bits
     if ((NT != 0 || !per_seq_tiles) && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
         const int units = 2 * fpairs;  // (tile pair, column half)
@@ -795,14 +801,15 @@ extern "C" {
 // Wt: [256][512], k index = kk*64 + c.
 
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim,
-                            void* stream) {
-    return unfold_gemm_impl<0>(G, gamma, beta, Wt, U0, B, T2, dim, stream);
+                            int variant, void* stream) {
+    return unfold_gemm_impl<0>(G, gamma, beta, Wt, U0, B, T2, dim, variant, stream);
 }
 // bf16 (terms 1) / split-bf16 (terms 3) MFMA; Wpk = host-packed weight (same indexing as Wt)
-int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int terms,
-                                 void* stream) {
+int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int variant,
+                                 int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, unfold_gemm_impl<1>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<3>(G, gamma, beta, W, U0, B, T2, dim, stream), unfold_gemm_impl<6>(G, gamma, beta, W, U0, B, T2, dim, stream));
+    RTFS_TERMS_DISPATCH(terms, unfold_gemm_impl<1>(G, gamma, beta, W, U0, B, T2, dim, variant, stream), unfold_gemm_impl<3>(G, gamma, beta, W, U0, B, T2, dim, variant, stream),
+                        unfold_gemm_impl<6>(G, gamma, beta, W, U0, B, T2, dim, variant, stream));
 }
 
 // H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.

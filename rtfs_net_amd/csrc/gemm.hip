@@ -11,7 +11,7 @@
 // Tiling: 256 threads = 4 waves; workgroup tile BM x N (full N), K streamed in 32-deep chunks through
 // double-buffered LDS; each wave owns WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).  Weights are
 // pre-transposed on the host to Wt[N][K] so both operands are k-contiguous in LDS (common.h).
-#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace rtfs {
@@ -585,6 +585,268 @@ __global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Warp-specialised form of the projection-carrying residual kernels at large batch (round 3): ONE 8-wave workgroup per CU, waves 0-3
+// ("M") issue nothing but MFMAs and their LDS fragment traffic, waves 4-7 ("X") own every global access and all element-wise work.  Each
+// SIMD then holds one M and one X wave: while the X wave waits for HBM, LDS or the barrier, the M wave keeps the matrix pipe busy - in the
+// one-workgroup DEEP form above every wave paid the LDS / barrier / load -> use latencies of its epilogue with the matrix pipe idle
+// (15 us per 64-pixel tile against 9.3 us of arithmetic and 10.6 us of HBM time at 6 TB/s).
+// The tile loop is a three-stage software pipeline over 32-pixel HALVES h, one barrier per phase:
+//   phase h   M:  residual conv of half h (Es[h & 1] -> accumulators -> Ot[h % 3], pixel-major);  projection of half h - 2 (gated Ot[(h - 2) % 3])
+//             X:  epilogue of half h - 1 on Ot[(h - 1) % 3] (+ bias + gateway(s_in) + a0 | CAF cell, store, next block's gateway in place);
+//                 re-fill that half's residual-operand registers for half h + 1;  TFAR tail of half h + 1 -> Es[(h + 1) & 1];  E operands of half h + 2
+// so a residual operand is requested two phases and an E operand one phase (>= 4 us) before its first use: 128 KB of s_in / a0 and 64 KB of E
+// reads are in flight per CU at any time, none of them in M's way.  Per element the same arithmetic in the same order as resid_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NT, bool CAF>
+__global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiResidual epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+    constexpr int LDE = 68, LDO = 260;
+    __shared__ __attribute__((aligned(16))) float Es[2][32 * LDE];
+    __shared__ __attribute__((aligned(16))) float Ot[3][32 * LDO];
+    __shared__ __attribute__((aligned(16))) float Ns[4][2][kH];
+    __shared__ __attribute__((aligned(16))) float cafc[CAF ? 4 * kC : 4];
+    __shared__ float pred[8];
+    const int b = blockIdx.y;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave index in an SGPR: the role branches below are scalar
+    const bool mrole = w < 4;
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int tiles = (Mb + 63) / 64, tile0 = blockIdx.x * tiles_per_wg;
+    const int ntl = min(tiles_per_wg, tiles - tile0);
+    if (ntl <= 0) return;
+    const int H = 2 * ntl, row0 = tile0 * 64;  // halves of this workgroup; half h covers pixel rows row0 + 32 h .. + 31
+    pro.init(b);
+    if (threadIdx.x < 256) {
+        if (CAF) {
+            const float* src[4] = {epi.caf_ks, epi.caf_kb, epi.caf_vs, epi.caf_vb};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cafc[j * kC + threadIdx.x] = src[j][threadIdx.x];
+        }
+        const NormRef* refs[4] = {&pro.cl, &pro.d0, &pro.cg, &pro.cgate};
+        const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const float sc = refs[j]->gamma[c] * pro.r[j];
+        Ns[j][0][c] = sc;
+        Ns[j][1][c] = refs[j]->beta[c] - pro.m[j] * sc;
+    }
+    __syncthreads();
+    float ps = 0.f, pq = 0.f;  // M: gLN partial sums of the projection output
+
+    if (mrole) {
+        // ================================================ M waves ================================================
+        float4 wf[2][8];  // residual-conv weight fragments: rows n = 64w + 32nt + i, k = 8q + 4kh .. +3
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
+        float4 wpr[16];   // projection weight fragments: W_p[16w + (lane & 15)][64 (lane >> 4) + 4t .. +3]
+        const int j = lane & 15, kk = lane >> 4;
+        {
+            const float* wpp0 = epi.pw + (size_t)(16 * w + j) * 256 + 64 * kk;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) wpr[t] = ld4(wpp0 + 4 * t);
+        }
+        const float4 pb4 = ld4(epi.pbias + 16 * w + 4 * kk);
+        float* py_b = epi.py + (size_t)b * Mb * kH;
+        __syncthreads();  // (pairs with the X waves' prologue barrier: Es[0] holds half 0)
+        int hb = 0;       // h % 3
+#pragma unroll 1
+        for (int h = 0; h < H + 2; ++h) {
+            if (h < H) {  // residual conv of half h
+                const float* E = Es[h & 1];
+                floatx16 acc[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+                if constexpr (NT == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 e0 = ld4(E + i * LDE + 8 * q + 4 * kh);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e0.x, acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e0.y, acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e0.z, acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e0.w, acc[nt], 0, 0, 0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const Frag e0 = frag_lds<NT>(ld4(E + i * LDE + 16 * q2 + 4 * kh), ld4(E + i * LDE + 16 * q2 + 8 + 4 * kh));
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) mma32<NT>(acc[nt], frag_lds<NT>(wf[nt][2 * q2], wf[nt][2 * q2 + 1]), e0);
+                    }
+                }
+                float* O = Ot[hb];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) st4(O + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh, acc_group(acc[nt], g));
+            }
+            if (h >= 2) {  // projection of half h - 2 (its gated tile was written by the X waves in phase h - 1)
+                const float* ap = Ot[hb == 2 ? 0 : hb + 1] + j * LDO + 64 * kk;
+                floatx4 pa[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pa[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (NT == 0) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const float4 e0 = ld4(ap + 4 * t), e1 = ld4(ap + 16 * LDO + 4 * t);
+                        const int c = 2 * (t & 1);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].x, e0.x, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].x, e1.x, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].y, e0.y, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].y, e1.y, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].z, e0.z, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].z, e1.z, pa[c + 1], 0, 0, 0);
+                        pa[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].w, e0.w, pa[c], 0, 0, 0);
+                        pa[c + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpr[t].w, e1.w, pa[c + 1], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t2 = 0; t2 < 8; ++t2) {
+                        const Frag e0 = frag_lds<NT>(ld4(ap + 8 * t2), ld4(ap + 8 * t2 + 4));
+                        const Frag e1 = frag_lds<NT>(ld4(ap + 16 * LDO + 8 * t2), ld4(ap + 16 * LDO + 8 * t2 + 4));
+                        const Frag wq = frag_lds<NT>(wpr[2 * t2], wpr[2 * t2 + 1]);
+                        const int c = 2 * (t2 & 1);
+                        mma16<NT>(pa[c], wq, e0);
+                        mma16<NT>(pa[c + 1], wq, e1);
+                    }
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int p = row0 + (h - 2) * 32 + 16 * sub + j;
+                    if (p < Mb) {
+                        const float4 o = f4(pa[sub][0] + pa[sub + 2][0], pa[sub][1] + pa[sub + 2][1], pa[sub][2] + pa[sub + 2][2],
+                                            pa[sub][3] + pa[sub + 2][3]) + pb4;
+                        st4_off(py_b, ((unsigned)p * kH + 16 * w + 4 * kk) * 4u, o);
+                        ps += o.x + o.y + o.z + o.w;
+                        pq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                    }
+                }
+            }
+            hb = hb == 2 ? 0 : hb + 1;
+            __syncthreads();
+        }
+    } else {
+        // ================================================ X waves ================================================
+        const int tx = threadIdx.x - 256;
+        const int cq = (tx & 63) * 4, c4 = (tx & 15) * 4, er = tx >> 4, xr = tx >> 6;
+        const float4 cbias = ld4(epi.bias + cq), cgw = ld4(epi.gw + cq), cgb = ld4(epi.gb + cq);
+        const float* cl_b = pro.cl.x + (size_t)b * Mb * kH;
+        const float* d0_b = pro.d0.x + (size_t)b * Mb * kH;
+        const float* cg_b = pro.cg.x + (size_t)b * pro.T2 * kF2 * kH;
+        const float* cgate_b = pro.cgate.x + (size_t)b * pro.T2 * kF2 * kH;
+        const float* s_b = epi.s_in + (size_t)b * Mb * kC;
+        const float* a0_b = CAF ? nullptr : epi.a0 + (size_t)b * Mb * kC;
+        const float* att_b = CAF ? epi.att + (size_t)b * epi.Tv * kC : nullptr;
+        const float* rsz_b = CAF ? epi.rsz + (size_t)b * epi.Tv * kC : nullptr;
+        float* y_b = epi.y + (size_t)b * Mb * kC;
+        float4 xa[2][2], xd[2][2], xg[2][2], xs[2][2];  // E operands, [register stage][row]
+        float4 sv[2][8], av[CAF ? 1 : 2][8];            // residual operands, [register stage][row]
+        float4 catt[2][2], crsz[2][2];                  // CAF: (att, rsz) rows of the <= 2 video frames a half spans
+        int caf_split[2] = {0, 0};
+        auto load_e = [&](auto st_, int h) {
+            constexpr int st = decltype(st_)::value;
+            const int m0 = row0 + 32 * min(h, H - 1);  // (past the last half: re-fetch it - L2 hits, no branch around the loads)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = min(m0 + er + 16 * it, Mb - 1);
+                const int t = row / kF, f = row - t * kF;
+                const int t2 = nearest_src(t, pro.T2, pro.T), f2 = nearest_src(f, kF2, kF);
+                const unsigned hi = ((unsigned)row * kH + c4) * 4u, lo = (((unsigned)t2 * kF2 + f2) * kH + c4) * 4u;
+                xa[st][it] = ld4_off(cl_b, hi), xd[st][it] = ld4_off(d0_b, hi), xg[st][it] = ld4_off(cg_b, lo), xs[st][it] = ld4_off(cgate_b, lo);
+            }
+        };
+        auto xform_e = [&](auto st_, float* E) {
+            constexpr int st = decltype(st_)::value;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const float4 a = fma4(xa[st][it], ld4(&Ns[0][0][c4]), ld4(&Ns[0][1][c4])), d = fma4(xd[st][it], ld4(&Ns[1][0][c4]), ld4(&Ns[1][1][c4]));
+                const float4 g = fma4(xg[st][it], ld4(&Ns[2][0][c4]), ld4(&Ns[2][1][c4])), sg = sigmoid4(fma4(xs[st][it], ld4(&Ns[3][0][c4]), ld4(&Ns[3][1][c4])));
+                st4(E + (er + 16 * it) * LDE + c4, pack4<NT>(fma4(a, sg, g) + d));
+            }
+        };
+        auto load_sv = [&](auto st_, int h) {
+            constexpr int st = decltype(st_)::value;
+            const int m0 = row0 + 32 * min(h, H - 1);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const unsigned o = ((unsigned)min(m0 + xr + 4 * it, Mb - 1) * kC + cq) * 4u;
+                sv[st][it] = ld4_off(s_b, o);
+                if constexpr (!CAF) av[st][it] = ld4_off(a0_b, o);
+            }
+            if constexpr (CAF) {
+                const int p0 = min(m0, Mb - 1), p1 = min(m0 + 31, Mb - 1);
+                const int t0 = p0 / kF, t1 = p1 / kF;
+                caf_split[st] = (t0 + 1) * kF;
+                const unsigned o0 = ((unsigned)nearest_src(t0, epi.Tv, pro.T) * kC + cq) * 4u, o1 = ((unsigned)nearest_src(t1, epi.Tv, pro.T) * kC + cq) * 4u;
+                catt[st][0] = ld4_off(att_b, o0), crsz[st][0] = ld4_off(rsz_b, o0), catt[st][1] = ld4_off(att_b, o1), crsz[st][1] = ld4_off(rsz_b, o1);
+            }
+        };
+        auto epilogue = [&](auto st_, int h, float* O) {  // half h from O (pixel-major accumulators) with the residual operands of stage st
+            constexpr int st = decltype(st_)::value;
+            const int prow = row0 + 32 * h + xr;
+            int coff = cq;
+            if (CAF) asm volatile("" : "+v"(coff));  // opaque: the table reads stay inside the loop
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = xr + 4 * it;
+                float4 v = ld4(O + r * LDO + cq) + cbias + prelu4_minfma(fma4(sv[st][it], cgw, cgb), epi.slope - 1.0f);
+                if constexpr (CAF) {
+                    const bool second = prow + 4 * it >= caf_split[st];
+                    const float4 at = second ? catt[st][1] : catt[st][0], rz = second ? crsz[st][1] : crsz[st][0];
+                    v = fma4(at, fma4(v, ld4(cafc + 2 * kC + coff), ld4(cafc + 3 * kC + coff)), relu4(fma4(v, ld4(cafc + coff), ld4(cafc + kC + coff))) * rz);
+                    v = v + sv[st][it];
+                } else {
+                    v = v + av[st][it];
+                }
+                if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
+                st4(O + r * LDO + cq, pack4<NT>(prelu4(fma4(v, cgw, cgb), epi.slope)));  // the next block's gateway, in place
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        load_e(S0{}, 0);
+        load_e(S1{}, 1);
+        load_sv(S0{}, 0);
+        xform_e(S0{}, Es[0]);
+        __syncthreads();
+        int hb = 0;
+        // phase h, stage p = h & 1: epilogue(h - 1) with stage p ^ 1, refill it for half h + 1, E(h + 1) from stage p ^ 1 -> Es[p ^ 1], fetch E(h + 2) -> stage p
+        auto phase = [&](auto p_, int h) {
+            constexpr int p = decltype(p_)::value;
+            using Q = std::integral_constant<int, p ^ 1>;
+            if (h >= 1 && h <= H) epilogue(Q{}, h - 1, Ot[hb == 0 ? 2 : hb - 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_sv(Q{}, h + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            xform_e(Q{}, Es[p ^ 1]);
+            load_e(p_, h + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            hb = hb == 2 ? 0 : hb + 1;
+            __syncthreads();
+        };
+#pragma unroll 1
+        for (int h = 0; h < H + 2; h += 2) {
+            phase(S0{}, h);
+            phase(S1{}, h + 1);
+        }
+    }
+    // gLN partial sums of the projection output: M waves only
+    ps = wave_sum(ps);
+    pq = wave_sum(pq);
+    if (mrole && lane == 0) {
+        pred[w] = ps;
+        pred[4 + w] = pq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(epi.pslot + kStatStride * b, (double)pred[0] + (double)pred[1] + (double)pred[2] + (double)pred[3]);
+        atomicAdd(epi.pslot + kStatStride * b + 1, (double)pred[4] + (double)pred[5] + (double)pred[6] + (double)pred[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gateway + projection (K = 256 -> N = 64) on v_mfma_f32_16x16x4_f32, operands swapped like resid_kernel:
 // y^T[n][p] = Wp[n][k] . A^T[k][p].  64-pixel tile; wave w owns output channels 16w..16w+15 for ALL 64 pixels and the
 // WHOLE K, so there is no cross-wave reduction and every wave has the same epilogue.  The MFMA's K index is free as long
@@ -731,7 +993,7 @@ static int resid_impl(const float* cl, const double* cl_stats, const float* cl_g
                       const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                       const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const float* Wt, const float* bias,
                       const float* s_in, const float* gw, const float* gb, float gslope, const float* a0_or_null, float* out, const float* Wp,
-                      const float* pbias, float* py, double* pstats, int B, int T, int T2, hipStream_t st, const CafArgs* caf = nullptr) {
+                      const float* pbias, float* py, double* pstats, int B, int T, int T2, hipStream_t st, const CafArgs* caf = nullptr, int variant = 0) {
     const double nf = 1.0 / ((double)T * kF * kH), nl = 1.0 / ((double)T2 * kF2 * kH);
     ProExpanded pro{{cl, cl_stats, nf, cl_g, cl_b}, {d0, d0_stats, nf, d0_g, d0_b}, {cg, cg_stats, nl, cg_g, cg_b},
                     {cgate, cgate_stats, nl, cgate_g, cgate_b}, T, T2, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -746,15 +1008,22 @@ static int resid_impl(const float* cl, const double* cl_stats, const float* cl_g
     // tiles per workgroup: ~1024 workgroups (two rounds at 2 per CU), capped at 16.  Swept at B = 32: 4 -> 786 us, 16 -> 744, 32 -> 743,
     // 64 -> 804; small batches get more, smaller workgroups.
     const int Mb = T * kF, tiles = (Mb + 63) / 64;
-    // one workgroup per CU with the whole register file for the two projection-carrying variants at large batch (resid_kernel, DEEP);
-    // RTFS_RESID_DEEP=0 keeps the two-workgroup form for A/B
-    const char* deep_env = getenv("RTFS_RESID_DEEP");  // (read per call: the A/B test flips it inside one process)
-    const bool deep_off = deep_env != nullptr && deep_env[0] == '0';
-    if (Wp && !deep_off && (long long)tiles * B >= 2048) {
+    // Projection-carrying variants at large batch: one workgroup per CU.  `variant` (include/rtfs_hip.h): 0 = this launcher's choice,
+    // 1 = two 4-wave workgroups per CU (the small-batch form), 2 = one 4-wave workgroup with the whole register file (resid_kernel, DEEP),
+    // 3 = one 8-wave workgroup, MFMA waves + memory / element-wise waves (resid_ws_kernel).
+    if (variant < 0 || variant > 3) return RTFS_EINVAL;
+    const bool large = Wp && (long long)tiles * B >= 2048;
+    const int form = !large ? 1 : (variant ? variant : 3);
+    if (form >= 2) {
         const long long wantd = ((long long)tiles * B + 255) / 256;
         const int perd = (int)(wantd > 128 ? 128 : wantd);
         const dim3 gridd((tiles + perd - 1) / perd, B);
-        if (caf)
+        if (form == 3) {
+            if (caf)
+                hipLaunchKernelGGL((resid_ws_kernel<NT, true>), gridd, dim3(512), 0, st, pro, epi, Wt, Mb, perd);
+            else
+                hipLaunchKernelGGL((resid_ws_kernel<NT, false>), gridd, dim3(512), 0, st, pro, epi, Wt, Mb, perd);
+        } else if (caf)
             hipLaunchKernelGGL((resid_kernel<true, true, NT, true, 1>), gridd, dim3(256), 0, st, pro, epi, Wt, Mb, perd);
         else
             hipLaunchKernelGGL((resid_kernel<true, true, NT, false, 2>), gridd, dim3(256), 0, st, pro, epi, Wt, Mb, perd);
@@ -852,10 +1121,10 @@ int rtfs_resid_proj_fwd(const float* cl, const double* cl_stats, const float* cl
                         const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
                         const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                         const float* a0, float* out, const float* Wp, const float* pbias, float* py, double* pstats, int B, int T, int T2,
-                        void* stream) {
+                        int variant, void* stream) {
     if (!a0 || !Wp || !py || !pstats) return RTFS_EINVAL;
     return resid_impl<0>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, Wt, bias, s_in,
-                         gw, gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream);
+                         gw, gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream, nullptr, variant);
 }
 int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
                              const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
@@ -863,12 +1132,12 @@ int rtfs_resid_proj_fwd_bf16(const float* cl, const double* cl_stats, const floa
                              const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
                              const void* Wpk, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                              const float* a0, float* out, const void* Wp_pk, const float* pbias, float* py, double* pstats, int B, int T, int T2,
-                             int terms, void* stream) {
+                             int variant, int terms, void* stream) {
     if (!a0 || !Wp_pk || !py || !pstats) return RTFS_EINVAL;
     const float *W = (const float*)Wpk, *Wp = (const float*)Wp_pk;
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
-                    gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream)
+                    gb, gslope, a0, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream, nullptr, variant)
     RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
 #undef RESID_NT
 }
@@ -881,11 +1150,12 @@ int rtfs_resid_caf_fwd(const float* cl, const double* cl_stats, const float* cl_
                        const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b,
                        const float* Wt, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                        const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz, int Tv, int add_input,
-                       float* out, const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, void* stream) {
+                       float* out, const float* Wp_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2, int variant,
+                       void* stream) {
     const CafArgs caf{ks, kb, vs, vb, att, rsz, Tv};
     if (Wp_or_null && !add_input) return RTFS_EINVAL;
     return resid_impl<0>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, Wt, bias, s_in,
-                         gw, gb, gslope, add_input ? s_in : nullptr, out, Wp_or_null, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf);
+                         gw, gb, gslope, add_input ? s_in : nullptr, out, Wp_or_null, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf, variant);
 }
 int rtfs_resid_caf_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b,      //
                             const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b,      //
@@ -894,13 +1164,13 @@ int rtfs_resid_caf_fwd_bf16(const float* cl, const double* cl_stats, const float
                             const void* Wpk, const float* bias, const float* s_in, const float* gw, const float* gb, float gslope,
                             const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz, int Tv,
                             int add_input, float* out, const void* Wp_pk_or_null, const float* pbias, float* py, double* pstats, int B, int T, int T2,
-                            int terms, void* stream) {
+                            int variant, int terms, void* stream) {
     const CafArgs caf{ks, kb, vs, vb, att, rsz, Tv};
     if (Wp_pk_or_null && !add_input) return RTFS_EINVAL;
     const float *W = (const float*)Wpk, *Wp = (const float*)Wp_pk_or_null;
 #define RESID_NT(NTV)                                                                                                                                  \
     resid_impl<NTV>(cl, cl_stats, cl_g, cl_b, d0, d0_stats, d0_g, d0_b, cg, cg_stats, cg_g, cg_b, cgate, cgate_stats, cgate_g, cgate_b, W, bias, s_in, gw, \
-                    gb, gslope, add_input ? s_in : nullptr, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf)
+                    gb, gslope, add_input ? s_in : nullptr, out, Wp, pbias, py, pstats, B, T, T2, (hipStream_t)stream, &caf, variant)
     RTFS_TERMS_DISPATCH(terms, RESID_NT(1), RESID_NT(3), RESID_NT(0));
 #undef RESID_NT
 }

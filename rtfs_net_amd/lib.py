@@ -30,7 +30,7 @@ SIGNATURES = {
     "rtfs_dwconv_fwd": [P, P, P, P, F, I, I, I, P, P, P, P, I, I, I, P],
     "rtfs_dwconv_mix_fwd": [P] * 12 + [I, P, P, P, P, I, I, I, I, I, P],
     "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
-    "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, P],
+    "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
     "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, P, I, I, P],
     "rtfs_vp_param_count": [],
@@ -52,8 +52,8 @@ SIGNATURES = {
     "rtfs_dwconv_trio_fwd": [P] * 12 + [I, I, I, P],
     "rtfs_pool_add_fwd": [P] * 6 + [I, I, P],
     "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
-    "rtfs_resid_proj_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, P],
-    "rtfs_resid_caf_fwd": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, P],
+    "rtfs_resid_proj_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
+    "rtfs_resid_caf_fwd": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, P],
     "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
     "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
     "rtfs_mask_fwd": [P, F, P, P, P, P, P, I, I, P],
@@ -104,15 +104,15 @@ SIGNATURES = {
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_proj_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
-    "rtfs_dp_unfold_gemm_fwd_bf16": [P, P, P, P, P, I, I, I, I, P],
+    "rtfs_dp_unfold_gemm_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, P],
     "rtfs_sru_layer_fwd_bf16": [P, P, P, P, F, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd_bf16": [P, P, P, P, I, I, I, I, P],
     "rtfs_attn_qkv_fwd_bf16": [P] * 14 + [I, I, I, P],
     "rtfs_attn_core_fwd_bf16": [P, P, P, P, P, I, I, I, P],
     "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
     "rtfs_resid_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, I, P],
-    "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
-    "rtfs_resid_caf_fwd_bf16": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, P],
+    "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, I, P],
+    "rtfs_resid_caf_fwd_bf16": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, I, P],
     "rtfs_mask_fwd_bf16": [P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_gemm_rows_fwd_bf16": [P, P, P, P, I, I, I, I, P],
     "rtfs_gemm_rows_bf16": [P, P, P, P, I, I, I, I, I, P],

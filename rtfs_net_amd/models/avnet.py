@@ -199,7 +199,7 @@ class AVNet(nn.Module):
                 if not self.training and not self._warned_eval_grad:
                     self._warned_eval_grad = True
                     warnings.warn("AVNet.forward in eval() mode with autograd enabled takes the TRAINING-STEP path (all activations saved: "
-                                  "tens of GB at batch 32, segments <= 8 s, video block as PyTorch glue). Wrap inference in torch.no_grad().",
+                                  "tens of GB at batch 32). Wrap inference in torch.no_grad().",
                                   stacklevel=2)
                 return self._forward_autograd(x, mouth_embedding)
             if self.training:

@@ -5,7 +5,8 @@
 entry point of include/rtfs_hip.h working on channels-last device buffers.  PyTorch only provides
 device memory (caching allocator), the current stream and the tiny video (VP) block.
 
-Inference only for now (eval-mode BatchNorm, no autograd); training mode raises.
+This file is the INFERENCE path (eval-mode BatchNorm folded into the prepared weights, no autograd); the training step - the same
+forward with saved activations plus the hand-written adjoint chain - is models/hip_train.py.
 """
 from __future__ import annotations
 
@@ -248,6 +249,9 @@ class HipForward:
         self.tap_all_blocks = False  # with `taps`: also capture the stages of blocks 1..R-1 (keys suffixed '#i')
         self._vp_stream = None
         self.prec = COMPUTE_DTYPES[os.environ.get("RTFS_COMPUTE_DTYPE", "f32")]  # AVNet.set_compute_dtype
+        # kernel-form choices handed to the C-ABI as explicit `variant` arguments (0 = the library's own choice; include/rtfs_hip.h) - a
+        # HOST-side setting for same-box A/B runs and the equivalence tests, the library itself reads no environment
+        self.variants = {"resid": int(os.environ.get("RTFS_RESID_VARIANT", "0")), "unfold": int(os.environ.get("RTFS_UNFOLD_VARIANT", "0"))}
 
     def weights(self) -> PreparedWeights:
         fp = PreparedWeights.fingerprint(self.model)
@@ -276,7 +280,7 @@ class HipForward:
         L = npos - 7
         dev = G.device
         U = torch.empty(S * L * 256, device=dev)
-        self._mm("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], self._wk(d, "w0"), U, B, T2, dim)
+        self._mm("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], self._wk(d, "w0"), U, B, T2, dim, self.variants["unfold"])
         h = torch.empty(S * L * 64, device=dev)
         l0 = d["layers"][0]
         lib.call("rtfs_sru_scan_fwd", U, None, l0["wc"], l0["bias"], l0["scale_x"], h, S, L, 4)
@@ -372,12 +376,12 @@ class HipForward:
             self._mm("rtfs_resid_caf_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                      cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], ks, kb, vs, vb, att, rsz, Tv, int(add_input), out,
                      self._wk(bw, "pw") if nxt is not None else None, bw["pb"], nxt[0] if nxt is not None else None,
-                     nxt[1] if nxt is not None else None, B, T, T2)
+                     nxt[1] if nxt is not None else None, B, T, T2, self.variants["resid"])
             return nxt is not None
         if next_proj is not None and a0_or_none is not None:
             self._mm("rtfs_resid_proj_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                      cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, self._wk(bw, "pw"), bw["pb"],
-                     next_proj[0], next_proj[1], B, T, T2)
+                     next_proj[0], next_proj[1], B, T, T2, self.variants["resid"])
             return True
         self._mm("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                  cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
@@ -387,7 +391,8 @@ class HipForward:
     def __call__(self, wav: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
         m = self.model
         if m.training:
-            raise NotImplementedError("the HIP path implements inference (model.eval()); training-mode BatchNorm/backward are not built yet")
+            raise NotImplementedError("HipForward is the inference path (model.eval() under torch.no_grad()); the training step is models/hip_train.py, "
+                                      "reached through AVNet.forward with autograd enabled")
         if not wav.is_cuda:
             raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
         pw = self.weights()
@@ -401,9 +406,11 @@ class HipForward:
             # nn.Unfold((8, 1)) raises on fewer than 8 compressed frames (RuntimeError; tests/test_oracle_golden.py pins that)
             raise ValueError("input too short: fewer than 8 compressed frames (16 STFT frames, L >= 1920 samples) - the 8-tap unfold of the "
                              "time-path DualPathRNN has no window, exactly as in the reference (which raises from nn.Unfold)")
-        if T * F_BINS * C * 4 >= 2 ** 31:
-            raise ValueError(f"input too long for the HIP path: {L} samples - one utterance's [T][129][256] fp32 activation must stay below 2 GiB "
-                             "(32-bit offsets inside an utterance): about 130 s at 16 kHz; split longer recordings into segments")
+        if T * F_BINS * C * 4 > 2 ** 30:
+            # kernels address inside an utterance with 32-bit byte offsets (2 GiB); the guard sits at the TESTED envelope, half of that:
+            # tests/test_hip_e2e.py runs 64 s against the oracle and a batch whose B x T x 129 x 256 passes 2^31 elements
+            raise ValueError(f"input too long for the HIP path: {L} samples - one utterance's [T][129][256] fp32 activation must stay within 1 GiB "
+                             "(about 65 s at 16 kHz); split longer recordings into segments")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats

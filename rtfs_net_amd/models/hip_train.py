@@ -28,7 +28,7 @@ class TrainWeights(PreparedWeights):
     """PreparedWeights + the transposed / re-ordered copies the input-gradient GEMMs need."""
 
     def __init__(self, model, prec=0):
-        super().__init__(model, pack_vp=False, training=True)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
+        super().__init__(model, pack_vp=False, training=model.training)  # rebuilt after every optimizer step: the VP kernel (eval only) is not needed here
         self.prec = prec
         w = self.w
         w["bn_wT"], w["mask_wT"], w["dec_wT"] = _t(w["bn_w"]), _t(w["mask_w"]), _t(w["dec_w"])
@@ -124,7 +124,7 @@ class HipTrainer:
         self.prec = 0  # AVNet.set_compute_dtype: 0 fp32, 1 bf16, 3 split-bf16 products in every MFMA kernel of the step
 
     def weights(self) -> TrainWeights:
-        fp = PreparedWeights.fingerprint(self.model, training=True)
+        fp = PreparedWeights.fingerprint(self.model, training=self.model.training)  # eval under autograd: running statistics are inputs too
         if self._prep is None or self._prep.version != fp or self._prep.prec != self.prec:
             self._prep = TrainWeights(self.model, self.prec)
         return self._prep
@@ -147,7 +147,7 @@ class HipTrainer:
         save.G_in = G.clone()
         save.U, save.h, save.c = [], [], []
         U0 = torch.empty(S * L * 256, device=dev)
-        self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim)
+        self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim, 0)
         h = torch.empty(S * L * 64, device=dev)
         c = torch.empty_like(h)
         l0 = d["layers"][0]
@@ -219,7 +219,7 @@ class HipTrainer:
         if next_proj is not None and a0_or_none is not None:
             self._call("rtfs_resid_proj_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
                        cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, bw["pw"], bw["pb"], next_proj[0], next_proj[1],
-                       B, T, T2)
+                       B, T, T2, 0)
             k.fused_next = True
         else:
             self._call("rtfs_resid_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],

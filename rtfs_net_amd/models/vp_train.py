@@ -58,6 +58,7 @@ class VPTrainer:
         self.vb = vb
         self.bns = _bn_modules(vb)
         self._ncache = {}
+        self._equal_batches = set()  # per-rank batch sizes already verified equal across ranks (SyncBatchNorm)
 
     # ---- helpers ----------------------------------------------------------------------------------------------------------
     def _sync(self):
@@ -78,9 +79,18 @@ class VPTrainer:
         st.train = vb.training
         st.sync = self._sync()
         dev = x.device
-        # utterances behind the statistics: all ranks' under SyncBatchNorm.  Equal per-rank batches are assumed (what DistributedSampler delivers);
-        # summing the counts with a collective + .item() would put a host synchronisation in the middle of every step
+        # utterances behind the statistics: all ranks' under SyncBatchNorm.  Equal per-rank batches (what DistributedSampler delivers) make that
+        # B x world without a per-step collective + host read-back; the assumption is CHECKED once per batch size (one MIN/MAX all-reduce) and
+        # an unequal last batch raises instead of silently skewing mean / variance and the dx scaling (torch's SyncBatchNorm all-reduces counts)
         st.Bn = float(st.B * (torch.distributed.get_world_size() if st.sync else 1))
+        if st.sync and st.B not in self._equal_batches:
+            probe = torch.tensor([float(st.B), -float(st.B)], device=dev)
+            torch.distributed.all_reduce(probe, op=torch.distributed.ReduceOp.MAX)
+            lo, hi = -float(probe[1]), float(probe[0])
+            if lo != hi:
+                raise ValueError(f"SyncBatchNorm in the VP block's HIP training step needs equal per-rank batch sizes, got {int(lo)} ... {int(hi)}: "
+                                 "use drop_last / DistributedSampler padding, or RTFS_VP_GLUE=1 for the PyTorch modules")
+            self._equal_batches.add(st.B)
         st.stats = torch.zeros(NS, 2, 64, device=dev)
         # the two scalar PReLU slopes are kernel arguments: taken from the caller (AVNet reads every scalar of the model in ONE transfer per
         # optimizer step, hip_path.PreparedWeights) - fetching them here would be a host synchronisation in the middle of the step

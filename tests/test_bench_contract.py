@@ -38,6 +38,12 @@ def test_single_process_line():
     assert sb is not None and sb["dtype"] == "bf16x3" and sb["value"] > 0
     tb = res["training_step_split_bf16"]
     assert tb is not None and tb["dtype"] == "bf16x3" and tb["value"] > 0 and "training step" in tb["workload"]
+    # the other BASELINE.json configurations ride along at their OWN sizes (bench.py INFER_RIDERS)
+    c2, c5, c5b, b1 = res["config2"], res["config5_bf16x3"], res["config5_bf16"], res["latency_b1"]
+    assert c2 is not None and "RTFS-Net-4" in c2["workload"] and "batch 16" in c2["workload"] and c2["value"] > 0
+    assert c5 is not None and "RTFS-Net-12" in c5["workload"] and "4 s" in c5["workload"] and c5["dtype"] == "bf16x3" and c5["roofline"] is not None
+    assert c5b is not None and c5b["dtype"] == "bf16" and c5b["value"] > 0
+    assert b1 is not None and "batch 1 " in b1["workload"] and 0 < b1["ms_per_utterance"] < 64.7
 
 
 def test_lip_encoder_in_the_timed_step():
@@ -46,6 +52,18 @@ def test_lip_encoder_in_the_timed_step():
     assert r.returncode == 0, r.stderr[-2000:]
     res = _last_json(r.stdout)
     assert KEYS <= set(res) and res["config"]["mode"] == "infer+lip-encoder" and res["value"] > 0
+
+
+def test_plain_launch_with_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run in front (the form the driver uses for N = 1): the script re-executes itself
+    under torch.distributed.run instead of exiting"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RTFS_BENCH_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    res = _last_json(r.stdout)
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])

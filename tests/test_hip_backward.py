@@ -1,18 +1,36 @@
-"""GPU parity of the training step: gradients of every parameter from the HIP backward chain (audio branch) and the
-torch-glue video branch, against torch autograd of the oracle in float64, in eval mode (BatchNorm running statistics)
-and train mode (batch statistics; dropout forced to 0 because the oracle has none).
+"""GPU parity of the training step: gradients of EVERY parameter from the HIP backward chain (audio branch, CAF, VP block) against torch
+autograd of the oracle in float64, in eval mode (BatchNorm running statistics) and train mode (batch statistics; dropout forced to 0
+because the oracle has none), plus the BatchNorm running statistics the train-mode step leaves behind.
 
-Tolerance: ||g - ref|| <= 3e-3 * (||ref|| + 1e-4 * largest gradient norm) per parameter tensor (1e-2 for the scalar PReLU
-slopes); fp32 sums over ~1e5 elements against a float64 reference give ~1e-4.
+Deterministic: one input seed per case, one tolerance per precision, no retries.
+  fp32 / bf16x6 step:  ||g - ref|| <= 3e-3 * (||ref|| + 1e-4 * largest gradient norm) per parameter tensor; 1e-2 for the scalar PReLU
+                       slopes (ONE signed fp32 sum over ~1e5 activations each); median over the tensors < 1e-3.
+  bf16x3 step:         1.5e-3 per tensor, 1e-2 on the scalar slopes, median < 1e-3 - on the SMOOTH-REGIME weights of util.smooth_regime
+                       (observed on MI355X: median 1e-5 ... 2e-5, worst tensor 2.8e-4).
+Activation kinks: an fp32 evaluation that lands on the other side of a PReLU / ReLU kink than float64 is off by O(1) in that element's
+derivative.  One element of an audio tensor is noise, one element of the 50-token video branch moves ~100 tensors by 1e-2 - so every case
+runs on lip embeddings that util.stable_emb has moved (deterministically, only if needed: the default full-length input has a video
+activation 3e-6 of its site's rms away from 0) out of round-off distance of every video-branch kink.  The split-bf16 step carries ~70x the
+fp32 round-off and flips thousands of AUDIO activations on ordinary weights; its GEMM entry points are what differs from the fp32 step, and
+they are checked where the function is smooth (slopes in [0.97, 1], ReLU inputs positive), tightly, instead of loosely where it is not.
 """
 import pytest
 import torch
 
-from util import make_model, rel, synth
+from util import make_model, rel, smooth_regime, stable_emb, synth
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-3
-AUDIO_SKIP = ("refinement_module.video_net.",)
+GLUE_VIDEO = ("refinement_module.video_net.",)
+
+CASES = [
+    (False, 2, 4096, 2, 6),     # eval, two blocks
+    (True, 2, 4096, 2, 6),      # train; Tv = 6 < 8: the VP block runs as PyTorch glue (models/avnet.py) on 6 / 3 / 2 / 1 tokens
+    (True, 2, 8192, 2, 12),     # train, Tv = 12: VP block on the HIP training kernels (csrc/vp_train.hip), batch statistics over 2 x (12, 6, 3, 2) positions
+    (True, 3, 16000, 1, 25),    # train, B = 3, Tv = 25, R = 1 (block 0 only: a0_mode 4)
+    (False, 1, 12100, 1, 19),   # T2 = 47: 40-step time sequences (all-taps Toeplitz weight gradient, 2-tile fold kernel on both dual paths); odd L
+    (False, 1, 4096, 3, 6),     # R = 3: a MIDDLE block (rtfs_proj_gateway_bwd with da0 += ds)
+    (False, 1, 32000, 2, 50),   # one full-length utterance (T2 = 125, 57- / 118-step sequences): the shapes of BASELINE config 3
+]
 
 
 def _oracle_grads(sd, cfg, mix, emb, wgt, training, dtype=torch.float64):
@@ -22,96 +40,79 @@ def _oracle_grads(sd, cfg, mix, emb, wgt, training, dtype=torch.float64):
     sd64 = {k: (v.to(dtype).clone().requires_grad_(not k.endswith(nograd)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     out = avnet_forward(sd64, cfg, mix.to(dtype), emb.to(dtype), training=training)
     (out * wgt.to(dtype)).sum().backward()
-    return out.detach(), {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
+    grads = {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
+    stats = {k: v.detach() for k, v in sd64.items() if k.endswith(("running_mean", "running_var"))}  # F.batch_norm(training=True) updated them in place
+    return out.detach(), grads, stats
 
 
-@pytest.mark.parametrize("training,B,L,R,Tv", [(False, 2, 4096, 2, 6), (True, 2, 4096, 2, 6), (False, 1, 12100, 1, 19), (False, 1, 4096, 3, 6),
-                                               (False, 1, 32000, 2, 50)])
+@pytest.mark.parametrize("training,B,L,R,Tv", CASES)
 def test_parameter_gradients(training, B, L, R, Tv):
     _check_parameter_gradients(training, B, L, R, Tv, "f32")
 
 
-@pytest.mark.parametrize("training,B,L,R,Tv", [(True, 2, 4096, 2, 6), (False, 1, 4096, 3, 6), (False, 1, 32000, 2, 50)])
+@pytest.mark.parametrize("training,B,L,R,Tv", [CASES[1], CASES[2], CASES[5], CASES[6]])
 def test_parameter_gradients_split_bf16_step(training, B, L, R, Tv):
-    """the same check with `set_compute_dtype("bf16x3")`: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain as
-    three-term split-bf16 products on the bf16 MFMA pipe (fp32 accumulation).  Every *_bf16 entry point agrees with its fp32 sibling to
-    4.5e-6 (tools/check_bf16_entries.py), i.e. 70x the fp32 round-off; that noise moves ~70x more activations across their ReLU / PReLU
-    kinks, and a kink flip changes a gradient by O(1) at that element - the parameter gradients therefore sit sqrt(70) ~ 8x further from
-    float64 than the fp32 step's (observed: worst tensor 3.7e-2 vs 4.8e-3, median 1e-3).  REPORTED tolerance: 6e-2 per tensor (the 15 scalar
-    PReLU slopes, one heavily cancelling sum each, only to their order of magnitude: observed up to 0.4), median over tensors 5e-3.
-    Which inputs put an activation next to a kink is a property of the input seed and of the summation order of every fp32 kernel upstream
-    (tools/grad_seed_probe.py, round 2: medians 1.5e-3 ... 9e-3 over five seeds for THIS step, 2e-6 ... 3e-4 for the fp32 step - the same
-    all-or-nothing pattern), so the short cases run on up to three input seeds and must meet the tolerance on one of them: a kernel error
-    fails on every seed, a kink flip on some."""
-    last = None
-    for seed in ((None,) if L >= 32000 else (None, 3, 4)):
-        try:
-            _check_parameter_gradients(training, B, L, R, Tv, "bf16x3", seed)
-            return
-        except AssertionError as e:
-            last = e
-    raise last
+    """`set_compute_dtype("bf16x3")`: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain as three-term split-bf16
+    products on the bf16 MFMA pipe (fp32 accumulation), on the smooth-regime weights (module docstring)."""
+    _check_parameter_gradients(training, B, L, R, Tv, "bf16x3")
 
 
-@pytest.mark.parametrize("training,B,L,R,Tv", [(True, 2, 4096, 2, 6), (False, 1, 4096, 3, 6)])
+@pytest.mark.parametrize("training,B,L,R,Tv", [CASES[1], CASES[5]])
 def test_parameter_gradients_fp32_equivalent_split_step(training, B, L, R, Tv):
     """`set_compute_dtype("bf16x6")`: every MFMA product of the step as six bf16 products of the three-way split operands - fp32-level
     accuracy, so the fp32 step's tolerance applies unchanged"""
     _check_parameter_gradients(training, B, L, R, Tv, "bf16x6")
 
 
-def _check_parameter_gradients(training, B, L, R, Tv, dtype, seed=None):
-    """third case: T2 = 47 -> time-path sequences of 40 steps, long enough for the all-taps Toeplitz weight-gradient kernel and the
-    2-position-tile fold kernel on BOTH dual paths (the short cases only reach them on the frequency path); odd L, B = 1.
-    fourth case: R = 3 -> a MIDDLE block, whose adjoint runs rtfs_proj_gateway_bwd with a0_mode 2 (da0 += ds).
-    fifth case: one full-length utterance (L = 32000: T2 = 125, 57- / 118-step sequences) - the shapes of BASELINE config 3.  It runs
-    on input seed 2: with the default seed ONE PReLU activation of the 50-token video branch lies within fp32 round-off of its kink,
-    and every fp32 evaluation that lands on the other side of it than float64 does (this build, and torch's own fp32 autograd of the
-    oracle on some CPUs - tools/grad_vs_fp32.py) is off by 2e-3 ... 4e-2 on ~100 tensors downstream of that one element; seeds 1-3
-    show the all-or-nothing pattern (median error 3e-3 with the flip, 4e-5 ... 1e-4 without).  A property of the function, not of a kernel -
-    and which seed is affected changes with any re-ordering of fp32 sums in any kernel, so this case asserts what a kernel error cannot
-    satisfy instead of a per-tensor 3e-3: median over the 363 tensors < 5e-3 and every tensor within 6e-2 (scalar slopes 0.5)."""
+def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
             mod.p = 0.0
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
+    mix, _, emb = synth.synth_inputs(B, L, Tv)
+    if dtype == "bf16x3":
+        sd = smooth_regime(sd, cfg, mix, emb, training)
+        model.load_state_dict(sd)
+    emb = stable_emb(sd, cfg, emb, training)
     model.train(training)
     model.set_compute_dtype(dtype)
-    if seed is None:
-        seed = 2 if L >= 32000 else synth.INPUT_SEED
-    mix, _, emb = synth.synth_inputs(B, L, Tv, seed=seed)
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(7))
     out = model(mix.cuda(), emb.cuda())
     (out * wgt.cuda()).sum().backward()
-    ref_out, ref = _oracle_grads(sd, cfg, mix, emb, wgt, training)
+    ref_out, ref, ref_stats = _oracle_grads(sd, cfg, mix, emb, wgt, training)
     assert rel(out.detach(), ref_out) < 1e-3
+    tol, tol_scalar = (1.5e-3, 1e-2) if dtype == "bf16x3" else (3e-3, 1e-2)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
+    glue_video = training and Tv < 8  # the VP block as PyTorch glue on <= 7 tokens with batch statistics over B x (1 ... 6) positions: not a kernel of this build
     scale = max(float(g.norm()) for g in ref.values())
-    checked, errs = 0, []
+    checked, errs, bad = 0, [], []
     for n, p in model.named_parameters():
         assert p.grad is not None, n
         if float(ref[n].norm()) < 1e-6 * scale:
             assert float(p.grad.norm()) < 1e-4 * scale, n  # analytically zero gradients (softmax shift invariance, bias before BatchNorm)
             continue
-        if n.startswith(AUDIO_SKIP) and training:
-            continue  # torch glue on 2-7 tokens with train-mode BatchNorm: fp32 noise, not a kernel of this build
-        # PReLU slopes: ONE number = a signed sum over ~1e5 activations with heavy cancellation, accumulated in fp32
-        # mixed tolerance (as allclose): tensors whose whole gradient is ~1e-4 of the largest one are cancellation residue
-        # of fp32 sums (softmax over Tv, BatchNorm) and are held to the absolute floor instead
+        if glue_video and n.startswith(GLUE_VIDEO):
+            continue
+        # mixed tolerance (as allclose): tensors whose whole gradient is ~1e-4 of the largest one are cancellation residue of fp32 sums
+        # (softmax over Tv, BatchNorm) and are held to the absolute floor instead
         err = float((p.grad.double().cpu() - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale)
-        if L >= 32000:  # full length: a near-kink activation may flip (docstring) - every tensor must still be right to its leading digits
-            assert err < (0.5 if p.numel() <= 12 else 6e-2), (n, err)
-        elif dtype in ("f32", "bf16x6"):
-            assert err < (1e-2 if p.numel() <= 12 else TOL), (n, err)
-        else:
-            assert err < (1.0 if p.numel() <= 12 else 6e-2), (n, err)  # scalar PReLU slopes: one heavily cancelling sum each - order of magnitude only
+        if err >= (tol_scalar if p.numel() <= 12 else tol):
+            bad.append((round(err, 5), n))
         errs.append(err)
         checked += 1
     assert checked > 150
     errs.sort()
-    print(f"{dtype}: median gradient error {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}")
-    assert errs[len(errs) // 2] < (1e-3 if (dtype in ("f32", "bf16x6") and L < 32000) else 5e-3)  # (full length: a kink flip moves ~100 tensors, docstring)
+    print(f"{dtype} train={training} B={B} L={L} R={R} Tv={Tv}: median gradient error {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}, {checked} tensors")
+    assert not bad, sorted(bad, reverse=True)[:12]
+    assert errs[len(errs) // 2] < 1e-3
+    if training:  # running statistics of the 26 VP BatchNorm1d + 2 CAF BatchNorm2d layers after one step (momentum 0.1, unbiased variance)
+        got = {k: v for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+        assert len(got) == 56 and set(got) == set(ref_stats)
+        for k, v in got.items():
+            if glue_video and k.startswith(GLUE_VIDEO) and k.endswith("running_var"):
+                continue  # (unbiased variance over 2 positions: n / (n - 1) of a difference of two fp32 numbers)
+            assert rel(v, ref_stats[k]) < 1e-4, (k, rel(v, ref_stats[k]))
 
 
 def test_input_of_caf_video_side_gets_gradient():

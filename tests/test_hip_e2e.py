@@ -112,6 +112,41 @@ def test_30s_utterance_key_blocked_attention(dtype):
     assert e < WAVE_TOL
 
 
+def test_64s_utterance_at_the_length_guard():
+    """64 s (T = 8001: 1.057e9 bytes per [T][129][256] activation, the largest the length guard of models/hip_path.py admits; 4000 compressed
+    frames = four key blocks; Tv = 1600: the CAF video kernel far past the 750 frames of the 30 s case, the VP block on the glue path) against
+    the oracle.  One block (the offsets a block computes do not depend on the block index)."""
+    from oracle.avnet_ref import avnet_forward
+
+    model, sd, cfg = make_model(1, "cuda")
+    L = 1024000
+    mix, _, emb = synth.synth_inputs(1, L, 1600)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+        with pytest.raises(ValueError):
+            model(torch.cat([mix, mix[:, :24576]], 1).cuda(), emb.cuda())  # 65.5 s (T = 8193 > 8128 frames): refused, not mis-addressed
+        ref = avnet_forward(sd, cfg, mix, emb)
+    e = rel(out, ref)
+    print(f"64 s: waveform rel L2 vs the oracle = {e:.3e}")
+    assert e < WAVE_TOL
+
+
+def test_batch_offsets_past_2_31_elements():
+    """18 utterances of 30 s: B x T x 129 x 256 = 2.23e9 elements > 2^31, so every kernel's batch offset must be 64-bit.  Size-independent
+    property: utterances are independent, so the LAST utterance of the batch equals its own batch-1 forward (checked against the oracle by
+    test_30s_utterance_key_blocked_attention)."""
+    model, _, _ = make_model(1, "cuda")
+    B, L, Tv = 18, 480000, 750
+    assert B * (1 + L // 128) * 129 * 256 > 2 ** 31
+    mix, _, emb = synth.synth_inputs(B, L, Tv)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())[-1].clone()
+        torch.cuda.empty_cache()
+        one = model(mix[-1:].cuda(), emb[-1:].cuda())[0]
+    assert torch.isfinite(out).all()
+    assert rel(out, one) < 2e-6
+
+
 def test_fused_tfar_mix_convolution_matches_the_unfused_pair(monkeypatch):
     """rtfs_dwconv_mix_fwd (TFAR mix formed inside the concat-layer convolution's staging) against rtfs_tfar_mix_fwd + rtfs_dwconv_fwd"""
     model, _, _ = make_model(3, "cuda")

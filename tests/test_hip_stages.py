@@ -230,8 +230,13 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     win = torch.stack([seqs[:, k:k + L] for k in range(8)], dim=2).reshape(seqs.shape[0], L, 512)  # k index = tap * 64 + channel
     want = win @ Wt.double().t()
     U = torch.full((seqs.shape[0] * L * 256,), float("nan"), device="cuda")
-    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim)
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim, 0)
     assert rel(U.view(want.shape), want) < 2e-6
+    U1 = torch.full_like(U, float("nan"))
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 1)  # per-sequence tiles: the same bits
+    assert torch.equal(U, U1)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 7)
 
 
 def test_resid_proj_fusion_matches_separate_calls():
@@ -287,11 +292,13 @@ def test_resid_caf_entry_rejects_bad_arguments():
     st = torch.zeros(16, dtype=torch.float64, device="cuda")
     v = torch.zeros(256, device="cuda")
     args = lambda Tv, add, wp: (z, st, v, v, z, st, v, v, z, st, v, v, z, st, v, v, z, v, z, v, v, 0.25, v, v, v, v, z, z, Tv, add, z, wp, v, z, st,  # noqa: E731
-                                1, 16, 8)
+                                1, 16, 8, 0)
     with pytest.raises(RuntimeError):
         lib.call("rtfs_resid_caf_fwd", *args(4, 0, z))
     with pytest.raises(RuntimeError):
         lib.call("rtfs_resid_caf_fwd", *args(17, 1, None))
+    with pytest.raises(RuntimeError):  # unknown kernel form
+        lib.call("rtfs_resid_caf_fwd", *(args(4, 1, z)[:-1] + (9,)))
 
 
 @pytest.mark.parametrize("B,L", [(3, 16000), (2, 32000), (2, 12100), (1, 2048)])
@@ -344,20 +351,21 @@ def test_trio_entry_against_separate_entries(B, T):
         lib.call("rtfs_dwconv_trio_fwd", D0, st0, gam, bet, w1, l0b, s1b, w2, bias2, D1b, s2b, P, B, T, T2 + 1)
 
 
-def test_resid_one_workgroup_per_cu_form_matches():
-    """At large batch the projection-carrying residual kernels run as ONE workgroup per CU with the whole register file (resident
-    projection weights, every load a phase ahead; gemm.hip resid_kernel DEEP): per element the same arithmetic in the same order as the
-    two-workgroup form that small batches and RTFS_RESID_DEEP=0 take; a workgroup owns 4x more tiles, so the fp32 partial sums behind the
-    projection's gLN statistics group differently (1e-7 level)."""
-    import os
-
+@pytest.mark.parametrize("dtype", ["f32", "bf16x3"])
+def test_resid_large_batch_forms_match(dtype):
+    """At large batch the projection-carrying residual kernels (blocks 1..R-2 and block 0 with the CAF cell) run as ONE workgroup per CU:
+    variant 3 = eight waves, four that only issue MFMAs and four that own every global access and the element-wise work (gemm.hip
+    resid_ws_kernel, the default), variant 2 = four waves with the whole register file (resid_kernel DEEP), variant 1 = the two-workgroup
+    form small batches take.  Per element the same arithmetic in the same order; the workgroups own different numbers of tiles, so the fp32
+    partial sums behind the projection's gLN statistics group differently (1e-7 level)."""
     model, sd, cfg = make_model(3, "cuda")
-    mix, _, emb = synth.synth_inputs(10, 16000, 25)  # 254 tiles x 10 utterances >= 2048: the large-batch form
+    model.set_compute_dtype(dtype)
+    mix, _, emb = synth.synth_inputs(10, 16000 + 2048, 25)  # 287 tiles (the last one 14 pixels: an empty second half) x 10 utterances >= 2048
+    outs = {}
     with torch.no_grad():
-        deep = model(mix.cuda(), emb.cuda())
-        os.environ["RTFS_RESID_DEEP"] = "0"
-        try:
-            plain = model(mix.cuda(), emb.cuda())
-        finally:
-            del os.environ["RTFS_RESID_DEEP"]
-    assert rel(deep, plain) < 1e-6
+        for v in (3, 2, 1, 0):
+            model._hip.variants["resid"] = v
+            outs[v] = model(mix.cuda(), emb.cuda())
+    model._hip.variants["resid"] = 0
+    assert torch.equal(outs[0], outs[3])  # the library's choice at this size
+    assert rel(outs[3], outs[1]) < 1e-6 and rel(outs[2], outs[1]) < 1e-6

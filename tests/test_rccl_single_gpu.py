@@ -31,7 +31,7 @@ def test_ddp_syncbn_step_over_rccl_world_size_one():
             if isinstance(mod, torch.nn.MultiheadAttention):
                 mod.dropout = 0.0
         model.train()
-        B, L, Tv = 2, 4096, 6
+        B, L, Tv = 2, 4096, 12  # Tv >= 8: the VP block's HIP training kernels under SyncBatchNorm modules (world size 1: no collective)
         mix, _, emb = synth.synth_inputs(B, L, Tv)
         wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(11))
         mix, emb, wgt = mix.cuda(), emb.cuda(), wgt.cuda()
@@ -54,8 +54,6 @@ def test_ddp_syncbn_step_over_rccl_world_size_one():
         scale = max(float(g.norm()) for g in ref.values())
         for n, p in net.module.named_parameters():
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
-            if n.startswith("refinement_module.video_net."):
-                continue  # PyTorch glue; SyncBatchNorm's kernels differ from BatchNorm1d's in fp32 round-off on 2 x {6,3,2,1} positions
             err = float((p.grad - ref[n]).norm()) / (float(ref[n].norm()) + 1e-4 * scale)
             assert err < (2e-2 if p.numel() <= 12 else 5e-3), (n, err)
     finally:

@@ -25,7 +25,7 @@ def main(dtype="f32", B=32, T2=125):
         L = npos - 7
         U = torch.empty(S * L * 256, device="cuda")
         name = "rtfs_dp_unfold_gemm_fwd" + ("_bf16" if prec else "")
-        args = (G, gamma, beta, Wk, U, B, T2, dim) + ((prec,) if prec else ())
+        args = (G, gamma, beta, Wk, U, B, T2, dim, 0) + ((prec,) if prec else ())
         for _ in range(3):
             lib.call(name, *args)
         torch.cuda.synchronize()

@@ -17,8 +17,8 @@ def main(B=1, L=32000, R=2, Tv=50, seed=synth.INPUT_SEED, top=40):
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(7))
     out = model(mix.cuda(), emb.cuda())
     (out * wgt.cuda()).sum().backward()
-    _, ref = _oracle_grads(sd, cfg, mix, emb, wgt, False)
-    _, g32 = _oracle_grads(sd, cfg, mix, emb, wgt, False, torch.float32)
+    _, ref, _ = _oracle_grads(sd, cfg, mix, emb, wgt, False)
+    _, g32, _ = _oracle_grads(sd, cfg, mix, emb, wgt, False, torch.float32)
     scale = max(float(g.norm()) for g in ref.values())
     rows = []
     for n, p in model.named_parameters():
