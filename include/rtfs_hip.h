@@ -128,6 +128,12 @@ int rtfs_caf_video_fwd(const float* v /*[B][512][Tv]*/, const float* att_w, cons
                        void* stream);
 int rtfs_caf_fuse_fwd(const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att, const float* rsz,
                       const float* a0_or_null, float* out, int B, int T, int Tv, void* stream);
+/* adjoint of rtfs_caf_video_fwd (training step; the forward is the same kernel in both modes - the video side has no BatchNorm): datt, drsz
+ * [B][Tv][256] -> dv [B][512][Tv] (written) and the eight parameter gradients, ADDED into the caller's zeroed buffers (shapes of the parameters) */
+int rtfs_caf_video_bwd(const float* v, const float* att_w, const float* att_b, const float* att_g, const float* att_be, const float* rs_w,
+                       const float* rs_b, const float* rs_g, const float* rs_be, const float* datt, const float* drsz, float* dv, float* d_att_w,
+                       float* d_att_b, float* d_att_g, float* d_att_be, float* d_rs_w, float* d_rs_b, float* d_rs_g, float* d_rs_be, int B, int Tv,
+                       void* stream);
 
 /* Block 0 of the refinement loop: rtfs_resid_fwd (a0_or_null = NULL: the block runs on a0 itself, refinement_module.py:55) fused with
  * rtfs_caf_fuse_fwd (ATTNFusionCell's audio side, fusion.py:259-272, applied to the block output in the epilogue registers; add_input != 0
@@ -352,6 +358,19 @@ int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const float* y_sta
                           const float* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
                           const float* gb, float gslope, const float* Wp, float* dWp, float* dbp, float* dgw, float* dgb, float* dgslope, float* dx, int B,
                           int T, void* stream);
+
+/* GlobalAttention of the VP block in the training step (layers/attention.py:28-73,192-220 MultiHeadSelfAttention incl. nn.MultiheadAttention,
+ * layers/conv_layers.py:218-259 FeedForwardNetwork), csrc/vp_attn.hip: g, out, dout, dg [B][64][Tg], 2 <= Tg <= 16; params / dparams
+ * [rtfs_vp_attn_param_count()] in the order norm1 (w, b), in_proj (w [192][64], b), out_proj (w [64][64], b), norm2 (w, b), FFN encoder conv
+ * [128][64], its gLN (w, b), refiner dw conv [128][3] + bias, decoder conv [64][128], its gLN (w, b); pe: rows of the positional encoding
+ * [>= Tg][64]; masks_or_null: per utterance rtfs_vp_attn_mask_size(Tg) multiplicative keep-masks of ONE step - attention-probability dropout
+ * [8][Tg][Tg], dropout of the attention output [Tg][64], the three DropPath factors (after the MHSA, the refiner, the decoder) - or NULL for no
+ * dropout.  rtfs_vp_attn_bwd recomputes the forward, writes dg and ADDS the parameter gradients of all B utterances into dparams. */
+int rtfs_vp_attn_param_count(void);
+int rtfs_vp_attn_mask_size(int Tg);
+int rtfs_vp_attn_fwd(const float* g, const float* params, const float* pe, const float* masks_or_null, float* out, int B, int Tg, void* stream);
+int rtfs_vp_attn_bwd(const float* g, const float* params, const float* pe, const float* masks_or_null, const float* dout, float* dg, float* dparams, int B,
+                     int Tg, void* stream);
 
 #ifdef __cplusplus
 }

@@ -328,44 +328,47 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                 st4(tile + r * RS + c * 64 + c4, (first && MODE != 3) ? xform(vh[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c) : vh[i]);
         }
         __syncthreads();
-        // ---- 8 output columns from a sliding window over LDS (column c of the block lives in window slot c & 3)
+        // ---- 8 output columns, OPS = 4 per step (round 3): for each of the four tap rows the step reads the OPS + 3 window columns of that row
+        // once and every tap once, and feeds OPS outputs from them - 11 ds_read_b128 per output quad instead of 20 (16 taps + 4 new window
+        // entries per single output before).  With one output per step the kernel read 80 bytes of LDS per output float against 8 bytes of
+        // HBM traffic: LDS issue, not HBM, set the pace of the compute phase.  Row-at-a-time keeps the window at 7 registers quads.
+        constexpr int OPS = 4;
         const float* trow = tile + tr * RS + c4;
-        float4 win[4][4];
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) win[c][r] = ld4(trow + r * RS + c * 64);
 #pragma unroll 1
-        for (int jb = 0; jb < TC; jb += 4) {
-        int woff = c4;
-        asm volatile("" : "+v"(woff));  // re-read the taps from LDS here: hoisted out of the loops they pin 64 VGPRs per convolution (spills)
+        for (int jb = 0; jb < TC; jb += OPS) {
+            int woff = c4;
+            asm volatile("" : "+v"(woff));  // re-read the taps from LDS here: hoisted out of the loops they pin 64 VGPRs per convolution (spills)
+            float4 acc[NCONV][OPS];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = jb + jj;
+            for (int k = 0; k < NCONV; ++k)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) win[(jj + 3) & 3][r] = ld4(trow + r * RS + (j + 3) * 64);
-            float4 acc[NCONV];
+                for (int jj = 0; jj < OPS; ++jj) acc[k][jj] = bias4[k];
+#pragma unroll 1
+            for (int dt = 0; dt < 4; ++dt) {  // (rolled: unrolled, hipcc issues all 28 window and 16 NCONV tap reads first and spills)
+                float4 wr[OPS + 3];
 #pragma unroll
-            for (int k = 0; k < NCONV; ++k) acc[k] = bias4[k];
+                for (int c = 0; c < OPS + 3; ++c) wr[c] = ld4(trow + dt * RS + (jb + c) * 64);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int df = 0; df < 4; ++df)
 #pragma unroll
-                for (int df = 0; df < 4; ++df) {
-                    const float4 x = win[(jj + df) & 3][dt];
+                    for (int k = 0; k < NCONV; ++k) {
+                        const float4 tap = ld4(&ws[k][(dt * 4 + df) * 64 + woff]);  // quad-broadcast LDS read, shared by the OPS outputs
 #pragma unroll
-                    for (int k = 0; k < NCONV; ++k) acc[k] = fma4(ld4(&ws[k][(dt * 4 + df) * 64 + woff]), x, acc[k]);  // taps: quad-broadcast LDS reads
-                    // (register-resident taps for NCONV == 1 were measured slower: 64 more VGPRs -> spills in the staging phase)
-                }
-            const int fo = fb + j;
-            if (tvalid && fo < f1) {
+                        for (int jj = 0; jj < OPS; ++jj) acc[k][jj] = fma4(tap, wr[jj + df], acc[k][jj]);
+                    }
+            }
 #pragma unroll
-                for (int k = 0; k < NCONV; ++k) {
-                    st4(a.out[k] + orow + (size_t)fo * kH, acc[k]);
-                    s[k] += acc[k].x + acc[k].y + acc[k].z + acc[k].w;
-                    q[k] += acc[k].x * acc[k].x + acc[k].y * acc[k].y + acc[k].z * acc[k].z + acc[k].w * acc[k].w;
+            for (int jj = 0; jj < OPS; ++jj) {
+                const int fo = fb + jb + jj;
+                if (tvalid && fo < f1) {
+#pragma unroll
+                    for (int k = 0; k < NCONV; ++k) {
+                        st4(a.out[k] + orow + (size_t)fo * kH, acc[k][jj]);
+                        s[k] += acc[k][jj].x + acc[k][jj].y + acc[k][jj].z + acc[k][jj].w;
+                        q[k] += acc[k][jj].x * acc[k][jj].x + acc[k][jj].y * acc[k][jj].y + acc[k][jj].z * acc[k][jj].z + acc[k][jj].w * acc[k][jj].w;
+                    }
                 }
             }
-        }
         }
     }
 #pragma unroll
@@ -477,33 +480,36 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
             if (idx < R * 3 * 16) st4(tile + r * RS + c * 64 + c4, first ? xform(vh[i], t0 - 1 + r, fb - 1 + c) : vh[i]);
         }
         __syncthreads();
-        // ---- pass 1: 8 stride-1 output columns from a sliding window over LDS (column c of the block lives in window slot c & 3)
+        // ---- pass 1: 8 stride-1 output columns, 4 per step: per tap row the 7 window columns and the 4 taps are read once and feed 4 outputs
+        // (11 ds_read_b128 per output quad instead of 20; see dwconv_s1_kernel)
         {
             const float* trow = tile + tr * RS + c4;
-            float4 win[4][4];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) win[c][r] = ld4(trow + r * RS + c * 64);
 #pragma unroll 1
             for (int jb = 0; jb < TC; jb += 4) {
                 int woff = c4;
-                asm volatile("" : "+v"(woff));  // taps re-read from LDS per group of 4 columns (hoisted they pin 64 VGPRs)
+                asm volatile("" : "+v"(woff));  // taps re-read from LDS per step (hoisted they pin 64 VGPRs)
+                float4 acc[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] = f4(0, 0, 0, 0);
+#pragma unroll 1
+                for (int dt = 0; dt < 4; ++dt) {
+                    float4 wr[7];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) wr[c] = ld4(trow + dt * RS + (jb + c) * 64);
+#pragma unroll
+                    for (int df = 0; df < 4; ++df) {
+                        const float4 tap = ld4(&ws[0][(dt * 4 + df) * 64 + woff]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[jj] = fma4(tap, wr[jj + df], acc[jj]);
+                    }
+                }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int j = jb + jj;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) win[(jj + 3) & 3][r] = ld4(trow + r * RS + (j + 3) * 64);
-                    float4 acc = f4(0, 0, 0, 0);
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                        for (int df = 0; df < 4; ++df) acc = fma4(ld4(&ws[0][(dt * 4 + df) * 64 + woff]), win[(jj + df) & 3][dt], acc);
-                    const int fo = fb + j;
+                    const int fo = fb + jb + jj;
                     if (tvalid && fo < f1) {
-                        st4(a.out1 + orow + (size_t)fo * kH, acc);
-                        s1 += acc.x + acc.y + acc.z + acc.w;
-                        q1 += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+                        st4(a.out1 + orow + (size_t)fo * kH, acc[jj]);
+                        s1 += acc[jj].x + acc[jj].y + acc[jj].z + acc[jj].w;
+                        q1 += acc[jj].x * acc[jj].x + acc[jj].y * acc[jj].y + acc[jj].z * acc[jj].z + acc[jj].w * acc[jj].w;
                     }
                 }
             }
@@ -669,6 +675,131 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
     }
 }
 
+// Adjoint of caf_video_kernel (training step; the forward kernel is mode-independent: gLN only, no BatchNorm on the video side).
+// One workgroup per utterance, thread = audio channel c = convolution group c: it owns input rows 2c, 2c + 1, the four attention-embedding
+// channels 4c .. 4c + 3 and resize channel c, recomputes their forward values from v (two block-wide gLN statistics, one softmax row) and
+// walks its Tv positions three times: softmax dot, gLN adjoint sums, input / parameter gradients.  Parameter gradients of the B workgroups
+// are added into the caller's (zeroed) buffers with one atomic per value.
+//   datt, drsz: [B][Tv][256];  dv: [B][512][Tv] (written);  d_att_w [1024][2], d_att_b / d_att_g / d_att_be [1024], d_rs_w [256][2], d_rs_b / d_rs_g / d_rs_be [256]
+__global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restrict__ v, const float* __restrict__ att_w, const float* __restrict__ att_b,
+                                                            const float* __restrict__ att_g, const float* __restrict__ att_be,
+                                                            const float* __restrict__ rs_w, const float* __restrict__ rs_b, const float* __restrict__ rs_g,
+                                                            const float* __restrict__ rs_be, const float* __restrict__ datt, const float* __restrict__ drsz,
+                                                            float* __restrict__ dv, float* __restrict__ d_att_w, float* __restrict__ d_att_b,
+                                                            float* __restrict__ d_att_g, float* __restrict__ d_att_be, float* __restrict__ d_rs_w,
+                                                            float* __restrict__ d_rs_b, float* __restrict__ d_rs_g, float* __restrict__ d_rs_be, int Tv) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
+    const float* v0 = v + ((size_t)b * 512 + 2 * c) * Tv;
+    const float* v1 = v0 + Tv;
+    float aw0[4], aw1[4], ab[4], ag[4], abe[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int o = c * 4 + h;
+        aw0[h] = att_w[2 * o], aw1[h] = att_w[2 * o + 1], ab[h] = att_b[o], ag[h] = att_g[o], abe[h] = att_be[o];
+    }
+    const float rw0 = rs_w[2 * c], rw1 = rs_w[2 * c + 1], rb = rs_b[c], rg = rs_g[c];
+    auto block4 = [&](float a, float b_, float& ra, float& rb_) {  // two block-wide sums
+        a = wave_sum(a), b_ = wave_sum(b_);
+        __syncthreads();
+        if (lane == 0) red[w] = a, red[4 + w] = b_;
+        __syncthreads();
+        ra = red[0] + red[1] + red[2] + red[3], rb_ = red[4] + red[5] + red[6] + red[7];
+    };
+    // forward statistics, as the forward kernel computes them (mean first, then centred squares)
+    float s_att = 0.f, s_rs = 0.f;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) s_att += fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h]));
+        s_rs += fmaf(rw0, x0, fmaf(rw1, x1, rb));
+    }
+    float m_att, m_rs;
+    block4(s_att, s_rs, m_att, m_rs);
+    const float n_att = 1024.f * Tv, n_rs = 256.f * Tv;
+    m_att /= n_att, m_rs /= n_rs;
+    float q_att = 0.f, q_rs = 0.f;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float d = fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att;
+            q_att = fmaf(d, d, q_att);
+        }
+        const float d = fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs;
+        q_rs = fmaf(d, d, q_rs);
+    }
+    float r_att, r_rs;
+    block4(q_att, q_rs, r_att, r_rs);
+    r_att = 1.0f / sqrtf(r_att / n_att + kEps), r_rs = 1.0f / sqrtf(r_rs / n_rs + kEps);
+    auto att_at = [&](int t) {
+        const float x0 = v0[t], x1 = v1[t];
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) m += fmaf((fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att, ag[h], abe[h]);
+        return m * 0.25f;
+    };
+    float mx = -3.0e38f;
+    for (int t = 0; t < Tv; ++t) mx = fmaxf(mx, att_at(t));
+    float sum = 0.f;
+    for (int t = 0; t < Tv; ++t) sum += __expf(att_at(t) - mx);
+    const float inv = 1.0f / sum;
+    const float* dab = datt + (size_t)b * Tv * 256 + c;
+    const float* drb = drsz + (size_t)b * Tv * 256 + c;
+    // softmax adjoint: d(head mean)_t = p_t (dp_t - sum_t' p_t' dp_t')
+    float sdot = 0.f;
+    for (int t = 0; t < Tv; ++t) sdot = fmaf(__expf(att_at(t) - mx) * inv, dab[(size_t)t * 256], sdot);
+    // gLN adjoint sums: S1 = sum u, S2 = sum u xhat (u = dy gamma) over the whole utterance; d gamma / d beta of this thread's channels
+    float s1a = 0.f, s2a = 0.f, s1r = 0.f, s2r = 0.f, dga[4] = {0.f, 0.f, 0.f, 0.f}, dba = 0.f, dgr = 0.f, dbr = 0.f;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+        const float dy = __expf(att_at(t) - mx) * inv * (dab[(size_t)t * 256] - sdot) * 0.25f;  // the same for the four heads (mean over them)
+        dba += dy;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float xh = (fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att;
+            dga[h] = fmaf(dy, xh, dga[h]);
+            s1a = fmaf(dy, ag[h], s1a), s2a = fmaf(dy * ag[h], xh, s2a);
+        }
+        const float dr = drb[(size_t)t * 256], xr = (fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs;
+        dgr = fmaf(dr, xr, dgr), dbr += dr;
+        s1r = fmaf(dr, rg, s1r), s2r = fmaf(dr * rg, xr, s2r);
+    }
+    float S1a, S2a, S1r, S2r;
+    block4(s1a, s2a, S1a, S2a);
+    block4(s1r, s2r, S1r, S2r);
+    S1a /= n_att, S2a /= n_att, S1r /= n_rs, S2r /= n_rs;
+    // input and convolution-parameter gradients
+    float dw0[4] = {0.f, 0.f, 0.f, 0.f}, dw1[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f}, drw0 = 0.f, drw1 = 0.f, drb_ = 0.f;
+    float* dv0 = dv + ((size_t)b * 512 + 2 * c) * Tv;
+    float* dv1 = dv0 + Tv;
+    for (int t = 0; t < Tv; ++t) {
+        const float x0 = v0[t], x1 = v1[t];
+        const float dy = __expf(att_at(t) - mx) * inv * (dab[(size_t)t * 256] - sdot) * 0.25f;
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float xh = (fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att;
+            const float draw = r_att * (dy * ag[h] - S1a - xh * S2a);
+            dw0[h] = fmaf(draw, x0, dw0[h]), dw1[h] = fmaf(draw, x1, dw1[h]), dbb[h] += draw;
+            g0 = fmaf(aw0[h], draw, g0), g1 = fmaf(aw1[h], draw, g1);
+        }
+        const float xr = (fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs;
+        const float draw = r_rs * (drb[(size_t)t * 256] * rg - S1r - xr * S2r);
+        drw0 = fmaf(draw, x0, drw0), drw1 = fmaf(draw, x1, drw1), drb_ += draw;
+        dv0[t] = fmaf(rw0, draw, g0);
+        dv1[t] = fmaf(rw1, draw, g1);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int o = c * 4 + h;
+        atomicAdd(d_att_w + 2 * o, dw0[h]), atomicAdd(d_att_w + 2 * o + 1, dw1[h]), atomicAdd(d_att_b + o, dbb[h]);
+        atomicAdd(d_att_g + o, dga[h]), atomicAdd(d_att_be + o, dba);
+    }
+    atomicAdd(d_rs_w + 2 * c, drw0), atomicAdd(d_rs_w + 2 * c + 1, drw1), atomicAdd(d_rs_b + c, drb_);
+    atomicAdd(d_rs_g + c, dgr), atomicAdd(d_rs_be + c, dbr);
+}
+
 // out = relu(x*ks+kb) * rsz[b][tv(t)] + att[b][tv(t)] * (x*vs+vb) [+ a0];  x,out,a0: [B][T][F][256]; tv(t) = floor(t*Tv/T)
 __global__ __launch_bounds__(256) void caf_fuse_kernel(const float* __restrict__ x, const float* __restrict__ ks, const float* __restrict__ kb,
                                                        const float* __restrict__ vs, const float* __restrict__ vb, const float* __restrict__ att,
@@ -827,6 +958,17 @@ int rtfs_caf_video_fwd(const float* v, const float* att_w, const float* att_b, c
     if (B <= 0 || Tv <= 0) return RTFS_EINVAL;
     hipLaunchKernelGGL(caf_video_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, att_out,
                        rsz_out, Tv);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+int rtfs_caf_video_bwd(const float* v, const float* att_w, const float* att_b, const float* att_g, const float* att_be, const float* rs_w,
+                       const float* rs_b, const float* rs_g, const float* rs_be, const float* datt, const float* drsz, float* dv, float* d_att_w,
+                       float* d_att_b, float* d_att_g, float* d_att_be, float* d_rs_w, float* d_rs_b, float* d_rs_g, float* d_rs_be, int B, int Tv,
+                       void* stream) {
+    if (B <= 0 || Tv <= 0) return RTFS_EINVAL;
+    hipLaunchKernelGGL(caf_video_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, datt, drsz,
+                       dv, d_att_w, d_att_b, d_att_g, d_att_be, d_rs_w, d_rs_b, d_rs_g, d_rs_be, Tv);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "rtfs_resid_caf_fwd": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, P],
     "rtfs_caf_video_fwd": [P] * 11 + [I, I, P],
     "rtfs_caf_fuse_fwd": [P] * 9 + [I, I, I, P],
+    "rtfs_caf_video_bwd": [P] * 20 + [I, I, P],
     "rtfs_mask_fwd": [P, F, P, P, P, P, P, I, I, P],
     "rtfs_istft_fwd": [P, P, P, I, I, P],
     # ---- backward (training step) ----
@@ -101,6 +102,10 @@ SIGNATURES = {
     "rtfs_vp_dwconv_bwd": [P, P, P, P, P, F, P, F, I, P, P, P, P, F, I, F, P, P, P, P, I, P, I, I, I, I, P],
     "rtfs_vp_pool_bwd": [P, P, I, I, I, I, I, I, P],
     "rtfs_vp_gate_proj_bwd": [P, P, P, P, P, F, P, F, I, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, P],
+    "rtfs_vp_attn_param_count": [],
+    "rtfs_vp_attn_mask_size": [I],
+    "rtfs_vp_attn_fwd": [P, P, P, P, P, I, I, P],
+    "rtfs_vp_attn_bwd": [P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_proj_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],

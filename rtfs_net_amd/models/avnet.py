@@ -221,8 +221,8 @@ class AVNet(nn.Module):
         return tr
 
     def _forward_autograd(self, x, mouth_embedding):
-        """Training step: VP block + CAF video projections in torch autograd (glue); the audio branch is ONE
-        autograd.Function whose forward and backward are HIP kernel chains (models/hip_train.py)."""
+        """Training step: every stage is a torch.autograd.Function over HIP kernel chains - the audio branch in two stages split at the CAF
+        cell (models/hip_train.py), the VP block and the CAF cell's video side in models/vp_train.py; PyTorch autograd only connects them."""
         from .hip_train import AVNetHipStageA, AVNetHipStageB, HipTrainer, StepCtx
 
         if not x.is_cuda:
@@ -252,7 +252,7 @@ class AVNet(nn.Module):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
             vb = rm.video_net.get_block(0)
             if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
-                # convolution / BatchNorm chain of the VP block on HIP kernels, GlobalAttention in between as PyTorch glue (models/vp_train.py)
+                # the VP block on HIP kernels: convolution / BatchNorm chain and GlobalAttention (models/vp_train.py)
                 from .vp_train import vp_block_train
 
                 sc = self._trainer.weights()._scal  # every scalar of the model, one transfer per optimizer step
@@ -261,10 +261,9 @@ class AVNet(nn.Module):
             else:
                 v1 = vb(vin)
             cell = rm.crossmodal_fusion.get_fusion_block(0).audio_lstm
-            B = v1.shape[0]
-            att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)  # layers/fusion.py:262-264
-            att = torch.softmax(att, -1).transpose(1, 2).contiguous()                                   # [B, Tv, 256]
-            rsz = cell.resize(v1).transpose(1, 2).contiguous()
+            from .vp_train import caf_video_train
+
+            att, rsz = caf_video_train(cell, v1)  # layers/fusion.py:255,262-265 on HIP kernels (forward + adjoint), [B, Tv, 256] each
         att.record_stream(cur)
         rsz.record_stream(cur)
         self._trainer.video_stream = side

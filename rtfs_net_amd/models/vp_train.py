@@ -2,12 +2,14 @@
 
 The reference runs the 1-D `TDANetBlock` (separators/tdanet.py:106-133, config yaml:74-92) as ~100 small PyTorch ops forward and ~300
 backward, with `BatchNorm1d` batch statistics (SyncBatchNorm under DDP, train.py:145) at 26 places.  Here the convolution / BatchNorm
-chain is two `torch.autograd.Function`s around the one stage that stays PyTorch glue, the 13-token `GlobalAttention`
-(LayerNorm + nn.MultiheadAttention + FFN, dropout / DropPath, layers/attention.py:28-73,192-220):
+chain is two `torch.autograd.Function`s around the 13-token `GlobalAttention` (LayerNorm + nn.MultiheadAttention + FFN, dropout / DropPath,
+layers/attention.py:28-73,192-220), which is a third one:
 
-    x [B,512,T] --VPStageA--> g [B,64,Tg] --globalatt (torch)--> g' --VPStageB--> out [B,512,T]
+    x [B,512,T] --VPStageA--> g [B,64,Tg] --VPAttnFn--> g' --VPStageB--> out [B,512,T]
 
 * stage A: gateway, projection (+BN+PReLU), the four down-sampling convolutions (+BN), pooled sum;
+* GlobalAttention: since round 3 one forward and one backward launch of csrc/vp_attn.hip (`VPAttnFn`; the stochastic layers take one draw of
+  keep-masks per step from torch.rand - the only ATen kernels left in the block);
 * stage B: the 4 + 3 InjectionMultiSum units (21 convolutions + BN), residual conv + gateway residual.
 
 BatchNorm never runs as an op: producers accumulate per-channel (sum, sum of squares) into a slot of one statistics tensor, consumers
@@ -396,11 +398,144 @@ class _Holder:
     slopes = None
 
 
+# ---- GlobalAttention on HIP (csrc/vp_attn.hip) ------------------------------------------------------------------------------------
+def attn_supported(ga) -> bool:
+    """the RTFS-Net family's GlobalAttention: 64 channels, 8 heads, positional encoding, FFN 64 -> 128 -> 64 with a k = 3 depth-wise refiner"""
+    try:
+        m, f = ga.MHSA, ga.FFN
+        return (type(ga).__name__ == "GlobalAttention" and m.attention.embed_dim == 64 and m.attention.num_heads == 8 and m.attention.in_proj_weight is not None
+                and f.encoder.out_chan == 128 and f.refiner.kernel_size == 3 and abs(m.norm1.eps - EPS) < 1e-12 and abs(m.norm2.eps - EPS) < 1e-12)
+    except AttributeError:
+        return False
+
+
+def attn_params(ga):
+    """the 16 parameter tensors in the packing order of csrc/vp_attn.hip (VaOff)"""
+    m, f = ga.MHSA, ga.FFN
+    return [m.norm1.weight, m.norm1.bias, m.attention.in_proj_weight, m.attention.in_proj_bias, m.attention.out_proj.weight, m.attention.out_proj.bias,
+            m.norm2.weight, m.norm2.bias, f.encoder.full_layer[2].weight, f.encoder.full_layer[3].norm.weight, f.encoder.full_layer[3].norm.bias,
+            f.refiner.full_layer[2].weight, f.refiner.full_layer[2].bias, f.decoder.full_layer[2].weight, f.decoder.full_layer[3].norm.weight,
+            f.decoder.full_layer[3].norm.bias]
+
+
+_MASK_CACHE = {}
+
+
+def attn_masks(ga, B, Tg, dev):
+    """One draw of the stochastic layers of a training step as multiplicative keep-masks [B][8 Tg^2 + 64 Tg + 3] (0 or 1 / keep probability):
+    nn.MultiheadAttention's dropout on the attention probabilities, nn.Dropout on the attention output (attention.py:67-68), DropPath after the
+    MHSA (:73), after the FFN refiner and after the FFN decoder (conv_layers.py:253-256; per-utterance Bernoulli, scaled by 1 / keep as timm does).
+    None in eval mode or when every probability is 0."""
+    m, f = ga.MHSA, ga.FFN
+    if not ga.training:
+        return None
+    ps = (float(m.attention.dropout), float(m.dropout_layer.p), float(m.drop_path_layer.p), float(f.dropout_layer.p))
+    if max(ps) == 0.0:
+        return None
+    key = (Tg, ps, str(dev))
+    tab = _MASK_CACHE.get(key)
+    if tab is None:  # per-column drop probability and scale, built once per shape (host -> device copies are blocking transfers)
+        na, ne = 8 * Tg * Tg, Tg * 64
+        thr = torch.tensor([ps[0]] * na + [ps[1]] * ne + [ps[2], ps[3], ps[3]])
+        tab = _MASK_CACHE[key] = (thr.to(dev), (1.0 / (1.0 - thr)).to(dev))
+    thr, scl = tab
+    return (torch.rand(B, thr.numel(), device=dev) >= thr).to(torch.float32) * scl
+
+
+class VPAttnFn(torch.autograd.Function):
+    """g [B,64,Tg] -> GlobalAttention(g): one HIP launch forward, one backward (which recomputes the forward in LDS: only g and the masks are kept)"""
+
+    @staticmethod
+    def forward(ctx, ga, masks, g, *params):
+        with torch.no_grad():
+            g = g.detach().float().contiguous()
+            B, _, Tg = g.shape
+            packed = torch.cat([p.detach().float().reshape(-1) for p in params])
+            pe = ga.MHSA.pos_enc.pe[0, :Tg].float().contiguous()
+            out = torch.empty_like(g)
+            lib.call("rtfs_vp_attn_fwd", g, packed, pe, masks, out, B, Tg)
+        ctx.ga, ctx.saved, ctx.shapes = ga, (g, packed, pe, masks), [p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, packed, pe, masks = ctx.saved
+        B, _, Tg = g.shape
+        with torch.no_grad():
+            dg = torch.empty_like(g)
+            dpar = torch.zeros_like(packed)
+            lib.call("rtfs_vp_attn_bwd", g, packed, pe, masks, dout.detach().float().contiguous(), dg, dpar, B, Tg)
+            grads, o = [], 0
+            for shp in ctx.shapes:
+                n = int(torch.Size(shp).numel())
+                grads.append(dpar[o:o + n].view(shp))
+                o += n
+        ctx.saved = None
+        return (None, None, dg) + tuple(grads)
+
+
+def global_attention_train(ga, g: torch.Tensor) -> torch.Tensor:
+    """GlobalAttention of the VP block under autograd on the HIP kernels; other configurations / more than 16 tokens: the PyTorch module"""
+    if not attn_supported(ga) or not (2 <= g.shape[-1] <= 16) or g.shape[1] != 64:
+        return ga(g)
+    params = attn_params(ga)
+    if packed_count() != sum(p.numel() for p in params):
+        raise RuntimeError("GlobalAttention parameter packing does not match csrc/vp_attn.hip (VaOff)")
+    return VPAttnFn.apply(ga, attn_masks(ga, g.shape[0], g.shape[-1], g.device), g, *params)
+
+
+def packed_count() -> int:
+    return lib.load().rtfs_vp_attn_param_count()
+
+
 def vp_block_train(trainer: VPTrainer, x: torch.Tensor, slopes=None) -> torch.Tensor:
-    """the VP block of one training step: HIP stage A -> GlobalAttention (PyTorch) -> HIP stage B.
+    """the VP block of one training step: HIP stage A -> GlobalAttention (HIP, csrc/vp_attn.hip) -> HIP stage B.
     slopes: (gateway PReLU slope, projection PReLU slope) as Python floats if the caller already has them on the host."""
     holder = _Holder()
     holder.slopes = slopes
     g = VPStageA.apply(trainer, holder, x, *trainer.params_a())
-    g2 = trainer.vb.globalatt(g)
+    g2 = global_attention_train(trainer.vb.globalatt[0], g)
     return VPStageB.apply(trainer, holder, g2, *trainer.params_b())
+
+
+# ---- video side of the CAF cell under autograd (csrc/tfar.hip caf_video_kernel / caf_video_bwd_kernel) -------------------------------
+class CAFVideoFn(torch.autograd.Function):
+    """v1 [B,512,Tv] -> (att, rsz) [B,Tv,256]: attention_embed / resize grouped 1x1 convolutions + gLN, head mean, softmax over Tv
+    (layers/fusion.py:255,262-265).  No BatchNorm on this side, so the forward is the inference kernel; the adjoint recomputes it."""
+
+    @staticmethod
+    def forward(ctx, v1, *params):
+        with torch.no_grad():
+            v1 = v1.detach().float().contiguous()
+            B, _, Tv = v1.shape
+            ps = [p.detach().float().contiguous() for p in params]
+            att = torch.empty(B, Tv, 256, device=v1.device)
+            rsz = torch.empty_like(att)
+            lib.call("rtfs_caf_video_fwd", v1, *ps, att, rsz, B, Tv)
+        ctx.saved = (v1, ps)
+        return att, rsz
+
+    @staticmethod
+    def backward(ctx, datt, drsz):
+        v1, ps = ctx.saved
+        B, _, Tv = v1.shape
+        with torch.no_grad():
+            dv = torch.empty_like(v1)
+            flat = torch.zeros(sum(p.numel() for p in ps), device=v1.device)
+            grads, o = [], 0
+            for p in ps:
+                grads.append(flat[o:o + p.numel()])
+                o += p.numel()
+            lib.call("rtfs_caf_video_bwd", v1, *ps, datt.detach().float().contiguous(), drsz.detach().float().contiguous(), dv, *grads, B, Tv)
+        ctx.saved = None
+        return (dv,) + tuple(g.view(p.shape) for g, p in zip(grads, ps))
+
+
+def caf_video_train(cell, v1):
+    """(att, rsz) of ATTNFusionCell's video side on HIP kernels, forward and backward; parameter order of rtfs_caf_video_fwd"""
+    a, r = cell.attention_embed.full_layer, cell.resize.full_layer
+    if v1.shape[1] != 512 or cell.in_chan_a != 256 or cell.kernel_size != 4:
+        B = v1.shape[0]
+        att = cell.attention_embed(v1).reshape(B, cell.in_chan_a, cell.kernel_size, -1).mean(2)
+        return torch.softmax(att, -1).transpose(1, 2).contiguous(), cell.resize(v1).transpose(1, 2).contiguous()
+    return CAFVideoFn.apply(v1, a[2].weight, a[2].bias, a[3].norm.weight, a[3].norm.bias, r[2].weight, r[2].bias, r[3].norm.weight, r[3].norm.bias)

@@ -368,4 +368,9 @@ def test_resid_large_batch_forms_match(dtype):
             outs[v] = model(mix.cuda(), emb.cuda())
     model._hip.variants["resid"] = 0
     assert torch.equal(outs[0], outs[3])  # the library's choice at this size
-    assert rel(outs[3], outs[1]) < 1e-6 and rel(outs[2], outs[1]) < 1e-6
+    # fp32: only the 1e-7-level regrouping of the statistics' partial sums; split-bf16: that perturbation re-rounds the hi / lo operand splits
+    # downstream, i.e. the mode's own 2^-18 product error is re-drawn (tools/check_bf16_entries.py: 4.5e-6 per entry point)
+    tol = 1e-6 if dtype == "f32" else 3e-5
+    e31, e21 = rel(outs[3], outs[1]), rel(outs[2], outs[1])
+    print(f"{dtype}: 8-wave vs two-workgroup form {e31:.2e}, 4-wave one-workgroup vs two-workgroup form {e21:.2e}")
+    assert e31 < tol and e21 < tol

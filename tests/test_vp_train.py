@@ -48,7 +48,7 @@ def test_vp_block_training_step_matches_the_glue(train, B, Tv):
     scale = max(float(p.grad.norm()) for p in ref.parameters())
     for (n, p), (_, q) in zip(vb.named_parameters(), ref.named_parameters()):
         assert p.grad is not None, n
-        e = float((p.grad - q.grad).norm()) / (float(q.grad.norm()) + 1e-5 * scale)
+        e = float((p.grad - q.grad).norm()) / (float(q.grad.norm()) + 1e-4 * scale)  # (conv biases in front of a batch-statistics BatchNorm: analytically zero)
         worst = max(worst, (n, e), key=lambda kv: kv[1])
     print("worst parameter gradient:", worst)
     assert worst[1] < (2e-3 if train else 2e-4), worst  # (train mode: 26 chained batch normalisations on B * T <= 150 positions amplify fp32 round-off)
@@ -109,3 +109,103 @@ def test_vp_block_training_step_matches_the_oracle(train, B, Tv):
         for n, b in vb.named_buffers():
             if n.endswith(("running_mean", "running_var")):
                 assert rel(b, sd64[f"{VIDEO_PREFIX}.{n}"]) < 1e-4, n
+
+
+def _global_attention_with_masks(ga, g, masks):
+    """torch restatement of MultiHeadSelfAttention.forward (layers/attention.py:57-73) + FeedForwardNetwork.forward (conv_layers.py:250-257) with the
+    stochastic layers' keep-masks of one step injected (layout of rtfs_net_amd.models.vp_train.attn_masks)"""
+    B, C, Tg = g.shape
+    na, ne = 8 * Tg * Tg, Tg * 64
+    m_attn, m_el, dp = masks[:, :na].view(B, 8, Tg, Tg), masks[:, na:na + ne].view(B, Tg, 64), masks[:, na + ne:]
+    m, f = ga.MHSA, ga.FFN
+    y = m.norm1(g.transpose(1, 2)) + m.pos_enc.pe[:, :Tg]
+    qkv = y @ m.attention.in_proj_weight.t() + m.attention.in_proj_bias
+    q, k, v = (t.view(B, Tg, 8, 8).transpose(1, 2) for t in qkv.split(64, dim=-1))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8 ** 0.5, -1) * m_attn
+    o = (p @ v).transpose(1, 2).reshape(B, Tg, 64)
+    a = o @ m.attention.out_proj.weight.t() + m.attention.out_proj.bias
+    x1 = m.norm2(a * m_el + y).transpose(1, 2) * dp[:, 0].view(B, 1, 1) + g
+    r = f.refiner(f.encoder(x1)) * dp[:, 1].view(B, 1, 1)
+    return f.decoder(r) * dp[:, 2].view(B, 1, 1) + x1
+
+
+@pytest.mark.parametrize("B,Tg,drop", [(3, 7, True), (2, 13, True), (4, 4, False), (1, 16, True), (2, 2, False)])
+def test_global_attention_hip_training_kernels(B, Tg, drop):
+    """csrc/vp_attn.hip (rtfs_vp_attn_fwd / _bwd through VPAttnFn) against torch autograd: output, input gradient and all 16 parameter
+    gradients, with one explicit draw of the dropout / DropPath keep-masks (and, without masks, against the module itself in eval mode)."""
+    from rtfs_net_amd.models import vp_train as vt
+
+    vb = _block(True)
+    ga = vb.globalatt[0]
+    assert vt.attn_supported(ga)
+    gen = torch.Generator().manual_seed(10 * B + Tg)
+    g = torch.randn(B, 64, Tg, generator=gen).cuda()
+    wgt = torch.randn(B, 64, Tg, generator=gen).cuda()
+    masks = None
+    if drop:
+        for mod in ga.modules():  # restore the stochastic layers (the helper switched them off)
+            if isinstance(getattr(mod, "p", None), float):
+                mod.p = 0.1
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.1
+        ga.FFN.dropout_layer.p = 0.3  # (a per-utterance factor: make a drop likely at these batch sizes)
+        torch.manual_seed(5)
+        masks = vt.attn_masks(ga, B, Tg, g.device)
+        assert masks is not None and masks.shape == (B, 8 * Tg * Tg + 64 * Tg + 3)
+        keep = masks[:, :8 * Tg * Tg]
+        assert bool(((keep == 0) | ((keep - 1 / 0.9).abs() < 1e-6)).all()) and 0.02 < float((keep == 0).float().mean()) < 0.25
+    params = vt.attn_params(ga)
+    g1 = g.clone().requires_grad_(True)
+    out = vt.VPAttnFn.apply(ga, masks, g1, *params)
+    (out * wgt).sum().backward()
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    g2 = g.clone().requires_grad_(True)
+    if drop:
+        ref = _global_attention_with_masks(ga, g2, masks)
+    else:
+        ga.eval()
+        ref = ga(g2)
+    (ref * wgt).sum().backward()
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 2e-6
+    assert rel(g1.grad, g2.grad) < 2e-5
+    scale = max(float(p.grad.norm()) for p in params)
+    for i, p in enumerate(params):
+        e = float((got[i] - p.grad).norm()) / (float(p.grad.norm()) + 1e-5 * scale)
+        assert e < 1e-4, (i, tuple(p.shape), e)
+
+
+@pytest.mark.parametrize("B,Tv", [(3, 50), (2, 12), (1, 100), (2, 7), (1, 230)])
+def test_caf_video_side_hip_training_kernels(B, Tv):
+    """CAFVideoFn (rtfs_caf_video_fwd + rtfs_caf_video_bwd) against torch autograd over the cell's modules (layers/fusion.py:255,262-265 as the
+    glue path of round 2 ran it): att, rsz, the input gradient and the eight parameter gradients"""
+    from rtfs_net_amd.models.vp_train import caf_video_train
+
+    model, _, _ = make_model(2, "cuda")
+    cell = model.refinement_module.crossmodal_fusion.get_fusion_block(0).audio_lstm
+    gen = torch.Generator().manual_seed(Tv)
+    v = torch.randn(B, 512, Tv, generator=gen).cuda()
+    wa, wr = torch.randn(B, Tv, 256, generator=gen).cuda(), torch.randn(B, Tv, 256, generator=gen).cuda()
+    params = [p for n, p in cell.named_parameters() if n.startswith(("attention_embed.", "resize."))]
+    assert len(params) == 8
+    v1 = v.clone().requires_grad_(True)
+    att, rsz = caf_video_train(cell, v1)
+    ((att * wa).sum() * 50 + (rsz * wr).sum()).backward()  # (softmax outputs are ~1/Tv: weight them up)
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    v2 = v.clone().requires_grad_(True)
+    a = torch.softmax(cell.attention_embed(v2).reshape(B, 256, 4, -1).mean(2), -1).transpose(1, 2)
+    r = cell.resize(v2).transpose(1, 2)
+    ((a * wa).sum() * 50 + (r * wr).sum()).backward()
+    torch.cuda.synchronize()
+    assert rel(att, a) < 2e-6 and rel(rsz, r) < 2e-6
+    assert rel(v1.grad, v2.grad) < 5e-5
+    scale = max(float(p.grad.norm()) for p in params)
+    for g, p in zip(got, params):
+        # (the attention embedding's gLN shift is analytically gradient-free - a per-channel constant cancels in the softmax over Tv: both sides
+        # hold fp32 residue there, hence the absolute floor)
+        e = float((g - p.grad).norm()) / (float(p.grad.norm()) + 1e-3 * scale)
+        assert e < 2e-4, (tuple(p.shape), e)
