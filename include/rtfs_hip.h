@@ -321,41 +321,42 @@ int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int 
 /* =====================================================================================================================
  * VP (video) block, TRAINING step: the convolution / BatchNorm1d chain of the 1-D TDANetBlock (separators/tdanet.py:106-133,
  * is2d = False) with batch statistics, and its adjoints.  Tensors [B][64][T] (512 channels for block input / output), fp32.  A BatchNorm is never a
- * kernel of its own: producers write the pre-norm tensor and accumulate per-channel (sum, sum of squares) into `stats` [2][64]; consumers take
+ * kernel of its own: producers write the pre-norm tensor and accumulate per-channel (sum, sum of squares) into `stats` [2][64] (float64, like the
+ * gLN slots of the audio branch: order-independent sums, variance differenced in float64); consumers take
  * (stats, gamma, beta, inv_n = 1 / positions) and normalise on read - the host all-reduces the slot in between under SyncBatchNorm (train.py:145).
  * NULL stats = no normalisation.  Adjoint: a kernel leaves the gradient w.r.t. a BatchNorm OUTPUT, rtfs_vp_bn_bwd_reduce forms
- * sums [2][64] = (sum dyhat, sum dyhat * xhat) = (dbeta, dgamma), rtfs_vp_dwconv_bwd / rtfs_vp_gate_proj_bwd apply the BatchNorm adjoint on read
- * (batch_stats = 0: running statistics, no coupling terms).  The GlobalAttention stage of the block stays PyTorch (rtfs_net_amd/models/vp_train.py).
+ * sums [2][64] (float64) = (sum dyhat, sum dyhat * xhat) = (dbeta, dgamma), rtfs_vp_dwconv_bwd / rtfs_vp_gate_proj_bwd apply the BatchNorm adjoint on read
+ * (batch_stats = 0: running statistics, no coupling terms).  The GlobalAttention stage of the block: rtfs_vp_attn_fwd / _bwd below.
  */
 int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, float gslope, const float* Wp /*[64][512]*/, const float* bp, float* r, float* y,
-                          float* stats, int B, int T, void* stream);
+                          double* stats, int B, int T, void* stream);
 /* depth-wise k = 3 (+bias) of BN(src) [PReLU'd if in_act = 1]; stride 1 ('same') or 2 (pad 1); optional second convolution (w1 -> out1, stats1) of the same input */
-int rtfs_vp_dwconv_fwd(const float* src, const float* in_stats, const float* in_gamma, const float* in_beta, float in_inv_n, int in_act, float in_slope,
-                       const float* w0 /*[64][3]*/, const float* b0_or_null, float* out0, float* stats0, const float* w1_or_null, float* out1, float* stats1,
+int rtfs_vp_dwconv_fwd(const float* src, const double* in_stats, const float* in_gamma, const float* in_beta, float in_inv_n, int in_act, float in_slope,
+                       const float* w0 /*[64][3]*/, const float* b0_or_null, float* out0, double* stats0, const float* w1_or_null, float* out1, double* stats1,
                        int B, int Tin, int Tout, int stride, void* stream);
 /* g = sum_i adaptive_avg_pool1d(BN_i(raw_i), Tg)  (tdanet.py:117-118); inv_n_i = 1 / positions behind the statistics of tensor i */
-int rtfs_vp_pool_fwd(const float* const* raw, const float* const* stats, const float* const* gamma, const float* const* beta, int T0, int T1, int T2, int T3,
+int rtfs_vp_pool_fwd(const float* const* raw, const double* const* stats, const float* const* gamma, const float* const* beta, int T0, int T1, int T2, int T3,
                      float inv_n0, float inv_n1, float inv_n2, float inv_n3, float* g, int B, int Tg, void* stream);
 /* InjectionMultiSum mix (layers/fusion.py:59-67): out = BN(loc) * sigmoid(BN(gate))^ + BN(emb)^ (+ BN(res)); ^ = nearest up-sampling To -> Tn */
-int rtfs_vp_mix_fwd(const float* loc, const float* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
-                    const float* gate_stats, const float* gate_g, const float* gate_b, const float* emb, const float* emb_stats, const float* emb_g,
-                    const float* emb_b, float inv_n_glob, const float* res_or_null, const float* res_stats, const float* res_g, const float* res_b, float* out,
+int rtfs_vp_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
+                    const double* gate_stats, const float* gate_g, const float* gate_b, const float* emb, const double* emb_stats, const float* emb_g,
+                    const float* emb_b, float inv_n_glob, const float* res_or_null, const double* res_stats, const float* res_g, const float* res_b, float* out,
                     int B, int Tn, int To, void* stream);
 int rtfs_vp_resid_fwd(const float* e, const float* Wr /*[512][64]*/, const float* br, const float* r, float* out, int B, int T, void* stream);
 int rtfs_vp_resid_bwd(const float* dout, const float* e, const float* Wr, float* de, float* dWr, float* dbr, int B, int T, void* stream);
-int rtfs_vp_mix_bwd(const float* dout, const float* loc, const float* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
-                    const float* gate_stats, const float* gate_g, const float* gate_b, float inv_n_glob, float* dloc, float* dgate, float* demb,
+int rtfs_vp_mix_bwd(const float* dout, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
+                    const double* gate_stats, const float* gate_g, const float* gate_b, float inv_n_glob, float* dloc, float* dgate, float* demb,
                     float* dres_acc_or_null, int B, int Tn, int To, void* stream);
-int rtfs_vp_bn_bwd_reduce(const float* dyhat, const float* raw, const float* stats, const float* gamma, const float* beta, float inv_n, float* sums, int B,
+int rtfs_vp_bn_bwd_reduce(const float* dyhat, const float* raw, const double* stats, const float* gamma, const float* beta, float inv_n, double* sums, int B,
                           int T, void* stream);
 /* dW: [3][64] (tap-major) accumulated; dsrc = gradient w.r.t. the BatchNorm output of `src` (through the PReLU if in_act = 1), stored or accumulated */
-int rtfs_vp_dwconv_bwd(const float* dyhat, const float* raw, const float* out_stats, const float* out_gamma, const float* out_beta, float out_inv_n,
-                       const float* sums, float inv_n_all, int batch_stats, const float* src, const float* in_stats, const float* in_gamma,
+int rtfs_vp_dwconv_bwd(const float* dyhat, const float* raw, const double* out_stats, const float* out_gamma, const float* out_beta, float out_inv_n,
+                       const double* sums, float inv_n_all, int batch_stats, const float* src, const double* in_stats, const float* in_gamma,
                        const float* in_beta, float in_inv_n, int in_act, float in_slope, const float* w, float* dW, float* dbias_or_null,
                        float* dsrc_or_null, int accumulate, float* dslope_or_null, int B, int Tin, int Tout, int stride, void* stream);
 int rtfs_vp_pool_bwd(const float* dg, float* const* d /*accumulated*/, int T0, int T1, int T2, int T3, int B, int Tg, void* stream);
-int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const float* y_stats, const float* y_gamma, const float* y_beta, float y_inv_n,
-                          const float* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
+int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const double* y_stats, const float* y_gamma, const float* y_beta, float y_inv_n,
+                          const double* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
                           const float* gb, float gslope, const float* Wp, float* dWp, float* dbp, float* dgw, float* dgb, float* dgslope, float* dx, int B,
                           int T, void* stream);
 

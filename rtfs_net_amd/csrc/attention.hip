@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 // in blocks of 1024 through the same [32][1024] LDS score tile, in two sweeps - (1) running row maximum / sum of exponentials over
 // all blocks (the online-softmax recurrence), (2) scores recomputed block by block, normalised with the FINAL statistics and
 // accumulated into O = P V (all 8 feature tiles of the wave stay in registers across the blocks; no rescaling of accumulators).
-// QK^T is computed twice (16 of the core's 80 MMAC per key-query pair); inference only (no LSE output).
+// QK^T is computed twice (16 of the core's 80 MMAC per key-query pair).  Training: the final statistics give the log-sum-exp the adjoint needs.
 // ------------------------------------------------------------------------------------------------
 template <int PREC>
 __global__ __launch_bounds__(256) void attn_core_long_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
-                                                             float* __restrict__ O, int T2) {
+                                                             float* __restrict__ O, float* __restrict__ LSE, int T2) {
     constexpr int MAXKT = 32, LDS_S = MAXKT * 32 + 4;
     __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
     __shared__ float rmax[32], rsum[32];
@@ -345,6 +345,8 @@ __global__ __launch_bounds__(256) void attn_core_long_kernel(const float* __rest
             }
         }
     }
+    __syncthreads();
+    if (LSE && threadIdx.x < 32 && q0 + threadIdx.x < T2) LSE[headoff + q0 + threadIdx.x] = rmax[threadIdx.x] + __logf(rsum[threadIdx.x]);
     // ---- sweep 2: P = exp(S - max) / sum per block, O += P V ----
     floatx16 acc[8];
 #pragma unroll
@@ -509,9 +511,8 @@ template <int NT>
 static int attn_core_impl(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
     dim3 grid((T2 + 31) / 32, kHeads, B);
-    if (T2 > 1024) {  // past 16.4 s of audio the [32][T2] score tile no longer fits the LDS: key-blocked two-sweep kernel (inference only)
-        if (LSE_or_null) return RTFS_EINVAL;
-        hipLaunchKernelGGL((attn_core_long_kernel<NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, T2);
+    if (T2 > 1024) {  // past 16.4 s of audio the [32][T2] score tile no longer fits the LDS: key-blocked two-sweep kernel
+        hipLaunchKernelGGL((attn_core_long_kernel<NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }

@@ -239,9 +239,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
     }
     __syncthreads();
     // P = exp(S - LSE), dP = dO V^T, dS = P (dP - D) / 16; wave w owns key tiles w, w+4, ...
+    // Keys are walked in blocks of MAXKT tiles (the LDS dS tile): P is recomputed from the FINAL log-sum-exp, so the blocks are independent
+    // and dQ simply accumulates over them - no length limit (round 3; the reference has none, attention.py:171-173)
     const float* qrow = Qg + (size_t)min(q0 + i, T2 - 1) * 256 + 4 * kh;
     const float* drow = orow(dO, q0 + i) + 4 * kh;
-    for (int kt = w; kt < NT; kt += 4) {
+    floatx16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll 1
+    for (int kb0 = 0; kb0 < NT; kb0 += MAXKT) {
+    const int kb1 = min(NT, kb0 + MAXKT);
+    if (kb0) __syncthreads();  // the previous block's dS tile has been consumed
+    for (int kt = kb0 + w; kt < kb1; kt += 4) {
         const int key = min(kt * 32 + i, T2 - 1);
         const float* krow = Kg + (size_t)key * 256 + 4 * kh;
         const float* vrow = Vg + (size_t)key * 1024 + 4 * kh;
@@ -269,20 +280,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
             const int row = acc_row(r);
             const bool kvalid = kt * 32 + i < T2;
             const float p = kvalid ? __expf(sa[r] * 0.0625f - Ls[row]) : 0.f;
-            Ps[row * LDP + kt * 32 + i] = p * (pa[r] - Ds[row]) * 0.0625f;
+            Ps[row * LDP + (kt - kb0) * 32 + i] = p * (pa[r] - Ds[row]) * 0.0625f;
         }
     }
     __syncthreads();
-    // dQ[32 x 256] = dS K; wave w owns features [64w, 64w+64)
-    floatx16 acc[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    // dQ[32 x 256] += dS K; wave w owns features [64w, 64w+64)
     const float* pa_ = Ps + i * LDP + 4 * kh;
-    for (int kq = 0; kq < NT * 4; ++kq) {
+    for (int kq = 0; kq < (kb1 - kb0) * 4; ++kq) {
         const float4 p = ld4(pa_ + 8 * kq);
-        const int key = 8 * kq + 4 * kh;
+        const int key = kb0 * 32 + 8 * kq + 4 * kh;
         float kb[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -296,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const float* __rest
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, kb[n][2], acc[n], 0, 0, 0);
             acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, kb[n][3], acc[n], 0, 0, 0);
         }
+    }
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -328,7 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
     // first operand (rows) = keys of this tile, second operand (lanes) = queries of tile qt
     const float* krow = Kg + (size_t)min(k0 + i, T2 - 1) * 256 + 4 * kh;
     const float* vrow = Vg + (size_t)min(k0 + i, T2 - 1) * 1024 + 4 * kh;
-    for (int qt = w; qt < NT; qt += 4) {
+    // Queries are walked in blocks of MAXKT tiles (the two LDS tiles); past the first block the dV / dK accumulators start from the partial
+    // sums the previous block left in global memory (one block for T2 <= 32 MAXKT: then nothing is re-read) - no length limit
+#pragma unroll 1
+    for (int qb0 = 0; qb0 < NT; qb0 += MAXKT) {
+    const int qb1 = min(NT, qb0 + MAXKT);
+    if (qb0) __syncthreads();  // the previous block's tiles have been consumed
+    for (int qt = qb0 + w; qt < qb1; qt += 4) {
         const int tq = min(qt * 32 + i, T2 - 1);
         const float* qrow = Qg + (size_t)tq * 256 + 4 * kh;
         const float* drow = orow(qt * 32 + i) + 4 * kh;
@@ -358,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
             const int row = acc_row(r);  // key inside the tile
             const bool kvalid = k0 + row < T2;
             const float p = (qvalid && kvalid) ? __expf(sa[r] * 0.0625f - lse) : 0.f;
-            Pt[row * LDP + qt * 32 + i] = p;
-            St[row * LDP + qt * 32 + i] = p * (pa[r] - dd) * 0.0625f;
+            Pt[row * LDP + (qt - qb0) * 32 + i] = p;
+            St[row * LDP + (qt - qb0) * 32 + i] = p * (pa[r] - dd) * 0.0625f;
         }
     }
     __syncthreads();
@@ -371,11 +384,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + acc_row(r);
+                acc[n][r] = (qb0 && key < T2) ? dV[(headoff + key) * 1024 + n0 + n * 32 + i] : 0.f;
+            }
         const float* pa_ = Pt + i * LDP + 4 * kh;
-        for (int qq = 0; qq < NT * 4; ++qq) {
+        for (int qq = 0; qq < (qb1 - qb0) * 4; ++qq) {
             const float4 p = ld4(pa_ + 8 * qq);
-            const int tq = 8 * qq + 4 * kh;
+            const int tq = qb0 * 32 + 8 * qq + 4 * kh;
             float vb[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -404,11 +420,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + acc_row(r);
+            acc[n][r] = (qb0 && key < T2) ? dK[(headoff + key) * 256 + w * 64 + n * 32 + i] : 0.f;
+        }
     const float* sa_ = St + i * LDP + 4 * kh;
-    for (int qq = 0; qq < NT * 4; ++qq) {
+    for (int qq = 0; qq < (qb1 - qb0) * 4; ++qq) {
         const float4 p = ld4(sa_ + 8 * qq);
-        const int tq = 8 * qq + 4 * kh;
+        const int tq = qb0 * 32 + 8 * qq + 4 * kh;
         float qb[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -430,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const float* __res
             const int key = k0 + acc_row(r);
             if (key < T2) dK[(headoff + key) * 256 + w * 64 + n * 32 + i] = acc[n][r];
         }
+    }
 }
 
 // per-token 64x64 transpose: out[tok][j][i] = in[tok][i][j]
@@ -476,7 +496,7 @@ int rtfs_attn_qkv_norm_bwd(const float* dQ, const float* dK, const float* dV, co
 // Q,K,dQ,dK: [B][4][T2][256]; V,dV: [B][4][T2][1024]; O,dO: [B][T2][64][64] (O layout); LSE, Dws: [B][4][T2]
 int rtfs_attn_core_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE, float* Dws, float* dQ,
                        float* dK, float* dV, int B, int T2, void* stream) {
-    if (B <= 0 || T2 <= 0 || T2 > 512) return RTFS_EINVAL;
+    if (B <= 0 || T2 <= 0) return RTFS_EINVAL;  // (more than 512 compressed frames: the kernels walk keys / queries in blocks of 512)
     dim3 grid((T2 + 31) / 32, kHeadsB, B);
     hipStream_t st = (hipStream_t)stream;
 #define CORE_BWD(M)                                                                                                     \

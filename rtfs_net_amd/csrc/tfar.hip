@@ -8,6 +8,7 @@
 //   rtfs_caf_fuse_fwd   audio side: key/value depth-wise 1x1 + BatchNorm(eval) folded, k1 + k2 (fusion.py:259-272) [+ a0]
 //
 // Thread mapping for all H=64 tensors: 16 consecutive lanes own the 64 channels of one pixel (float4 each).
+#include <type_traits>
 #include "common.h"
 
 namespace rtfs {
@@ -625,22 +626,37 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
     }
     const float rw0 = rs_w[2 * c], rw1 = rs_w[2 * c + 1], rb = rs_b[c], rg = rs_g[c], rbe = rs_be[c];
 
+    // Every pass walks the thread's two input rows in batches of 8 positions with the 16 loads issued first (addresses clamped, never under a
+    // branch): a rolled loop pays one L2 / HBM latency per position, and with ONE workgroup per utterance this kernel is pure latency - it sits
+    // on the critical path of small batches (round 3: 540 -> ~100 us).
+    auto sweep = [&](auto&& body) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < Tv; t0 += 8) {
+            float a0[8], a1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = min(t0 + j, Tv - 1);
+                a0[j] = v0[t], a1[j] = v1[t];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (t0 + j < Tv) body(t0 + j, a0[j], a1[j]);
+        }
+    };
     // pass 1: gLN statistics of both pre-norm tensors (two-pass: mean first, then centred squares)
     float s_att = 0.f, s_rs = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
+    sweep([&](int, float x0, float x1) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) s_att += fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h]));
         s_rs += fmaf(rw0, x0, fmaf(rw1, x1, rb));
-    }
+    });
     s_att = wave_sum(s_att), s_rs = wave_sum(s_rs);
     if (lane == 0) red[w] = s_att, red[4 + w] = s_rs;
     __syncthreads();
     const float m_att = (red[0] + red[1] + red[2] + red[3]) / (1024.f * Tv);
     const float m_rs = (red[4] + red[5] + red[6] + red[7]) / (256.f * Tv);
     float q_att = 0.f, q_rs = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
+    sweep([&](int, float x0, float x1) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const float d = fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att;
@@ -648,7 +664,7 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
         }
         const float d = fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs;
         q_rs = fmaf(d, d, q_rs);
-    }
+    });
     q_att = wave_sum(q_att), q_rs = wave_sum(q_rs);
     if (lane == 0) red[8 + w] = q_att, red[12 + w] = q_rs;
     __syncthreads();
@@ -656,23 +672,22 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
     const float r_rs = 1.0f / sqrtf((red[12] + red[13] + red[14] + red[15]) / (256.f * Tv) + kEps);
 
     // pass 2: head mean -> softmax over Tv (max, sum, write); resize branch written directly
-    auto att_at = [&](int t) {
-        const float x0 = v0[t], x1 = v1[t];
+    auto att_of = [&](float x0, float x1) {
         float m = 0.f;
 #pragma unroll
         for (int h = 0; h < 4; ++h) m += fmaf((fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att, ag[h], abe[h]);
         return m * 0.25f;
     };
     float mx = -3.0e38f;
-    for (int t = 0; t < Tv; ++t) mx = fmaxf(mx, att_at(t));
+    sweep([&](int, float x0, float x1) { mx = fmaxf(mx, att_of(x0, x1)); });
     float sum = 0.f;
-    for (int t = 0; t < Tv; ++t) sum += __expf(att_at(t) - mx);
+    sweep([&](int, float x0, float x1) { sum += __expf(att_of(x0, x1) - mx); });
     const float inv = 1.0f / sum;
-    for (int t = 0; t < Tv; ++t) {
+    sweep([&](int t, float x0, float x1) {
         const size_t o = ((size_t)b * Tv + t) * 256 + c;
-        att_out[o] = __expf(att_at(t) - mx) * inv;
-        rsz_out[o] = fmaf((fmaf(rw0, v0[t], fmaf(rw1, v1[t], rb)) - m_rs) * r_rs, rg, rbe);
-    }
+        att_out[o] = __expf(att_of(x0, x1) - mx) * inv;
+        rsz_out[o] = fmaf((fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs, rg, rbe);
+    });
 }
 
 // Adjoint of caf_video_kernel (training step; the forward kernel is mode-independent: gLN only, no BatchNorm on the video side).
@@ -706,21 +721,40 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
         __syncthreads();
         ra = red[0] + red[1] + red[2] + red[3], rb_ = red[4] + red[5] + red[6] + red[7];
     };
+    const float* dab = datt + (size_t)b * Tv * 256 + c;
+    const float* drb = drsz + (size_t)b * Tv * 256 + c;
+    // batches of 8 positions, all loads of a batch first (see caf_video_kernel); GRADS: the two upstream gradients ride along
+    auto sweep = [&](auto grads, auto&& body) {
+        constexpr bool G = decltype(grads)::value;
+#pragma unroll 1
+        for (int t0 = 0; t0 < Tv; t0 += 8) {
+            float a0[8], a1[8], ga[G ? 8 : 1], gr[G ? 8 : 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = min(t0 + j, Tv - 1);
+                a0[j] = v0[t], a1[j] = v1[t];
+                if constexpr (G) ga[j] = dab[(size_t)t * 256], gr[j] = drb[(size_t)t * 256];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (t0 + j < Tv) body(t0 + j, a0[j], a1[j], ga[G ? j : 0], gr[G ? j : 0]);
+        }
+    };
+    using NoG = std::integral_constant<bool, false>;
+    using WithG = std::integral_constant<bool, true>;
     // forward statistics, as the forward kernel computes them (mean first, then centred squares)
     float s_att = 0.f, s_rs = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
+    sweep(NoG{}, [&](int, float x0, float x1, float, float) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) s_att += fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h]));
         s_rs += fmaf(rw0, x0, fmaf(rw1, x1, rb));
-    }
+    });
     float m_att, m_rs;
     block4(s_att, s_rs, m_att, m_rs);
     const float n_att = 1024.f * Tv, n_rs = 256.f * Tv;
     m_att /= n_att, m_rs /= n_rs;
     float q_att = 0.f, q_rs = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
+    sweep(NoG{}, [&](int, float x0, float x1, float, float) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const float d = fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att;
@@ -728,32 +762,28 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
         }
         const float d = fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs;
         q_rs = fmaf(d, d, q_rs);
-    }
+    });
     float r_att, r_rs;
     block4(q_att, q_rs, r_att, r_rs);
     r_att = 1.0f / sqrtf(r_att / n_att + kEps), r_rs = 1.0f / sqrtf(r_rs / n_rs + kEps);
-    auto att_at = [&](int t) {
-        const float x0 = v0[t], x1 = v1[t];
+    auto att_of = [&](float x0, float x1) {
         float m = 0.f;
 #pragma unroll
         for (int h = 0; h < 4; ++h) m += fmaf((fmaf(aw0[h], x0, fmaf(aw1[h], x1, ab[h])) - m_att) * r_att, ag[h], abe[h]);
         return m * 0.25f;
     };
     float mx = -3.0e38f;
-    for (int t = 0; t < Tv; ++t) mx = fmaxf(mx, att_at(t));
+    sweep(NoG{}, [&](int, float x0, float x1, float, float) { mx = fmaxf(mx, att_of(x0, x1)); });
     float sum = 0.f;
-    for (int t = 0; t < Tv; ++t) sum += __expf(att_at(t) - mx);
+    sweep(NoG{}, [&](int, float x0, float x1, float, float) { sum += __expf(att_of(x0, x1) - mx); });
     const float inv = 1.0f / sum;
-    const float* dab = datt + (size_t)b * Tv * 256 + c;
-    const float* drb = drsz + (size_t)b * Tv * 256 + c;
     // softmax adjoint: d(head mean)_t = p_t (dp_t - sum_t' p_t' dp_t')
     float sdot = 0.f;
-    for (int t = 0; t < Tv; ++t) sdot = fmaf(__expf(att_at(t) - mx) * inv, dab[(size_t)t * 256], sdot);
+    sweep(WithG{}, [&](int, float x0, float x1, float da, float) { sdot = fmaf(__expf(att_of(x0, x1) - mx) * inv, da, sdot); });
     // gLN adjoint sums: S1 = sum u, S2 = sum u xhat (u = dy gamma) over the whole utterance; d gamma / d beta of this thread's channels
     float s1a = 0.f, s2a = 0.f, s1r = 0.f, s2r = 0.f, dga[4] = {0.f, 0.f, 0.f, 0.f}, dba = 0.f, dgr = 0.f, dbr = 0.f;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
-        const float dy = __expf(att_at(t) - mx) * inv * (dab[(size_t)t * 256] - sdot) * 0.25f;  // the same for the four heads (mean over them)
+    sweep(WithG{}, [&](int, float x0, float x1, float da, float dr) {
+        const float dy = __expf(att_of(x0, x1) - mx) * inv * (da - sdot) * 0.25f;  // the same for the four heads (mean over them)
         dba += dy;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -761,10 +791,10 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
             dga[h] = fmaf(dy, xh, dga[h]);
             s1a = fmaf(dy, ag[h], s1a), s2a = fmaf(dy * ag[h], xh, s2a);
         }
-        const float dr = drb[(size_t)t * 256], xr = (fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs;
+        const float xr = (fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs;
         dgr = fmaf(dr, xr, dgr), dbr += dr;
         s1r = fmaf(dr, rg, s1r), s2r = fmaf(dr * rg, xr, s2r);
-    }
+    });
     float S1a, S2a, S1r, S2r;
     block4(s1a, s2a, S1a, S2a);
     block4(s1r, s2r, S1r, S2r);
@@ -773,9 +803,8 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
     float dw0[4] = {0.f, 0.f, 0.f, 0.f}, dw1[4] = {0.f, 0.f, 0.f, 0.f}, dbb[4] = {0.f, 0.f, 0.f, 0.f}, drw0 = 0.f, drw1 = 0.f, drb_ = 0.f;
     float* dv0 = dv + ((size_t)b * 512 + 2 * c) * Tv;
     float* dv1 = dv0 + Tv;
-    for (int t = 0; t < Tv; ++t) {
-        const float x0 = v0[t], x1 = v1[t];
-        const float dy = __expf(att_at(t) - mx) * inv * (dab[(size_t)t * 256] - sdot) * 0.25f;
+    sweep(WithG{}, [&](int t, float x0, float x1, float da, float dr) {
+        const float dy = __expf(att_of(x0, x1) - mx) * inv * (da - sdot) * 0.25f;
         float g0 = 0.f, g1 = 0.f;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -785,11 +814,11 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
             g0 = fmaf(aw0[h], draw, g0), g1 = fmaf(aw1[h], draw, g1);
         }
         const float xr = (fmaf(rw0, x0, fmaf(rw1, x1, rb)) - m_rs) * r_rs;
-        const float draw = r_rs * (drb[(size_t)t * 256] * rg - S1r - xr * S2r);
+        const float draw = r_rs * (dr * rg - S1r - xr * S2r);
         drw0 = fmaf(draw, x0, drw0), drw1 = fmaf(draw, x1, drw1), drb_ += draw;
         dv0[t] = fmaf(rw0, draw, g0);
         dv1[t] = fmaf(rw1, draw, g1);
-    }
+    });
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const int o = c * 4 + h;

@@ -19,8 +19,9 @@ namespace rtfs {
 
 constexpr int TVH = 64, TVIN = 512;
 
-struct VBn {              // a BatchNorm read "on read": statistics slot [2][64] = (sum x, sum x^2) over n positions
-    const float* stats;   // nullptr: no normalisation (identity)
+struct VBn {              // a BatchNorm read "on read": statistics slot [2][64] = (sum x, sum x^2) over n positions, float64: the sums of the
+                          // <= B x 100 fp32 values are exact to 1e-16 whatever the order of the atomics, and E[x^2] - mean^2 is differenced in float64
+    const double* stats;  // nullptr: no normalisation (identity)
     const float* gamma;
     const float* beta;
     float inv_n;          // 1 / (B * T) of the normalised tensor (all ranks under SyncBatchNorm)
@@ -31,18 +32,21 @@ __device__ __forceinline__ void vbn_coef(const VBn& r, int c, float& mean, float
         mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
         return;
     }
-    mean = r.stats[c] * r.inv_n;
-    const float var = fmaxf(r.stats[TVH + c] * r.inv_n - mean * mean, 0.f);
-    rstd = 1.0f / sqrtf(var + kEps);
+    const double m = r.stats[c] * (double)r.inv_n;
+    const double var = fmax(r.stats[TVH + c] * (double)r.inv_n - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)kEps));
     sc = r.gamma[c] * rstd;
     sh = r.beta[c] - mean * sc;
 }
 
 // sum over the 4 time phases of a per-thread partial that belongs to channel c = tid & 63, then ONE atomic per channel
-__device__ __forceinline__ void phase_reduce_atomic(float v, float* lds /*256*/, float* out) {
+template <class Out>  // float: parameter gradients; double: BatchNorm statistics / adjoint sums (order-independent to 1e-16)
+__device__ __forceinline__ void phase_reduce_atomic(float v, float* lds /*256*/, Out* out) {
     lds[threadIdx.x] = v;
     __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(out + threadIdx.x, lds[threadIdx.x] + lds[64 + threadIdx.x] + lds[128 + threadIdx.x] + lds[192 + threadIdx.x]);
+    if (threadIdx.x < 64)
+        atomicAdd(out + threadIdx.x, (Out)lds[threadIdx.x] + (Out)lds[64 + threadIdx.x] + (Out)lds[128 + threadIdx.x] + (Out)lds[192 + threadIdx.x]);
     __syncthreads();
 }
 
@@ -50,7 +54,7 @@ __device__ __forceinline__ void phase_reduce_atomic(float v, float* lds /*256*/,
 // gateway (dw 1x1 + bias + PReLU) and projection conv:  r = prelu(x*gw + gb),  y = Wp . r + bp  (pre-BatchNorm) + statistics of y
 __global__ __launch_bounds__(256) void vp_gate_proj_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gw, const float* __restrict__ gb,
                                                                float gslope, const float* __restrict__ Wp, const float* __restrict__ bp,
-                                                               float* __restrict__ r, float* __restrict__ y, float* __restrict__ stats, int T) {
+                                                               float* __restrict__ r, float* __restrict__ y, double* __restrict__ stats, int T) {
     // grid (B, ceil(T / 4)): one 4-step tile per workgroup - 9 KB of LDS, so that these side-stream kernels fit next to the resident workgroups of
     // the audio branch (a 32 KB tile made every launch wait for a CU to drain: the video chain then ran SLOWER than the PyTorch glue it replaces)
     __shared__ float red[256];
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256) void vp_gate_proj_fwd_kernel(const float* __re
 // depth-wise k = 3 convolution (+ bias) of a tensor that is normalised (and optionally PReLU'd) on read; stride 1 ('same': pad 1, 1) or 2 (pad 1).
 // in_act: 0 none, 1 PReLU(in_slope) after the normalisation.  nconv in {1, 2}: two convolutions of the same input (IMS global embedding + gate).
 __global__ __launch_bounds__(256) void vp_dwconv_fwd_kernel(const float* __restrict__ src, VBn in, int in_act, float in_slope, const float* __restrict__ w0,
-                                                            const float* __restrict__ b0, float* __restrict__ o0, float* __restrict__ st0,
-                                                            const float* __restrict__ w1, float* __restrict__ o1, float* __restrict__ st1, int Tin,
+                                                            const float* __restrict__ b0, float* __restrict__ o0, double* __restrict__ st0,
+                                                            const float* __restrict__ w1, float* __restrict__ o1, double* __restrict__ st1, int Tin,
                                                             int Tout, int stride) {
     __shared__ float red[256];
     const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void vp_mix_bwd_kernel(const float* __restrict
 
 // (sum dyhat, sum dyhat * xhat) per channel of one BatchNorm = (dbeta, dgamma); sums [2][64] accumulated with atomics
 __global__ __launch_bounds__(256) void vp_bn_bwd_reduce_kernel(const float* __restrict__ dyhat, const float* __restrict__ raw, VBn bn,
-                                                               float* __restrict__ sums, int T) {
+                                                               double* __restrict__ sums, int T) {
     __shared__ float red[256];
     const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6;
     float mean, rstd, sc, sh;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void vp_bn_bwd_reduce_kernel(const float* __re
 // where u = the transformed input (BatchNorm [+ PReLU] of `src`).  du is the gradient w.r.t. that transformed input; with in_act == 1 it is
 // taken through the PReLU (dslope accumulated) so that what is stored is always the gradient w.r.t. the input's BatchNorm output.
 __global__ __launch_bounds__(256) void vp_dwconv_bwd_kernel(const float* __restrict__ dyhat, const float* __restrict__ raw, VBn obn,
-                                                            const float* __restrict__ sums, float inv_n_all, int batch_stats, const float* __restrict__ src,
+                                                            const double* __restrict__ sums, float inv_n_all, int batch_stats, const float* __restrict__ src,
                                                             VBn in, int in_act, float in_slope, const float* __restrict__ w, float* __restrict__ dW,
                                                             float* __restrict__ dbias, float* __restrict__ dsrc, int accumulate,
                                                             float* __restrict__ dslope, int Tin, int Tout, int stride) {
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void vp_dwconv_bwd_kernel(const float* __restr
     float omean, orstd, osc, osh, imean, irstd, isc, ish;
     vbn_coef(obn, c, omean, orstd, osc, osh);
     vbn_coef(in, c, imean, irstd, isc, ish);
-    const float m1 = batch_stats ? sums[c] * inv_n_all : 0.f, m2 = batch_stats ? sums[TVH + c] * inv_n_all : 0.f;
+    const float m1 = batch_stats ? (float)(sums[c] * (double)inv_n_all) : 0.f, m2 = batch_stats ? (float)(sums[TVH + c] * (double)inv_n_all) : 0.f;
     const size_t oo = ((size_t)b * TVH + c) * Tout, oi = ((size_t)b * TVH + c) * Tin;
     const float w0 = w[c * 3], w1 = w[c * 3 + 1], w2 = w[c * 3 + 2];
     float gw0 = 0.f, gw1 = 0.f, gw2 = 0.f, gb = 0.f, gsl = 0.f;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void vp_pool_bwd_kernel(const float* __restric
 // gradient, which reaches r through the gateway residual.
 //   dy = BN adjoint (on read);  dWp += dy . r^T;  dbp += sum dy;  dr = Wp^T dy + dout;  u = x gw + gb:  dgw += sum dr prelu'(u) x, dgb, dgslope;  dx = dr prelu'(u) gw
 __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __restrict__ dyhat, const float* __restrict__ y, VBn ybn,
-                                                               const float* __restrict__ sums, float inv_n_all, int batch_stats, const float* __restrict__ dout,
+                                                               const double* __restrict__ sums, float inv_n_all, int batch_stats, const float* __restrict__ dout,
                                                                const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ gw,
                                                                const float* __restrict__ gb, float gslope, const float* __restrict__ Wp,
                                                                float* __restrict__ dWp, float* __restrict__ dbp, float* __restrict__ dgw,
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
     const int b = blockIdx.x, c = threadIdx.x & 63, ph = threadIdx.x >> 6, k0 = blockIdx.y * 64;
     float mean, rstd, sc, sh;
     vbn_coef(ybn, c, mean, rstd, sc, sh);
-    const float m1 = batch_stats ? sums[c] * inv_n_all : 0.f, m2 = batch_stats ? sums[TVH + c] * inv_n_all : 0.f;
+    const float m1 = batch_stats ? (float)(sums[c] * (double)inv_n_all) : 0.f, m2 = batch_stats ? (float)(sums[TVH + c] * (double)inv_n_all) : 0.f;
     const float* rb = r + ((size_t)b * TVIN + k0) * T;
     const float* xb = x + ((size_t)b * TVIN + k0) * T;
     const float* db = dout + ((size_t)b * TVIN + k0) * T;
@@ -424,14 +428,14 @@ __global__ __launch_bounds__(256) void vp_gate_proj_bwd_kernel(const float* __re
 
 using namespace rtfs;
 
-static VBn mk_bn(const float* stats, const float* gamma, const float* beta, float inv_n) { return VBn{stats, gamma, beta, inv_n}; }
+static VBn mk_bn(const double* stats, const float* gamma, const float* beta, float inv_n) { return VBn{stats, gamma, beta, inv_n}; }
 
 #define VP_CHECK(cond) \
     if (!(cond)) return RTFS_EINVAL
 
 extern "C" {
 
-int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, float gslope, const float* Wp, const float* bp, float* r, float* y, float* stats,
+int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, float gslope, const float* Wp, const float* bp, float* r, float* y, double* stats,
                           int B, int T, void* stream) {
     VP_CHECK(B > 0 && T > 0);
     hipLaunchKernelGGL(vp_gate_proj_fwd_kernel, dim3(B, (T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gw, gb, gslope, Wp, bp, r, y, stats, T);
@@ -439,8 +443,8 @@ int rtfs_vp_gate_proj_fwd(const float* x, const float* gw, const float* gb, floa
     return RTFS_OK;
 }
 
-int rtfs_vp_dwconv_fwd(const float* src, const float* in_stats, const float* in_gamma, const float* in_beta, float in_inv_n, int in_act, float in_slope,
-                       const float* w0, const float* b0, float* out0, float* stats0, const float* w1, float* out1, float* stats1, int B, int Tin, int Tout,
+int rtfs_vp_dwconv_fwd(const float* src, const double* in_stats, const float* in_gamma, const float* in_beta, float in_inv_n, int in_act, float in_slope,
+                       const float* w0, const float* b0, float* out0, double* stats0, const float* w1, float* out1, double* stats1, int B, int Tin, int Tout,
                        int stride, void* stream) {
     VP_CHECK(B > 0 && Tin > 0 && Tout > 0 && (stride == 1 || stride == 2) && (in_act == 0 || in_act == 1));
     hipLaunchKernelGGL(vp_dwconv_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, src, mk_bn(in_stats, in_gamma, in_beta, in_inv_n), in_act, in_slope,
@@ -449,7 +453,7 @@ int rtfs_vp_dwconv_fwd(const float* src, const float* in_stats, const float* in_
     return RTFS_OK;
 }
 
-int rtfs_vp_pool_fwd(const float* const* raw, const float* const* stats, const float* const* gamma, const float* const* beta, int T0, int T1, int T2, int T3,
+int rtfs_vp_pool_fwd(const float* const* raw, const double* const* stats, const float* const* gamma, const float* const* beta, int T0, int T1, int T2, int T3,
                      float inv_n0, float inv_n1, float inv_n2, float inv_n3, float* g, int B, int Tg, void* stream) {
     VP_CHECK(B > 0 && Tg > 0);
     const int T[4] = {T0, T1, T2, T3};
@@ -461,9 +465,9 @@ int rtfs_vp_pool_fwd(const float* const* raw, const float* const* stats, const f
     return RTFS_OK;
 }
 
-int rtfs_vp_mix_fwd(const float* loc, const float* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
-                    const float* gate_stats, const float* gate_g, const float* gate_b, const float* emb, const float* emb_stats, const float* emb_g,
-                    const float* emb_b, float inv_n_glob, const float* res, const float* res_stats, const float* res_g, const float* res_b, float* out,
+int rtfs_vp_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
+                    const double* gate_stats, const float* gate_g, const float* gate_b, const float* emb, const double* emb_stats, const float* emb_g,
+                    const float* emb_b, float inv_n_glob, const float* res, const double* res_stats, const float* res_g, const float* res_b, float* out,
                     int B, int Tn, int To, void* stream) {
     VP_CHECK(B > 0 && Tn > 0 && To > 0);
     hipLaunchKernelGGL(vp_mix_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, loc, mk_bn(loc_stats, loc_g, loc_b, inv_n_loc), gate,
@@ -488,8 +492,8 @@ int rtfs_vp_resid_bwd(const float* dout, const float* e, const float* Wr, float*
     return RTFS_OK;
 }
 
-int rtfs_vp_mix_bwd(const float* dout, const float* loc, const float* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
-                    const float* gate_stats, const float* gate_g, const float* gate_b, float inv_n_glob, float* dloc, float* dgate, float* demb,
+int rtfs_vp_mix_bwd(const float* dout, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, float inv_n_loc, const float* gate,
+                    const double* gate_stats, const float* gate_g, const float* gate_b, float inv_n_glob, float* dloc, float* dgate, float* demb,
                     float* dres_acc_or_null, int B, int Tn, int To, void* stream) {
     VP_CHECK(B > 0 && Tn > 0 && To > 0);
     hipLaunchKernelGGL(vp_mix_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dout, loc, mk_bn(loc_stats, loc_g, loc_b, inv_n_loc), gate,
@@ -498,7 +502,7 @@ int rtfs_vp_mix_bwd(const float* dout, const float* loc, const float* loc_stats,
     return RTFS_OK;
 }
 
-int rtfs_vp_bn_bwd_reduce(const float* dyhat, const float* raw, const float* stats, const float* gamma, const float* beta, float inv_n, float* sums, int B,
+int rtfs_vp_bn_bwd_reduce(const float* dyhat, const float* raw, const double* stats, const float* gamma, const float* beta, float inv_n, double* sums, int B,
                           int T, void* stream) {
     VP_CHECK(B > 0 && T > 0);
     hipLaunchKernelGGL(vp_bn_bwd_reduce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dyhat, raw, mk_bn(stats, gamma, beta, inv_n), sums, T);
@@ -506,8 +510,8 @@ int rtfs_vp_bn_bwd_reduce(const float* dyhat, const float* raw, const float* sta
     return RTFS_OK;
 }
 
-int rtfs_vp_dwconv_bwd(const float* dyhat, const float* raw, const float* out_stats, const float* out_gamma, const float* out_beta, float out_inv_n,
-                       const float* sums, float inv_n_all, int batch_stats, const float* src, const float* in_stats, const float* in_gamma,
+int rtfs_vp_dwconv_bwd(const float* dyhat, const float* raw, const double* out_stats, const float* out_gamma, const float* out_beta, float out_inv_n,
+                       const double* sums, float inv_n_all, int batch_stats, const float* src, const double* in_stats, const float* in_gamma,
                        const float* in_beta, float in_inv_n, int in_act, float in_slope, const float* w, float* dW, float* dbias_or_null,
                        float* dsrc_or_null, int accumulate, float* dslope_or_null, int B, int Tin, int Tout, int stride, void* stream) {
     VP_CHECK(B > 0 && Tin > 0 && Tout > 0 && Tout <= 104 && (stride == 1 || stride == 2));
@@ -528,8 +532,8 @@ int rtfs_vp_pool_bwd(const float* dg, float* const* d, int T0, int T1, int T2, i
     return RTFS_OK;
 }
 
-int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const float* y_stats, const float* y_gamma, const float* y_beta, float y_inv_n,
-                          const float* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
+int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const double* y_stats, const float* y_gamma, const float* y_beta, float y_inv_n,
+                          const double* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
                           const float* gb, float gslope, const float* Wp, float* dWp, float* dbp, float* dgw, float* dgb, float* dgslope, float* dx, int B,
                           int T, void* stream) {
     VP_CHECK(B > 0 && T > 0 && T <= 104);

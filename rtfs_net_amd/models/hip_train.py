@@ -243,8 +243,8 @@ class HipTrainer:
         T2 = (T - 2) // 2 + 1
         if T2 < 8:
             raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
-        if T2 > 512:
-            raise ValueError(f"training segment too long for the HIP path: {T2} compressed frames, the attention adjoint holds 512 (about 8 s)")
+        if T * F_BINS * C * 4 > 2 ** 30:  # (the inference path's guard, hip_path.HipForward: 32-bit offsets inside an utterance, tested envelope)
+            raise ValueError(f"training segment too long for the HIP path: {L} samples (about 65 s at most)")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats

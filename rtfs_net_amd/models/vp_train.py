@@ -93,7 +93,7 @@ class VPTrainer:
                 raise ValueError(f"SyncBatchNorm in the VP block's HIP training step needs equal per-rank batch sizes, got {int(lo)} ... {int(hi)}: "
                                  "use drop_last / DistributedSampler padding, or RTFS_VP_GLUE=1 for the PyTorch modules")
             self._equal_batches.add(st.B)
-        st.stats = torch.zeros(NS, 2, 64, device=dev)
+        st.stats = torch.zeros(NS, 2, 64, device=dev, dtype=torch.float64)  # float64 slots (order-independent sums; E[x^2] - mean^2 differenced in float64)
         # the two scalar PReLU slopes are kernel arguments: taken from the caller (AVNet reads every scalar of the model in ONE transfer per
         # optimizer step, hip_path.PreparedWeights) - fetching them here would be a host synchronisation in the middle of the step
         if slopes is None:
@@ -101,8 +101,8 @@ class VPTrainer:
         st.gslope, st.pslope = slopes
         if not st.train:  # running statistics as slots: sum = mean n, sum of squares = (var + mean^2) n with n = 1
             with torch.no_grad():
-                rm = torch.stack([b.running_mean.float() for b in self.bns])
-                rv = torch.stack([b.running_var.float() for b in self.bns])
+                rm = torch.stack([b.running_mean.double() for b in self.bns])
+                rv = torch.stack([b.running_var.double() for b in self.bns])
                 st.stats[:, 0], st.stats[:, 1] = rm, rv + rm * rm
         st.gam = [b.weight.detach().float().contiguous() for b in self.bns]
         st.bet = [b.bias.detach().float().contiguous() for b in self.bns]
@@ -127,8 +127,8 @@ class VPTrainer:
         ins = in_bn if in_bn is not None else (None, None, None, 1.0)
         b0 = conv0.bias.detach().float().contiguous() if conv0.bias is not None else None
         # in eval mode the output slots already hold the running statistics: the kernel's accumulation goes to a scratch slot
-        s0 = st.stats[idx0] if st.train else torch.zeros(2, 64, device=dev)
-        s1 = (st.stats[idx1] if st.train else torch.zeros(2, 64, device=dev)) if conv1 is not None else None
+        s0 = st.stats[idx0] if st.train else torch.zeros(2, 64, device=dev, dtype=torch.float64)
+        s1 = (st.stats[idx1] if st.train else torch.zeros(2, 64, device=dev, dtype=torch.float64)) if conv1 is not None else None
         lib.call("rtfs_vp_dwconv_fwd", src, ins[0], ins[1], ins[2], ins[3], in_act, in_slope, self._w3(conv0), b0, o0, s0,
                  self._w3(conv1) if conv1 is not None else None, o1, s1, st.B, Tin, Tout, stride)
         return o0, o1
@@ -145,7 +145,7 @@ class VPTrainer:
         gconv, pconv = vb.gateway.full_layer[2], vb.projection.full_layer[2]
         st.gw, st.gb = gconv.weight.detach().float().reshape(512).contiguous(), gconv.bias.detach().float().contiguous()
         st.Wp, st.bp = pconv.weight.detach().float().reshape(64, 512).contiguous(), pconv.bias.detach().float().contiguous()
-        s0 = st.stats[0] if st.train else torch.zeros(2, 64, device=dev)
+        s0 = st.stats[0] if st.train else torch.zeros(2, 64, device=dev, dtype=torch.float64)
         lib.call("rtfs_vp_gate_proj_fwd", x, st.gw, st.gb, st.gslope, st.Wp, st.bp, st.r, st.y, s0, B, T)
         self._allreduce(st, st.stats[0])
         st.raw = []
@@ -207,9 +207,10 @@ class VPTrainer:
             key = (st.Bn, st.T, str(st.stats.device))
             n = self._ncache.get(key)
             if n is None:  # (built once per shape: a host -> device copy of a Python list is a blocking transfer)
-                n = self._ncache[key] = torch.tensor([st.Bn * T for T in self._slot_lengths(st)], device=st.stats.device).view(NS, 1)
+                n = self._ncache[key] = torch.tensor([st.Bn * T for T in self._slot_lengths(st)], device=st.stats.device, dtype=torch.float64).view(NS, 1)
             mean = st.stats[:, 0] / n
-            var = (st.stats[:, 1] / n - mean * mean).clamp_min(0) * (n / (n - 1).clamp_min(1))
+            var = ((st.stats[:, 1] / n - mean * mean).clamp_min(0) * (n / (n - 1).clamp_min(1))).float()
+            mean = mean.float()
             mom = self.bns[0].momentum if self.bns[0].momentum is not None else 0.1
             rms, rvs = [b.running_mean for b in self.bns], [b.running_var for b in self.bns]
             torch._foreach_mul_(rms, 1 - mom)
@@ -273,8 +274,8 @@ class VPTrainer:
         dout = dout.detach().float().contiguous()
         st.dout = dout
         B, Ts, Tg = st.B, st.Ts, st.Tg
-        st.sums = torch.zeros(NS, 2, 64, device=dev)
-        st.local_sums = st.sums if not st.sync else torch.zeros(NS, 2, 64, device=dev)
+        st.sums = torch.zeros(NS, 2, 64, device=dev, dtype=torch.float64)
+        st.local_sums = st.sums if not st.sync else torch.zeros(NS, 2, 64, device=dev, dtype=torch.float64)
         st.dW = torch.zeros(NS, 3, 64, device=dev)
         st.dbias = torch.zeros(NS, 64, device=dev)
         st.dds = [torch.zeros(B, 64, Ts[i], device=dev) for i in range(4)]  # gradients w.r.t. the BatchNorm outputs of the four down-sampled tensors
@@ -330,9 +331,9 @@ class VPTrainer:
 
     def grads_a(self, st):
         s = st.local_sums
-        gs = [st.dgw.view(512, 1, 1), st.dgb, st.dgslope, st.dWp.view(64, 512, 1), st.dbp, s[0, 1].clone(), s[0, 0].clone(), st.dpslope]
+        gs = [st.dgw.view(512, 1, 1), st.dgb, st.dgslope, st.dWp.view(64, 512, 1), st.dbp, s[0, 1].float(), s[0, 0].float(), st.dpslope]
         for i in range(4):
-            gs += [st.dW[1 + i].t().reshape(64, 1, 3).contiguous(), st.dbias[1 + i].clone(), s[1 + i, 1].clone(), s[1 + i, 0].clone()]
+            gs += [st.dW[1 + i].t().reshape(64, 1, 3).contiguous(), st.dbias[1 + i].clone(), s[1 + i, 1].float(), s[1 + i, 0].float()]
         return gs
 
     def params_b(self):
@@ -348,7 +349,7 @@ class VPTrainer:
         s = st.local_sums
         gs = []
         for idx in range(5, NS):
-            gs += [st.dW[idx].t().reshape(64, 1, 3).contiguous(), s[idx, 1].clone(), s[idx, 0].clone()]
+            gs += [st.dW[idx].t().reshape(64, 1, 3).contiguous(), s[idx, 1].float(), s[idx, 0].float()]
         gs += [st.dWr.view(512, 64, 1), st.dbr]
         return gs
 

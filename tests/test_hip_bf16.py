@@ -64,6 +64,28 @@ def test_config5_rtfs12_4s_against_reference_golden(dtype):
     assert e < TOL[dtype][1]
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_config5_bench_shape_batch16(dtype):
+    """BASELINE config 5 at the batch the bench rider runs it (RTFS-Net-12, 4 s, 16 utterances per GPU; the large-batch kernel forms - flattened
+    layer-0 tiles, one-workgroup residual kernels - on the bf16 pipe).  Utterance 0 is the reference's golden input: it must come out of the batch as
+    it does alone (utterances are independent; the kernel forms differ between batch 1 and 16, so the comparison carries the mode's own product
+    error once more: bound = the mode's waveform tolerance) and within that tolerance of the REFERENCE's waveform."""
+    z = load_npz("rtfs12_4s_b1.npz")
+    model, _, _ = make_model(12, "cuda")
+    mix, _, emb = synth.synth_inputs(16, 64000, 100)
+    one_mix, _, one_emb = synth.synth_inputs(1, 64000, 100)
+    mix[0], emb[0] = one_mix[0], one_emb[0]
+    model.set_compute_dtype(dtype)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+        alone = model(mix[:1].cuda(), emb[:1].cuda())
+    model.set_compute_dtype("f32")
+    assert torch.isfinite(out).all()
+    e_ref, e_inv = rel(out[:1], torch.from_numpy(z["out"])), rel(out[:1], alone)
+    print(f"RTFS-Net-12, 4 s, batch 16, {dtype}: utterance 0 vs the reference {e_ref:.3e}, vs its batch-1 forward {e_inv:.3e}")
+    assert e_ref < TOL[dtype][1] and e_inv < TOL[dtype][1]
+
+
 def test_bf16_modes_are_inference_only_and_switchable():
     model, _, _ = make_model(2, "cuda")
     with pytest.raises(ValueError):

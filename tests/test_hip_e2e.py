@@ -79,6 +79,11 @@ def test_train_mode_runs_under_autograd_and_is_refused_without():
     assert out.requires_grad and out.grad_fn is not None and torch.isfinite(out).all()
     with torch.no_grad(), pytest.raises(NotImplementedError):
         model(mix.cuda(), emb.cuda())
+    # a 10-s segment (625 compressed frames: the attention adjoint walks its keys in two blocks; round 2 refused > 8 s; Tv = 250: VP glue path)
+    mix, _, emb = synth.synth_inputs(1, 160000, 250)
+    model.zero_grad(set_to_none=True)
+    model(mix.cuda(), emb.cuda()).square().mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
 
 
 def test_long_utterance_8s():

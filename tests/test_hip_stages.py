@@ -374,3 +374,32 @@ def test_resid_large_batch_forms_match(dtype):
     e31, e21 = rel(outs[3], outs[1]), rel(outs[2], outs[1])
     print(f"{dtype}: 8-wave vs two-workgroup form {e31:.2e}, 4-wave one-workgroup vs two-workgroup form {e21:.2e}")
     assert e31 < tol and e21 < tol
+
+
+@pytest.mark.parametrize("B,T2", [(2, 125), (1, 300), (1, 625), (1, 1100)])
+def test_attention_core_forward_and_adjoint_isolated(B, T2):
+    """rtfs_attn_core_fwd (with the log-sum-exp output of the training step) + rtfs_attn_core_bwd against float64 autograd of
+    softmax(Q K^T / 16) V (attention.py:171-173) on the GPU.  T2 = 625 (10 s): the adjoint walks keys / queries in two blocks of 512;
+    T2 = 1100 (17.6 s): the forward is the key-blocked two-sweep kernel, whose final statistics supply the log-sum-exp."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(T2)
+    Q = (torch.randn(B, 4, T2, 256, generator=g) * 0.5).cuda()
+    K = (torch.randn(B, 4, T2, 256, generator=g) * 0.5).cuda()
+    V = torch.randn(B, 4, T2, 1024, generator=g).cuda()
+    dOh = torch.randn(B, 4, T2, 1024, generator=g).cuda()  # per head [T2][16 ch][64 f]
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (Q, K, V))
+    ref = torch.softmax(q64 @ k64.transpose(-1, -2) / 16.0, -1) @ v64
+    (ref * dOh.double()).sum().backward()
+    # O layout of the kernels: [B][T2][64 ch = head * 16 + c][64 f]
+    to_o = lambda t: t.view(B, 4, T2, 16, 64).permute(0, 2, 1, 3, 4).reshape(B, T2, 4096).contiguous()  # noqa: E731
+    O = torch.empty(B * T2 * 4096, device="cuda")
+    LSE = torch.empty(B * 4 * T2, device="cuda")
+    lib.call("rtfs_attn_core_fwd", Q, K, V, O, LSE, B, T2)
+    assert rel(O.view(B, T2, 4096), to_o(ref.detach().float())) < 2e-6
+    lse_ref = torch.logsumexp(q64.detach() @ k64.detach().transpose(-1, -2) / 16.0, -1)
+    assert float((LSE.view(B, 4, T2).double() - lse_ref).abs().max()) < 1e-4
+    dO = to_o(dOh)
+    dQ, dK, dV, D = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty(B * 4 * T2, device="cuda")
+    lib.call("rtfs_attn_core_bwd", Q, K, V, O, dO, LSE, D, dQ, dK, dV, B, T2)
+    assert rel(dQ, q64.grad) < 2e-5 and rel(dK, k64.grad) < 2e-5 and rel(dV, v64.grad) < 2e-5
