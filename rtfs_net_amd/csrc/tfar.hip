@@ -606,6 +606,38 @@ __global__ __launch_bounds__(256) void tfar_mix_kernel(NormRefLite loc, NormRefL
     st4(out + o, fma4(l, g, e));
 }
 
+// One pass over the positions of an utterance's video tensor vb [512][Tv] (contiguous) for the CAF video kernels: thread c receives
+// body(t, vb[2c][t], vb[2c + 1][t]) for t = 0 .. Tv - 1 in order.  The rows are staged through LDS in nh groups of R = 512 / nh rows: coalesced
+// global reads (the group is one contiguous R x Tv block), transposed into X[t][row] (row stride R + 2 floats: 8-byte aligned pairs, 2-way
+// conflicts on the staging writes only), then the 256 / nh threads that own the group's rows walk t.  Dynamic LDS: Tv (R + 2) floats.
+template <class Body>
+__device__ __forceinline__ void caf_staged_sweep(const float* __restrict__ vb, int Tv, int nh, int c, Body&& body) {
+    extern __shared__ __attribute__((aligned(16))) float caf_x[];
+    const int R = 512 / nh, LDX = R + 2, per = 256 / nh;
+    for (int h = 0; h < nh; ++h) {
+        __syncthreads();  // the previous group / pass has been consumed
+        const float* src = vb + (size_t)h * R * Tv;
+        for (int idx = threadIdx.x; idx < R * Tv; idx += 256) {
+            const int ch = idx / Tv, t = idx - ch * Tv;
+            caf_x[t * LDX + ch] = src[idx];
+        }
+        __syncthreads();
+        if (c / per == h) {
+            const float* xp = caf_x + 2 * (c - h * per);
+            for (int t = 0; t < Tv; ++t) {
+                const float2 x = *reinterpret_cast<const float2*>(xp + t * LDX);
+                body(t, x.x, x.y);
+            }
+        }
+    }
+}
+// number of channel groups for caf_staged_sweep (0: the tensor does not fit in <= 8 groups - direct reads); LDS budget 150 KB
+static int caf_groups(int Tv) {
+    for (int nh = 1; nh <= 8; nh *= 2)
+        if ((size_t)Tv * (512 / nh + 2) * sizeof(float) <= 150 * 1024) return nh;
+    return 0;
+}
+
 // Video side of the CAF cell, one workgroup per utterance, thread = audio channel c (256).
 //   v: [B][512][Tv] (NCW, as produced by the VP block).  att_w [1024][2], att_b/att_g/att_be [1024]; rs_w [256][2], rs_b/rs_g/rs_be [256].
 //   att_out, rsz_out: [B][Tv][256]
@@ -613,7 +645,7 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
                                                         const float* __restrict__ att_g, const float* __restrict__ att_be,
                                                         const float* __restrict__ rs_w, const float* __restrict__ rs_b, const float* __restrict__ rs_g,
                                                         const float* __restrict__ rs_be, float* __restrict__ att_out, float* __restrict__ rsz_out,
-                                                        int Tv) {
+                                                        int Tv, int nh) {
     __shared__ float red[16];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
     const float* v0 = v + ((size_t)b * 512 + 2 * c) * Tv;
@@ -626,10 +658,16 @@ __global__ __launch_bounds__(256) void caf_video_kernel(const float* __restrict_
     }
     const float rw0 = rs_w[2 * c], rw1 = rs_w[2 * c + 1], rb = rs_b[c], rg = rs_g[c], rbe = rs_be[c];
 
-    // Every pass walks the thread's two input rows in batches of 8 positions with the 16 loads issued first (addresses clamped, never under a
-    // branch): a rolled loop pays one L2 / HBM latency per position, and with ONE workgroup per utterance this kernel is pure latency - it sits
-    // on the critical path of small batches (round 3: 540 -> ~100 us).
+    // Every pass walks the thread's two input rows.  Thread c's rows 2c, 2c + 1 are Tv floats apart from its neighbours': read directly, every
+    // wave-load touches 64 cache lines and the kernel is bound by the texture-address unit (540 us; batching 8 positions per latency: 487 us).
+    // Round 3: caf_staged_sweep - the utterance's [512][Tv] block is contiguous, so it is copied into LDS with perfectly coalesced loads,
+    // transposed ([t][row]), in nh channel groups that fit the LDS, and the passes read their (x0, x1) pairs as one conflict-free 8-byte LDS
+    // read.  nh = 0 (the block would need more than 8 groups: Tv > ~580): the direct reads, 8 positions per batch with the loads first.
     auto sweep = [&](auto&& body) {
+        if (nh > 0) {
+            caf_staged_sweep(v + (size_t)b * 512 * Tv, Tv, nh, c, [&](int t, float x0, float x1) { body(t, x0, x1); });
+            return;
+        }
 #pragma unroll 1
         for (int t0 = 0; t0 < Tv; t0 += 8) {
             float a0[8], a1[8];
@@ -702,7 +740,7 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rs_be, const float* __restrict__ datt, const float* __restrict__ drsz,
                                                             float* __restrict__ dv, float* __restrict__ d_att_w, float* __restrict__ d_att_b,
                                                             float* __restrict__ d_att_g, float* __restrict__ d_att_be, float* __restrict__ d_rs_w,
-                                                            float* __restrict__ d_rs_b, float* __restrict__ d_rs_g, float* __restrict__ d_rs_be, int Tv) {
+                                                            float* __restrict__ d_rs_b, float* __restrict__ d_rs_g, float* __restrict__ d_rs_be, int Tv, int nh) {
     __shared__ float red[16];
     const int b = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
     const float* v0 = v + ((size_t)b * 512 + 2 * c) * Tv;
@@ -726,6 +764,12 @@ __global__ __launch_bounds__(256) void caf_video_bwd_kernel(const float* __restr
     // batches of 8 positions, all loads of a batch first (see caf_video_kernel); GRADS: the two upstream gradients ride along
     auto sweep = [&](auto grads, auto&& body) {
         constexpr bool G = decltype(grads)::value;
+        if (nh > 0) {  // (the upstream gradients are read [t][c]: coalesced across the threads as they are)
+            caf_staged_sweep(v + (size_t)b * 512 * Tv, Tv, nh, c, [&](int t, float x0, float x1) {
+                body(t, x0, x1, G ? dab[(size_t)t * 256] : 0.f, G ? drb[(size_t)t * 256] : 0.f);
+            });
+            return;
+        }
 #pragma unroll 1
         for (int t0 = 0; t0 < Tv; t0 += 8) {
             float a0[8], a1[8], ga[G ? 8 : 1], gr[G ? 8 : 1];
@@ -853,6 +897,16 @@ __global__ __launch_bounds__(256) void caf_fuse_kernel(const float* __restrict__
 }  // namespace rtfs
 
 using namespace rtfs;
+
+static int caf_set_lds(const void* fn, bool* flags) {  // dynamic LDS beyond 64 KB needs the attribute, once per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return RTFS_ELAUNCH;
+    if (!flags[dev]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return RTFS_ELAUNCH;
+        flags[dev] = true;
+    }
+    return RTFS_OK;
+}
 
 template <int STRIDE, int MODE>
 static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
@@ -985,8 +1039,12 @@ int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* lo
 int rtfs_caf_video_fwd(const float* v, const float* att_w, const float* att_b, const float* att_g, const float* att_be, const float* rs_w,
                        const float* rs_b, const float* rs_g, const float* rs_be, float* att_out, float* rsz_out, int B, int Tv, void* stream) {
     if (B <= 0 || Tv <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(caf_video_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, att_out,
-                       rsz_out, Tv);
+    const int nh = caf_groups(Tv);
+    const size_t lds = nh ? (size_t)Tv * (512 / nh + 2) * sizeof(float) : 0;
+    static bool set[16] = {};
+    if (caf_set_lds(reinterpret_cast<const void*>(caf_video_kernel), set) != RTFS_OK) return RTFS_ELAUNCH;
+    hipLaunchKernelGGL(caf_video_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, att_out,
+                       rsz_out, Tv, nh);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -996,8 +1054,12 @@ int rtfs_caf_video_bwd(const float* v, const float* att_w, const float* att_b, c
                        float* d_att_b, float* d_att_g, float* d_att_be, float* d_rs_w, float* d_rs_b, float* d_rs_g, float* d_rs_be, int B, int Tv,
                        void* stream) {
     if (B <= 0 || Tv <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(caf_video_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, datt, drsz,
-                       dv, d_att_w, d_att_b, d_att_g, d_att_be, d_rs_w, d_rs_b, d_rs_g, d_rs_be, Tv);
+    const int nh = caf_groups(Tv);
+    const size_t lds = nh ? (size_t)Tv * (512 / nh + 2) * sizeof(float) : 0;
+    static bool set[16] = {};
+    if (caf_set_lds(reinterpret_cast<const void*>(caf_video_bwd_kernel), set) != RTFS_OK) return RTFS_ELAUNCH;
+    hipLaunchKernelGGL(caf_video_bwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, v, att_w, att_b, att_g, att_be, rs_w, rs_b, rs_g, rs_be, datt, drsz,
+                       dv, d_att_w, d_att_b, d_att_g, d_att_be, d_rs_w, d_rs_b, d_rs_g, d_rs_be, Tv, nh);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
