@@ -478,14 +478,14 @@ int rtfs_vp_mix_fwd(const float* loc, const double* loc_stats, const float* loc_
 }
 
 int rtfs_vp_resid_fwd(const float* e, const float* Wr, const float* br, const float* r, float* out, int B, int T, void* stream) {
-    VP_CHECK(B > 0 && T > 0 && T <= 104);
+    VP_CHECK(B > 0 && T > 0 && T <= 4096);
     hipLaunchKernelGGL(vp_resid_fwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, e, Wr, br, r, out, T);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
 
 int rtfs_vp_resid_bwd(const float* dout, const float* e, const float* Wr, float* de, float* dWr, float* dbr, int B, int T, void* stream) {
-    VP_CHECK(B > 0 && T > 0 && T <= 104);
+    VP_CHECK(B > 0 && T > 0 && T <= 4096);
     if (hipMemsetAsync(de, 0, (size_t)B * TVH * T * sizeof(float), (hipStream_t)stream) != hipSuccess) return RTFS_ELAUNCH;
     hipLaunchKernelGGL(vp_resid_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dout, e, Wr, de, dWr, dbr, T);
     RTFS_LAUNCH_CHECK();
@@ -514,7 +514,7 @@ int rtfs_vp_dwconv_bwd(const float* dyhat, const float* raw, const double* out_s
                        const double* sums, float inv_n_all, int batch_stats, const float* src, const double* in_stats, const float* in_gamma,
                        const float* in_beta, float in_inv_n, int in_act, float in_slope, const float* w, float* dW, float* dbias_or_null,
                        float* dsrc_or_null, int accumulate, float* dslope_or_null, int B, int Tin, int Tout, int stride, void* stream) {
-    VP_CHECK(B > 0 && Tin > 0 && Tout > 0 && Tout <= 104 && (stride == 1 || stride == 2));
+    VP_CHECK(B > 0 && Tin > 0 && Tout > 0 && Tout <= 4096 && (stride == 1 || stride == 2));
     hipLaunchKernelGGL(vp_dwconv_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dyhat, raw, mk_bn(out_stats, out_gamma, out_beta, out_inv_n), sums,
                        inv_n_all, batch_stats, src, mk_bn(in_stats, in_gamma, in_beta, in_inv_n), in_act, in_slope, w, dW, dbias_or_null, dsrc_or_null,
                        accumulate, dslope_or_null, Tin, Tout, stride);
@@ -536,7 +536,7 @@ int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const double* y_st
                           const double* sums, float inv_n_all, int batch_stats, const float* dout, const float* x, const float* r, const float* gw,
                           const float* gb, float gslope, const float* Wp, float* dWp, float* dbp, float* dgw, float* dgb, float* dgslope, float* dx, int B,
                           int T, void* stream) {
-    VP_CHECK(B > 0 && T > 0 && T <= 104);
+    VP_CHECK(B > 0 && T > 0 && T <= 4096);
     hipLaunchKernelGGL(vp_gate_proj_bwd_kernel, dim3(B, 8), dim3(256), 0, (hipStream_t)stream, dyhat, y, mk_bn(y_stats, y_gamma, y_beta, y_inv_n), sums,
                        inv_n_all, batch_stats, dout, x, r, gw, gb, gslope, Wp, dWp, dbp, dgw, dgb, dgslope, dx, T);
     RTFS_LAUNCH_CHECK();

@@ -251,7 +251,7 @@ class AVNet(nn.Module):
         with torch.cuda.stream(side):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
             vb = rm.video_net.get_block(0)
-            if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
+            if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 4096 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
                 # the VP block on HIP kernels: convolution / BatchNorm chain and GlobalAttention (models/vp_train.py)
                 from .vp_train import vp_block_train
 

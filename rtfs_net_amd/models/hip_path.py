@@ -439,11 +439,20 @@ class HipForward:
         rsz = torch.empty_like(att)
         with torch.cuda.stream(self._vp_stream):
             vin = m.video_bottleneck(emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
-            if w["vp"] is not None and 8 <= Tv <= 100 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
+            vblock = m.refinement_module.video_net.get_block(0)
+            use_hip = w["vp"] is not None and os.environ.get("RTFS_VP_GLUE", "0") != "1"
+            if use_hip and 8 <= Tv <= 100:
                 v1 = torch.empty_like(vin)
                 lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
-            else:  # other video_params / lengths: PyTorch-ROCm glue (models/modules.py)
-                v1 = m.refinement_module.video_net.get_block(0)(vin).contiguous()
+            elif use_hip and 100 < Tv <= 4096:
+                # longer than the one-kernel form's LDS (4 s): the multi-launch kernels of the training step with running-statistics slots
+                # (models/vp_train.py; GlobalAttention on HIP up to 16 pooled tokens = Tv <= 128, the PyTorch module beyond)
+                from .vp_train import vp_block_eval
+
+                v1 = vp_block_eval(vblock, vin, (pw._scal["refinement_module.video_net.blocks.gateway.full_layer.4.weight"],
+                                                 pw._scal["refinement_module.video_net.blocks.projection.full_layer.4.weight"]))
+            else:  # other video_params / fewer than 8 frames: PyTorch-ROCm glue (models/modules.py)
+                v1 = vblock(vin).contiguous()
             # the CAF cell's video side (one workgroup per utterance, 64 us) rides on the side stream as well
             lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
                      w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)

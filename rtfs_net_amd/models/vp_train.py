@@ -499,6 +499,31 @@ def vp_block_train(trainer: VPTrainer, x: torch.Tensor, slopes=None) -> torch.Te
     return VPStageB.apply(trainer, holder, g2, *trainer.params_b())
 
 
+_EVAL_TRAINERS = {}
+
+
+@torch.no_grad()
+def vp_block_eval(vb, x, slopes=None):
+    """The VP block in eval mode WITHOUT autograd on the multi-launch kernels (any length up to 4096 frames; the one-kernel inference form
+    csrc/vp.hip holds 4 s): stage A, GlobalAttention (HIP up to 16 pooled tokens, else the module), stage B; BatchNorm from the running statistics."""
+    tr = _EVAL_TRAINERS.get(id(vb))
+    if tr is None or tr.vb is not vb or tr.bns[0] is not vb.projection.full_layer[3]:
+        if not supported(vb):
+            return vb(x).contiguous()
+        tr = _EVAL_TRAINERS[id(vb)] = VPTrainer(vb)
+    if vb.training:
+        raise RuntimeError("vp_block_eval is the inference path (model.eval())")
+    g, st = tr.forward_a(x, slopes)
+    ga = vb.globalatt[0]
+    if attn_supported(ga) and 2 <= g.shape[-1] <= 16:
+        g2 = torch.empty_like(g)
+        packed = torch.cat([p.detach().float().reshape(-1) for p in attn_params(ga)])
+        lib.call("rtfs_vp_attn_fwd", g, packed, ga.MHSA.pos_enc.pe[0, :g.shape[-1]].float().contiguous(), None, g2, g.shape[0], g.shape[-1])
+    else:
+        g2 = ga(g)
+    return tr.forward_b(st, g2)
+
+
 # ---- video side of the CAF cell under autograd (csrc/tfar.hip caf_video_kernel / caf_video_bwd_kernel) -------------------------------
 class CAFVideoFn(torch.autograd.Function):
     """v1 [B,512,Tv] -> (att, rsz) [B,Tv,256]: attention_embed / resize grouped 1x1 convolutions + gLN, head mean, softmax over Tv

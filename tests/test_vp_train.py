@@ -25,7 +25,7 @@ def _block(train):
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("B,Tv", [(3, 50), (2, 25), (4, 13), (1, 100)])
+@pytest.mark.parametrize("B,Tv", [(3, 50), (2, 25), (4, 13), (1, 100), (2, 230)])
 def test_vp_block_training_step_matches_the_glue(train, B, Tv):
     from rtfs_net_amd.models.vp_train import VPTrainer, supported, vp_block_train
 
@@ -61,7 +61,7 @@ def test_vp_block_training_step_matches_the_glue(train, B, Tv):
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("B,Tv", [(3, 50), (2, 25), (2, 12), (1, 100)])
+@pytest.mark.parametrize("B,Tv", [(3, 50), (2, 25), (2, 12), (1, 100), (1, 230)])
 def test_vp_block_training_step_matches_the_oracle(train, B, Tv):
     """the same step against float64 autograd of the ORACLE's TDANetBlock restatement (oracle/avnet_ref.py tdanet_block, pinned to the
     reference by tests/golden): output, input gradient, every parameter gradient, and in train mode the 26 running means / variances
@@ -209,3 +209,20 @@ def test_caf_video_side_hip_training_kernels(B, Tv):
         # hold fp32 residue there, hence the absolute floor)
         e = float((g - p.grad).norm()) / (float(p.grad.norm()) + 1e-3 * scale)
         assert e < 2e-4, (tuple(p.shape), e)
+
+
+@pytest.mark.parametrize("B,Tv", [(2, 120), (1, 230), (1, 1000)])
+def test_vp_block_eval_chain_for_long_inputs(B, Tv):
+    """inputs longer than the one-kernel inference form holds (Tv > 100 = 4 s): the multi-launch kernels with running statistics
+    (models/vp_train.py vp_block_eval; GlobalAttention on HIP for Tv = 120 (15 pooled tokens), the module beyond) against the oracle's block"""
+    from oracle import avnet_ref
+    from rtfs_net_amd.models.vp_train import vp_block_eval
+    from util import VIDEO_PREFIX
+
+    model, sd, cfg = make_model(2, "cuda")
+    vb = model.refinement_module.video_net.get_block(0).eval()
+    x = torch.randn(B, 512, Tv, generator=torch.Generator().manual_seed(Tv))
+    out = vp_block_eval(vb, x.cuda())
+    with torch.no_grad():
+        ref = avnet_ref.tdanet_block(x, avnet_ref.P(sd).sub(VIDEO_PREFIX), avnet_ref.normalise_cfg(cfg)["video"])
+    assert rel(out, ref) < 2e-5
