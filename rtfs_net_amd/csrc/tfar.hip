@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
         asm volatile("" : "+v"(moff));  // opaque per block: the constants are re-read from LDS instead of living in 16 VGPRs
         auto xform = [&](float4 x, float4 g, float4 e, int ti, int fi) {
             if (MODE >= 1) x = fma4(x, sc, sh);
-            if (MODE == 2) x = prelu4(x, a.slope);
+            if (MODE == 2) x = prelu4_minfma(x, a.slope - 1.0f);  // (the same form as the interior path below)
             if (MODE == 3) x = fma4(x, sigmoid4(fma4(g, ld4(mixc + moff), ld4(mixc + 64 + moff))), fma4(e, ld4(mixc + 128 + moff), ld4(mixc + 192 + moff)));
             if (!(ti >= 0 && ti < T && fi >= 0 && fi < F)) x = f4(0, 0, 0, 0);
             return x;
@@ -298,20 +298,45 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                 vh[i] = ld4(tile + r * RS + (c + TC) * 64 + c4);
             }
         }
+        // Blocks whose (16+3) x (8+3) input window lies inside the tensor (3 of 4 at the headline shape) take a lean path: no clamping of the 10
+        // load addresses, no per-element zero-padding select, the transform in native 4-vectors (common.h) - the staging code was ~45 % of this
+        // kernel's VALU instructions (PMC, round 3: 44 M VALU per launch against 16.6 M for the convolution's FMAs; VALU 50 % busy).
+        const bool interior = t0 >= 1 && t0 + TR + 1 < T && fb >= 1 && fb + TC + 1 < F;  // (workgroup-uniform)
         if (MODE != 3) {
+            if (interior) {
+                const unsigned boff = (((unsigned)(t0 - 1) * F + (fb - 1 + 3)) * kH) * 4u;
 #pragma unroll
-            for (int i = 0; i < NN; ++i) {
-                const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
-                const int ti = t0 - 1 + r, fi = fb - 1 + c;
-                vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+                for (int i = 0; i < NN; ++i) {
+                    const int r = i == NN - 1 ? min((int)(threadIdx.x >> 7) + 2 * i, R - 1) : (int)(threadIdx.x >> 7) + 2 * i;
+                    vn[i] = ld4_off(inb, boff + (((unsigned)r * F + ((threadIdx.x >> 4) & 7)) * kH + c4) * 4u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) {
+                    const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+                    const int ti = t0 - 1 + r, fi = fb - 1 + c;
+                    vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+                }
             }
         }
         __syncthreads();  // previous block's window reads are done
         if (MODE != 3) {
+            if (interior) {
+                const float4v scv = to_v4(sc), shv = to_v4(sh);
+                const float am1 = a.slope - 1.0f;
 #pragma unroll
-            for (int i = 0; i < NN; ++i) {
-                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
-                vn[i] = xform(vn[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c);
+                for (int i = 0; i < NN; ++i) {
+                    float4v x = to_v4(vn[i]);
+                    if (MODE >= 1) x = x * scv + shv;
+                    if (MODE == 2) x = __builtin_elementwise_min(x, float4v{0.f, 0.f, 0.f, 0.f}) * am1 + x;  // prelu(x) = x + (a - 1) min(x, 0)
+                    vn[i] = to_f4(x);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) {
+                    const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                    vn[i] = xform(vn[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c);
+                }
             }
             store_new(0, NN);
         } else {
@@ -339,25 +364,30 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
         for (int jb = 0; jb < TC; jb += OPS) {
             int woff = c4;
             asm volatile("" : "+v"(woff));  // re-read the taps from LDS here: hoisted out of the loops they pin 64 VGPRs per convolution (spills)
-            float4 acc[NCONV][OPS];
+            float4v accv[NCONV][OPS];
 #pragma unroll
             for (int k = 0; k < NCONV; ++k)
 #pragma unroll
-                for (int jj = 0; jj < OPS; ++jj) acc[k][jj] = bias4[k];
+                for (int jj = 0; jj < OPS; ++jj) accv[k][jj] = to_v4(bias4[k]);
 #pragma unroll 1
             for (int dt = 0; dt < 4; ++dt) {  // (rolled: unrolled, hipcc issues all 28 window and 16 NCONV tap reads first and spills)
-                float4 wr[OPS + 3];
+                float4v wr[OPS + 3];
 #pragma unroll
-                for (int c = 0; c < OPS + 3; ++c) wr[c] = ld4(trow + dt * RS + (jb + c) * 64);
+                for (int c = 0; c < OPS + 3; ++c) wr[c] = ld4v(trow + dt * RS + (jb + c) * 64);
 #pragma unroll
                 for (int df = 0; df < 4; ++df)
 #pragma unroll
                     for (int k = 0; k < NCONV; ++k) {
-                        const float4 tap = ld4(&ws[k][(dt * 4 + df) * 64 + woff]);  // quad-broadcast LDS read, shared by the OPS outputs
+                        const float4v tap = ld4v(&ws[k][(dt * 4 + df) * 64 + woff]);  // quad-broadcast LDS read, shared by the OPS outputs
 #pragma unroll
-                        for (int jj = 0; jj < OPS; ++jj) acc[k][jj] = fma4(tap, wr[jj + df], acc[k][jj]);
+                        for (int jj = 0; jj < OPS; ++jj) accv[k][jj] = tap * wr[jj + df] + accv[k][jj];  // native vectors: v_pk_fma_f32 without operand shuffles (common.h)
                     }
             }
+            float4 acc[NCONV][OPS];
+#pragma unroll
+            for (int k = 0; k < NCONV; ++k)
+#pragma unroll
+                for (int jj = 0; jj < OPS; ++jj) acc[k][jj] = to_f4(accv[k][jj]);
 #pragma unroll
             for (int jj = 0; jj < OPS; ++jj) {
                 const int fo = fb + jb + jj;
@@ -489,21 +519,24 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
             for (int jb = 0; jb < TC; jb += 4) {
                 int woff = c4;
                 asm volatile("" : "+v"(woff));  // taps re-read from LDS per step (hoisted they pin 64 VGPRs)
-                float4 acc[4];
+                float4v accv[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[jj] = f4(0, 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) accv[jj] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
                 for (int dt = 0; dt < 4; ++dt) {
-                    float4 wr[7];
+                    float4v wr[7];
 #pragma unroll
-                    for (int c = 0; c < 7; ++c) wr[c] = ld4(trow + dt * RS + (jb + c) * 64);
+                    for (int c = 0; c < 7; ++c) wr[c] = ld4v(trow + dt * RS + (jb + c) * 64);
 #pragma unroll
                     for (int df = 0; df < 4; ++df) {
-                        const float4 tap = ld4(&ws[0][(dt * 4 + df) * 64 + woff]);
+                        const float4v tap = ld4v(&ws[0][(dt * 4 + df) * 64 + woff]);
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[jj] = fma4(tap, wr[jj + df], acc[jj]);
+                        for (int jj = 0; jj < 4; ++jj) accv[jj] = tap * wr[jj + df] + accv[jj];  // native vectors: v_pk_fma_f32 without shuffles (common.h)
                     }
                 }
+                float4 acc[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[jj] = to_f4(accv[jj]);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int fo = fb + jb + jj;
@@ -522,21 +555,21 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
             const float* base = tile + (2 * lt) * RS + (4 * lp) * 64 + c4;
 #pragma unroll 1
             for (int o = 0; o < 2; ++o) {  // (rolled: one 4 x 4 window of registers at a time)
-                float4 x[4][4];
+                float4v x[4][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[c][r] = ld4(base + r * RS + (2 * o + c) * 64);
-                float4 acc = bias2;
+                    for (int r = 0; r < 4; ++r) x[c][r] = ld4v(base + r * RS + (2 * o + c) * 64);
+                float4v accv = to_v4(bias2);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                    for (int df = 0; df < 4; ++df) acc = fma4(ld4(&ws[1][(dt * 4 + df) * 64 + woff]), x[df][dt], acc);
+                    for (int df = 0; df < 4; ++df) accv = ld4v(&ws[1][(dt * 4 + df) * 64 + woff]) * x[df][dt] + accv;
                 // pooling window: rows dt = 1, 2 (, 3), columns df = 1, 2, 3 of the same 4 x 4 window
-                float4 rs[3];
+                float4v rs[3];
 #pragma unroll
                 for (int dt = 1; dt < 4; ++dt) rs[dt - 1] = x[1][dt] + x[2][dt] + x[3][dt];
-                const float4 pool = (rs[0] + rs[1] + rs[2] * mt3) * pinv;
+                const float4 acc = to_f4(accv), pool = to_f4((rs[0] + rs[1] + rs[2] * mt3) * pinv);
                 const int f2 = (fb >> 1) + 2 * lp + o;
                 if (t2valid && f2 < kF2 && 2 * f2 < f1) {
                     st4(a.out2 + orow2 + (size_t)f2 * kH, acc);

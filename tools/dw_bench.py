@@ -1,10 +1,11 @@
 """GPU micro-benchmark of the depth-wise convolution family at the headline shapes (B = 32, 2 s): the entry points alone, median of 30 launches.
 RTFS_HIP_LIB selects the library build (tools/build_variant.sh) for same-box A/B runs."""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtfs_net_amd import lib  # noqa: E402
 
 
