@@ -70,4 +70,4 @@ def test_bench_plain_launch_reexecutes_under_torchrun():
     if torch.cuda.is_available():
         return  # (on a GPU box tests/test_bench_contract.py exercises the real thing)
     assert r.returncode != 0
-    assert (r.stdout + r.stderr).count("bench.py needs an MI355X") == 2
+    assert "bench.py needs an MI355X" in (r.stdout + r.stderr)  # (the elastic agent may stop the second rank as soon as the first has failed)
