@@ -71,11 +71,6 @@ int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, co
 /* variant: 0 = the library's choice (tiles cut from the flattened (sequence, window) row index), 1 = tiles padded per sequence (A/B; same bits) */
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, float* U0, int B, int T2, int dim,
                             int variant, void* stream);
-/* the same with the weight additionally given in FRAGMENT order: Wfrag[np][wn][kq][n][lane][4] = Wt[128 np + 64 wn + 32 n + (lane & 31)][8 kq + 4 (lane >> 5) .. + 3]
- * (np, wn, n in {0, 1}, kq in 0 .. 63) - the order in which a wave of the large-batch kernel consumes it, so that the K loop reads its A operand straight
- * from L2 with coalesced 1 KB loads, without LDS staging or barriers (fp32; shapes the large-batch kernel does not serve use Wt; identical bits either way) */
-int rtfs_dp_unfold_gemm_frag_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, const float* Wfrag, float* U0, int B,
-                                 int T2, int dim, void* stream);
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,
                       void* stream);
 /* SRU layers 1-3 with the input projection U = Hprev . W fused into the recurrence (U never reaches HBM): Wt [192][64], row = m*64 + dir*32 + j;

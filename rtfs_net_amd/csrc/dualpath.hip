@@ -327,20 +327,14 @@ constexpr int kSegSkew = 36;  // floats (= 9 slots) per segment index
 struct FlatTile {  // geometry of one 64-row tile (wave-uniform)
     int r0, s0, l0, n0, n1;  // first flattened row, its (sequence, position); rows of segment 0, 1 (segment 2 = the rest)
 };
-// DIRECT (round 3, fp32 only): the weight operand never touches LDS.  The host stores W in FRAGMENT order - for (column half np, wave
-// column wn, k step kq = 8 k values, 32-column tile n) the 64 lanes' 16-byte fragments are one contiguous 1 KB block - so a wave fetches its
-// A fragments with perfectly coalesced loads straight from L2 (512 KB of weights, resident), one k-chunk ahead, into the registers the
-// MFMAs of the same k step have just read.  The K loop then has NO barrier and no weight staging (round 2 measured -6 % for exactly that
-// skeleton); the two waves that share a column half read the same lines (L1 / L2 hits).  Workgroup barriers remain where the slabs change.
-template <int NT = 0, bool DIRECT = false>
+template <int NT = 0>
 __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst,
                                                                  int S, int total_tiles) {
     constexpr int BK = 32, N = 256, NP = 128;  // columns per pass
     constexpr int NIT = (2 * kFlatRows * 16 + 255) / 256;
     __shared__ __attribute__((aligned(16))) float slab[2][kFlatRows * kSlabLd + 2 * kSegSkew];
-    __shared__ __attribute__((aligned(16))) float Bs[DIRECT ? 1 : 2][DIRECT ? 4 : NP * BK];
-    static_assert(!DIRECT || NT == 0, "fragment-ordered weights: fp32 only");
+    __shared__ __attribute__((aligned(16))) float Bs[2][NP * BK];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const float4 g4 = ld4(gamma + (threadIdx.x & 15) * 4), b4 = ld4(beta + (threadIdx.x & 15) * 4);
@@ -437,19 +431,10 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
         u0 = (int)(U * blockIdx.x / gridDim.x), u1 = (int)(U * (blockIdx.x + 1) / gridDim.x);
     }
     if (u0 >= u1) return;
-    // DIRECT: A fragments of one k-chunk, [k step q][column tile n]; fragment (np, wn, kq, n) of lane l sits at Wt[((((np 2 + wn) 64 + kq) 2 + n) 64 + l) 4]
-    float4 afr[DIRECT ? 4 : 1][2];
-    auto frag_base = [&](int np) { return Wt + ((size_t)((np * 2 + wn) * 64) * 2 * 64 + lane) * 4; };
-    if constexpr (DIRECT) {
-        const float* wf0 = frag_base(u0 & 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) afr[q][0] = ld4(wf0 + (q * 2) * 256), afr[q][1] = ld4(wf0 + (q * 2 + 1) * 256);
-    } else {
-        load_b(u0 & 1, 0);
-    }
+    load_b(u0 & 1, 0);
     fetch_slabs(u0 >> 1);
     store_slabs(u0 >> 1);
-    if constexpr (!DIRECT) store_b(Bs[0]);
+    store_b(Bs[0]);
     __syncthreads();
 
     const int sw = i & 7;
@@ -469,33 +454,6 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
         }
         floatx16 acc[2][2];  // [weight tile][row tile]
         acc_zero(acc);
-        if constexpr (DIRECT) {
-            const float* wf = frag_base(np);
-            const float* wfn = frag_base((u + 1) & 1);  // the next unit's column half (the last unit re-reads its own: L2 hits, no branch around loads)
-#pragma unroll 1
-            for (int kc = 0; kc < NK; ++kc) {
-                const int k0 = kc * BK, kk = k0 >> 6, c0 = k0 & 63;
-                const float* sp = slab[wm] + kk * kSlabLd + c0 + 4 * kh;
-                const float* nxt = kc + 1 < NK ? wf + (size_t)(kc + 1) * 8 * 256 : wfn;  // (wave-uniform select)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 b[2];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) b[m] = ld4(sp + prow[m] + 8 * q);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][n].x, b[m].x, acc[n][m], 0, 0, 0);
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][n].y, b[m].y, acc[n][m], 0, 0, 0);
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][n].z, b[m].z, acc[n][m], 0, 0, 0);
-                            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[q][n].w, b[m].w, acc[n][m], 0, 0, 0);
-                        }
-                    // this k step of the NEXT chunk, into the registers just read (4 k steps = ~4000 cycles ahead of its use)
-                    afr[q][0] = ld4(nxt + (q * 2) * 256), afr[q][1] = ld4(nxt + (q * 2 + 1) * 256);
-                }
-            }
-        } else {
 #pragma unroll 1
         for (int kc = 0; kc < NK; ++kc) {
             const int cur = kc & 1;
@@ -540,7 +498,6 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             __syncthreads();
         }
         if (has_next) load_b((u + 1) & 1, 0);
-        }
         if (pair * 2 + wm < total_tiles) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -555,17 +512,9 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             }
         }
         if (!has_next) break;
-        if constexpr (DIRECT) {
-            if (new_pair) {  // (workgroup-uniform) the slabs change: every wave must have left the K loop before they are overwritten
-                __syncthreads();
-                store_slabs(pair + 1);
-                __syncthreads();
-            }
-        } else {
-            if (new_pair) store_slabs(pair + 1);  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
-            store_b(Bs[0]);
-            __syncthreads();
-        }
+        if (new_pair) store_slabs(pair + 1);  // every wave left the last k-chunk (barrier above): the slabs and Bs[0] are free
+        store_b(Bs[0]);
+        __syncthreads();
     }
 }
 
@@ -848,32 +797,12 @@ static int convt_impl(const float* H3, const float* Wt, const float* bias, float
 
 extern "C" {
 
-// fp32 layer-0 GEMM with the weight ALSO given in fragment order (csrc/dualpath.hip unfold_gemm128f_kernel DIRECT; models/hip_path.py frag_order):
-// large batches of sequences with >= 32 windows run the barrier-free K loop, everything else falls back to the Wt path (same bits).
-static int unfold_gemm_frag_impl(const float* G, const float* gamma, const float* beta, const float* Wt, const float* Wfrag, float* U0, int B, int T2, int dim,
-                                 void* stream) {
-    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || !Wfrag) return RTFS_EINVAL;
-    SeqMap m = make_map(dim, B, T2);
-    const int S = dim == 4 ? B * T2 : B * kF2;
-    const int tps = (m.L + 63) / 64, total = S * tps, npairs = (total + 1) / 2, resident = 2 * 256;
-    if (npairs < 256 || m.L < 32) return unfold_gemm_impl<0>(G, gamma, beta, Wt, U0, B, T2, dim, 0, stream);
-    const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2, units = 2 * fpairs;
-    hipLaunchKernelGGL((unfold_gemm128f_kernel<0, true>), dim3(units < resident ? units : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,
-                       Wfrag, U0, S, ftiles);
-    RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
-}
-
 // G: [B][T2][F2][64].  U0: [S][L][256] with S = B*T2 (dim 4) or B*F2 (dim 3), L = npos-7, column = (dir*32+j)*4+m.
 // Wt: [256][512], k index = kk*64 + c.
 
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim,
                             int variant, void* stream) {
     return unfold_gemm_impl<0>(G, gamma, beta, Wt, U0, B, T2, dim, variant, stream);
-}
-int rtfs_dp_unfold_gemm_frag_fwd(const float* G, const float* gamma, const float* beta, const float* Wt, const float* Wfrag, float* U0, int B, int T2,
-                                 int dim, void* stream) {
-    return unfold_gemm_frag_impl(G, gamma, beta, Wt, Wfrag, U0, B, T2, dim, stream);
 }
 // bf16 (terms 1) / split-bf16 (terms 3) MFMA; Wpk = host-packed weight (same indexing as Wt)
 int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float* beta, const void* Wpk, float* U0, int B, int T2, int dim, int variant,

@@ -31,7 +31,6 @@ SIGNATURES = {
     "rtfs_dwconv_mix_fwd": [P] * 12 + [I, P, P, P, P, I, I, I, I, I, P],
     "rtfs_pool_fwd": [P, P, P, P, P, P, P, P, P, I, I, I, P],
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, I, P],
-    "rtfs_dp_unfold_gemm_frag_fwd": [P, P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
     "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, P, I, I, P],
     "rtfs_vp_param_count": [],
@@ -173,15 +172,8 @@ _prof_pred = None
 _prof_events = []
 
 
-def _prof_match(name):
-    if _prof_name is None:
-        return False
-    names = _prof_name if isinstance(_prof_name, (tuple, list)) else (_prof_name,)
-    return any(name == n or name == str(n) + "_bf16" for n in names)
-
-
-def profile_begin(name, pred=None):
-    """Time every launch of ONE entry point (or of a tuple of alternative names) with HIP events recorded on the launch stream (bench.py roofline).
+def profile_begin(name: str, pred=None):
+    """Time every launch of ONE entry point with HIP events recorded on the launch stream (bench.py roofline).
     `pred(int_args)` (optional) narrows that to the launches whose integer arguments (shapes / modes) it accepts."""
     global _prof_name, _prof_events, _prof_labels, _prof_pred
     _prof_name, _prof_events, _prof_labels, _prof_pred = name, [], [], pred
@@ -242,7 +234,7 @@ def _same_device(name, dev, t):
 
 def _launch(name, conv, args, dev):
     stream = torch.cuda.current_stream(dev).cuda_stream
-    if (_prof_match(name) and (_prof_pred is None or _prof_pred(tuple(a for a in args if isinstance(a, int))))) or _prof_name == "*":
+    if ((name == _prof_name or name == str(_prof_name) + "_bf16") and (_prof_pred is None or _prof_pred(tuple(a for a in args if isinstance(a, int))))) or _prof_name == "*":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # torch's current stream == the stream handed to the kernel
         rc = getattr(load(), name)(*conv, stream)

@@ -45,12 +45,6 @@ def pack_bf16(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi.view(N, K // 4, 4), lo.view(N, K // 4, 4)], -1).contiguous()
 
 
-def frag_order(w: torch.Tensor) -> torch.Tensor:
-    """fp32 layer-0 weight [256][512] -> the FRAGMENT order of rtfs_dp_unfold_gemm_frag_fwd (include/rtfs_hip.h):
-    [np][wn][kq][n][lane = kh * 32 + i][4] = w[128 np + 64 wn + 32 n + i][8 kq + 4 kh .. + 3]"""
-    return w.detach().float().reshape(2, 2, 2, 32, 64, 2, 4).permute(0, 1, 4, 2, 5, 3, 6).contiguous()
-
-
 def pack_vp_params(sd, prefix="refinement_module.video_net.blocks."):
     """VP block parameters packed in the order of VpOff (csrc/vp.hip), BatchNorm1d folded with its running statistics (eval)."""
     eps = 1e-5
@@ -202,7 +196,6 @@ class PreparedWeights:
             d = {"g": _f32(sd[q + "norm.gamma"].reshape(H)), "b": _f32(sd[q + "norm.beta"].reshape(H))}
             w0 = sd[q + "rnn.rnn_lst.0.weight"].float()  # [c*8+kk][n] -> [n][kk*64+c]
             d["w0"] = _f32(w0.reshape(H, 8, 256).permute(2, 1, 0).reshape(256, 512))
-            d["w0f"] = frag_order(d["w0"])  # (fp32 path: the same weight in the consumption order of the large-batch kernel)
             d["layers"] = []
             for l in range(4):
                 lw = {"wc": _f32(sd[q + f"rnn.rnn_lst.{l}.weight_c"]), "bias": _f32(sd[q + f"rnn.rnn_lst.{l}.bias"]),
@@ -287,10 +280,7 @@ class HipForward:
         L = npos - 7
         dev = G.device
         U = torch.empty(S * L * 256, device=dev)
-        if self.prec == 0 and self.variants["unfold"] == 0:
-            lib.call("rtfs_dp_unfold_gemm_frag_fwd", G, d["g"], d["b"], d["w0"], d["w0f"], U, B, T2, dim)  # barrier-free K loop at large batch
-        else:  # variant 1: tiles padded per sequence, 2: flattened tiles with LDS-staged weights (the round-2 kernel)
-            self._mm("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], self._wk(d, "w0"), U, B, T2, dim, self.variants["unfold"] % 2)
+        self._mm("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], self._wk(d, "w0"), U, B, T2, dim, self.variants["unfold"])
         h = torch.empty(S * L * 64, device=dev)
         l0 = d["layers"][0]
         lib.call("rtfs_sru_scan_fwd", U, None, l0["wc"], l0["bias"], l0["scale_x"], h, S, L, 4)

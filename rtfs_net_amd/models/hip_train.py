@@ -147,10 +147,7 @@ class HipTrainer:
         save.G_in = G.clone()
         save.U, save.h, save.c = [], [], []
         U0 = torch.empty(S * L * 256, device=dev)
-        if self.prec == 0:
-            lib.call("rtfs_dp_unfold_gemm_frag_fwd", G, d["g"], d["b"], d["w0"], d["w0f"], U0, B, T2, dim)
-        else:
-            self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim, 0)
+        self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim, 0)
         h = torch.empty(S * L * 64, device=dev)
         c = torch.empty_like(h)
         l0 = d["layers"][0]

@@ -237,12 +237,6 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     assert torch.equal(U, U1)
     with pytest.raises(RuntimeError):
         lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 7)
-    # the weight in fragment order: barrier-free K loop at large batch (B = 13 / 8 / 5 x 125 here), the Wt path otherwise - the same bits
-    from rtfs_net_amd.models.hip_path import frag_order
-
-    U2 = torch.full_like(U, float("nan"))
-    lib.call("rtfs_dp_unfold_gemm_frag_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), frag_order(Wt).cuda(), U2, B, T2, dim)
-    assert torch.equal(U, U2)
 
 
 def test_resid_proj_fusion_matches_separate_calls():
