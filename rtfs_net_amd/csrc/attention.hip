@@ -20,6 +20,21 @@ constexpr int kQkvN = 96;  // 4 heads x (4 q + 4 k + 16 v) output channels
 // Column order n: [0,16) Q (h*4+e), [16,32) K (h*4+e), [32,96) V (h*16+c).
 // gamma/beta are host-permuted to the output order: gq,gk [4][256], gv [4][1024] (index e*64+f / c*64+f).
 // ------------------------------------------------------------------------------------------------
+// LN4D apply for one element as three scalar VALU instructions that the compiler cannot pair into v_pk_*_f32.  The packed forms it chose
+// for the scatter below (v_pk_mul_f32 with op_sel:[0,1] on the (mean, rstd) register pair) sporadically produced rstd = 0 for the low
+// element of lanes 48..63 - the output was beta for 16 consecutive float4 stores, ~100 such rows per launch in the bf16 mode, a few
+// per forward in the split-bf16 mode - whenever two workgroups shared a CU; one workgroup per CU or scalar arithmetic never showed it
+// (tools/qkv_det.py reproduces it in seconds).  Same rounding as fmaf((y - mean) * rstd, g, b).
+__device__ __forceinline__ float ln_apply(float y, float mean, float rstd, float g, float b) {
+    float o;
+    asm("v_sub_f32 %0, %1, %2\n\tv_mul_f32 %0, %0, %3\n\tv_fma_f32 %0, %0, %4, %5" : "=&v"(o) : "v"(y), "v"(mean), "v"(rstd), "v"(g), "v"(b));
+    return o;
+}
+__device__ __forceinline__ float4 ln_apply4(float4 y, const float* st2, float4 g, float4 b) {
+    const float mean = st2[0], rstd = st2[1];
+    return f4(ln_apply(y.x, mean, rstd, g.x, b.x), ln_apply(y.y, mean, rstd, g.y, b.y), ln_apply(y.z, mean, rstd, g.z, b.z), ln_apply(y.w, mean, rstd, g.w, b.w));
+}
+
 template <int NT = 0>  // precision (common.h); NT != 0: Wt host-PACKED
 __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restrict__ G, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                        const float* __restrict__ slope, const float* __restrict__ gq, const float* __restrict__ bq,
@@ -116,10 +131,8 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
             const float* sk = st[tok * 12 + 4 + h];
             const float4 yq = f4(yr[0], yr[LDY], yr[2 * LDY], yr[3 * LDY]), yk = f4(yr[16], yr[LDY + 16], yr[2 * LDY + 16], yr[3 * LDY + 16]);
             const float4 gq4 = ld4(gq + i), bq4 = ld4(bq + i), gk4 = ld4(gk + i), bk4 = ld4(bk + i);
-            st4(Q + o, f4(fmaf((yq.x - sq[0]) * sq[1], gq4.x, bq4.x), fmaf((yq.y - sq[0]) * sq[1], gq4.y, bq4.y), fmaf((yq.z - sq[0]) * sq[1], gq4.z, bq4.z),
-                          fmaf((yq.w - sq[0]) * sq[1], gq4.w, bq4.w)));
-            st4(Kx + o, f4(fmaf((yk.x - sk[0]) * sk[1], gk4.x, bk4.x), fmaf((yk.y - sk[0]) * sk[1], gk4.y, bk4.y), fmaf((yk.z - sk[0]) * sk[1], gk4.z, bk4.z),
-                           fmaf((yk.w - sk[0]) * sk[1], gk4.w, bk4.w)));
+            st4(Q + o, ln_apply4(yq, sq, gq4, bq4));
+            st4(Kx + o, ln_apply4(yk, sk, gk4, bk4));
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {  // V: [h][c*64+f], 4096 elements per token
@@ -130,8 +143,7 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
             const float* sv = st[tok * 12 + 8 + h];
             const float4 y = f4(yr[0], yr[LDY], yr[2 * LDY], yr[3 * LDY]);
             const float4 g4 = ld4(gv + i), b4 = ld4(bv + i);
-            st4(V + o, f4(fmaf((y.x - sv[0]) * sv[1], g4.x, b4.x), fmaf((y.y - sv[0]) * sv[1], g4.y, b4.y), fmaf((y.z - sv[0]) * sv[1], g4.z, b4.z),
-                          fmaf((y.w - sv[0]) * sv[1], g4.w, b4.w)));
+            st4(V + o, ln_apply4(y, sv, g4, b4));
         }
     }
 }

@@ -25,6 +25,13 @@ struct SeqMap {  // sequence s -> base element offset; positions are pos_stride 
     int npos;  // positions per sequence (F2 or T2)
     int L;     // npos - 8 + 1 windows
     __device__ __forceinline__ size_t base(int s) const { return (size_t)(s / seq_div) * stride_hi + (size_t)(s % seq_div) * stride_lo; }
+    // 32-bit BYTE offset of (sequence s, position pos): seq_div is 1 or 64 (a shift), the whole tensor is < 2^32 bytes whenever the large-batch
+    // kernel runs (checked on the host) - the staging code of the layer-0 GEMM issued ~60 VALU instructions per 16-byte load with the general form
+    int seq_shift;
+    unsigned magicL;  // floor(2^32 / L) + 1: n / L == __umulhi(n, magicL) for n L < 2^32 (checked on the host)
+    __device__ __forceinline__ unsigned off32(int s, int pos) const {
+        return (((unsigned)(s >> seq_shift) * (unsigned)stride_hi + (unsigned)(s & (seq_div - 1)) * (unsigned)stride_lo) + (unsigned)pos * (unsigned)pos_stride) * 4u;
+    }
 };
 
 constexpr int kSlabRows = 64 + 7;
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
     auto tile_of = [&](int gt) {
         FlatTile t;
         t.r0 = gt * 64;
-        t.s0 = t.r0 / L;
+        t.s0 = (int)__umulhi((unsigned)t.r0, map.magicL);  // = r0 / L (exact: S L^2 < 2^32, checked by the launcher)
         t.l0 = t.r0 - t.s0 * L;
         t.n0 = min(L - t.l0, 64);
         t.n1 = min(L, 64 - t.n0);
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
             const int j = min((idx - st * kFlatRows * 16) >> 4, kFlatRows - 1);
             int sq, pos, g;
             slab_row(t[st], j, sq, pos, g);
-            sraw[it] = ld4(src + map.base(min(sq, S - 1)) + (size_t)min(pos, map.npos - 1) * map.pos_stride + (threadIdx.x & 15) * 4);
+            sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
         }
     };
     // LayerNormalization4D over the 64 channels of each position (normalizations.py:33-37) -> LDS slabs
@@ -753,6 +760,8 @@ static SeqMap make_map(int dim, int B, int T2) {
         m.seq_div = kF2, m.stride_hi = (long long)T2 * kF2 * kH, m.stride_lo = kH, m.pos_stride = (long long)kF2 * kH, m.npos = T2;
     }
     m.L = m.npos - 7;
+    m.seq_shift = dim == 4 ? 0 : 6;  // seq_div = 1 or kF2 = 64
+    m.magicL = (unsigned)((1ULL << 32) / (unsigned)m.L) + 1u;
     return m;
 }
 
@@ -769,7 +778,7 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
         return RTFS_OK;
     }
     const bool per_seq_tiles = variant == 1;  // second-generation kernel (tiles padded per sequence), kept selectable for A/B: same bits
-    if ((NT != 0 || !per_seq_tiles) && m.L >= 32) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64)
+    if ((NT != 0 || !per_seq_tiles) && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32)) {  // a 64-row tile then spans at most three sequences (1 + L + L >= 64); 32-bit staging offsets
         const int ftiles = (int)(((long long)S * m.L + 63) / 64), fpairs = (ftiles + 1) / 2;
         const int units = 2 * fpairs;  // (tile pair, column half)
         hipLaunchKernelGGL(unfold_gemm128f_kernel<NT>, dim3(units < resident ? units : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta,

@@ -403,3 +403,52 @@ def test_attention_core_forward_and_adjoint_isolated(B, T2):
     dQ, dK, dV, D = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.empty(B * 4 * T2, device="cuda")
     lib.call("rtfs_attn_core_bwd", Q, K, V, O, dO, LSE, D, dQ, dK, dV, B, T2)
     assert rel(dQ, q64.grad) < 2e-5 and rel(dK, k64.grad) < 2e-5 and rel(dV, v64.grad) < 2e-5
+
+
+@pytest.mark.parametrize("terms", [0, 1, 3, 6])
+def test_attention_qkv_isolated_values_and_repeatability(terms):
+    """rtfs_attn_qkv_fwd(_bf16) at the bench shape (32 x 125 tokens, two workgroups per CU) against a float64 restatement of the 12
+    ConvActNorm modules (attention.py:30-66: 1x1 conv -> PReLU -> LN4D over (channel, F)), and bit-for-bit the same over 40 launches.
+    Regression test for the packed-fp32 scatter: in the bf16 modes it sporadically wrote beta instead of the normalised value for 16
+    consecutive float4 stores (zeros here, where beta = 0) - tools/qkv_det.py, attention.hip ln_apply."""
+    from rtfs_net_amd import lib
+    from rtfs_net_amd.models.hip_path import pack_bf16
+
+    B, T2 = 32, 125
+    g = torch.Generator(device="cuda").manual_seed(5)
+    G = torch.randn(B * T2, 64, 64, device="cuda", generator=g)  # [token][f][channel]
+    W = torch.randn(96, 64, device="cuda", generator=g) * 0.1
+    bias = torch.randn(96, device="cuda", generator=g) * 0.1
+    slope = torch.full((96,), 0.25, device="cuda")
+    gq, bq = torch.rand(4, 256, device="cuda", generator=g) + 0.5, torch.zeros(4, 256, device="cuda")
+    gv, bv = torch.rand(4, 1024, device="cuda", generator=g) + 0.5, torch.zeros(4, 1024, device="cuda")
+    Wk = pack_bf16(W) if terms in (1, 3) else W
+    name = "rtfs_attn_qkv_fwd" + ("_bf16" if terms else "")
+
+    def launch():
+        Q = torch.full((B, 4, T2, 256), float("nan"), device="cuda")
+        K = torch.full_like(Q, float("nan"))
+        V = torch.full((B, 4, T2, 1024), float("nan"), device="cuda")
+        lib.call(name, G, Wk, bias, slope, gq, bq, gq, bq, gv, bv, Q, K, V, None, B, T2, *((terms,) if terms else ()))
+        return Q, K, V
+
+    first = launch()
+    for _ in range(40):
+        for a, b in zip(launch(), first):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # float64 restatement for the first 8 tokens of every utterance: y[f][n] = PReLU(G W^T + b); columns [0,16) Q, [16,32) K, [32,96) V
+    tok = torch.arange(B * T2, device="cuda").view(B, T2)[:, :8].reshape(-1)
+    y = G[tok].double() @ W.double().t() + bias.double()
+    y = torch.where(y >= 0, y, y * slope.double())  # [tokens][f][96]
+
+    def ln(cols, per_head, gamma):  # LN4D over (channel, f) per token and head; output [tokens][4][per_head * 64], index c * 64 + f
+        z = y[:, :, cols].view(-1, 64, 4, per_head).permute(0, 2, 3, 1)  # [tokens][head][c][f]
+        mu = z.mean((2, 3), keepdim=True)
+        var = ((z - mu) ** 2).mean((2, 3), keepdim=True)
+        return ((z - mu) / torch.sqrt(var + 1e-5)).reshape(-1, 4, per_head * 64) * gamma.double()
+
+    tol = {0: 3e-6, 6: 3e-6, 3: 3e-5, 1: 2e-2}[terms]
+    for out, cols, per_head, gamma in ((first[0], slice(0, 16), 4, gq), (first[1], slice(16, 32), 4, gq), (first[2], slice(32, 96), 16, gv)):
+        got = out[:, :, :8].permute(0, 2, 1, 3).reshape(-1, 4, per_head * 64)
+        assert not bool(torch.isnan(out).any())
+        assert rel(got, ln(cols, per_head, gamma).float()) < tol
