@@ -93,6 +93,7 @@ struct ProExpanded {
 // pixel row and, per accumulator register group, 4 consecutive output channels `col..col+3`.
 template <bool HAS_BIAS, bool ACCUM = false>
 struct EpiBias {  // y (= or +=) acc (+ bias)
+    static constexpr bool kAccum = ACCUM;
     float* __restrict__ y;
     const float* __restrict__ bias;
     int N;
@@ -137,6 +138,7 @@ struct EpiResidual {
 
 // S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
 struct EpiMask {
+    static constexpr bool kAccum = false;
     float* __restrict__ y;
     const float* __restrict__ bias;
     const float* __restrict__ emb;
@@ -146,8 +148,12 @@ struct EpiMask {
         store2e(b, Mb, row, col, vr, vi, ld4(emb + o), ld4(emb + o + 128));
     }
     __device__ void store2e(int b, int Mb, int row, int col, float4 vr, float4 vi, float4 er, float4 ei) const {
+        store2eb(b, Mb, row, col, vr, vi, er, ei, ld4(bias + col), ld4(bias + col + 128));
+    }
+    // (bias quads handed in: a caller that keeps them in registers has no load - and no vmcnt(0) - inside its store loop)
+    __device__ void store2eb(int b, int Mb, int row, int col, float4 vr, float4 vi, float4 er, float4 ei, float4 br, float4 bi) const {
         const size_t o = ((size_t)b * Mb + row) * kC + col;
-        const float4 mr = relu4(vr + ld4(bias + col)), mi = relu4(vi + ld4(bias + col + 128));
+        const float4 mr = relu4(vr + br), mi = relu4(vi + bi);
         if (m_out) {
             st4(m_out + o, mr);
             st4(m_out + o + 128, mi);
@@ -936,9 +942,200 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
     block_stats_commit(s, qq, red, epi.slot, b);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary form of the 256 -> 256 pixel GEMMs at large batch (audio bottleneck tdavnet.py:59,89; S3 mask
+// mask_generator.py:67-99; their input-gradient GEMMs in the training step), fp32, round 3.
+// pixel_gemm_kernel<256, 256, 64, ...> re-stages the whole 256 KB weight through LDS for every 64-pixel tile (16 chunks, one
+// barrier each: 4 GB of L2 -> LDS weight traffic per launch at B = 32, matrix pipe 67-71 % busy).  Here ONE 4-wave workgroup
+// per CU keeps the weight in registers for its whole life - wave w owns output channels [64 w, 64 w + 64) x all 256 k =
+// 256 registers per lane, the MFMA A operand - and walks `tiles_per_wg` consecutive 32-pixel tiles of one utterance.  Only the
+// pixel tile goes through LDS (the B operand: one ds_read_b128 per 8 MFMAs, requested one step ahead), and the K loop of a tile -
+// 256 MFMAs per wave - never stops for a tile hand-over: everything else rides between its steps,
+//   steps 0-7    previous tile's accumulators (read out of the matrix registers at the end of their tile) -> LDS, pixel-major;
+//   step  8      barrier;   steps 9-17  previous tile's epilogue: whole 1 KB pixel rows LDS -> registers -> epi -> HBM;
+//   steps 18-25  next tile's rows (requested one tile ago, in registers since) -> pro.xform -> the other LDS tile;
+//   steps 26-27  global loads of the tile after next (and of the S3 embedding rows this tile's epilogue will need);
+// one more barrier at the end of the tile (this tile's fragments all read, next tile written).  What the matrix pipe still waits for
+// is the VALU share of that work (rule 9 of DESIGN.md: fp32 MFMA and VALU do not overlap) - ~200 instructions per 16384 pipe cycles.
+// Same products, same k order per accumulator as pixel_gemm_kernel (k ascending in 8-quads) => bit-identical output.
+// ------------------------------------------------------------------------------------------------
+template <class Pro, class Epi, bool PAIRED>
+__global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+    constexpr int LD = 260, TP = 32;
+    __shared__ __attribute__((aligned(16))) float As[2][TP * LD];  // pixel tiles [pixel][k], double-buffered
+    __shared__ __attribute__((aligned(16))) float Ot[TP * LD];     // previous tile's output [pixel][channel]
+    __shared__ __attribute__((aligned(16))) float ptab[2 * kC];
+    const int b = blockIdx.y;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    pro.init(b, ptab);
+
+    float4 wf[2][32];  // W fragments: rows n = 64 w + 32 nt + i, k = 8 q + 4 kh .. +3
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * kC + 8 * q + 4 * kh);
+    // half of the weight lives in the accumulation registers (256 + 256 per lane) and is read by the MFMAs from there: bound to that class
+    // here, or hipcc treats those registers as spill slots and copies every value back to a VGPR before its MFMA (~100 VALU per tile)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) asm volatile("" : "+a"(wf[0][q].x), "+a"(wf[0][q].y), "+a"(wf[0][q].z), "+a"(wf[0][q].w));
+    __syncthreads();  // ptab
+
+    const int ntile = (Mb + TP - 1) / TP;
+    const int tile0 = blockIdx.x * tiles_per_wg, tile_end = min(tile0 + tiles_per_wg, ntile);
+    if (tile0 >= ntile) return;
+    // Every global access of the tile loop goes through a buffer descriptor of this utterance's [Mb][256] slab: byte offset = per-thread
+    // constant + wave-uniform tile offset (one VALU add per access), rows past the end are answered with zeros / dropped by the range
+    // check - no clamps, no branches around loads or stores (a store under a branch makes every later vmcnt wait conservative).
+    const unsigned slab = (unsigned)Mb * kC * 4u;
+    const size_t uoff = (size_t)b * Mb * kC;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pro.x) + uoff, 0, (int)slab, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(epi.y + uoff, 0, (int)slab, 0x00020000);
+    auto bld = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) {
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return f4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    auto bst = [](const __amdgpu_buffer_rsrc_t& r, unsigned off, float4 v) {
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, (int)off, 0, 0);
+    };
+    constexpr unsigned kNowhere = 0x40000000u;  // past the end of any slab (the launcher keeps slabs below 2^30 bytes)
+    // staging and plain epilogue: thread = (channel quad cq, rows w + 4 it): one wave-instruction moves one pixel's whole 1 KB row
+    const int cq = lane * 4;
+    const unsigned voff = (unsigned)(w * kC + cq) * 4u;
+    float4 raw[8];
+    auto load_a = [&](int tile) {  // (tiles past the end re-fetch the last one: L2 hits)
+        const unsigned base = (unsigned)(min(tile, tile_end - 1) * TP) * kC * 4u;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) raw[it] = bld(rx, voff + (base + it * 4u * kC * 4u));
+    };
+    auto store_a1 = [&](float* dst, int it) { st4(dst + (w + 4 * it) * LD + cq, pro.xform(raw[it], cq, ptab)); };
+    // S3 mask epilogue: thread = (channel quad q4 of the real half, rows pr + 8 it)
+    const int q4 = (threadIdx.x & 31) * 4, pr = threadIdx.x >> 5;
+    const unsigned voffe = (unsigned)(pr * kC + q4) * 4u;
+    float4 er[4], ei[4];
+    __amdgpu_buffer_rsrc_t re = ry, rm = ry;
+    if constexpr (PAIRED) {
+        re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.emb) + uoff, 0, (int)slab, 0x00020000);
+        rm = __builtin_amdgcn_make_buffer_rsrc(epi.m_out ? epi.m_out + uoff : epi.y, 0, epi.m_out ? (int)slab : 0, 0x00020000);  // no mask output: every store dropped
+    }
+    auto load_emb = [&](unsigned base) {
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const unsigned o = voffe + (base + it * 8u * kC * 4u);
+                er[it] = bld(re, o), ei[it] = bld(re, o + 512u);
+            }
+        }
+    };
+    float4 hold[8];  // previous tile's accumulators [nt][g]
+    float4 orow[8];  // previous tile's output rows on their way out
+    auto ot_write = [&](int it) { st4(Ot + i * LD + 64 * w + 32 * (it >> 2) + 8 * (it & 3) + 4 * kh, hold[it]); };
+    auto ot_read = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            orow[it] = PAIRED ? ld4(Ot + (pr + 8 * (it & 3)) * LD + q4 + 128 * (it >> 2)) : ld4(Ot + (w + 4 * it) * LD + cq);
+    };
+    float4 cc = f4(0, 0, 0, 0), cci = f4(0, 0, 0, 0);  // per-thread column constants (bias quads), loaded once
+    if constexpr (PAIRED)
+        cc = ld4(epi.bias + q4), cci = ld4(epi.bias + q4 + 128);
+    else
+        cc = epi.colconst(cq);
+    auto epi_out = [&](int it, unsigned base) {
+        if constexpr (PAIRED) {  // EpiMask::store2e (mask_generator.py:70-82)
+            if (it < 4) {
+                const unsigned o = voffe + (base + it * 8u * kC * 4u);
+                const float4 mr = relu4(orow[it] + cc), mi = relu4(orow[it + 4] + cci), xr = er[it], xi = ei[it];
+                bst(rm, o, mr);
+                bst(rm, o + 512u, mi);
+                bst(ry, o, f4(xr.x * mr.x - xi.x * mi.x, xr.y * mr.y - xi.y * mi.y, xr.z * mr.z - xi.z * mi.z, xr.w * mr.w - xi.w * mi.w));
+                bst(ry, o + 512u, f4(fmaf(xr.x, mi.x, xi.x * mr.x), fmaf(xr.y, mi.y, xi.y * mr.y), fmaf(xr.z, mi.z, xi.z * mr.z), fmaf(xr.w, mi.w, xi.w * mr.w)));
+            }
+        } else {  // EpiBias<HAS_BIAS, false>::store
+            bst(ry, voff + (base + it * 4u * kC * 4u), orow[it] + cc);
+        }
+    };
+
+    load_a(tile0);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) store_a1(As[0], it);
+    load_emb(kNowhere);  // (not used: the same sequence of memory operations as at the end of a tile)
+    load_a(tile0 + 1);
+    __syncthreads();
+    unsigned prev_base = kNowhere;  // no previous tile yet: every store of its epilogue is dropped
+
+#pragma unroll 1
+    for (int tile = tile0; tile < tile_end; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        const float* ep = As[cur] + i * LD + 4 * kh;
+        float* An = As[cur ^ 1];
+        const unsigned tile_base = (unsigned)(tile * TP) * kC * 4u;
+        floatx16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        // one wave per SIMD: nobody else covers the LDS latency, so the fragment of step q + 1 is read before the MFMAs of step q
+        // (every step pinned with sched_barrier: left alone, hipcc reads each fragment right before its first MFMA and waits for it)
+        float4 eb[2];
+        eb[0] = ld4(ep);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            if (q + 1 < 32) eb[(q + 1) & 1] = ld4(ep + 8 * (q + 1));
+            // (order of the memory operations inside a tile: stores, then loads, and every load is consumed in the NEXT tile before that
+            // tile's stores - vmcnt counts loads and stores alike, and a wait for a load that has younger stores behind it waits for their
+            // acknowledgements as well)
+            if (q < 8) ot_write(q);
+            if (q == 8) __syncthreads();
+            if (q == 9) ot_read();
+            if (q >= 10 && q < 18) epi_out(q - 10, prev_base);
+            if (q == 14) load_emb(tile_base);  // this tile's embedding rows: its epilogue runs inside the next tile
+            if (q >= 18 && q < 26) store_a1(An, q - 18);
+            if (q == 26) load_a(tile + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 e = eb[q & 1];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e.w, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) hold[it] = acc_group(acc[it >> 2], it & 3);
+        prev_base = tile_base;
+        __syncthreads();  // every wave has read its last fragment of this tile and the previous output tile; the next tile is in LDS
+    }
+    // the last tile's epilogue
+#pragma unroll
+    for (int it = 0; it < 8; ++it) ot_write(it);
+    __syncthreads();
+    ot_read();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) epi_out(it, prev_base);
+}
+
+// the weight-stationary form pays one 256 KB weight read per workgroup: worth it from ~32 tiles per workgroup on
+static bool ws256_applies(int B, int Mb) { return (long long)((Mb + 31) / 32) * B >= 32 * 256 && (long long)Mb * kC * 4 < (1ll << 30); }
+
+template <bool PAIRED, class Pro, class Epi>
+static int launch_ws256(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
+    if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
+    // one workgroup per CU: workgroups per utterance = ceil(256 / B), consecutive tiles of one utterance each
+    const int tiles = (Mb + 31) / 32;
+    const int per_utt = (256 + B - 1) / B;
+    const int per = (tiles + per_utt - 1) / per_utt;
+    hipLaunchKernelGGL((ws256_kernel<Pro, Epi, PAIRED>), dim3((tiles + per - 1) / per, B), dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
 template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK = 32, int NT = 0, class Pro, class Epi>
 static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
     if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
+    if constexpr (K == 256 && N == 256 && NT == 0 && !Epi::kAccum) {
+        if (ws256_applies(B, Mb)) return launch_ws256<PAIRED>(pro, epi, Wt, B, Mb, st);
+    }
     dim3 grid((Mb + BM - 1) / BM, B);
     hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, BK, Pro, Epi, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
     RTFS_LAUNCH_CHECK();
