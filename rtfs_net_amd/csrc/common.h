@@ -70,6 +70,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), every lane gets the total: the xor butterfly 8, 4, 2, 1 of
+//   for (o = 8; o; o >>= 1) v += __shfl_xor(v, o)
+// with the same operand pairs (after the step for bit b the partial sums no longer depend on that bit of the lane index, so rotating the
+// row by 2^b reaches a lane that holds exactly what lane ^ 2^b holds) - bit-identical, 4 v_add_f32_dpp instead of 4 ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -525,6 +525,151 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
     }
 }
 
+// Layer-0 kernel, fourth generation (round 3), large batches, fp32: WEIGHT-STATIONARY.  The kernels above re-stage W0 (512 KB) through LDS for
+// every tile pair - 16 chunks x 2 column halves, one barrier each - and reach 77 % matrix-pipe occupancy.  Here a workgroup keeps one
+// 128-column half of W0 in registers for its whole life (wave w: columns 128 h + 32 w .. + 31 x all 512 k = 256 registers per lane, the MFMA
+// A operand; two workgroups - two CUs - share a range of row tiles, one per column half) and walks 64-row tiles cut from the FLATTENED row
+// index exactly as unfold_gemm128f_kernel does (same tile geometry, same slab layout incl. the segment skew).  The K loop of a tile - 512
+// MFMAs per wave, B fragments read from the LayerNorm-ed slab one step ahead - never stops: between its steps ride
+//   steps 0-5    the NEXT tile's raw rows (requested one tile ago) -> LayerNormalization4D -> the other slab;
+//   steps 6-13   the PREVIOUS tile's accumulators (moved out of the matrix registers at the end of their tile) -> U0, 8 stores;
+//   step  14     the global loads of the tile after next;
+// and one barrier per tile.  (Order: loads are consumed before the tile's stores are issued, stores go through a buffer descriptor without
+// a branch - vmcnt counts both, see ws256_kernel in gemm.hip.)  Same products in the same k order per accumulator => bit-identical U0.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst, int S,
+                                                           int total_tiles) {
+    constexpr int NIT = (kFlatRows * 16 + 255) / 256;  // 6
+    __shared__ __attribute__((aligned(16))) float slab[2][(kFlatRows + 1) * kSlabLd + 2 * kSegSkew];  // (+ one scratch row)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int half = blockIdx.x & 1, slot = blockIdx.x >> 1, nslots = gridDim.x >> 1;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
+    const int L = map.L;
+
+    float4 wf[64];  // W0 fragments: row n = 128 half + 32 w + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
+#pragma unroll
+    for (int q = 0; q < 64; ++q) wf[q] = ld4(Wt + (size_t)(128 * half + 32 * w + i) * 512 + 8 * q + 4 * kh);
+    // 44 of the 64 live in the accumulation registers and are read by the MFMAs from there (bound to that class here: otherwise hipcc
+    // uses those registers as spill slots and copies every value back to a VGPR before its MFMA)
+#pragma unroll
+    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));
+
+    const int t0 = (int)((long long)total_tiles * slot / nslots), t1 = (int)((long long)total_tiles * (slot + 1) / nslots);
+    if (t0 >= t1) return;
+    auto tile_of = [&](int gt) {
+        FlatTile t;
+        t.r0 = gt * 64;
+        t.s0 = (int)__umulhi((unsigned)t.r0, map.magicL);  // = r0 / L (exact: S L^2 < 2^32, checked by the launcher)
+        t.l0 = t.r0 - t.s0 * L;
+        t.n0 = min(L - t.l0, 64);
+        t.n1 = min(L, 64 - t.n0);
+        return t;
+    };
+    // slab row j of a tile -> (sequence, position, segment, valid)
+    auto slab_row = [&](const FlatTile& t, int j, int& sq, int& pos, int& g) {
+        const int e0 = t.n0 + 7, e1 = e0 + t.n1 + 7, n2 = 64 - t.n0 - t.n1;
+        g = (j >= e0) + (j >= e1);
+        const int jj = j - (g == 0 ? 0 : (g == 1 ? e0 : e1));
+        const int ng = g == 0 ? t.n0 : (g == 1 ? t.n1 : n2);
+        sq = t.s0 + g;
+        pos = (g == 0 ? t.l0 : 0) + jj;
+        return ng > 0 && jj < ng + 7 && sq < S && pos < map.npos;
+    };
+    float4 sraw[NIT];
+    unsigned sinfo[NIT];  // where a fetched row goes: float offset in its slab (scratch row behind the slab for rows past it), bit 31 = zero padding
+    auto fetch = [&](int tile) {  // (tiles past the end re-fetch the last one: L2 hits, never used)
+        const FlatTile t = tile_of(min(tile, t1 - 1));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int j = (int)(threadIdx.x >> 4) + 16 * it;
+            const bool inr = j < kFlatRows;
+            int sq, pos, g;
+            const bool ok = slab_row(t, min(j, kFlatRows - 1), sq, pos, g) && inr;
+            sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
+            sinfo[it] = (unsigned)((inr ? j * kSlabLd + g * kSegSkew : kFlatRows * kSlabLd + 2 * kSegSkew) + c4) | (ok ? 0u : 0x80000000u);
+        }
+    };
+    // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37), one 16-row group of the slab per call.
+    // (v_rsq_f32 for 1 / sqrt: hipcc expands the IEEE form into ~35 instructions with branches, and every VALU instruction of this kernel is
+    // paid in matrix-pipe time; <= 1 ulp of rstd against the LDS-staged kernels, which keep the IEEE form)
+    auto stage1 = [&](float* sl, int it) {
+        const float4 v = sraw[it];
+        const float mean = row16_sum(v.x + v.y + v.z + v.w) * (1.f / 64.f);
+        const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        const float sqs = row16_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+        const float rstd = __builtin_amdgcn_rsqf(sqs * (1.f / 64.f) + kEps);
+        const float4 y = (int)sinfo[it] >= 0 ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
+        st4(sl + (sinfo[it] & 0x7fffffffu), y);
+    };
+    // U0 rows through a buffer descriptor: rows past the end (and the "previous tile" of the first one) are dropped by the range check
+    const long long R = (long long)S * L;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
+    const unsigned ocol = (unsigned)(i * 256 + 128 * half + 32 * w + 4 * kh) * 4u;  // this lane's row i, first column quad
+    floatx16 hold0, hold1;                                                           // previous tile's accumulators [m]
+    auto out1 = [&](int it, unsigned base) {
+        const float4 v = acc_group(it >> 2 ? hold1 : hold0, it & 3);
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ru,
+                                               (int)(ocol + (base + (unsigned)((it >> 2) * 32 * 1024 + (it & 3) * 32))), 0, 0);
+    };
+
+    fetch(t0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) stage1(slab[0], it);
+    fetch(t0 + 1);
+    __syncthreads();
+    unsigned prev_base = 0xC0000000u;  // no previous tile yet: every store of its write-back is dropped (the launcher keeps U0 below 2^31 bytes)
+
+#pragma unroll 1
+    for (int tile = t0; tile < t1; ++tile) {
+        const int cur = (tile - t0) & 1;
+        const FlatTile t = tile_of(tile);
+        float* sn = slab[cur ^ 1];
+        // slab offset (floats) of this lane's output row in the two row tiles: row ri + 7 g, skewed by its segment g
+        const float* bp[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ri = 32 * m + i, g = (ri >= t.n0) + (ri >= t.n0 + t.n1);
+            bp[m] = slab[cur] + (ri + 7 * g) * kSlabLd + g * kSegSkew + 4 * kh;
+        }
+        floatx16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        // one wave per SIMD: the fragments of step q + 1 are read before the MFMAs of step q (pinned with sched_barrier)
+        float4 eb[2][2];
+        eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            if (q + 1 < 64) {
+                const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
+                eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+            }
+            if (q < NIT) stage1(sn, q);
+            if (q >= 6 && q < 14) out1(q - 6, prev_base);
+            if (q == 14) fetch(tile + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        hold0 = acc[0], hold1 = acc[1];
+        prev_base = (unsigned)t.r0 * 1024u;
+        __syncthreads();  // every wave has read its last fragment of this slab; the next slab is complete
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) out1(it, prev_base);
+}
+
 // Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.
 //   KM == 4 (layer 0): U[s][l][lane][4] = (u0, u1, u2, x')          -> one 16-byte load per lane per step
 //   KM == 3 (layers 1-3): U[s][l][m][lane], m = 0..2, skip input x' = X[s][l][lane] * scale_x
@@ -767,13 +912,21 @@ static SeqMap make_map(int dim, int B, int T2) {
 
 template <int NT>
 static int unfold_gemm_impl(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim, int variant, void* stream) {
-    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || variant < 0 || variant > 1) return RTFS_EINVAL;
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || variant < 0 || variant > 2) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
     const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
     if (npairs < 256 || (NT != 0 && m.L < 32)) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
         hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0, NT>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
+    // fp32, large batch: the weight-stationary kernel (variant 2 keeps the LDS-staged flattened-tile kernel selectable for A/B: same bits)
+    if (NT == 0 && variant == 0 && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
+        (long long)S * m.L * 1024 < (1LL << 31) && ((long long)S * m.L + 63) / 64 >= 8 * 128) {  // (>= 8 tiles per workgroup to pay for its 256 KB weight read)
+        const int ftiles = (int)(((long long)S * m.L + 63) / 64);
+        hipLaunchKernelGGL(unfold_ws_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, ftiles);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }

@@ -211,12 +211,13 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
 
 
-@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16)])
+@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     """rtfs_dp_unfold_gemm_fwd in isolation (LN4D over channels + 8-tap unfold + layer-0 GEMM, rnn_layers.py:146-150) against float64 on
     the CPU, at sizes that take the large-batch kernel (tiles cut from the flattened row index: 2- and 3-sequence tiles, ragged end)
-    and a few that take the small-batch one."""
+    a few that take the small-batch one, and two that take the weight-stationary kernel (>= 1024 flattened 64-row tiles; its LayerNorm uses
+    v_rsq_f32, so it agrees with the LDS-staged kernels to 1 ulp of rstd, not bit for bit)."""
     from rtfs_net_amd import lib
 
     g = torch.Generator().manual_seed(100 * B + T2 + dim)
@@ -233,8 +234,12 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim, 0)
     assert rel(U.view(want.shape), want) < 2e-6
     U1 = torch.full_like(U, float("nan"))
-    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 1)  # per-sequence tiles: the same bits
-    assert torch.equal(U, U1)
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 1)  # per-sequence tiles
+    U2 = torch.full_like(U, float("nan"))
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U2, B, T2, dim, 2)  # LDS-staged flattened tiles: the same bits
+    assert torch.equal(U2, U1)
+    weight_stationary = (seqs.shape[0] * L + 63) // 64 >= 1024 and L >= 32
+    assert rel(U, U2) < 1e-6 and (weight_stationary or torch.equal(U, U2))
     with pytest.raises(RuntimeError):
         lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 7)
 

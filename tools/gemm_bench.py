@@ -1,6 +1,6 @@
 """GPU micro-benchmark of the layer-0 unfold GEMM entry point (both dual paths at the bench shape) + an output checksum for A/B runs.
 
-    [RTFS_UNFOLD_PIPE=1] python tools/gemm_bench.py [dtype: f32|bf16|bf16x3] [B] [T2]
+    python tools/gemm_bench.py [dtype: f32|bf16|bf16x3] [B] [T2] [variant: 0 launcher's choice | 1 per-sequence tiles | 2 LDS-staged flattened tiles]
 """
 import os
 import sys
@@ -13,7 +13,7 @@ from rtfs_net_amd import lib  # noqa: E402
 from rtfs_net_amd.models.hip_path import COMPUTE_DTYPES, pack_bf16  # noqa: E402
 
 
-def main(dtype="f32", B=32, T2=125):
+def main(dtype="f32", B=32, T2=125, variant=0):
     prec = COMPUTE_DTYPES[dtype]
     g = torch.Generator().manual_seed(0)
     G = torch.randn(B, T2, 64, 64, generator=g).cuda()
@@ -25,7 +25,7 @@ def main(dtype="f32", B=32, T2=125):
         L = npos - 7
         U = torch.empty(S * L * 256, device="cuda")
         name = "rtfs_dp_unfold_gemm_fwd" + ("_bf16" if prec else "")
-        args = (G, gamma, beta, Wk, U, B, T2, dim, 0) + ((prec,) if prec else ())
+        args = (G, gamma, beta, Wk, U, B, T2, dim, variant) + ((prec,) if prec else ())
         for _ in range(3):
             lib.call(name, *args)
         torch.cuda.synchronize()
@@ -37,8 +37,8 @@ def main(dtype="f32", B=32, T2=125):
         torch.cuda.synchronize()
         t = sorted(a.elapsed_time(b) for a, b in ev)
         fl = 2.0 * S * L * 512 * 256
-        print(f"{dtype} dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {float(U.double().sum()):.10e} {float(U.double().abs().sum()):.10e}")
+        print(f"{dtype} variant {variant} dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {float(U.double().sum()):.10e} {float(U.double().abs().sum()):.10e}")
 
 
 if __name__ == "__main__":
-    main(*(sys.argv[1:2] or ["f32"]), *[int(a) for a in sys.argv[2:4]])
+    main(*(sys.argv[1:2] or ["f32"]), *[int(a) for a in sys.argv[2:5]])
