@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
 // and one barrier per tile.  (Order: loads are consumed before the tile's stores are issued, stores go through a buffer descriptor without
 // a branch - vmcnt counts both, see ws256_kernel in gemm.hip.)  Same products in the same k order per accumulator => bit-identical U0.
 template <int DUMMY = 0>
-__global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ws_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst, int S,
                                                            int total_tiles) {
     constexpr int NIT = (kFlatRows * 16 + 255) / 256;  // 6
@@ -578,31 +578,32 @@ __global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const flo
         return ng > 0 && jj < ng + 7 && sq < S && pos < map.npos;
     };
     float4 sraw[NIT];
-    unsigned sinfo[NIT];  // where a fetched row goes: float offset in its slab (scratch row behind the slab for rows past it), bit 31 = zero padding
-    auto fetch = [&](int tile) {  // (tiles past the end re-fetch the last one: L2 hits, never used)
-        const FlatTile t = tile_of(min(tile, t1 - 1));
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int j = (int)(threadIdx.x >> 4) + 16 * it;
-            const bool inr = j < kFlatRows;
-            int sq, pos, g;
-            const bool ok = slab_row(t, min(j, kFlatRows - 1), sq, pos, g) && inr;
-            sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
-            sinfo[it] = (unsigned)((inr ? j * kSlabLd + g * kSegSkew : kFlatRows * kSlabLd + 2 * kSegSkew) + c4) | (ok ? 0u : 0x80000000u);
-        }
+    unsigned sinfo[NIT];  // where a fetched row goes: float offset in its slab (scratch row behind the slab for rows past it)
+    FlatTile tf;  // geometry of the tile being fetched
+    auto fetch_begin = [&](int tile) { tf = tile_of(min(tile, t1 - 1)); };  // (tiles past the end re-fetch the last one: L2 hits, never used)
+    auto fetch1 = [&](int it) {
+        const int j = (int)(threadIdx.x >> 4) + 16 * it;
+        const bool inr = j < kFlatRows;
+        int sq, pos, g;
+        slab_row(tf, min(j, kFlatRows - 1), sq, pos, g);
+        sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
+        sinfo[it] = (unsigned)((inr ? j * kSlabLd + g * kSegSkew : kFlatRows * kSlabLd + 2 * kSegSkew) + c4);
     };
-    // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37), one 16-row group of the slab per call.
+    // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37), one 16-row group of the slab at a time, in three
+    // pieces that fit between two MFMAs.  Slab rows that no valid output row reads (the unused halo slots of a tile, rows past the last
+    // sequence) get the LayerNorm of whatever clamped row was fetched for them - finite values that only meet dropped output rows.
     // (v_rsq_f32 for 1 / sqrt: hipcc expands the IEEE form into ~35 instructions with branches, and every VALU instruction of this kernel is
     // paid in matrix-pipe time; <= 1 ulp of rstd against the LDS-staged kernels, which keep the IEEE form)
-    auto stage1 = [&](float* sl, int it) {
+    float4 ln_d;
+    float ln_s;
+    auto stage_a = [&](int it) {
         const float4 v = sraw[it];
         const float mean = row16_sum(v.x + v.y + v.z + v.w) * (1.f / 64.f);
-        const float4 d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-        const float sqs = row16_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
-        const float rstd = __builtin_amdgcn_rsqf(sqs * (1.f / 64.f) + kEps);
-        const float4 y = (int)sinfo[it] >= 0 ? fma4(d * rstd, g4, b4) : f4(0, 0, 0, 0);
-        st4(sl + (sinfo[it] & 0x7fffffffu), y);
+        ln_d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        ln_s = ln_d.x * ln_d.x + ln_d.y * ln_d.y + ln_d.z * ln_d.z + ln_d.w * ln_d.w;
     };
+    auto stage_b = [&]() { ln_s = __builtin_amdgcn_rsqf(row16_sum(ln_s) * (1.f / 64.f) + kEps); };
+    auto stage_c = [&](float* sl, int it) { st4(sl + sinfo[it], fma4(ln_d * ln_s, g4, b4)); };
     // U0 rows through a buffer descriptor: rows past the end (and the "previous tile" of the first one) are dropped by the range check
     const long long R = (long long)S * L;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
@@ -614,10 +615,18 @@ __global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const flo
                                                (int)(ocol + (base + (unsigned)((it >> 2) * 32 * 1024 + (it & 3) * 32))), 0, 0);
     };
 
-    fetch(t0);
+    fetch_begin(t0);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) stage1(slab[0], it);
-    fetch(t0 + 1);
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        stage_a(it);
+        stage_b();
+        stage_c(slab[0], it);
+    }
+    fetch_begin(t0 + 1);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
     __syncthreads();
     unsigned prev_base = 0xC0000000u;  // no previous tile yet: every store of its write-back is dropped (the launcher keeps U0 below 2^31 bytes)
 
@@ -641,19 +650,33 @@ __global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const flo
         // one wave per SIMD: the fragments of step q + 1 are read before the MFMAs of step q (pinned with sched_barrier)
         float4 eb[2][2];
         eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+        // (two half loops: one 64-step body exceeds hipcc's full-unroll budget, and a partially unrolled loop indexes the weight registers
+        // dynamically, i.e. puts them in scratch)
+        auto half_loop = [&](auto qh) {
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {
+        for (int qq = 0; qq < 32; ++qq) {
+            const int q = decltype(qh)::value * 32 + qq;
             if (q + 1 < 64) {
                 const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
                 eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
             }
-            if (q < NIT) stage1(sn, q);
-            if (q >= 6 && q < 14) out1(q - 6, prev_base);
-            if (q == 14) fetch(tile + 2);
             __builtin_amdgcn_sched_barrier(0);
             const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the tile's other work, one small piece per step, BETWEEN two MFMAs of the step (an LDS / buffer instruction then issues in the
+            // shadow of a running MFMA; bunched in front of a step they cost 2-3x their VALU time).  Order of the memory operations: the
+            // loads of the previous tile are consumed (steps 0-17) before this tile's stores (18-25), this tile's loads come last (26-32).
+            if (q < 18) {
+                if (q % 3 == 0) stage_a(q / 3);
+                if (q % 3 == 1) stage_b();
+                if (q % 3 == 2) stage_c(sn, q / 3);
+            }
+            if (q >= 18 && q < 26) out1(q - 18, prev_base);
+            if (q == 26) fetch_begin(tile + 2);
+            if (q >= 27 && q < 27 + NIT) fetch1(q - 27);
+            __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
@@ -662,6 +685,9 @@ __global__ __launch_bounds__(256, 1) void unfold_ws_kernel(SeqMap map, const flo
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        };
+        half_loop(std::integral_constant<int, 0>{});
+        half_loop(std::integral_constant<int, 1>{});
         hold0 = acc[0], hold1 = acc[1];
         prev_base = (unsigned)t.r0 * 1024u;
         __syncthreads();  // every wave has read its last fragment of this slab; the next slab is complete

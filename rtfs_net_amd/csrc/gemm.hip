@@ -1083,6 +1083,13 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
             // (order of the memory operations inside a tile: stores, then loads, and every load is consumed in the NEXT tile before that
             // tile's stores - vmcnt counts loads and stores alike, and a wait for a load that has younger stores behind it waits for their
             // acknowledgements as well)
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 e = eb[q & 1];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].x, e.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].x, e.x, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the step's share of the hand-over work sits BETWEEN two MFMAs of the step: its LDS / buffer instructions then issue in the shadow
+            // of a running MFMA (bunched in front of the step they cost 2-3x their VALU time: measured on unfold_ws_kernel, dualpath.hip)
             if (q < 8) ot_write(q);
             if (q == 8) __syncthreads();
             if (q == 9) ot_read();
@@ -1091,14 +1098,12 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
             if (q >= 18 && q < 26) store_a1(An, q - 18);
             if (q == 26) load_a(tile + 2);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 e = eb[q & 1];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].x, e.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].y, e.y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].z, e.z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][q].w, e.w, acc[nt], 0, 0, 0);
-            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].y, e.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].y, e.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].z, e.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].z, e.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].w, e.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].w, e.w, acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
