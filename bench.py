@@ -242,10 +242,11 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                     "mfma_tflops_algorithmic": (fl[4] + fl[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12}
         elif kern == "rtfs_dp_unfold_gemm_fwd":
             tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)  # launches alternate dim 4 (freq), dim 3 (time)
-            roof = {"kernel": "rtfs::unfold_gemm128f_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA)",
+            roof = {"kernel": "rtfs::unfold_ws_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA, weight-stationary form at "
+                              "large batch; rtfs::unfold_gemm128f_kernel / toeplitz_gemm_kernel below 1024 row tiles)",
                     "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
-                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_gemm128", a),
+                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_ws" if a.batch * T2 * 57 >= 1024 * 64 else "unfold_gemm128", a),
                     "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
         elif kern == "rtfs_wgrad":
             # dW0[256][512] += dU0[S*L][256]^T . X_unfold[S*L][512]: the same 2*S*L*512*256 flop as the forward layer-0 GEMM

@@ -696,6 +696,161 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int it = 0; it < 8; ++it) out1(it, prev_base);
 }
 
+// ConvTranspose kernel, weight-stationary (round 3, large batches, fp32): the structure of unfold_ws_kernel on the zero-padded SRU output.
+// W' (64 x 512 = 128 KB) lives in registers - wave (wn, wm): output channels 32 wn .. + 31 x all 512 k = 256 registers per lane, the MFMA A
+// operand; the two waves of a column half hold the same fragments and own one 64-row tile each (wm) - and a workgroup walks pairs of 64-row
+// tiles (two frequency sequences, or the two halves of one time sequence).  Between the steps of the uninterrupted K loop (512 MFMAs per wave
+// and pair) ride, one small piece per step:
+//   steps 0-8    the NEXT pair's h3 rows (requested one pair ago; rows outside the sequence come back as zeros from the buffer range check)
+//                -> the other two slabs;
+//   steps 9-16   the PREVIOUS pair's accumulators + bias + residual rows (fetched one pair ago) -> G, in place;
+//   steps 17-24  this pair's residual rows;   steps 25-33  the h3 rows of the pair after next;
+// one barrier per pair.  Same products in the same k order per accumulator as convt_gemm2_kernel => bit-identical G.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void convt_ws_kernel(SeqMap map, const float* __restrict__ src,
+                                                                                                     const float* __restrict__ Wt,
+                                                                                                     const float* __restrict__ bias, float* __restrict__ dst,
+                                                                                                     int S, int tiles_per_seq, int total_tiles) {
+    constexpr int NIT = (2 * kSlabRows * 16 + 255) / 256;  // 9
+    __shared__ __attribute__((aligned(16))) float slab[2][2][(kSlabRows + 1) * kSlabLd];  // [buffer][tile of the pair] (+ one scratch row)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int L = map.L;
+
+    float4 wf[64];  // W' fragments: row n = 32 wn + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
+#pragma unroll
+    for (int q = 0; q < 64; ++q) wf[q] = ld4(Wt + (size_t)(32 * wn + i) * 512 + 8 * q + 4 * kh);
+#pragma unroll
+    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));  // (see unfold_ws_kernel)
+
+    const int npairs = (total_tiles + 1) / 2;
+    const int p0 = (int)((long long)npairs * blockIdx.x / gridDim.x), p1 = (int)((long long)npairs * (blockIdx.x + 1) / gridDim.x);
+    if (p0 >= p1) return;
+    // h3 [S][L][64] and G through buffer descriptors: out-of-range offsets read zeros / drop the store
+    constexpr unsigned kNowhere = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)((long long)S * L * 256), 0x00020000);
+    const long long gbytes = ((long long)(S >> map.seq_shift) * map.stride_hi) * 4;  // the whole G tensor
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)gbytes, 0x00020000);
+    auto bld = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) {
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return f4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
+    // staging: thread -> per iteration (tile of the pair, slab row): constants of the thread
+    float4 sraw[NIT];
+    int s_tile = 0, s_seq[2], s_m0[2];  // the pair being fetched
+    auto locate = [&](int pair, int (&sq)[2], int (&mm)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gt = min(pair * 2 + q, total_tiles - 1);
+            sq[q] = gt / tiles_per_seq;
+            mm[q] = (gt - sq[q] * tiles_per_seq) * 64;
+        }
+    };
+    auto fetch_begin = [&](int pair) { locate(min(pair, p1 - 1), s_seq, s_m0); };  // (pairs past the end re-fetch the last one: never used)
+    auto fetch1 = [&](int it) {
+        const int idx = threadIdx.x + it * 256;
+        const int q = idx >= kSlabRows * 16 ? 1 : 0;
+        const int row = (idx - q * kSlabRows * 16) >> 4;
+        const int l = s_m0[q] + row - 7;
+        const unsigned off = ((unsigned)(s_seq[q] * L + l) * 64u + (unsigned)c4) * 4u;
+        sraw[it] = bld(rh, (unsigned)l < (unsigned)L ? off : kNowhere);  // zero padding = rows outside the sequence
+    };
+    auto stage1 = [&](float (*sl)[(kSlabRows + 1) * kSlabLd], int it) {
+        const int idx = threadIdx.x + it * 256;
+        const int q = idx >= kSlabRows * 16 ? 1 : 0;
+        const int row = min((idx - q * kSlabRows * 16) >> 4, kSlabRows);  // (the last iteration's surplus threads write the scratch row)
+        st4(sl[q] + row * kSlabLd + c4, sraw[it]);
+    };
+    // write-back: lane = (row i of row tile m, channels 32 wn + 8 g + 4 kh .. +3); residual rows fetched one pair ahead
+    floatx16 hold0, hold1;
+    float4 res[8];
+    float4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = ld4(bias + wn * 32 + 8 * g + 4 * kh);
+    unsigned roff[2] = {kNowhere, kNowhere}, roff_prev[2] = {kNowhere, kNowhere};  // byte offset of this lane's two output rows (or nowhere)
+    auto rows_of = [&](int pair, unsigned (&ro)[2]) {
+        int sq[2], mm[2];
+        locate(pair, sq, mm);
+        const bool live = pair * 2 + wm < total_tiles;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = mm[wm] + 32 * m + i;
+            ro[m] = live && row < map.npos ? map.off32(sq[wm], row) + (unsigned)(wn * 32 + 4 * kh) * 4u : kNowhere;
+        }
+    };
+    auto res1 = [&](int it) { res[it] = bld(rg, roff[it >> 2] + (unsigned)(it & 3) * 32u); };
+    auto out1 = [&](int it) {
+        const float4 v = acc_group(it >> 2 ? hold1 : hold0, it & 3) + bq[it & 3] + res[it];
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rg,
+                                               (int)(roff_prev[it >> 2] + (unsigned)(it & 3) * 32u), 0, 0);
+    };
+
+    fetch_begin(p0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) stage1(slab[0], it);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) res1(it);  // (nowhere: zeros; the same sequence of memory operations as inside the loop)
+    fetch_begin(p0 + 1);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int pair = p0; pair < p1; ++pair) {
+        const int cur = (pair - p0) & 1;
+        float(*sn)[(kSlabRows + 1) * kSlabLd] = slab[cur ^ 1];
+        rows_of(pair, roff);
+        const float* bp[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) bp[m] = slab[cur][wm] + (32 * m + i) * kSlabLd + 4 * kh;
+        floatx16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        float4 eb[2][2];
+        eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+        auto half_loop = [&](auto qh) {
+#pragma unroll
+            for (int qq = 0; qq < 32; ++qq) {
+                const int q = decltype(qh)::value * 32 + qq;
+                if (q + 1 < 64) {
+                    const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
+                    eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < NIT) stage1(sn, q);
+                if (q >= 9 && q < 17) out1(q - 9);
+                if (q >= 17 && q < 25) res1(q - 17);
+                if (q == 25) fetch_begin(pair + 2);
+                if (q >= 25 && q < 25 + NIT) fetch1(q - 25);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        half_loop(std::integral_constant<int, 0>{});
+        half_loop(std::integral_constant<int, 1>{});
+        hold0 = acc[0], hold1 = acc[1];
+        roff_prev[0] = roff[0], roff_prev[1] = roff[1];
+        __syncthreads();  // every wave has read its last fragment of these slabs; the next pair's slabs are complete
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) out1(it);
+}
+
 // Bidirectional SRU recurrence, one wave per sequence: lane = dir*32 + j.
 //   KM == 4 (layer 0): U[s][l][lane][4] = (u0, u1, u2, x')          -> one 16-byte load per lane per step
 //   KM == 3 (layers 1-3): U[s][l][m][lane], m = 0..2, skip input x' = X[s][l][lane] * scale_x
@@ -978,6 +1133,12 @@ static int convt_impl(const float* H3, const float* Wt, const float* bias, float
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.npos + 63) / 64, total = S * tps;
+    // fp32, large batch (>= 4 tile pairs per CU; 32-bit offsets): the weight-stationary kernel
+    if (NT == 0 && total >= 2 * 4 * 256 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31)) {
+        hipLaunchKernelGGL(convt_ws_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, S, tps, total);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
     hipLaunchKernelGGL(convt_gemm2_kernel<NT>, dim3((total + 1) / 2), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, tps, total);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;

@@ -372,7 +372,10 @@ def test_resid_large_batch_forms_match(dtype):
             model._hip.variants["resid"] = v
             outs[v] = model(mix.cuda(), emb.cuda())
     model._hip.variants["resid"] = 0
-    assert torch.equal(outs[0], outs[3])  # the library's choice at this size
+    # the library's choice at this size is variant 3.  Not asserted bit for bit: the gLN statistics are fp64 atomic sums of fp32 partials, and the
+    # arrival order of the atomics occasionally (about 1 run in 15 of this test inside the whole suite) moves a statistic by one fp64 ulp, which can
+    # flip an fp32 rounding downstream - in the split-bf16 mode that re-draws the hi / lo operand splits (tools/repeatability.py)
+    assert rel(outs[0], outs[3]) < (1e-7 if dtype == "f32" else 3e-5)
     # fp32: only the 1e-7-level regrouping of the statistics' partial sums; split-bf16: that perturbation re-rounds the hi / lo operand splits
     # downstream, i.e. the mode's own 2^-18 product error is re-drawn (tools/check_bf16_entries.py: 4.5e-6 per entry point)
     tol = 1e-6 if dtype == "f32" else 3e-5
@@ -510,3 +513,28 @@ def test_pixel_gemm_256_weight_stationary_form():
     ys = torch.empty(n * 256, device="cuda")
     lib.call("rtfs_gemm_rows", xcl.view(-1, 256)[:n].contiguous(), Wd, None, ys, n, 256, 256, 0)
     assert torch.equal(ys.view(torch.int32), y[: n * 256].view(torch.int32))
+
+
+@pytest.mark.parametrize("B,T2", [(17, 125), (9, 250), (3, 125)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_convt_entry_isolated(B, T2, dim):
+    """rtfs_dp_convt_fwd in isolation (ConvTranspose1d(64 -> 64, k = 8) + bias + residual, in place; rnn_layers.py:129,153-156) against float64
+    on the CPU: two sizes that take the weight-stationary kernel (>= 2048 64-row tiles: full / ragged time tiles, odd tile counts) and one
+    that takes the LDS-staged kernel."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(7 * B + T2 + dim)
+    S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
+    L = npos - 7
+    H3 = torch.randn(S, L, 64, generator=g)
+    W = torch.randn(64, 512, generator=g) * 0.05  # [out channel][k' * 64 + in channel], k' = 7 - tap (the layout the host prepares)
+    bias = torch.randn(64, generator=g) * 0.1
+    G0 = torch.randn(B, T2, 64, 64, generator=g)
+    G = G0.clone().cuda()
+    lib.call("rtfs_dp_convt_fwd", H3.cuda(), W.cuda(), bias.cuda(), G, B, T2, dim)
+    hp = torch.zeros(S, npos + 14, 64, dtype=torch.float64)
+    hp[:, 7:7 + L] = H3.double()
+    win = torch.stack([hp[:, k:k + npos] for k in range(8)], dim=2).reshape(S, npos, 512)
+    y = win @ W.double().t() + bias.double()
+    y = y.view(B, T2, 64, 64) if dim == 4 else y.view(B, 64, T2, 64).permute(0, 2, 1, 3)
+    assert rel(G.cpu(), y + G0.double()) < 2e-6
