@@ -530,12 +530,11 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
 // 128-column half of W0 in registers for its whole life (wave w: columns 128 h + 32 w .. + 31 x all 512 k = 256 registers per lane, the MFMA
 // A operand; two workgroups - two CUs - share a range of row tiles, one per column half) and walks 64-row tiles cut from the FLATTENED row
 // index exactly as unfold_gemm128f_kernel does (same tile geometry, same slab layout incl. the segment skew).  The K loop of a tile - 512
-// MFMAs per wave, B fragments read from the LayerNorm-ed slab one step ahead - never stops: between its steps ride
-//   steps 0-5    the NEXT tile's raw rows (requested one tile ago) -> LayerNormalization4D -> the other slab;
-//   steps 6-13   the PREVIOUS tile's accumulators (moved out of the matrix registers at the end of their tile) -> U0, 8 stores;
-//   step  14     the global loads of the tile after next;
-// and one barrier per tile.  (Order: loads are consumed before the tile's stores are issued, stores go through a buffer descriptor without
-// a branch - vmcnt counts both, see ws256_kernel in gemm.hip.)  Same products in the same k order per accumulator => bit-identical U0.
+// MFMAs per wave, B fragments read from the LayerNorm-ed slab one step ahead - never stops, not even between tiles: the LayerNorm staging of
+// the next tile, the write-back of the previous one, the global loads of the tile after next and the two barriers of a tile all ride between
+// its MFMAs (schedule at the tile loop below).  Stores go through a buffer descriptor without a branch and loads are consumed before the
+// tile's stores are issued: vmcnt counts both, see ws256_kernel in gemm.hip.  Same products in the same k order per accumulator as the
+// LDS-staged kernels (bit-identical U0 with the IEEE 1 / sqrt in the LayerNorm; the shipped form uses v_rsq_f32, see stage_b).
 template <int DUMMY = 0>
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ws_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst, int S,
@@ -608,13 +607,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const long long R = (long long)S * L;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
     const unsigned ocol = (unsigned)(i * 256 + 128 * half + 32 * w + 4 * kh) * 4u;  // this lane's row i, first column quad
-    floatx16 hold0, hold1;                                                           // previous tile's accumulators [m]
-    auto out1 = [&](int it, unsigned base) {
-        const float4 v = acc_group(it >> 2 ? hold1 : hold0, it & 3);
-        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ru,
-                                               (int)(ocol + (base + (unsigned)((it >> 2) * 32 * 1024 + (it & 3) * 32))), 0, 0);
-    };
-
     fetch_begin(t0);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) fetch1(it);
@@ -629,71 +621,104 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int it = 0; it < NIT; ++it) fetch1(it);
     __syncthreads();
     unsigned prev_base = 0xC0000000u;  // no previous tile yet: every store of its write-back is dropped (the launcher keeps U0 below 2^31 bytes)
-
-#pragma unroll 1
-    for (int tile = t0; tile < t1; ++tile) {
-        const int cur = (tile - t0) & 1;
-        const FlatTile t = tile_of(tile);
-        float* sn = slab[cur ^ 1];
-        // slab offset (floats) of this lane's output row in the two row tiles: row ri + 7 g, skewed by its segment g
-        const float* bp[2];
+    // slab offset (floats) of this lane's output row in the two row tiles of a tile: row ri + 7 g, skewed by its segment g
+    auto rows_in = [&](const FlatTile& t, const float* sl, const float* (&bp)[2]) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int ri = 32 * m + i, g = (ri >= t.n0) + (ri >= t.n0 + t.n1);
-            bp[m] = slab[cur] + (ri + 7 * g) * kSlabLd + g * kSegSkew + 4 * kh;
+            bp[m] = sl + (ri + 7 * g) * kSlabLd + g * kSegSkew + 4 * kh;
         }
-        floatx16 acc[2];
+    };
+    // The tile loop is unrolled by two: even tiles live in slab[0] and accumulator set A, odd tiles in slab[1] and set B.  The write-back of a
+    // tile reads its accumulators in place while the next tile fills the other set, the first fragments of the next tile are read during the
+    // last step of the current one, and the two barriers a tile needs sit between MFMAs in the middle of it - the MFMA stream never stops at a
+    // tile boundary.  Per tile, one small piece per step, BETWEEN two MFMAs of the step (an LDS / buffer instruction then issues in the shadow of
+    // a running MFMA; bunched in front of a step they cost 2-3x their VALU time):
+    //   step  1      barrier: every wave has left the previous tile, its slab may be overwritten;
+    //   steps 2-19   the NEXT tile's raw rows (requested one tile ago) -> LayerNormalization4D -> that slab;
+    //   steps 20-27  the PREVIOUS tile's accumulators -> U0 (8 stores);   steps 28-34  the global loads of the tile after next;
+    //   step  40     barrier: the next tile's slab is complete;   step 62: the next tile's row geometry;   step 63: its first fragments.
+    // (Order of the memory operations: the loads of the previous tile are consumed before this tile's stores, this tile's loads come last.)
+    floatx16 accA[2], accB[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[m][r] = 0.f, accB[m][r] = 0.f;
+    const float* bp[2];
+    float4 eb[2][2];
+    rows_in(tile_of(t0), slab[0], bp);
+    eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+    auto out1 = [&](const floatx16 (&h)[2], int it, unsigned base) {
+        const float4 v = acc_group(h[it >> 2], it & 3);
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ru,
+                                               (int)(ocol + (base + (unsigned)((it >> 2) * 32 * 1024 + (it & 3) * 32))), 0, 0);
+    };
+    auto body = [&](auto par, int tile, floatx16 (&acc)[2], const floatx16 (&accp)[2]) {
+        constexpr int PAR = decltype(par)::value;
+        float* sn = slab[PAR ^ 1];
+        const float* bpn[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        // one wave per SIMD: the fragments of step q + 1 are read before the MFMAs of step q (pinned with sched_barrier)
-        float4 eb[2][2];
-        eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
         // (two half loops: one 64-step body exceeds hipcc's full-unroll budget, and a partially unrolled loop indexes the weight registers
         // dynamically, i.e. puts them in scratch)
         auto half_loop = [&](auto qh) {
 #pragma unroll
-        for (int qq = 0; qq < 32; ++qq) {
-            const int q = decltype(qh)::value * 32 + qq;
-            if (q + 1 < 64) {
-                const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
-                eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+            for (int qq = 0; qq < 32; ++qq) {
+                const int q = decltype(qh)::value * 32 + qq;
+                if (q + 1 < 64) {
+                    const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
+                    eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+                } else {
+                    eb[0][0] = ld4(bpn[0]), eb[0][1] = ld4(bpn[1]);  // step 0 of the next tile
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 1) __syncthreads();
+                if (q >= 2 && q < 20) {
+                    if ((q - 2) % 3 == 0) stage_a((q - 2) / 3);
+                    if ((q - 2) % 3 == 1) stage_b();
+                    if ((q - 2) % 3 == 2) stage_c(sn, (q - 2) / 3);
+                }
+                if (q >= 20 && q < 28) out1(accp, q - 20, prev_base);
+                if (q == 28) fetch_begin(tile + 2);
+                if (q >= 29 && q < 29 + NIT) fetch1(q - 29);
+                if (q == 40) __syncthreads();
+                if (q == 62) rows_in(tile_of(min(tile + 1, t1 - 1)), sn, bpn);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // the tile's other work, one small piece per step, BETWEEN two MFMAs of the step (an LDS / buffer instruction then issues in the
-            // shadow of a running MFMA; bunched in front of a step they cost 2-3x their VALU time).  Order of the memory operations: the
-            // loads of the previous tile are consumed (steps 0-17) before this tile's stores (18-25), this tile's loads come last (26-32).
-            if (q < 18) {
-                if (q % 3 == 0) stage_a(q / 3);
-                if (q % 3 == 1) stage_b();
-                if (q % 3 == 2) stage_c(sn, q / 3);
-            }
-            if (q >= 18 && q < 26) out1(q - 18, prev_base);
-            if (q == 26) fetch_begin(tile + 2);
-            if (q >= 27 && q < 27 + NIT) fetch1(q - 27);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         };
         half_loop(std::integral_constant<int, 0>{});
         half_loop(std::integral_constant<int, 1>{});
-        hold0 = acc[0], hold1 = acc[1];
-        prev_base = (unsigned)t.r0 * 1024u;
-        __syncthreads();  // every wave has read its last fragment of this slab; the next slab is complete
+        bp[0] = bpn[0], bp[1] = bpn[1];
+        prev_base = (unsigned)(tile * 64) * 1024u;
+    };
+    bool last_is_b = false;
+#pragma unroll 1
+    for (int tile = t0; tile < t1; tile += 2) {
+        body(std::integral_constant<int, 0>{}, tile, accA, accB);
+        last_is_b = tile + 1 < t1;
+        if (!last_is_b) break;
+        body(std::integral_constant<int, 1>{}, tile + 1, accB, accA);
     }
+    if (last_is_b) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) out1(it, prev_base);
+        for (int it = 0; it < 8; ++it) out1(accB, it, prev_base);
+    } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) out1(accA, it, prev_base);
+    }
 }
 
 // ConvTranspose kernel, weight-stationary (round 3, large batches, fp32): the structure of unfold_ws_kernel on the zero-padded SRU output.
