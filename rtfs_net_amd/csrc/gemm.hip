@@ -77,12 +77,20 @@ struct ProExpanded {
     NormRef cl, d0;      // full resolution [B][T][F][64]
     NormRef cg, cgate;   // compressed      [B][T2][F2][64]
     int T, T2;
-    float m[4], r[4];
-    __device__ void init(int b) {
-        stats_finalize(cl.slot, b, cl.inv_n, m[0], r[0]);
-        stats_finalize(d0.slot, b, d0.inv_n, m[1], r[1]);
-        stats_finalize(cg.slot, b, cg.inv_n, m[2], r[2]);
-        stats_finalize(cgate.slot, b, cgate.inv_n, m[3], r[3]);
+    float m[4], r[4];  // (host side leaves these zero; kept for the launchers' aggregate initialisers)
+    // (scale, shift) of channel c of gLN j (0 cl, 1 d0, 2 cg, 3 cgate) of utterance b, folded from (mean, rstd, gamma, beta).  Written without
+    // touching *this (const, selects on j): modifying this by-value kernel argument, or indexing its members with a run-time j through an array
+    // of pointers, forces the whole struct into SCRATCH, and every later read of T / T2 in the tile loop then is a scratch load followed by
+    // `s_waitcnt vmcnt(0)` - a full drain of the software-pipelined global loads, once per phase (found in round 3: 208 bytes of scratch per lane).
+    __device__ void fold(int b, int j, int c, float& sc, float& sh) const {
+        const double* slot = j == 0 ? cl.slot : (j == 1 ? d0.slot : (j == 2 ? cg.slot : cgate.slot));
+        const double inv_n = j == 0 ? cl.inv_n : (j == 1 ? d0.inv_n : (j == 2 ? cg.inv_n : cgate.inv_n));
+        const float* gp = j == 0 ? cl.gamma : (j == 1 ? d0.gamma : (j == 2 ? cg.gamma : cgate.gamma));
+        const float* bp = j == 0 ? cl.beta : (j == 1 ? d0.beta : (j == 2 ? cg.beta : cgate.beta));
+        float mean, rstd;
+        stats_finalize(slot, b, inv_n, mean, rstd);
+        sc = gp[c] * rstd;
+        sh = bp[c] - mean * sc;
     }
 };
 
@@ -331,7 +339,6 @@ __global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded 
     float ps = 0.f, pq = 0.f;  // PROJ: gLN partial sums of the projection output
     const int b = blockIdx.y;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
-    pro.init(b);
     const int cq = (threadIdx.x & 63) * 4;  // this thread's channel quad in the coalesced epilogue
     const float4 cbias = ld4(epi.bias + cq), cgw = ld4(epi.gw + cq), cgb = ld4(epi.gb + cq);
     __shared__ __attribute__((aligned(16))) float cafc[CAF ? 4 * kC : 4];  // CAF: ks | kb | vs | vb, re-read per epilogue row (16 VGPRs otherwise)
@@ -344,11 +351,11 @@ __global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded 
     __shared__ __attribute__((aligned(16))) float Ns[4][2][kH];
     const int c4 = (threadIdx.x & 15) * 4;
     {
-        const NormRef* refs[4] = {&pro.cl, &pro.d0, &pro.cg, &pro.cgate};
         const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
-        const float sc = refs[j]->gamma[c] * pro.r[j];
+        float sc, sh;
+        pro.fold(b, j, c, sc, sh);
         Ns[j][0][c] = sc;
-        Ns[j][1][c] = refs[j]->beta[c] - pro.m[j] * sc;
+        Ns[j][1][c] = sh;
     }
 
     float4 wf[2][8];  // W fragments: rows n = 64w + 32nt + i, k = 8q + 4kh .. +3
@@ -619,18 +626,17 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
     const int ntl = min(tiles_per_wg, tiles - tile0);
     if (ntl <= 0) return;
     const int H = 2 * ntl, row0 = tile0 * 64;  // halves of this workgroup; half h covers pixel rows row0 + 32 h .. + 31
-    pro.init(b);
     if (threadIdx.x < 256) {
         if (CAF) {
             const float* src[4] = {epi.caf_ks, epi.caf_kb, epi.caf_vs, epi.caf_vb};
 #pragma unroll
             for (int j = 0; j < 4; ++j) cafc[j * kC + threadIdx.x] = src[j][threadIdx.x];
         }
-        const NormRef* refs[4] = {&pro.cl, &pro.d0, &pro.cg, &pro.cgate};
         const int j = threadIdx.x >> 6, c = threadIdx.x & 63;
-        const float sc = refs[j]->gamma[c] * pro.r[j];
+        float sc, sh;
+        pro.fold(b, j, c, sc, sh);
         Ns[j][0][c] = sc;
-        Ns[j][1][c] = refs[j]->beta[c] - pro.m[j] * sc;
+        Ns[j][1][c] = sh;
     }
     __syncthreads();
     float ps = 0.f, pq = 0.f;  // M: gLN partial sums of the projection output
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
             for (int t = 0; t < 16; ++t) wpr[t] = ld4(wpp0 + 4 * t);
         }
         const float4 pb4 = ld4(epi.pbias + 16 * w + 4 * kk);
-        float* py_b = epi.py + (size_t)b * Mb * kH;
+        const __amdgpu_buffer_rsrc_t rpy = __builtin_amdgcn_make_buffer_rsrc(epi.py + (size_t)b * Mb * kH, 0, (int)((unsigned)Mb * kH * 4u), 0x00020000);
         __syncthreads();  // (pairs with the X waves' prologue barrier: Es[0] holds half 0)
         int hb = 0;       // h % 3
 #pragma unroll 1
@@ -721,10 +727,11 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {
                     const int p = row0 + (h - 2) * 32 + 16 * sub + j;
+                    const float4 o = f4(pa[sub][0] + pa[sub + 2][0], pa[sub][1] + pa[sub + 2][1], pa[sub][2] + pa[sub + 2][2],
+                                        pa[sub][3] + pa[sub + 2][3]) + pb4;
+                    __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, rpy,
+                                                           (int)(((unsigned)p * kH + 16 * w + 4 * kk) * 4u), 0, 0);
                     if (p < Mb) {
-                        const float4 o = f4(pa[sub][0] + pa[sub + 2][0], pa[sub][1] + pa[sub + 2][1], pa[sub][2] + pa[sub + 2][2],
-                                            pa[sub][3] + pa[sub + 2][3]) + pb4;
-                        st4_off(py_b, ((unsigned)p * kH + 16 * w + 4 * kk) * 4u, o);
                         ps += o.x + o.y + o.z + o.w;
                         pq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
                     }
@@ -746,7 +753,9 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
         const float* a0_b = CAF ? nullptr : epi.a0 + (size_t)b * Mb * kC;
         const float* att_b = CAF ? epi.att + (size_t)b * epi.Tv * kC : nullptr;
         const float* rsz_b = CAF ? epi.rsz + (size_t)b * epi.Tv * kC : nullptr;
-        float* y_b = epi.y + (size_t)b * Mb * kC;
+        // (stores through a buffer descriptor: rows past the end are dropped by its range check.  A store under a branch makes hipcc turn every
+        // later wait for an older load into a wait for the store acknowledgements as well - see ws256_kernel)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(epi.y + (size_t)b * Mb * kC, 0, (int)((unsigned)Mb * kC * 4u), 0x00020000);
         float4 xa[2][2], xd[2][2], xg[2][2], xs[2][2];  // E operands, [register stage][row]
         float4 sv[2][8], av[CAF ? 1 : 2][8];            // residual operands, [register stage][row]
         float4 catt[2][2], crsz[2][2];                  // CAF: (att, rsz) rows of the <= 2 video frames a half spans
@@ -806,7 +815,8 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
                 } else {
                     v = v + av[st][it];
                 }
-                if (prow + 4 * it < Mb) st4_off(y_b, ((unsigned)(prow + 4 * it) * kC + cq) * 4u, v);
+                __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ry,
+                                                       (int)(((unsigned)(prow + 4 * it) * kC + cq) * 4u), 0, 0);
                 st4(O + r * LDO + cq, pack4<NT>(prelu4(fma4(v, cgw, cgb), epi.slope)));  // the next block's gateway, in place
             }
         };
