@@ -550,10 +550,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     float4 wf[64];  // W0 fragments: row n = 128 half + 32 w + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
 #pragma unroll
     for (int q = 0; q < 64; ++q) wf[q] = ld4(Wt + (size_t)(128 * half + 32 * w + i) * 512 + 8 * q + 4 * kh);
-    // 44 of the 64 live in the accumulation registers and are read by the MFMAs from there (bound to that class here: otherwise hipcc
-    // uses those registers as spill slots and copies every value back to a VGPR before its MFMA)
-#pragma unroll
-    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));
 
     const int t0 = (int)((long long)total_tiles * slot / nslots), t1 = (int)((long long)total_tiles * (slot + 1) / nslots);
     if (t0 >= t1) return;
@@ -619,6 +615,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     fetch_begin(t0 + 1);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) fetch1(it);
+    // 44 of the 64 weight fragments live in the accumulation registers and are read by the MFMAs from there (bound to that class here - otherwise
+    // hipcc uses those registers as spill slots and copies every value back to a VGPR before its MFMA - and only here: the binding waits for the
+    // weight loads, which so far were in flight together with the first tile's rows)
+#pragma unroll
+    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));
     __syncthreads();
     unsigned prev_base = 0xC0000000u;  // no previous tile yet: every store of its write-back is dropped (the launcher keeps U0 below 2^31 bytes)
     // slab offset (floats) of this lane's output row in the two row tiles of a tile: row ri + 7 g, skewed by its segment g
@@ -746,8 +747,6 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     float4 wf[64];  // W' fragments: row n = 32 wn + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
 #pragma unroll
     for (int q = 0; q < 64; ++q) wf[q] = ld4(Wt + (size_t)(32 * wn + i) * 512 + 8 * q + 4 * kh);
-#pragma unroll
-    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));  // (see unfold_ws_kernel)
 
     const int npairs = (total_tiles + 1) / 2;
     const int p0 = (int)((long long)npairs * blockIdx.x / gridDim.x), p1 = (int)((long long)npairs * (blockIdx.x + 1) / gridDim.x);
@@ -821,6 +820,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     fetch_begin(p0 + 1);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));  // (see unfold_ws_kernel)
     __syncthreads();
 
 #pragma unroll 1
