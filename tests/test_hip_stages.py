@@ -519,7 +519,7 @@ def test_pixel_gemm_256_weight_stationary_form():
 @pytest.mark.parametrize("dim", [4, 3])
 def test_convt_entry_isolated(B, T2, dim):
     """rtfs_dp_convt_fwd in isolation (ConvTranspose1d(64 -> 64, k = 8) + bias + residual, in place; rnn_layers.py:129,153-156) against float64
-    on the CPU: two sizes that take the weight-stationary kernel (>= 2048 64-row tiles: full / ragged time tiles, odd tile counts) and one
+    on the CPU: two sizes that take the weight-stationary kernel (>= 1536 64-row tiles: full / ragged time tiles, odd tile counts) and one
     that takes the LDS-staged kernel."""
     from rtfs_net_amd import lib
 
