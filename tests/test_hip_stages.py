@@ -538,3 +538,25 @@ def test_convt_entry_isolated(B, T2, dim):
     y = win @ W.double().t() + bias.double()
     y = y.view(B, T2, 64, 64) if dim == 4 else y.view(B, 64, T2, 64).permute(0, 2, 1, 3)
     assert rel(G.cpu(), y + G0.double()) < 2e-6
+
+
+def test_weight_stationary_kernels_in_the_model():
+    """RTFS-Net-2 at the bench shape (batch 32, 2 s): the forward takes the weight-stationary kernels (256 -> 256 pixel GEMMs, layer-0 GEMM,
+    ConvTranspose GEMM) and the one-workgroup residual kernels.  (1) with the layer-0 GEMM forced to the LDS-staged kernel (variant 2) the
+    waveforms agree to 1e-6 (v_rsq in the weight-stationary kernel's LayerNorm); (2) every 8th utterance separated ALONE - a batch of one
+    takes the small-batch kernel of every stage - agrees with its row of the batch to 1e-5."""
+    model, sd, cfg = make_model(2, "cuda")
+    mix, _, emb = synth.synth_inputs(32, 32000, 50)
+    mix, emb = mix.cuda(), emb.cuda()
+    with torch.no_grad():
+        out = model(mix, emb)
+        model._hip.variants["unfold"] = 2
+        try:
+            staged = model(mix, emb)
+        finally:
+            model._hip.variants["unfold"] = 0
+        assert torch.isfinite(out).all()
+        assert rel(out, staged) < 1e-6
+        for j in range(0, 32, 8):
+            solo = model(mix[j:j + 1], emb[j:j + 1])
+            assert rel(solo[0], out[j]) < 1e-5, j
