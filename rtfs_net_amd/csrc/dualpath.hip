@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void unfold_gemm128f_kernel(SeqMap map, con
 // its MFMAs (schedule at the tile loop below).  Stores go through a buffer descriptor without a branch and loads are consumed before the
 // tile's stores are issued: vmcnt counts both, see ws256_kernel in gemm.hip.  Same products in the same k order per accumulator as the
 // LDS-staged kernels (bit-identical U0 with the IEEE 1 / sqrt in the LayerNorm; the shipped form uses v_rsq_f32, see stage_b).
-template <int DUMMY = 0>
+template <int NT = 0>  // 0 fp32; 1 / 3: bf16 / split-bf16 MFMA (common.h; Wt host-PACKED, the slab packed on store)
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ws_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ Wt, float* __restrict__ dst, int S,
                                                            int total_tiles) {
@@ -544,12 +544,24 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int half = blockIdx.x & 1, slot = blockIdx.x >> 1, nslots = gridDim.x >> 1;
     const int c4 = (threadIdx.x & 15) * 4;
+    const int cst = NT == 0 ? c4 : (c4 >> 4) * 16 + ((c4 >> 2) & 1) * 4 + ((c4 >> 3) & 1) * 2;  // float offset of this thread's channel quad inside a slab row
     const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
     const int L = map.L;
 
     float4 wf[64];  // W0 fragments: row n = 128 half + 32 w + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
 #pragma unroll
     for (int q = 0; q < 64; ++q) wf[q] = ld4(Wt + (size_t)(128 * half + 32 * w + i) * 512 + 8 * q + 4 * kh);
+    // bf16 modes: the host-packed slots [hi(k0 k1) hi(k2 k3) lo(k0 k1) lo(k2 k3)] of step q2 = quads 2 q2, 2 q2 + 1 regrouped ONCE into the
+    // 4-register operand tuples of v_mfma_f32_32x32x16_bf16 (hi and lo planes of the 8 k values 16 q2 + 4 kh + {0..3, 8..11})
+    bf16x8 whi[NT ? 32 : 1], wlo[NT ? 32 : 1];
+    if constexpr (NT != 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < 32; ++q2) {
+            const float4 s0 = wf[2 * q2], s1 = wf[2 * q2 + 1];
+            whi[q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y)});
+            wlo[q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.z), __float_as_uint(s0.w), __float_as_uint(s1.z), __float_as_uint(s1.w)});
+        }
+    }
 
     const int t0 = (int)((long long)total_tiles * slot / nslots), t1 = (int)((long long)total_tiles * (slot + 1) / nslots);
     if (t0 >= t1) return;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         int sq, pos, g;
         slab_row(tf, min(j, kFlatRows - 1), sq, pos, g);
         sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
-        sinfo[it] = (unsigned)((inr ? j * kSlabLd + g * kSegSkew : kFlatRows * kSlabLd + 2 * kSegSkew) + c4);
+        sinfo[it] = (unsigned)((inr ? j * kSlabLd + g * kSegSkew : kFlatRows * kSlabLd + 2 * kSegSkew) + cst);
     };
     // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37), one 16-row group of the slab at a time, in three
     // pieces that fit between two MFMAs.  Slab rows that no valid output row reads (the unused halo slots of a tile, rows past the last
@@ -598,7 +610,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         ln_s = ln_d.x * ln_d.x + ln_d.y * ln_d.y + ln_d.z * ln_d.z + ln_d.w * ln_d.w;
     };
     auto stage_b = [&]() { ln_s = __builtin_amdgcn_rsqf(row16_sum(ln_s) * (1.f / 64.f) + kEps); };
-    auto stage_c = [&](float* sl, int it) { st4(sl + sinfo[it], fma4(ln_d * ln_s, g4, b4)); };
+    // fp32: the 4 channels as they are.  bf16 modes: a row is 4 groups of 16 channels, each stored as [hi plane of the kh = 0 fragment half
+    // (channels 0-3, 8-11) | hi, kh = 1 (4-7, 12-15) | lo, kh = 0 | lo, kh = 1], 16 bytes each - a lane's ds_read_b128 is a whole MFMA operand tuple
+    // (the same 8 k values, in the same order, as the weight tuples above: no register shuffling in the K loop); this thread's channel quad is
+    // 8 bytes of a hi slot and 8 bytes of the lo slot 32 bytes further on
+    auto stage_c = [&](float* sl, int it) {
+        const float4 y = fma4(ln_d * ln_s, g4, b4);
+        if constexpr (NT == 0) {
+            st4(sl + sinfo[it], y);
+        } else {
+            const float4 pk = pack4<NT>(y);
+            *reinterpret_cast<float2*>(sl + sinfo[it]) = make_float2(pk.x, pk.y);
+            if constexpr (NT == 3) *reinterpret_cast<float2*>(sl + sinfo[it] + 8) = make_float2(pk.z, pk.w);
+        }
+    };
     // U0 rows through a buffer descriptor: rows past the end (and the "previous tile" of the first one) are dropped by the range check
     const long long R = (long long)S * L;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
@@ -618,8 +643,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     // 44 of the 64 weight fragments live in the accumulation registers and are read by the MFMAs from there (bound to that class here - otherwise
     // hipcc uses those registers as spill slots and copies every value back to a VGPR before its MFMA - and only here: the binding waits for the
     // weight loads, which so far were in flight together with the first tile's rows)
+    if constexpr (NT == 0) {
 #pragma unroll
-    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));
+        for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));
+    } else {
+#pragma unroll
+        for (int q2 = 0; q2 < 32; ++q2) asm volatile("" : "+a"(whi[q2]));
+        if constexpr (NT == 3) {
+#pragma unroll
+            for (int q2 = 0; q2 < 12; ++q2) asm volatile("" : "+a"(wlo[q2]));
+        }
+    }
     __syncthreads();
     unsigned prev_base = 0xC0000000u;  // no previous tile yet: every store of its write-back is dropped (the launcher keeps U0 below 2^31 bytes)
     // slab offset (floats) of this lane's output row in the two row tiles of a tile: row ri + 7 g, skewed by its segment g
@@ -638,7 +672,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     //   step  1      barrier: every wave has left the previous tile, its slab may be overwritten;
     //   steps 2-19   the NEXT tile's raw rows (requested one tile ago) -> LayerNormalization4D -> that slab;
     //   steps 20-27  the PREVIOUS tile's accumulators -> U0 (8 stores);   steps 28-34  the global loads of the tile after next;
-    //   step  40     barrier: the next tile's slab is complete;   step 62: the next tile's row geometry;   step 63: its first fragments.
+    //   step  40     barrier: the next tile's slab is complete;   step 58: the next tile's row geometry;   step 63: its first fragments.
+    // (bf16 / split-bf16: 32 steps of 16 k, two of these slots per step)
     // (Order of the memory operations: the loads of the previous tile are consumed before this tile's stores, this tile's loads come last.)
     floatx16 accA[2], accB[2];
 #pragma unroll
@@ -646,9 +681,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) accA[m][r] = 0.f, accB[m][r] = 0.f;
     const float* bp[2];
-    float4 eb[2][2];
+    float4 eb[2][2];      // fp32: [buffer][row tile]
+    float4 ebp[2][2][2];  // bf16: [buffer][row tile][slot]
     rows_in(tile_of(t0), slab[0], bp);
-    eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+    if constexpr (NT == 0) {
+        eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) ebp[0][m][0] = ld4(bp[m]), ebp[0][m][1] = ld4(bp[m] + 8);  // (hi, lo tuples of step 0)
+    }
     auto out1 = [&](const floatx16 (&h)[2], int it, unsigned base) {
         const float4 v = acc_group(h[it >> 2], it & 3);
         __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ru,
@@ -662,42 +703,89 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        // the tile's other work as 64 slots: one per step of the fp32 K loop, two per 16-k step of the bf16 loops
+        auto piece = [&](int sl_) {
+            if (sl_ == 1) __syncthreads();
+            if (sl_ >= 2 && sl_ < 20) {
+                if ((sl_ - 2) % 3 == 0) stage_a((sl_ - 2) / 3);
+                if ((sl_ - 2) % 3 == 1) stage_b();
+                if ((sl_ - 2) % 3 == 2) stage_c(sn, (sl_ - 2) / 3);
+            }
+            if (sl_ >= 20 && sl_ < 28) out1(accp, sl_ - 20, prev_base);
+            if (sl_ == 28) fetch_begin(tile + 2);
+            if (sl_ >= 29 && sl_ < 29 + NIT) fetch1(sl_ - 29);
+            if (sl_ == 40) __syncthreads();
+            if (sl_ == 58) rows_in(tile_of(min(tile + 1, t1 - 1)), sn, bpn);
+        };
         // (two half loops: one 64-step body exceeds hipcc's full-unroll budget, and a partially unrolled loop indexes the weight registers
         // dynamically, i.e. puts them in scratch)
         auto half_loop = [&](auto qh) {
+            if constexpr (NT == 0) {
 #pragma unroll
-            for (int qq = 0; qq < 32; ++qq) {
-                const int q = decltype(qh)::value * 32 + qq;
-                if (q + 1 < 64) {
-                    const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
-                    eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
-                } else {
-                    eb[0][0] = ld4(bpn[0]), eb[0][1] = ld4(bpn[1]);  // step 0 of the next tile
+                for (int qq = 0; qq < 32; ++qq) {
+                    const int q = decltype(qh)::value * 32 + qq;
+                    if (q + 1 < 64) {
+                        const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
+                        eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+                    } else {
+                        eb[0][0] = ld4(bpn[0]), eb[0][1] = ld4(bpn[1]);  // step 0 of the next tile
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q == 1) __syncthreads();
-                if (q >= 2 && q < 20) {
-                    if ((q - 2) % 3 == 0) stage_a((q - 2) / 3);
-                    if ((q - 2) % 3 == 1) stage_b();
-                    if ((q - 2) % 3 == 2) stage_c(sn, (q - 2) / 3);
+            } else {
+                // 16 k per step; the operand tuples of step q2 + 1 are read before the MFMAs of step q2
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    const int q2 = decltype(qh)::value * 16 + qq;
+                    float4(&nx)[2][2] = ebp[(q2 + 1) & 1];
+                    const float* b0 = q2 + 1 < 32 ? bp[0] + ((q2 + 1) >> 2) * kSlabLd + ((q2 + 1) & 3) * 16 : bpn[0];  // tap (q2 + 1) / 4, channel group (q2 + 1) % 4
+                    const float* b1 = q2 + 1 < 32 ? bp[1] + ((q2 + 1) >> 2) * kSlabLd + ((q2 + 1) & 3) * 16 : bpn[1];  // (step 0 of the next tile after the last step)
+                    nx[0][0] = ld4(b0), nx[1][0] = ld4(b1);
+                    if constexpr (NT == 3) nx[0][1] = ld4(b0 + 8), nx[1][1] = ld4(b1 + 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                    auto tuple = [](float4 v) { return __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}); };
+                    const Frag wq{whi[q2], wlo[q2], wlo[q2]};
+                    const Frag f0{tuple(ebp[q2 & 1][0][0]), tuple(ebp[q2 & 1][0][1]), tuple(ebp[q2 & 1][0][1])};
+                    const Frag f1{tuple(ebp[q2 & 1][1][0]), tuple(ebp[q2 & 1][1][1]), tuple(ebp[q2 & 1][1][1])};
+                    // the two accumulator chains alternate (a dependent 8-pass MFMA issued back to back waits for its predecessor); per accumulator
+                    // the order of mma32<NT>: lo.hi, hi.lo, hi.hi
+                    if constexpr (NT == 3) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.lo, f0.hi, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.lo, f1.hi, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f0.lo, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f1.lo, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2 + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f0.hi, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f1.hi, acc[1], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f0.hi, acc[0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq.hi, f1.hi, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2 + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (q >= 20 && q < 28) out1(accp, q - 20, prev_base);
-                if (q == 28) fetch_begin(tile + 2);
-                if (q >= 29 && q < 29 + NIT) fetch1(q - 29);
-                if (q == 40) __syncthreads();
-                if (q == 62) rows_in(tile_of(min(tile + 1, t1 - 1)), sn, bpn);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
         };
         half_loop(std::integral_constant<int, 0>{});
@@ -1129,11 +1217,11 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
-    // fp32, large batch: the weight-stationary kernel (variant 2 keeps the LDS-staged flattened-tile kernel selectable for A/B: same bits)
-    if (NT == 0 && variant == 0 && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
+    // fp32 / bf16 / split-bf16, large batch: the weight-stationary kernel (variant 2 keeps the LDS-staged flattened-tile kernel selectable for A/B)
+    if ((NT == 0 || NT == 1 || NT == 3) && variant == 0 && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
         (long long)S * m.L * 1024 < (1LL << 31) && ((long long)S * m.L + 63) / 64 >= 8 * 128) {  // (>= 8 tiles per workgroup to pay for its 256 KB weight read)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64);
-        hipLaunchKernelGGL(unfold_ws_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, ftiles);
+        hipLaunchKernelGGL(unfold_ws_kernel<(NT == 6 ? 0 : NT)>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, ftiles);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }

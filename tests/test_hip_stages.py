@@ -560,3 +560,33 @@ def test_weight_stationary_kernels_in_the_model():
         for j in range(0, 32, 8):
             solo = model(mix[j:j + 1], emb[j:j + 1])
             assert rel(solo[0], out[j]) < 1e-5, j
+
+
+@pytest.mark.parametrize("terms,tol", [(3, 3e-5), (1, 2e-2)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_unfold_gemm_bf16_weight_stationary_form(dim, terms, tol):
+    """rtfs_dp_unfold_gemm_fwd_bf16 at a size that takes the weight-stationary kernel (operand tuples read whole from a re-ordered slab row, weight
+    tuples regrouped once): against float64 within the mode's own error, and against the LDS-staged kernel of the same mode (variant 2) to the
+    level at which the two LayerNorm forms (v_rsq / IEEE) re-round the bf16 splits."""
+    from rtfs_net_amd import lib
+    from rtfs_net_amd.models.hip_path import pack_bf16
+
+    B, T2 = 10, 125
+    g = torch.Generator().manual_seed(40 + dim + terms)
+    G = torch.randn(B, T2, 64, 64, generator=g)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    Wt = torch.randn(256, 512, generator=g) * 0.05
+    x = G.double()
+    xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    seqs = xn.reshape(B * T2, 64, 64) if dim == 4 else xn.permute(0, 2, 1, 3).reshape(B * 64, T2, 64)
+    L = seqs.shape[1] - 7
+    win = torch.stack([seqs[:, k:k + L] for k in range(8)], dim=2).reshape(seqs.shape[0], L, 512)
+    want = win @ Wt.double().t()
+    Wk = pack_bf16(Wt.cuda())
+    outs = []
+    for variant in (0, 2):
+        U = torch.full((seqs.shape[0] * L * 256,), float("nan"), device="cuda")
+        lib.call("rtfs_dp_unfold_gemm_fwd_bf16", G.cuda(), gamma.cuda(), beta.cuda(), Wk, U, B, T2, dim, variant, terms)
+        assert rel(U.view(want.shape), want) < tol
+        outs.append(U)
+    assert rel(outs[0], outs[1]) < tol
