@@ -235,7 +235,8 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         if kern == "rtfs_dp_unfold_gemm_fwd" and terms:
             # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
             by = {4: 4.0 * (a.batch * T2 * F2 * H + a.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (a.batch * T2 * F2 * H + a.batch * F2 * (T2 - 7) * 256)}
-            roof = {"kernel": f"rtfs::unfold_gemm128f_kernel<{terms}> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on v_mfma_f32_32x32x16_bf16)",
+            roof = {"kernel": f"rtfs::unfold_ws_kernel<{terms}> (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on v_mfma_f32_32x32x16_bf16, "
+                              "weight-stationary form at large batch; unfold_gemm128f_kernel for the six-term split and below 1024 row tiles)",
                     "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                     "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,
