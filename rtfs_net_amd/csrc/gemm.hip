@@ -969,8 +969,8 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
 // is the VALU share of that work (rule 9 of DESIGN.md: fp32 MFMA and VALU do not overlap) - ~200 instructions per 16384 pipe cycles.
 // Same products, same k order per accumulator as pixel_gemm_kernel (k ascending in 8-quads) => bit-identical output.
 // ------------------------------------------------------------------------------------------------
-template <class Pro, class Epi, bool PAIRED>
-__global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
+template <class Pro, class Epi, bool PAIRED, int NT = 0>  // NT (common.h): 0 fp32; 1 / 3 bf16 / split-bf16 MFMA, Wt host-PACKED, the pixel tile packed on store
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void ws256_kernel(Pro pro, Epi epi, const float* __restrict__ Wt, int Mb, int tiles_per_wg) {
     constexpr int LD = 260, TP = 32;
     __shared__ __attribute__((aligned(16))) float As[2][TP * LD];  // pixel tiles [pixel][k], double-buffered
     __shared__ __attribute__((aligned(16))) float Ot[TP * LD];     // previous tile's output [pixel][channel]
@@ -986,8 +986,24 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
         for (int q = 0; q < 32; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * kC + 8 * q + 4 * kh);
     // half of the weight lives in the accumulation registers (256 + 256 per lane) and is read by the MFMAs from there: bound to that class
     // here, or hipcc treats those registers as spill slots and copies every value back to a VGPR before its MFMA (~100 VALU per tile)
+    // bf16 modes: the host-packed slots [hi(k0 k1) hi(k2 k3) lo(k0 k1) lo(k2 k3)] of step q2 = quads 2 q2, 2 q2 + 1 regrouped ONCE into the 4-register
+    // operand tuples of v_mfma_f32_32x32x16_bf16 (hi and lo planes of the 8 k values 16 q2 + 4 kh + {0..3, 8..11}; see unfold_ws_kernel, dualpath.hip)
+    bf16x8 whi[2][NT ? 16 : 1], wlo[2][NT ? 16 : 1];
+    if constexpr (NT == 0) {
 #pragma unroll
-    for (int q = 0; q < 32; ++q) asm volatile("" : "+a"(wf[0][q].x), "+a"(wf[0][q].y), "+a"(wf[0][q].z), "+a"(wf[0][q].w));
+        for (int q = 0; q < 32; ++q) asm volatile("" : "+a"(wf[0][q].x), "+a"(wf[0][q].y), "+a"(wf[0][q].z), "+a"(wf[0][q].w));
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const float4 s0 = wf[nt][2 * q2], s1 = wf[nt][2 * q2 + 1];
+                whi[nt][q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y)});
+                wlo[nt][q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.z), __float_as_uint(s0.w), __float_as_uint(s1.z), __float_as_uint(s1.w)});
+            }
+#pragma unroll
+        for (int q2 = 0; q2 < 16; ++q2) asm volatile("" : "+a"(whi[0][q2]), "+a"(whi[1][q2]));
+    }
     __syncthreads();  // ptab
 
     const int ntile = (Mb + TP - 1) / TP;
@@ -1017,7 +1033,19 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
 #pragma unroll
         for (int it = 0; it < 8; ++it) raw[it] = bld(rx, voff + (base + it * 4u * kC * 4u));
     };
-    auto store_a1 = [&](float* dst, int it) { st4(dst + (w + 4 * it) * LD + cq, pro.xform(raw[it], cq, ptab)); };
+    // fp32: the 4 channels as they are.  bf16 modes: a pixel row is 16 groups of 16 channels, each stored as [hi plane of the kh = 0 fragment half
+    // (channels 0-3, 8-11) | hi, kh = 1 | lo, kh = 0 | lo, kh = 1], 16 bytes each: a lane's ds_read_b128 is a whole MFMA operand tuple
+    const int cst = NT == 0 ? cq : (cq >> 4) * 16 + ((cq >> 2) & 1) * 4 + ((cq >> 3) & 1) * 2;
+    auto store_a1 = [&](float* dst, int it) {
+        const float4 y = pro.xform(raw[it], cq, ptab);
+        if constexpr (NT == 0) {
+            st4(dst + (w + 4 * it) * LD + cst, y);
+        } else {
+            const float4 pk = pack4<NT>(y);
+            *reinterpret_cast<float2*>(dst + (w + 4 * it) * LD + cst) = make_float2(pk.x, pk.y);
+            if constexpr (NT == 3) *reinterpret_cast<float2*>(dst + (w + 4 * it) * LD + cst + 8) = make_float2(pk.z, pk.w);
+        }
+    };
     // S3 mask epilogue: thread = (channel quad q4 of the real half, rows pr + 8 it)
     const int q4 = (threadIdx.x & 31) * 4, pr = threadIdx.x >> 5;
     const unsigned voffe = (unsigned)(pr * kC + q4) * 4u;
@@ -1084,22 +1112,12 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
         // one wave per SIMD: nobody else covers the LDS latency, so the fragment of step q + 1 is read before the MFMAs of step q
-        // (every step pinned with sched_barrier: left alone, hipcc reads each fragment right before its first MFMA and waits for it)
-        float4 eb[2];
-        eb[0] = ld4(ep);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            if (q + 1 < 32) eb[(q + 1) & 1] = ld4(ep + 8 * (q + 1));
-            // (order of the memory operations inside a tile: stores, then loads, and every load is consumed in the NEXT tile before that
-            // tile's stores - vmcnt counts loads and stores alike, and a wait for a load that has younger stores behind it waits for their
-            // acknowledgements as well)
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 e = eb[q & 1];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].x, e.x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].x, e.x, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // the step's share of the hand-over work sits BETWEEN two MFMAs of the step: its LDS / buffer instructions then issue in the shadow
-            // of a running MFMA (bunched in front of the step they cost 2-3x their VALU time: measured on unfold_ws_kernel, dualpath.hip)
+        // (every step pinned with sched_barrier: left alone, hipcc reads each fragment right before its first MFMA and waits for it).
+        // The tile's hand-over work as 32 slots, one per step of the fp32 K loop, two per 16-k step of the bf16 loops, each BETWEEN two MFMAs
+        // (its LDS / buffer instructions then issue in the shadow of a running MFMA).  Order of the memory operations inside a tile: stores,
+        // then loads, and every load is consumed in the NEXT tile before that tile's stores - vmcnt counts loads and stores alike, and a wait
+        // for a load that has younger stores behind it waits for their acknowledgements as well.
+        auto piece = [&](int q) {
             if (q < 8) ot_write(q);
             if (q == 8) __syncthreads();
             if (q == 9) ot_read();
@@ -1107,14 +1125,65 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
             if (q == 14) load_emb(tile_base);  // this tile's embedding rows: its epilogue runs inside the next tile
             if (q >= 18 && q < 26) store_a1(An, q - 18);
             if (q == 26) load_a(tile + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].y, e.y, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].y, e.y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].z, e.z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].z, e.z, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].w, e.w, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].w, e.w, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        if constexpr (NT == 0) {
+            float4 eb[2];
+            eb[0] = ld4(ep);
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                if (q + 1 < 32) eb[(q + 1) & 1] = ld4(ep + 8 * (q + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 e = eb[q & 1];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].x, e.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].x, e.x, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                piece(q);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].y, e.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].y, e.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].z, e.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].z, e.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[0][q].w, e.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[1][q].w, e.w, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // 16 k per step; (hi, lo) operand tuples of the pixel row, the two accumulator chains alternating (order per accumulator as mma32<NT>)
+            auto tuple = [](float4 v) { return __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}); };
+            float4 ebp[2][2];
+            ebp[0][0] = ld4(ep), ebp[0][1] = ld4(ep + 8);
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                if (q2 + 1 < 16) {
+                    ebp[(q2 + 1) & 1][0] = ld4(ep + 16 * (q2 + 1));
+                    if constexpr (NT == 3) ebp[(q2 + 1) & 1][1] = ld4(ep + 16 * (q2 + 1) + 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 fh = tuple(ebp[q2 & 1][0]), fl = tuple(ebp[q2 & 1][1]);
+                if constexpr (NT == 3) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[0][q2], fh, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[1][q2], fh, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(2 * q2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[0][q2], fl, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[1][q2], fl, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(2 * q2 + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[0][q2], fh, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[1][q2], fh, acc[1], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[0][q2], fh, acc[0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(2 * q2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[1][q2], fh, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(2 * q2 + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) hold[it] = acc_group(acc[it >> 2], it & 3);
@@ -1133,14 +1202,14 @@ __global__ __launch_bounds__(256, 1) void ws256_kernel(Pro pro, Epi epi, const f
 // the weight-stationary form pays one 256 KB weight read per workgroup: worth it from ~32 tiles per workgroup on
 static bool ws256_applies(int B, int Mb) { return (long long)((Mb + 31) / 32) * B >= 32 * 256 && (long long)Mb * kC * 4 < (1ll << 30); }
 
-template <bool PAIRED, class Pro, class Epi>
+template <bool PAIRED, int NT, class Pro, class Epi>
 static int launch_ws256(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
     if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
     // one workgroup per CU: workgroups per utterance = ceil(256 / B), consecutive tiles of one utterance each
     const int tiles = (Mb + 31) / 32;
     const int per_utt = (256 + B - 1) / B;
     const int per = (tiles + per_utt - 1) / per_utt;
-    hipLaunchKernelGGL((ws256_kernel<Pro, Epi, PAIRED>), dim3((tiles + per - 1) / per, B), dim3(256), 0, st, pro, epi, Wt, Mb, per);
+    hipLaunchKernelGGL((ws256_kernel<Pro, Epi, PAIRED, NT>), dim3((tiles + per - 1) / per, B), dim3(256), 0, st, pro, epi, Wt, Mb, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -1148,8 +1217,8 @@ static int launch_ws256(const Pro& pro, const Epi& epi, const float* Wt, int B, 
 template <int K, int N, int BM, int WM, int WN, bool PAIRED, int BK = 32, int NT = 0, class Pro, class Epi>
 static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb, hipStream_t st) {
     if (B <= 0 || Mb <= 0) return RTFS_EINVAL;
-    if constexpr (K == 256 && N == 256 && NT == 0 && !Epi::kAccum) {
-        if (ws256_applies(B, Mb)) return launch_ws256<PAIRED>(pro, epi, Wt, B, Mb, st);
+    if constexpr (K == 256 && N == 256 && (NT == 0 || NT == 1 || NT == 3) && !Epi::kAccum) {
+        if (ws256_applies(B, Mb)) return launch_ws256<PAIRED, NT>(pro, epi, Wt, B, Mb, st);
     }
     dim3 grid((Mb + BM - 1) / BM, B);
     hipLaunchKernelGGL((pixel_gemm_kernel<K, N, BM, WM, WN, PAIRED, BK, Pro, Epi, NT>), grid, dim3(256), 0, st, pro, epi, Wt, Mb);
