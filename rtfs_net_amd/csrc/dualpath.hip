@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 //   steps 9-16   the PREVIOUS pair's accumulators + bias + residual rows (fetched one pair ago) -> G, in place;
 //   steps 17-24  this pair's residual rows;   steps 25-33  the h3 rows of the pair after next;
 // one barrier per pair.  Same products in the same k order per accumulator as convt_gemm2_kernel => bit-identical G.
-template <int DUMMY = 0>
+template <int NT = 0>  // 0 fp32; 1 / 3: bf16 / split-bf16 MFMA (Wt host-PACKED, the slabs packed on store; operand tuples as in unfold_ws_kernel)
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void convt_ws_kernel(SeqMap map, const float* __restrict__ src,
                                                                                                      const float* __restrict__ Wt,
                                                                                                      const float* __restrict__ bias, float* __restrict__ dst,
@@ -830,6 +830,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int c4 = (threadIdx.x & 15) * 4;
+    const int cst = NT == 0 ? c4 : (c4 >> 4) * 16 + ((c4 >> 2) & 1) * 4 + ((c4 >> 3) & 1) * 2;  // float offset of this thread's channel quad inside a slab row
     const int L = map.L;
 
     float4 wf[64];  // W' fragments: row n = 32 wn + i, k = 8 q + 4 kh .. +3  (k = 64 tap + channel)
@@ -872,7 +873,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const int idx = threadIdx.x + it * 256;
         const int q = idx >= kSlabRows * 16 ? 1 : 0;
         const int row = min((idx - q * kSlabRows * 16) >> 4, kSlabRows);  // (the last iteration's surplus threads write the scratch row)
-        st4(sl[q] + row * kSlabLd + c4, sraw[it]);
+        if constexpr (NT == 0) {
+            st4(sl[q] + row * kSlabLd + cst, sraw[it]);
+        } else {
+            const float4 pk = pack4<NT>(sraw[it]);
+            *reinterpret_cast<float2*>(sl[q] + row * kSlabLd + cst) = make_float2(pk.x, pk.y);
+            if constexpr (NT == 3) *reinterpret_cast<float2*>(sl[q] + row * kSlabLd + cst + 8) = make_float2(pk.z, pk.w);
+        }
     };
     // write-back: lane = (row i of row tile m, channels 32 wn + 8 g + 4 kh .. +3); residual rows fetched one pair ahead
     floatx16 hold0, hold1;
@@ -908,8 +915,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     fetch_begin(p0 + 1);
 #pragma unroll
     for (int it = 0; it < NIT; ++it) fetch1(it);
+    bf16x8 whi[NT ? 32 : 1], wlo[NT ? 32 : 1];  // bf16 modes: operand tuples of step q2 (see unfold_ws_kernel)
+    if constexpr (NT == 0) {
 #pragma unroll
-    for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));  // (see unfold_ws_kernel)
+        for (int q = 0; q < 44; ++q) asm volatile("" : "+a"(wf[q].x), "+a"(wf[q].y), "+a"(wf[q].z), "+a"(wf[q].w));  // (see unfold_ws_kernel)
+    } else {
+#pragma unroll
+        for (int q2 = 0; q2 < 32; ++q2) {
+            const float4 s0 = wf[2 * q2], s1 = wf[2 * q2 + 1];
+            whi[q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.x), __float_as_uint(s0.y), __float_as_uint(s1.x), __float_as_uint(s1.y)});
+            wlo[q2] = __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(s0.z), __float_as_uint(s0.w), __float_as_uint(s1.z), __float_as_uint(s1.w)});
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 32; ++q2) asm volatile("" : "+a"(whi[q2]));
+    }
     __syncthreads();
 
 #pragma unroll 1
@@ -925,34 +944,84 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        float4 eb[2][2];
-        eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
-        auto half_loop = [&](auto qh) {
+        auto piece = [&](int q) {  // 64 slots: one per step of the fp32 K loop, two per 16-k step of the bf16 loops
+            if (q < NIT) stage1(sn, q);
+            if (q >= 9 && q < 17) out1(q - 9);
+            if (q >= 17 && q < 25) res1(q - 17);
+            if (q == 25) fetch_begin(pair + 2);
+            if (q >= 25 && q < 25 + NIT) fetch1(q - 25);
+        };
+        float4 eb[2][2];      // fp32: [buffer][row tile]
+        float4 ebp[2][2][2];  // bf16: [buffer][row tile][hi | lo]
+        if constexpr (NT == 0) {
+            eb[0][0] = ld4(bp[0]), eb[0][1] = ld4(bp[1]);
+        } else {
 #pragma unroll
-            for (int qq = 0; qq < 32; ++qq) {
-                const int q = decltype(qh)::value * 32 + qq;
-                if (q + 1 < 64) {
-                    const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
-                    eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+            for (int m = 0; m < 2; ++m) ebp[0][m][0] = ld4(bp[m]), ebp[0][m][1] = ld4(bp[m] + 8);
+        }
+        auto half_loop = [&](auto qh) {
+            if constexpr (NT == 0) {
+#pragma unroll
+                for (int qq = 0; qq < 32; ++qq) {
+                    const int q = decltype(qh)::value * 32 + qq;
+                    if (q + 1 < 64) {
+                        const int o = ((q + 1) >> 3) * kSlabLd + ((q + 1) & 7) * 8;  // tap (q + 1) / 8 = slab row offset, channel 8 ((q + 1) % 8)
+                        eb[(q + 1) & 1][0] = ld4(bp[0] + o), eb[(q + 1) & 1][1] = ld4(bp[1] + o);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const float4 e0 = eb[q & 1][0], e1 = eb[q & 1][1];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e0.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].x, e1.x, acc[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q < NIT) stage1(sn, q);
-                if (q >= 9 && q < 17) out1(q - 9);
-                if (q >= 17 && q < 25) res1(q - 17);
-                if (q == 25) fetch_begin(pair + 2);
-                if (q >= 25 && q < 25 + NIT) fetch1(q - 25);
-                __builtin_amdgcn_sched_barrier(0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e0.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].y, e1.y, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e0.z, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].z, e1.z, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e0.w, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[q].w, e1.w, acc[1], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                auto tuple = [](float4 v) { return __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}); };
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) {
+                    const int q2 = decltype(qh)::value * 16 + qq;
+                    if (q2 + 1 < 32) {
+                        const int o = ((q2 + 1) >> 2) * kSlabLd + ((q2 + 1) & 3) * 16;  // tap (q2 + 1) / 4, channel group (q2 + 1) % 4
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            ebp[(q2 + 1) & 1][m][0] = ld4(bp[m] + o);
+                            if constexpr (NT == 3) ebp[(q2 + 1) & 1][m][1] = ld4(bp[m] + o + 8);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 h0 = tuple(ebp[q2 & 1][0][0]), l0 = tuple(ebp[q2 & 1][0][1]), h1 = tuple(ebp[q2 & 1][1][0]), l1 = tuple(ebp[q2 & 1][1][1]);
+                    if constexpr (NT == 3) {  // per accumulator the order of mma32<3>: lo.hi, hi.lo, hi.hi; the two chains alternate
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[q2], h0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[q2], h1, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], l0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], l1, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2 + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], h0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], h1, acc[1], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], h0, acc[0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[q2], h1, acc[1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        piece(2 * q2 + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
         half_loop(std::integral_constant<int, 0>{});
@@ -1248,8 +1317,8 @@ static int convt_impl(const float* H3, const float* Wt, const float* bias, float
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.npos + 63) / 64, total = S * tps;
     // fp32, large batch (>= 3 tile pairs per CU - measured: 84.6 vs 90.5 us at 3.9 pairs, 49.4 vs 47.6 us at 2; 32-bit offsets): the weight-stationary kernel
-    if (NT == 0 && total >= 2 * 3 * 256 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31)) {
-        hipLaunchKernelGGL(convt_ws_kernel<0>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, S, tps, total);
+    if ((NT == 0 || NT == 1 || NT == 3) && total >= 2 * 3 * 256 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31)) {
+        hipLaunchKernelGGL(convt_ws_kernel<(NT == 6 ? 0 : NT)>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, S, tps, total);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }

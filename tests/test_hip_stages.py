@@ -519,12 +519,13 @@ def test_pixel_gemm_256_weight_stationary_form(terms, tol):
     assert torch.equal(ys.view(torch.int32), y[: n * 256].view(torch.int32))
 
 
+@pytest.mark.parametrize("terms,tol", [(0, 2e-6), (3, 2e-5), (1, 1e-2)])
 @pytest.mark.parametrize("B,T2", [(17, 125), (9, 250), (3, 125)])
 @pytest.mark.parametrize("dim", [4, 3])
-def test_convt_entry_isolated(B, T2, dim):
+def test_convt_entry_isolated(B, T2, dim, terms, tol):
     """rtfs_dp_convt_fwd in isolation (ConvTranspose1d(64 -> 64, k = 8) + bias + residual, in place; rnn_layers.py:129,153-156) against float64
     on the CPU: two sizes that take the weight-stationary kernel (>= 1536 64-row tiles: full / ragged time tiles, odd tile counts) and one
-    that takes the LDS-staged kernel."""
+    that takes the LDS-staged kernel; fp32, split-bf16 and bf16 MFMA."""
     from rtfs_net_amd import lib
 
     g = torch.Generator().manual_seed(7 * B + T2 + dim)
@@ -535,13 +536,18 @@ def test_convt_entry_isolated(B, T2, dim):
     bias = torch.randn(64, generator=g) * 0.1
     G0 = torch.randn(B, T2, 64, 64, generator=g)
     G = G0.clone().cuda()
-    lib.call("rtfs_dp_convt_fwd", H3.cuda(), W.cuda(), bias.cuda(), G, B, T2, dim)
+    if terms:
+        from rtfs_net_amd.models.hip_path import pack_bf16
+
+        lib.call("rtfs_dp_convt_fwd_bf16", H3.cuda(), pack_bf16(W.cuda()), bias.cuda(), G, B, T2, dim, terms)
+    else:
+        lib.call("rtfs_dp_convt_fwd", H3.cuda(), W.cuda(), bias.cuda(), G, B, T2, dim)
     hp = torch.zeros(S, npos + 14, 64, dtype=torch.float64)
     hp[:, 7:7 + L] = H3.double()
     win = torch.stack([hp[:, k:k + npos] for k in range(8)], dim=2).reshape(S, npos, 512)
     y = win @ W.double().t() + bias.double()
     y = y.view(B, T2, 64, 64) if dim == 4 else y.view(B, 64, T2, 64).permute(0, 2, 1, 3)
-    assert rel(G.cpu(), y + G0.double()) < 2e-6
+    assert rel(G.cpu(), y + G0.double()) < tol
 
 
 def test_weight_stationary_kernels_in_the_model():
