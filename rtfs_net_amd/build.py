@@ -14,13 +14,20 @@ SOURCES = ["gemm.hip", "dualpath.hip", "attention.hip", "tfar.hip", "stft.hip", 
            "bwd_misc.hip", "spread.hip", "loss.hip", "vp.hip", "vp_train.hip", "vp_attn.hip", "lip.hip"]
 LIB = os.path.join(HERE, "librtfs_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+# The video-branch kernels run on a SIDE stream, i.e. next to the main stream's bf16 MFMA kernels on the same CUs in the bf16 / split-bf16
+# modes.  Packed-fp32 instructions that swap operand halves (v_pk_*_f32 ... op_sel), which hipcc's SLP vectoriser produces by the hundred in
+# these kernels, returned wrong low halves next to bf16 MFMA traffic (rule 10: first seen inside attn_qkv_kernel): with the
+# plain-bf16 forward 20-29 of 30 runs differed from the first by up to 2e-3, 0 of 30 with the video branch on the main stream, 0 of 30
+# with these files built without the SLP vectoriser (vp_block_kernel: 256 -> 0 such instructions, caf_video_kernel: 55 -> 0).  The depth-wise
+# kernels of tfar.hip use native 4-vectors for their packed FMAs and are not affected by the switch.
+EXTRA_FLAGS = {src: ["-fno-slp-vectorize"] for src in ("vp.hip", "tfar.hip", "vp_train.hip", "vp_attn.hip")}
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.abspath(__file__)]  # (the flags live in this file)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -33,7 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -372,9 +372,10 @@ def test_resid_large_batch_forms_match(dtype):
             model._hip.variants["resid"] = v
             outs[v] = model(mix.cuda(), emb.cuda())
     model._hip.variants["resid"] = 0
-    # the library's choice at this size is variant 3.  Not asserted bit for bit: the gLN statistics are fp64 atomic sums of fp32 partials, and the
-    # arrival order of the atomics occasionally (about 1 run in 15 of this test inside the whole suite) moves a statistic by one fp64 ulp, which can
-    # flip an fp32 rounding downstream - in the split-bf16 mode that re-draws the hi / lo operand splits (tools/repeatability.py)
+    # the library's choice at this size is variant 3.  Inside the whole suite the bf16x3 case used to differ between the two runs about once in
+    # 15 (never alone): the video-branch kernels on the side stream carried packed-fp32 op_sel instructions, which return wrong low halves next to
+    # the main stream's bf16 MFMA traffic (DESIGN.md rule 10; rtfs_net_amd/build.py builds those files without the SLP vectoriser since).
+    # tools/repeat_small.py checks run-to-run bit identity over 150 forwards per mode; here the bound stays a tolerance.
     assert rel(outs[0], outs[3]) < (1e-7 if dtype == "f32" else 3e-5)
     # fp32: only the 1e-7-level regrouping of the statistics' partial sums; split-bf16: that perturbation re-rounds the hi / lo operand splits
     # downstream, i.e. the mode's own 2^-18 product error is re-drawn (tools/check_bf16_entries.py: 4.5e-6 per entry point)

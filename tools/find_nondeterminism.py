@@ -37,7 +37,7 @@ lib.call = spy
 import rtfs_net_amd.models.hip_path as hp  # noqa: E402
 
 hp.lib.call = spy
-for dtype in ("f32", "bf16x3"):
+for dtype in (sys.argv[3:] or ["f32", "bf16x3"]):
     model.set_compute_dtype(dtype)
     ref, found = None, {}
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
