@@ -171,6 +171,15 @@ struct EpiMask {
     }
 };
 
+// sum and sum of squares of a float4 in scalar VALU instructions.  Left to hipcc, the SLP vectoriser turned the gLN partial sums of the MFMA waves of
+// resid_ws_kernel into v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1] - the packed form that returned wrong low halves next to bf16 MFMA traffic
+// (DESIGN.md rule 10), here issued BETWEEN the bf16 MFMAs of the same wave.
+__device__ __forceinline__ void stat_sums(float4 o, float& s, float& q) {
+    asm("v_add_f32 %0, %2, %3\n\tv_mul_f32 %1, %2, %2\n\tv_add_f32 %0, %0, %4\n\tv_fmac_f32 %1, %3, %3\n\tv_add_f32 %0, %0, %5\n\tv_fmac_f32 %1, %4, %4\n\tv_fmac_f32 %1, %5, %5"
+        : "=&v"(s), "=&v"(q)
+        : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+}
+
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
@@ -584,8 +593,10 @@ __global__ __launch_bounds__(256, (DEEP ? 1 : 2)) void resid_kernel(ProExpanded 
                         const float4 o = f4(pa[sub][0] + pa[sub + 2][0], pa[sub][1] + pa[sub + 2][1], pa[sub][2] + pa[sub + 2][2],
                                             pa[sub][3] + pa[sub + 2][3]) + pb4;
                         st4(epi.py + ((size_t)b * Mb + p) * kH + 16 * w + 4 * kk, o);
-                        ps += o.x + o.y + o.z + o.w;
-                        pq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                        float s4, q4;
+                        stat_sums(o, s4, q4);  // (scalar VALU: no packed op_sel instruction next to the bf16 MFMAs)
+                        ps += s4;
+                        pq += q4;
                     }
                 }
             }
@@ -731,9 +742,11 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
                                         pa[sub][3] + pa[sub + 2][3]) + pb4;
                     __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)}, rpy,
                                                            (int)(((unsigned)p * kH + 16 * w + 4 * kk) * 4u), 0, 0);
-                    if (p < Mb) {
-                        ps += o.x + o.y + o.z + o.w;
-                        pq += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                    if (p < Mb) {  // (scalar VALU through inline asm: see stat_sums)
+                        float s4, q4;
+                        stat_sums(o, s4, q4);
+                        ps += s4;
+                        pq += q4;
                     }
                 }
             }
@@ -943,8 +956,10 @@ __global__ __launch_bounds__(256, 2) void proj_kernel(ProGateway pro, EpiBiasSta
             if (p < Mb) {
                 const float4 v = f4(acc[pt][0], acc[pt][1], acc[pt][2], acc[pt][3]) + bias4;
                 st4(epi.y + ((size_t)b * Mb + p) * kH + 16 * w + 4 * kk, v);
-                s += v.x + v.y + v.z + v.w;
-                qq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                float s4, q4;
+                stat_sums(v, s4, q4);  // (scalar VALU: no packed op_sel instruction next to the bf16 MFMAs)
+                s += s4;
+                qq += q4;
             }
         }
     }
