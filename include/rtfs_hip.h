@@ -70,7 +70,7 @@ int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, co
 /* dim 4: sequences along F (one per (b,t2)); dim 3: along T (one per (b,f2)).  S sequences of L = npos-7 windows. */
 /* variant: 0 = the library's choice (fp32 at >= 1024 flattened 64-row tiles: weight-stationary kernel, W0 resident in registers; else LDS-staged
  * kernels on tiles cut from the flattened (sequence, window) row index), 1 = tiles padded per sequence, 2 = LDS-staged flattened tiles (A/B: 1 and 2
- * give the same bits; the weight-stationary kernel's LayerNorm uses v_rsq_f32 and agrees to 1 ulp of rstd).  The bf16 entry takes 0 or 1. */
+ * give the same bits; the weight-stationary kernel's LayerNorm uses v_rsq_f32 and agrees to 1 ulp of rstd).  The bf16 entry takes the same range (0 .. 2). */
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, float* U0, int B, int T2, int dim,
                             int variant, void* stream);
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,

@@ -133,7 +133,7 @@ def to_2d(x):
 def stft_frames(x, win, hop):
     """torch.stft(center=True, reflect, periodic hann, onesided) then stack/transpose: encoder.py:161-173.
     [B, L] -> [B, 2, T, F]"""
-    window = torch.hann_window(win, dtype=x.dtype)
+    window = torch.hann_window(win).to(x.dtype)  # (the reference's buffer is built in float32, encoder.py:159, and only cast by .double())
     spec = torch.stft(x, n_fft=win, hop_length=hop, window=window, return_complex=True)
     return torch.stack([spec.real, spec.imag], 1).transpose(2, 3).contiguous()
 
@@ -152,7 +152,7 @@ def decoder(x, length, p: P, cfg):
     k = p["decoder.weight"].shape[-1]
     y = F.conv_transpose2d(x, p["decoder.weight"], p["decoder.bias"] if p.has("decoder.bias") else None, padding=(k - 1) // 2)
     spec = torch.complex(y[:, 0], y[:, 1]).transpose(1, 2).contiguous()
-    window = torch.hann_window(cfg["win"], dtype=x.dtype)
+    window = torch.hann_window(cfg["win"]).to(x.dtype)  # (float32-built buffer, decoder.py:108)
     out = torch.istft(spec, n_fft=cfg["win"], hop_length=cfg["hop"], window=window, length=length)
     return out.view(B, n_src, length)
 

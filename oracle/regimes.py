@@ -1,0 +1,99 @@
+"""ORACLE-side helpers of the gradient checks (test infrastructure, not product code): inputs and weights on which float64 autograd is a
+fair judge of an fp32 / split-bf16 training step.  Used by oracle/gen_golden_grads.py (which stores their RESULTS under tests/golden/, so the
+GPU box does none of this work) and by the few tests that still run the oracle live on small inputs.
+
+The gradient CASES of tests/test_hip_backward.py live here as well: the generator and the test iterate over the same list.
+"""
+import torch
+
+from . import avnet_ref
+
+# (training, B, L, R, Tv)
+GRAD_CASES = [
+    (False, 2, 4096, 2, 6),     # eval, two blocks
+    (True, 2, 4096, 2, 6),      # train; Tv = 6 < 8: the VP block runs as PyTorch glue (models/avnet.py) on 6 / 3 / 2 / 1 tokens
+    (True, 2, 8192, 2, 12),     # train, Tv = 12: VP block on the HIP training kernels (csrc/vp_train.hip), batch statistics over 2 x (12, 6, 3, 2) positions
+    (True, 3, 16000, 1, 25),    # train, B = 3, Tv = 25, R = 1 (block 0 only: a0_mode 4)
+    (False, 1, 12100, 1, 19),   # T2 = 47: 40-step time sequences (all-taps Toeplitz weight gradient, 2-tile fold kernel on both dual paths); odd L
+    (False, 1, 4096, 3, 6),     # R = 3: a MIDDLE block (rtfs_proj_gateway_bwd with da0 += ds)
+    (False, 1, 32000, 2, 50),   # one full-length utterance (T2 = 125, 57- / 118-step sequences): the shapes of BASELINE config 3
+]
+SMOOTH_CASES = [GRAD_CASES[1], GRAD_CASES[2], GRAD_CASES[5], GRAD_CASES[6]]  # the split-bf16 step's cases, on smooth_regime weights
+GRAD_WEIGHT_SEED = 7  # seed of the output weighting of the scalar loss (out * wgt).sum()
+
+
+def case_name(kind, training, B, L, R, Tv):
+    return f"grads_{kind}_{'train' if training else 'eval'}_B{B}_L{L}_R{R}_Tv{Tv}"
+
+# A PReLU / ReLU input that lies within fp32 round-off of 0 may land on either side of the kink in an fp32 evaluation; the gradient
+# of that ONE element then differs by O(1) from the float64 reference.  In the audio branch (>= 1e5 elements per site) one element is
+# noise; in the 50-token video branch it moves ~100 gradient tensors by 1e-2.  The gradient tests therefore make
+# the question moot instead of loosening tolerances: `stable_emb` nudges the lip embeddings until the float64 oracle sees no video-branch
+# activation within `margin` (relative to the site's rms) of its kink - a deterministic function of (weights, inputs).
+VIDEO_PREFIX = "refinement_module.video_net.blocks"
+
+
+def _video_margin(sd, cfg, emb, training):
+    """smallest |x| / rms(x) over the inputs of every PReLU / ReLU of the VP block (float64 oracle, tdanet_block on the video input)"""
+    sd64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items() if k.startswith(VIDEO_PREFIX)}
+    worst = [float("inf")]
+
+    def probe(x, kind):
+        rms = float(x.detach().pow(2).mean().sqrt()) + 1e-30
+        worst[0] = min(worst[0], float(x.detach().abs().min()) / rms)
+
+    avnet_ref.ACT_PROBE = probe
+    try:
+        with torch.no_grad():
+            avnet_ref.tdanet_block(emb.double(), avnet_ref.P(sd64).sub(VIDEO_PREFIX), avnet_ref.normalise_cfg(cfg)["video"], training=training)
+    finally:
+        avnet_ref.ACT_PROBE = None
+    return worst[0]
+
+
+def stable_emb(sd, cfg, emb, training, margin=2e-5, tries=60):
+    """lip embeddings with no video-branch activation within `margin` of a kink: `emb` itself if it already qualifies, else `emb` plus
+    seeded N(0, 1e-3) perturbations (try k uses generator seed k) - fp32 round-off of the VP chain is ~1e-6 relative, 20x inside"""
+    cand = emb
+    for k in range(tries):
+        if _video_margin(sd, cfg, cand, training) >= margin:
+            return cand
+        cand = emb + 1e-3 * torch.randn(emb.shape, generator=torch.Generator().manual_seed(k))
+    raise AssertionError("no kink-free lip embedding found")
+
+
+def smooth_regime(sd, cfg, mix, emb, training):
+    """A state dict on which the network is (numerically) smooth around (mix, emb): every PReLU slope in [0.97, 1.0] (a flip changes a
+    derivative by <= 3 %, not 60-90 %) and every ReLU input shifted, per channel, to >= 5 % of the site's rms (bias / beta of the layer in front of
+    it; exact, processed in forward order).  The split-bf16 training step carries ~70x the fp32 round-off, which moves thousands of AUDIO
+    activations across their kinks on ordinary weights (median gradient error 3e-3, worst tensor 4e-2 against float64: a property of the
+    function at that noise level, not of a kernel); on this state dict the same step must - and does - hold a tight per-tensor tolerance.
+    The activation adjoints themselves are fp32 kernels shared with the fp32 step, which the ordinary-weight tests hold to 3e-3."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if k.rsplit(".", 1)[-1] == "weight" and v.numel() == 1:
+            sd[k] = 0.96 + 0.1 * v
+    caf = "refinement_module.crossmodal_fusion.fusion_module.audio_lstm."
+    relu_bias = ["audio_bottleneck.full_layer.0.norm.bias", VIDEO_PREFIX + ".globalatt.0.FFN.refiner.full_layer.2.bias",
+                 caf + "key_embed.full_layer.3.bias", "mask_generator.mask_generator.1.full_layer.2.bias"]  # in forward order (avnet_forward)
+    for i, key in enumerate(relu_bias):
+        seen = []
+
+        def probe(x, kind):
+            if kind == "ReLU":
+                seen.append(x.detach())
+
+        sd64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        avnet_ref.ACT_PROBE = probe
+        try:
+            with torch.no_grad():
+                avnet_ref.avnet_forward(sd64, cfg, mix.double(), emb.double(), training=training)
+        finally:
+            avnet_ref.ACT_PROBE = None
+        assert len(seen) == len(relu_bias), len(seen)
+        x = seen[i]
+        dims = [d for d in range(x.ndim) if d != 1]
+        floor = 0.05 * float(x.pow(2).mean().sqrt())
+        shift = (floor - x.amin(dim=dims)).clamp_min(0)
+        sd[key] = (sd[key].double() + shift).to(sd[key].dtype)
+    return sd

@@ -55,18 +55,49 @@ def _lengths(T):
     return Ts
 
 
+class BatchCountProbe:
+    """SyncBatchNorm's utterance count, checked without a stall: SUM all-reduce of this rank's batch size (issued by EVERY rank on EVERY step),
+    asynchronous copy to pinned host memory, event; `verify()` waits for the event only and raises ValueError on unequal per-rank batches."""
+
+    def __init__(self, B, dev):
+        self.B, self.world = int(B), torch.distributed.get_world_size()
+        count = torch.full((1,), float(B), device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(count)
+        self.event = None
+        if count.is_cuda:
+            self.host = torch.empty(1, dtype=torch.float64, pin_memory=True)
+            self.host.copy_(count, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host = count
+
+    def verify(self):
+        if self.event is not None:
+            self.event.synchronize()
+        total = float(self.host[0])
+        if total != float(self.B * self.world):
+            raise ValueError(f"SyncBatchNorm in the VP block's HIP training step needs equal per-rank batch sizes: this rank holds {self.B} utterances, "
+                             f"the {self.world} ranks together {total:g}: use drop_last / DistributedSampler padding, or RTFS_VP_GLUE=1 for the PyTorch modules")
+
+
 class VPTrainer:
     def __init__(self, vb):
         self.vb = vb
         self.bns = _bn_modules(vb)
         self._ncache = {}
-        self._equal_batches = set()  # per-rank batch sizes already verified equal across ranks (SyncBatchNorm)
+        self._pending = None  # SyncBatchNorm: the step's all-reduced utterance count, not yet compared with B x world (BatchCountProbe)
 
     # ---- helpers ----------------------------------------------------------------------------------------------------------
     def _sync(self):
         bn = self.bns[0]
         return (isinstance(bn, torch.nn.SyncBatchNorm) and self.vb.training and torch.distributed.is_available() and torch.distributed.is_initialized()
                 and torch.distributed.get_world_size() > 1)
+
+    def check_equal_batches(self):
+        probe, self._pending = self._pending, None
+        if probe is not None:
+            probe.verify()
 
     def _allreduce(self, st, t):
         if st.sync:
@@ -82,17 +113,15 @@ class VPTrainer:
         st.sync = self._sync()
         dev = x.device
         # utterances behind the statistics: all ranks' under SyncBatchNorm.  Equal per-rank batches (what DistributedSampler delivers) make that
-        # B x world without a per-step collective + host read-back; the assumption is CHECKED once per batch size (one MIN/MAX all-reduce) and
-        # an unequal last batch raises instead of silently skewing mean / variance and the dx scaling (torch's SyncBatchNorm all-reduces counts)
+        # B x world without a host read-back in front of the first kernel.  The assumption is CHECKED every step: every rank issues the same
+        # one-element SUM all-reduce of its own B (the decision to communicate never depends on rank-local state - a per-rank cache of verified
+        # batch sizes would pair this collective with another rank's statistics all-reduce on an unequal last batch), the result travels to
+        # pinned host memory behind an event, and `check_equal_batches` reads it at the start of the step's backward (long complete by then: no
+        # stall) and raises before any gradient of the skewed statistics can reach the optimizer (torch's SyncBatchNorm all-reduces counts)
         st.Bn = float(st.B * (torch.distributed.get_world_size() if st.sync else 1))
-        if st.sync and st.B not in self._equal_batches:
-            probe = torch.tensor([float(st.B), -float(st.B)], device=dev)
-            torch.distributed.all_reduce(probe, op=torch.distributed.ReduceOp.MAX)
-            lo, hi = -float(probe[1]), float(probe[0])
-            if lo != hi:
-                raise ValueError(f"SyncBatchNorm in the VP block's HIP training step needs equal per-rank batch sizes, got {int(lo)} ... {int(hi)}: "
-                                 "use drop_last / DistributedSampler padding, or RTFS_VP_GLUE=1 for the PyTorch modules")
-            self._equal_batches.add(st.B)
+        self.check_equal_batches()  # a forward-only step that was never followed by a backward
+        if st.sync:
+            self._pending = BatchCountProbe(st.B, dev)
         st.stats = torch.zeros(NS, 2, 64, device=dev, dtype=torch.float64)  # float64 slots (order-independent sums; E[x^2] - mean^2 differenced in float64)
         # the two scalar PReLU slopes are kernel arguments: taken from the caller (AVNet reads every scalar of the model in ONE transfer per
         # optimizer step, hip_path.PreparedWeights) - fetching them here would be a host synchronisation in the middle of the step
@@ -388,6 +417,7 @@ class VPStageB(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         trainer, st = ctx.trainer, ctx.holder.st
+        trainer.check_equal_batches()
         with torch.no_grad():
             dg2 = trainer.backward_b(st, dout)
             grads = trainer.grads_b(st)
@@ -405,8 +435,11 @@ def attn_supported(ga) -> bool:
     try:
         m, f = ga.MHSA, ga.FFN
         return (type(ga).__name__ == "GlobalAttention" and m.attention.embed_dim == 64 and m.attention.num_heads == 8 and m.attention.in_proj_weight is not None
-                and f.encoder.out_chan == 128 and f.refiner.kernel_size == 3 and abs(m.norm1.eps - EPS) < 1e-12 and abs(m.norm2.eps - EPS) < 1e-12)
-    except AttributeError:
+                and f.encoder.out_chan == 128 and f.refiner.kernel_size == 3 and abs(m.norm1.eps - EPS) < 1e-12 and abs(m.norm2.eps - EPS) < 1e-12
+                # the kernels add the positional table and the packed in-projection bias unconditionally and index tokens batch-first
+                and hasattr(m.pos_enc, "pe") and m.attention.in_proj_bias is not None and m.attention.batch_first
+                and max(float(m.attention.dropout), float(m.dropout_layer.p), float(m.drop_path_layer.p), float(f.dropout_layer.p)) < 1.0)
+    except (AttributeError, TypeError):
         return False
 
 
@@ -460,6 +493,8 @@ class VPAttnFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("VPAttnFn: second backward through the same step (retain_graph=True): the saved tensors are released after the first one")
         g, packed, pe, masks = ctx.saved
         B, _, Tg = g.shape
         with torch.no_grad():
@@ -499,18 +534,17 @@ def vp_block_train(trainer: VPTrainer, x: torch.Tensor, slopes=None) -> torch.Te
     return VPStageB.apply(trainer, holder, g2, *trainer.params_b())
 
 
-_EVAL_TRAINERS = {}
 
 
 @torch.no_grad()
 def vp_block_eval(vb, x, slopes=None):
     """The VP block in eval mode WITHOUT autograd on the multi-launch kernels (any length up to 4096 frames; the one-kernel inference form
     csrc/vp.hip holds 4 s): stage A, GlobalAttention (HIP up to 16 pooled tokens, else the module), stage B; BatchNorm from the running statistics."""
-    tr = _EVAL_TRAINERS.get(id(vb))
-    if tr is None or tr.vb is not vb or tr.bns[0] is not vb.projection.full_layer[3]:
+    tr = vb.__dict__.get("_hip_eval_trainer")  # kept on the module itself (not a parameter / buffer / child: invisible to state_dict), dies with it
+    if tr is None or tr.bns[0] is not vb.projection.full_layer[3]:
         if not supported(vb):
             return vb(x).contiguous()
-        tr = _EVAL_TRAINERS[id(vb)] = VPTrainer(vb)
+        tr = vb.__dict__["_hip_eval_trainer"] = VPTrainer(vb)
     if vb.training:
         raise RuntimeError("vp_block_eval is the inference path (model.eval())")
     g, st = tr.forward_a(x, slopes)
@@ -543,6 +577,8 @@ class CAFVideoFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, datt, drsz):
+        if ctx.saved is None:
+            raise RuntimeError("CAFVideoFn: second backward through the same step (retain_graph=True): the saved tensors are released after the first one")
         v1, ps = ctx.saved
         B, _, Tv = v1.shape
         with torch.no_grad():

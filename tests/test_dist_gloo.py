@@ -103,3 +103,42 @@ def test_two_rank_sync_batchnorm_adjoint():
     for rank, edx, epg, n in res:
         assert n == 65.0
         assert edx < 1e-4 and epg < 1e-3, (rank, edx, epg)
+
+
+# ---- SyncBatchNorm utterance count of the VP block's HIP training step (unequal last batch) ------------------------------
+def _count_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtfs_net_amd.models.vp_train import BatchCountProbe
+
+    outcome = []
+    # three steps: equal batches, equal again (a per-rank cache of verified sizes would now skip the collective on rank 0 only), ragged last batch.
+    # Every rank issues exactly one count all-reduce per step, followed by a statistics-shaped float64 all-reduce: the pairing must stay intact.
+    for step, per_rank in enumerate([(8, 8), (8, 8), (8, 4)]):
+        probe = BatchCountProbe(per_rank[rank], torch.device("cpu"))
+        stats = torch.full((2, 64), float(rank + 1), dtype=torch.float64)
+        dist.all_reduce(stats)
+        assert float(stats[0, 0]) == 3.0
+        try:
+            probe.verify()
+            outcome.append("ok")
+        except ValueError as e:
+            outcome.append("ValueError" if "equal per-rank batch sizes" in str(e) else repr(e))
+    q.put((rank, outcome))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_unequal_last_batch_is_refused_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_count_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, outcome in res:
+        assert outcome == ["ok", "ok", "ValueError"], (rank, outcome)

@@ -1,57 +1,37 @@
-"""GPU parity of the training step: gradients of EVERY parameter from the HIP backward chain (audio branch, CAF, VP block) against torch
-autograd of the oracle in float64, in eval mode (BatchNorm running statistics) and train mode (batch statistics; dropout forced to 0
+"""GPU parity of the training step: gradients of EVERY parameter from the HIP backward chain (audio branch, CAF, VP block) against float64
+autograd of THE REFERENCE ITSELF (tests/golden/grads_*.npz, written by oracle/gen_golden_grads.py from /root/reference/src/models - which also holds
+the oracle restatement's autograd to 1e-7 of the reference's; the GPU box does no CPU-side oracle work for these cases), in eval mode (BatchNorm running statistics) and train mode (batch statistics; dropout forced to 0
 because the oracle has none), plus the BatchNorm running statistics the train-mode step leaves behind.
 
 Deterministic: one input seed per case, one tolerance per precision, no retries.
   fp32 / bf16x6 step:  ||g - ref|| <= 3e-3 * (||ref|| + 1e-4 * largest gradient norm) per parameter tensor; 5e-2 for the 15 scalar PReLU
                        slopes (ONE signed, heavily cancelling fp32 sum over 3e4 ... 2e6 activations each: observed up to 1.4e-2 at full
                        length, 4e-3 on the short cases); median over the tensors < 1e-3.
-  bf16x3 step:         1.5e-3 per tensor, 1e-2 on the scalar slopes, median < 1e-3 - on the SMOOTH-REGIME weights of util.smooth_regime
+  bf16x3 step:         1.5e-3 per tensor, 1e-2 on the scalar slopes, median < 1e-3 - on the SMOOTH-REGIME weights of oracle/regimes.py smooth_regime
                        (observed on MI355X: median 1e-5 ... 2e-5, worst tensor 2.8e-4).
 Activation kinks: an fp32 evaluation that lands on the other side of a PReLU / ReLU kink than float64 is off by O(1) in that element's
 derivative.  One element of an audio tensor is noise, one element of the 50-token video branch moves ~100 tensors by 1e-2 - so every case
-runs on lip embeddings that util.stable_emb has moved (deterministically, only if needed: the default full-length input has a video
+runs on lip embeddings that regimes.stable_emb has moved (deterministically, only if needed: the default full-length input has a video
 activation 3e-6 of its site's rms away from 0) out of round-off distance of every video-branch kink.  The split-bf16 step carries ~70x the
 fp32 round-off and flips thousands of AUDIO activations on ordinary weights; its GEMM entry points are what differs from the fp32 step, and
 they are checked where the function is smooth (slopes in [0.97, 1], ReLU inputs positive), tightly, instead of loosely where it is not.
 """
+import numpy as np
 import pytest
 import torch
 
-from util import make_model, rel, smooth_regime, stable_emb, synth
+from oracle.regimes import GRAD_CASES as CASES, GRAD_WEIGHT_SEED, SMOOTH_CASES, case_name
+from util import load_npz, make_model, rel, synth
 
 pytestmark = pytest.mark.gpu
 GLUE_VIDEO = ("refinement_module.video_net.",)
-
-CASES = [
-    (False, 2, 4096, 2, 6),     # eval, two blocks
-    (True, 2, 4096, 2, 6),      # train; Tv = 6 < 8: the VP block runs as PyTorch glue (models/avnet.py) on 6 / 3 / 2 / 1 tokens
-    (True, 2, 8192, 2, 12),     # train, Tv = 12: VP block on the HIP training kernels (csrc/vp_train.hip), batch statistics over 2 x (12, 6, 3, 2) positions
-    (True, 3, 16000, 1, 25),    # train, B = 3, Tv = 25, R = 1 (block 0 only: a0_mode 4)
-    (False, 1, 12100, 1, 19),   # T2 = 47: 40-step time sequences (all-taps Toeplitz weight gradient, 2-tile fold kernel on both dual paths); odd L
-    (False, 1, 4096, 3, 6),     # R = 3: a MIDDLE block (rtfs_proj_gateway_bwd with da0 += ds)
-    (False, 1, 32000, 2, 50),   # one full-length utterance (T2 = 125, 57- / 118-step sequences): the shapes of BASELINE config 3
-]
-
-
-def _oracle_grads(sd, cfg, mix, emb, wgt, training, dtype=torch.float64):
-    from oracle.avnet_ref import avnet_forward
-
-    nograd = ("running_mean", "running_var", "scale_x", ".pe")
-    sd64 = {k: (v.to(dtype).clone().requires_grad_(not k.endswith(nograd)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    out = avnet_forward(sd64, cfg, mix.to(dtype), emb.to(dtype), training=training)
-    (out * wgt.to(dtype)).sum().backward()
-    grads = {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.requires_grad and v.grad is not None}
-    stats = {k: v.detach() for k, v in sd64.items() if k.endswith(("running_mean", "running_var"))}  # F.batch_norm(training=True) updated them in place
-    return out.detach(), grads, stats
-
 
 @pytest.mark.parametrize("training,B,L,R,Tv", CASES)
 def test_parameter_gradients(training, B, L, R, Tv):
     _check_parameter_gradients(training, B, L, R, Tv, "f32")
 
 
-@pytest.mark.parametrize("training,B,L,R,Tv", [CASES[1], CASES[2], CASES[5], CASES[6]])
+@pytest.mark.parametrize("training,B,L,R,Tv", SMOOTH_CASES)
 def test_parameter_gradients_split_bf16_step(training, B, L, R, Tv):
     """`set_compute_dtype("bf16x3")`: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain as three-term split-bf16
     products on the bf16 MFMA pipe (fp32 accumulation), on the smooth-regime weights (module docstring)."""
@@ -65,26 +45,40 @@ def test_parameter_gradients_fp32_equivalent_split_step(training, B, L, R, Tv):
     _check_parameter_gradients(training, B, L, R, Tv, "bf16x6")
 
 
-def _check_parameter_gradients(training, B, L, R, Tv, dtype):
+def test_parameter_gradients_split_bf16_step_on_ordinary_weights():
+    """the split-bf16 step also on ORDINARY weights (active PReLU / ReLU kinks, slopes 0.1 ... 0.4), where its ~70x fp32 round-off flips
+    audio activations across their kinks: the documented looser bound (median < 5e-3, per tensor 6e-2) - a wrong operand fed to an activation
+    adjoint on the bf16 path shows as O(1) errors, far outside it"""
+    _check_parameter_gradients(*CASES[2], "bf16x3", kind="plain", tol=6e-2, tol_scalar=6e-2, tol_median=5e-3)
+
+
+def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None, tol_scalar=None, tol_median=1e-3):
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
             mod.p = 0.0
         if isinstance(mod, torch.nn.MultiheadAttention):
             mod.dropout = 0.0
-    mix, _, emb = synth.synth_inputs(B, L, Tv)
-    if dtype == "bf16x3":
-        sd = smooth_regime(sd, cfg, mix, emb, training)
+    kind = kind or ("smooth" if dtype == "bf16x3" else "plain")
+    z = load_npz(case_name(kind, training, B, L, R, Tv) + ".npz")
+    mix, _, _ = synth.synth_inputs(B, L, Tv)
+    assert np.array_equal(mix[:, :256].numpy(), z["mix_head"])
+    if kind == "smooth":  # smooth-regime weights (oracle/regimes.py): the fixture holds the entries that differ from the synthetic state dict
+        sd = dict(sd)
+        sd.update({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd.")})
         model.load_state_dict(sd)
-    emb = stable_emb(sd, cfg, emb, training)
+    emb = torch.from_numpy(z["emb"])  # kink-stable lip embeddings (regimes.stable_emb)
     model.train(training)
     model.set_compute_dtype(dtype)
-    wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(7))
+    wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(GRAD_WEIGHT_SEED))
     out = model(mix.cuda(), emb.cuda())
     (out * wgt.cuda()).sum().backward()
-    ref_out, ref, ref_stats = _oracle_grads(sd, cfg, mix, emb, wgt, training)
+    ref_out = torch.from_numpy(z["out"])
+    ref = {k[5:]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith("grad.")}
+    ref_stats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("stat.")}
     assert rel(out.detach(), ref_out) < 1e-3
-    tol, tol_scalar = (1.5e-3, 1e-2) if dtype == "bf16x3" else (3e-3, 5e-2)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
+    if tol is None:
+        tol, tol_scalar = (1.5e-3, 1e-2) if dtype == "bf16x3" else (3e-3, 5e-2)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
     glue_video = training and Tv < 8  # the VP block as PyTorch glue on <= 7 tokens with batch statistics over B x (1 ... 6) positions: not a kernel of this build
     scale = max(float(g.norm()) for g in ref.values())
     checked, errs, bad = 0, [], []
@@ -106,7 +100,7 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype):
     errs.sort()
     print(f"{dtype} train={training} B={B} L={L} R={R} Tv={Tv}: median gradient error {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}, {checked} tensors")
     assert not bad, sorted(bad, reverse=True)[:12]
-    assert errs[len(errs) // 2] < 1e-3
+    assert errs[len(errs) // 2] < tol_median
     if training:  # running statistics of the 26 VP BatchNorm1d + 2 CAF BatchNorm2d layers after one step (momentum 0.1, unbiased variance)
         got = {k: v for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
         assert len(got) == 56 and set(got) == set(ref_stats)

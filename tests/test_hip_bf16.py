@@ -23,10 +23,16 @@ def _run(model, mix, emb, dtype, all_blocks=True):
     with torch.no_grad():
         out = model(mix, emb)
     torch.cuda.synchronize()
-    taps = {k: v.detach().float().cpu().clone() for k, v in model._hip.taps.items()}
+    taps = {k: v.detach().float().clone() for k, v in model._hip.taps.items()}  # stay on the device: at B = 8 the stage taps are GBs
     model._hip.taps, model._hip.tap_all_blocks = None, False
     model.set_compute_dtype("f32")
-    return out.cpu(), taps
+    return out, taps
+
+
+def _rel_dev(a, b):
+    """relative L2 error on the device (float64 accumulation), one scalar to the host"""
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
 
 
 @pytest.mark.parametrize("B", [2, 8])  # B = 2: per-sequence Toeplitz tiles in the layer-0 GEMM; B = 8: the flattened-row persistent kernel
@@ -42,7 +48,7 @@ def test_every_stage_against_the_fp32_path(dtype, B):
     stage_tol, wave_tol = TOL[dtype]
     worst = ("", 0.0)
     for k in t32:
-        e = rel(t[k], t32[k])
+        e = _rel_dev(t[k], t32[k])
         worst = max(worst, (k, e), key=lambda kv: kv[1])
         assert e < stage_tol, (k, e)
     print(dtype, "worst stage vs fp32:", worst, " waveform vs fp32:", rel(out, out32))

@@ -6,7 +6,8 @@ import sys
 
 import torch
 
-from util import make_model, smooth_regime, stable_emb, synth, _video_margin
+from oracle.regimes import _video_margin, smooth_regime, stable_emb
+from util import make_model, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
