@@ -199,6 +199,12 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
 
     elapsed = max_over_ranks(elapsed, dev, dist)
     frames = sum_over_ranks(float((hi - lo) * T * a.steps), dev, dist)  # the units ALL ranks processed
+    nranks, devs = 1.0, [torch.cuda.get_device_name(dev) + f" #{local_rank}"]
+    if dist is not None:
+        nranks = sum_over_ranks(1.0, dev, dist)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devs[0])
+        devs = gathered
     handles = SimpleNamespace(model=model, sd=sd, cfg=cfg, L=L, T=T, Tv=Tv, dev=dev)
     if rank != 0:
         return None, handles
@@ -207,6 +213,8 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         "value": frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
+        "dist": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_reporting": int(round(nranks)),
+                                           "devices": sorted(set(devs))},  # what the collective layer itself saw (an 8-rank RCCL run is self-evidencing)
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps,
@@ -311,8 +319,42 @@ def cpu_baseline(res, h, a):
     m_or = separation_metrics(cmix[0].to(h.dev), tgt, c_or[0].to(h.dev))
     res["si_sdri_parity"] = {"hip_db": m_hip["si-snr_i"], "oracle_db": m_or["si-snr_i"], "abs_diff_db": abs(m_hip["si-snr_i"] - m_or["si-snr_i"]),
                              "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
-    res["cpu_baseline"] = {"value": h.T / dt, "unit": "frames/s", "cores": n, "kind": "port",
+    res["cpu_baseline"] = {"value": h.T / dt, "unit": "frames/s", "cores": n, "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
                            "sample": f"oracle/avnet_ref.py, RTFS-Net-{a.layers}, batch 1 x {a.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)"}
+    # BASELINE.json configs[0] (the reference's own CPU-runnable case): RTFS-Net-4, batch 1, 2 s, forward only, on the same thread count
+    # and on ONE thread (per-core figure); median of 3 after one warm-up each - a couple of seconds
+    try:
+        c1cfg = synth.rtfs_audionet(4)
+        c1mix, _, c1emb = synth.synth_inputs(1, 32000, 50)
+        c1sd = h.sd  # RTFS-Net-R state dicts share every key (the R repeats share one set of block weights)
+        c1 = {}
+        with torch.no_grad():
+            for label, nthr in (("threads", n), ("one_thread", 1)):
+                torch.set_num_threads(nthr)
+                avnet_forward(c1sd, c1cfg, c1mix, c1emb)
+                ts = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    avnet_forward(c1sd, c1cfg, c1mix, c1emb)
+                    ts.append(time.perf_counter() - t1)
+                c1[label] = sorted(ts)[1]
+        torch.set_num_threads(n)
+        res["cpu_baseline"]["config1"] = {"workload": "RTFS-Net-4, batch 1, 2 s, forward only (BASELINE.json configs[0])", "frames_per_s": 251 / c1["threads"],
+                                          "s_per_utterance": c1["threads"], "cores": n, "frames_per_s_one_thread": 251 / c1["one_thread"],
+                                          "s_per_utterance_one_thread": c1["one_thread"]}
+    except Exception as e:  # noqa: BLE001
+        res["cpu_baseline"]["config1"] = None
+        print(f"config-1 CPU rider failed: {type(e).__name__}: {e}", file=sys.stderr)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def brief(t):

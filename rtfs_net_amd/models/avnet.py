@@ -241,7 +241,7 @@ class AVNet(nn.Module):
         cur = torch.cuda.current_stream()
         if getattr(self, "_glue_stream", None) is None or self._glue_stream.device != x.device:
             self._glue_stream = torch.cuda.Stream(device=x.device)
-        side = self._glue_stream if os.environ.get("RTFS_VP_NO_SIDE", "0") != "1" else cur
+        side = self._glue_stream if self._hip.vp_side_stream else cur
         inputs_ready = cur.record_event()
         names = self._hip_param_names()
         params = dict(self.named_parameters())
@@ -251,7 +251,7 @@ class AVNet(nn.Module):
         with torch.cuda.stream(side):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
             vb = rm.video_net.get_block(0)
-            if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 4096 and os.environ.get("RTFS_VP_GLUE", "0") != "1":
+            if self._vp_trainer(vb) is not None and 8 <= vin.shape[-1] <= 4096 and not self._hip.vp_glue:
                 # the VP block on HIP kernels: convolution / BatchNorm chain and GlobalAttention (models/vp_train.py)
                 from .vp_train import vp_block_train
 

@@ -252,6 +252,12 @@ class HipForward:
         # kernel-form choices handed to the C-ABI as explicit `variant` arguments (0 = the library's own choice; include/rtfs_hip.h) - a
         # HOST-side setting for same-box A/B runs and the equivalence tests, the library itself reads no environment
         self.variants = {"resid": int(os.environ.get("RTFS_RESID_VARIANT", "0")), "unfold": int(os.environ.get("RTFS_UNFOLD_VARIANT", "0"))}
+        # A/B switches of the host-side fusion choices, read from the environment ONCE here (not per forward); tests flip the attributes
+        off = lambda name: os.environ.get(name, "0") == "1"  # noqa: E731
+        self.fuse = {"trio": not off("RTFS_NO_TRIO_FUSION"), "mix": not off("RTFS_NO_MIX_FUSION"), "proj": not off("RTFS_NO_PROJ_FUSION"),
+                     "caf": not off("RTFS_NO_CAF_FUSION")}
+        self.vp_glue = off("RTFS_VP_GLUE")  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
+        self.vp_side_stream = not off("RTFS_VP_NO_SIDE")
 
     def weights(self) -> PreparedWeights:
         fp = PreparedWeights.fingerprint(self.model)
@@ -313,7 +319,7 @@ class HipForward:
         G = low()
         f0l = bw["fusion_layers.0.local_embedding"]
         l0 = None
-        if os.environ.get("RTFS_NO_TRIO_FUSION", "0") != "1":
+        if self.fuse["trio"]:
             # the three readers of gLN(D0) - D1's stride-2 conv, the pooling, fusion_layers[0]'s local embedding - in one pass over D0
             l0, pooled = full(), low()
             lib.call("rtfs_dwconv_trio_fwd", D0, st[1], d0g, d0be, f0l[0], l0, st[3], d1w, d1b, D1, st[2], pooled, B, T, T2)
@@ -353,7 +359,7 @@ class HipForward:
         lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [g0, gg0, g1, gg1],
                  [st[5], st[6], st[7], st[8]], B, T2, F2)
         cl, cg, cgate = full(), low(), low()
-        fuse_mix = os.environ.get("RTFS_NO_MIX_FUSION", "0") != "1"
+        fuse_mix = self.fuse["mix"]
         if tap is not None or not fuse_mix:  # the mixed tensors themselves (stage taps of the tests; the un-fused A/B path)
             F0, F1 = full(), low()
             lib.call("rtfs_tfar_mix_fwd", l0, st[3], f0l[2], f0l[3], gg0, st[6], f0gate[2], f0gate[3], g0, st[5], f0g[2], f0g[3], F0, B, T, F_BINS, T2, F2)
@@ -440,7 +446,7 @@ class HipForward:
         with torch.cuda.stream(self._vp_stream):
             vin = m.video_bottleneck(emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
             vblock = m.refinement_module.video_net.get_block(0)
-            use_hip = w["vp"] is not None and os.environ.get("RTFS_VP_GLUE", "0") != "1"
+            use_hip = w["vp"] is not None and not self.vp_glue
             if use_hip and 8 <= Tv <= 100:
                 v1 = torch.empty_like(vin)
                 lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
@@ -462,7 +468,7 @@ class HipForward:
         # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
         x = torch.empty_like(a_emb)
         last = R == 1
-        fuse = len(blocks) == 1 and os.environ.get("RTFS_NO_PROJ_FUSION", "0") != "1"  # shared block weights: block i+1's projection = block i's
+        fuse = len(blocks) == 1 and self.fuse["proj"]  # shared block weights: block i+1's projection = block i's
 
         def caf_video():  # join the side stream: att / rsz (and v1 for the taps) are ready past this point
             cur.wait_stream(self._vp_stream)
@@ -470,7 +476,7 @@ class HipForward:
 
         y0_next = None
         # stage taps want the block output itself; Tv > T cannot happen on the product path (25 video frames / s vs 125 STFT frames / s)
-        if taps is None and Tv <= T and os.environ.get("RTFS_NO_CAF_FUSION", "0") != "1":
+        if taps is None and Tv <= T and self.fuse["caf"]:
             # block 0 + CAF cell (+ block 1's projection) in one residual kernel: the block output never reaches HBM (a10 / fusion.py:259-272)
             def caf_args():
                 caf_video()

@@ -152,12 +152,12 @@ def test_batch_offsets_past_2_31_elements():
     assert rel(out, one) < 2e-6
 
 
-def test_fused_tfar_mix_convolution_matches_the_unfused_pair(monkeypatch):
+def test_fused_tfar_mix_convolution_matches_the_unfused_pair():
     """rtfs_dwconv_mix_fwd (TFAR mix formed inside the concat-layer convolution's staging) against rtfs_tfar_mix_fwd + rtfs_dwconv_fwd"""
     model, _, _ = make_model(3, "cuda")
     mix, _, emb = synth.synth_inputs(2, 16000 + 77, 25)
     with torch.no_grad():
         fused = model(mix.cuda(), emb.cuda())
-        monkeypatch.setenv("RTFS_NO_MIX_FUSION", "1")
+        model._hip.fuse["mix"] = False
         plain = model(mix.cuda(), emb.cuda())
     assert rel(fused, plain) < 1e-6

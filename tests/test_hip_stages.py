@@ -253,11 +253,8 @@ def test_resid_proj_fusion_matches_separate_calls():
     mix, _, emb = synth.synth_inputs(3, 16000, 25)
     with torch.no_grad():
         fused = model(mix.cuda(), emb.cuda())
-        os.environ["RTFS_NO_PROJ_FUSION"] = "1"
-        try:
-            plain = model(mix.cuda(), emb.cuda())
-        finally:
-            del os.environ["RTFS_NO_PROJ_FUSION"]
+        model._hip.fuse["proj"] = False
+        plain = model(mix.cuda(), emb.cuda())
     assert rel(fused, plain) < 2e-6 and not torch.equal(fused, plain)
 
 
@@ -272,18 +269,14 @@ def test_caf_fusion_matches_separate_calls(R):
     model, sd, cfg = make_model(R, "cuda")
     mix, _, emb = synth.synth_inputs(3, 16000, 25)
 
-    def run(**env):
-        os.environ.update(env)
-        try:
-            with torch.no_grad():
-                return model(mix.cuda(), emb.cuda())
-        finally:
-            for k in env:
-                del os.environ[k]
+    def run(proj=True, caf=True):
+        model._hip.fuse.update(proj=proj, caf=caf)
+        with torch.no_grad():
+            return model(mix.cuda(), emb.cuda())
 
-    fused, plain = run(), run(RTFS_NO_CAF_FUSION="1")
+    fused, plain = run(), run(caf=False)
     assert rel(fused, plain) < 2e-6
-    fused_np, plain_np = run(RTFS_NO_PROJ_FUSION="1"), run(RTFS_NO_PROJ_FUSION="1", RTFS_NO_CAF_FUSION="1")
+    fused_np, plain_np = run(proj=False), run(proj=False, caf=False)
     assert rel(fused_np, plain_np) < 2e-7
     if R > 1:
         assert not torch.equal(fused, fused_np)  # the fused projection did run
@@ -316,11 +309,8 @@ def test_trio_fusion_matches_separate_calls(B, L):
     mix, _, emb = synth.synth_inputs(B, L, max(8, L // 640))
     with torch.no_grad():
         fused = model(mix.cuda(), emb.cuda())
-        os.environ["RTFS_NO_TRIO_FUSION"] = "1"
-        try:
-            plain = model(mix.cuda(), emb.cuda())
-        finally:
-            del os.environ["RTFS_NO_TRIO_FUSION"]
+        model._hip.fuse["trio"] = False
+        plain = model(mix.cuda(), emb.cuda())
     assert rel(fused, plain) < 2e-6
 
 
