@@ -1103,20 +1103,36 @@ __global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__
 //   A operand: lane (i, kh) supplies h_prev[t(i)][32kh + s] at MFMA step s (the K order is free as long as A and B agree), i.e.
 //   32 consecutive floats of one row = 8 x 16-byte loads;  B operand: W[(m, d, j=i)][32kh + s] via ds_read_b128.
 // ------------------------------------------------------------------------------------------------
+// Round 4 (same arithmetic, same bits): (1) ONE 8-wave workgroup per CU shares the 51 KB weight tile, staged with all of a thread's loads in flight (the
+// staging loop used to wait for each 16-byte load: ~6 us per workgroup, twice per CU on the freq path); (2) the weight fragments of MFMA group g + 1 are
+// requested BEFORE the 8 MFMAs of group g and pinned there with sched_barrier (hipcc placed each ds_read_b128 pair directly in front of its first MFMA
+// and waited: ~100 idle cycles of the matrix pipe per 512); (3) the recurrence issues NO global load: the skip inputs x' - the rows the MFMAs just
+// consumed as A fragments - are written to a wave-private LDS tile between the first MFMA groups and read back with ds_read_b32.  With loads and the
+// 32 per-step stores in flight together every wait for a load is `s_waitcnt vmcnt(0)` (loads and stores complete out of order with respect to each
+// other, so hipcc cannot count past a store): four full drains of store acknowledgements + the next chunk's A prefetch per chunk.  Measured on the
+// bench shapes (tools/sru_bench.py, same box): see DESIGN.md section 5.
 template <bool SAVE_C, int NT = 0>  // SAVE_C (training): also stores the cell states and the pre-activations U (the adjoint's inputs); NT: common.h
-__global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
+__global__ __launch_bounds__(512, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
                                                            const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
                                                            float* __restrict__ Cout, float* __restrict__ Uout, int S, int L) {
-    constexpr int LDW = 68;
+    constexpr int LDW = 68, LDX = 36;  // LDX: ds_write_b128 of 8 consecutive rows (one lane group) covers 32 distinct banks; the per-step reads are consecutive floats
     __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
+    __shared__ __attribute__((aligned(16))) float Xs[8][2][32 * LDX];  // per wave: x' of the chunk's 32 steps, [dir][step][j]
     // the gate rows (m = 1, 2) are pre-scaled by -log2(e): the recurrence then needs fma, v_exp, add, v_rcp per gate and nothing else
-    for (int idx = threadIdx.x; idx < 192 * 16; idx += 256) {
-        const int n = idx >> 4, q4 = (idx & 15) * 4;
-        const float sc = n >= 64 ? kNegLog2e : 1.0f;
-        st4(Ws + n * LDW + q4, pack4<NT>(ld4(Wt + n * 64 + q4) * sc));  // (Wt is the plain fp32 weight for every NT: packed here, after the scaling)
+    {
+        float4 stg[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) stg[k] = ld4(Wt + (size_t)(threadIdx.x + 512 * k) * 4);  // (Wt is the plain fp32 weight for every NT: packed here, after the scaling)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int idx = threadIdx.x + 512 * k, n = idx >> 4, q4 = (idx & 15) * 4;
+            st4(Ws + n * LDW + q4, pack4<NT>(stg[k] * (n >= 64 ? kNegLog2e : 1.0f)));
+        }
     }
     __syncthreads();
-    const int s = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: bases below live in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.x * 8 + wv;  // wave-uniform: bases below live in SGPRs
+    const int nch = (L + 31) >> 5;
     if (s >= S) return;
     const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const bool rev = lane >= 32;
@@ -1131,8 +1147,14 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
     const int dstr = rev ? -256 : 256, off0 = (rev ? (L - 1) * 256 : 0) + lane * 4;
     const int off0u = (rev ? (L - 1) * 768 : 0) + lane * 4;  // same for the [l][3][64] pre-activation rows
     constexpr float kUnscale = 1.0f / kNegLog2e;
+    float* xw = &Xs[wv][kh][i * LDX];          // this lane's row of the tile it WRITES: direction kh, local step i (its A-fragment row), columns 32 kh + 4 q of h_prev
+    const float* xr = &Xs[wv][kh][i];          // and the column it READS: direction kh (= rev), hidden unit i, local step k at + k * LDX
     float c = 0.f;
-    const int nch = (L + 31) >> 5;
+#ifdef SRU_TIMING
+    unsigned long long tm[24];
+    int ntm = 0;
+    tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
     // A fragments of the two directions (rows past the end are clamped; their steps are never scanned); the next chunk's are
     // fetched as soon as the MFMAs have consumed the current ones, i.e. under the 32 recurrence steps
     float4 a0[8], a1[8];
@@ -1153,47 +1175,60 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
         asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
                                         // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
         const float* wp = Ws + woff;
-        if constexpr (NT == 0) {
+        // MFMA groups g = 3 qq + m: fp32: qq = 0..7 (k quad), 2 fragment reads + 8 MFMAs; bf16 forms: qq = 0..3 (k octet), 4 reads + 2 (x terms) MFMAs
+        constexpr int NG = NT == 0 ? 24 : 12, NR = NT == 0 ? 2 : 4;
+        float4 bb[2][NR];
+        auto read_group = [&](float4(&dst)[NR], int g) {
+            const int qq = g / 3, m = g % 3;
+            if constexpr (NT == 0) {
+                dst[0] = ld4(wp + (m * 64) * LDW + 4 * qq), dst[1] = ld4(wp + (m * 64 + 32) * LDW + 4 * qq);
+            } else {
+                dst[0] = ld4(wp + (m * 64) * LDW + 8 * qq), dst[1] = ld4(wp + (m * 64) * LDW + 8 * qq + 4);
+                dst[2] = ld4(wp + (m * 64 + 32) * LDW + 8 * qq), dst[3] = ld4(wp + (m * 64 + 32) * LDW + 8 * qq + 4);
+            }
+        };
+#ifdef SRU_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
+        read_group(bb[0], 0);
+        Frag fa0, fa1;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-    #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const float4 b0 = ld4(wp + (m * 64) * LDW + 4 * q), b1 = ld4(wp + (m * 64 + 32) * LDW + 4 * q);
-                    if (q == 0) {  // the chain starts from a zero C operand (an inline constant): no accumulator clearing
-                        floatx16 z;
-    #pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, z, 0, 0, 0);
-                        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, z, 0, 0, 0);
-                    } else {
-                        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].x, b0.x, acc[0][m], 0, 0, 0);
-                        acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].x, b1.x, acc[1][m], 0, 0, 0);
-                    }
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].y, b0.y, acc[0][m], 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].y, b1.y, acc[1][m], 0, 0, 0);
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].z, b0.z, acc[0][m], 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].z, b1.z, acc[1][m], 0, 0, 0);
-                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q].w, b0.w, acc[0][m], 0, 0, 0);
-                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q].w, b1.w, acc[1][m], 0, 0, 0);
+        for (int g = 0; g < NG; ++g) {
+            const int qq = g / 3, m = g % 3;
+            if (g + 1 < NG) read_group(bb[(g + 1) & 1], g + 1);
+            if (g < 8) st4(xw + 4 * g, kh ? a1[g] : a0[g]);  // x' tile, one 16-byte piece per group (both fragments are still live: a*[g] is consumed by groups >= g)
+            __builtin_amdgcn_sched_barrier(0);
+            const float4(&b)[NR] = bb[g & 1];
+            if constexpr (NT == 0) {
+                if (qq == 0) {  // the chain starts from a zero C operand (an inline constant): no accumulator clearing
+                    floatx16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[qq].x, b[0].x, z, 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[qq].x, b[1].x, z, 0, 0, 0);
+                } else {
+                    acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[qq].x, b[0].x, acc[0][m], 0, 0, 0);
+                    acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[qq].x, b[1].x, acc[1][m], 0, 0, 0);
+                }
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[qq].y, b[0].y, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[qq].y, b[1].y, acc[1][m], 0, 0, 0);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[qq].z, b[0].z, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[qq].z, b[1].z, acc[1][m], 0, 0, 0);
+                acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[qq].w, b[0].w, acc[0][m], 0, 0, 0);
+                acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[qq].w, b[1].w, acc[1][m], 0, 0, 0);
+            } else {  // 16 k per step: this lane's k = 32 kh + 8 qq .. + 7 (the fp32 fragments of quads 2 qq, 2 qq + 1, packed in registers)
+                if (m == 0) fa0 = frag_f32<NT>(a0[2 * qq], a0[2 * qq + 1]), fa1 = frag_f32<NT>(a1[2 * qq], a1[2 * qq + 1]);
+                const Frag b0 = frag_lds<NT>(b[0], b[1]), b1 = frag_lds<NT>(b[2], b[3]);
+                if (qq == 0) {
+                    acc[0][m] = mma32_first<NT>(fa0, b0);
+                    acc[1][m] = mma32_first<NT>(fa1, b1);
+                } else {
+                    mma32<NT>(acc[0][m], fa0, b0);
+                    mma32<NT>(acc[1][m], fa1, b1);
                 }
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {  // 16 k per step: this lane's k = 32 kh + 8 p .. + 7 (the fp32 fragments of quads 2p, 2p + 1, packed in registers)
-                const Frag fa0 = frag_f32<NT>(a0[2 * p], a0[2 * p + 1]), fa1 = frag_f32<NT>(a1[2 * p], a1[2 * p + 1]);
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const Frag b0 = frag_lds<NT>(ld4(wp + (m * 64) * LDW + 8 * p), ld4(wp + (m * 64) * LDW + 8 * p + 4));
-                    const Frag b1 = frag_lds<NT>(ld4(wp + (m * 64 + 32) * LDW + 8 * p), ld4(wp + (m * 64 + 32) * LDW + 8 * p + 4));
-                    if (p == 0) {
-                        acc[0][m] = mma32_first<NT>(fa0, b0);
-                        acc[1][m] = mma32_first<NT>(fa1, b1);
-                    } else {
-                        mma32<NT>(acc[0][m], fa0, b0);
-                        mma32<NT>(acc[1][m], fa1, b1);
-                    }
-                }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ch + 1 < nch) load_a(sl0 + 32);
         // Half exchange: v_permlane32_swap X, Y swaps lanes 32-63 of X with lanes 0-31 of Y.  With X = a dir-0 accumulator register and
@@ -1216,45 +1251,60 @@ __global__ __launch_bounds__(256, 2) void sru_layer_kernel(const float* __restri
             }
         asm volatile("s_nop 1" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // recurrence: 4 groups of 8 steps; a group's skip inputs x' (rows just read as A fragments: L1/L2 hits) are fetched one
-        // group ahead
-        float xa[8], xb[8];
-        auto load_x = [&](float(&xv)[8], int g) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) xv[k] = ld1_off(hp, (unsigned)(off0 + min(sl0 + 8 * g + k, L - 1) * dstr));
-        };
-        auto steps = [&](const float(&xv)[8], int g, auto G) {
-            constexpr int gg = decltype(G)::value;
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) {
-                const int sl = sl0 + 8 * g + k8;
-                if (sl < L) {  // wave-uniform
-                    const int k = 8 * gg + k8;
-                    const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
-                    const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
-                    const unsigned off = (unsigned)(off0 + sl * dstr);
-                    const float x = xv[k8] * scale_x;
-                    const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
-                    const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
-                    c = u0 + (c - u0) * f;
-                    st1_off(hob, off, x + (c - x) * rg);
-                    if (SAVE_C) {
-                        st1_off(cob, off, c);
-                        const unsigned offu = (unsigned)(off0u + sl * (3 * dstr));
-                        st1_off(uob, offu, u0), st1_off(uob, offu + 256, u1 * kUnscale), st1_off(uob, offu + 512, u2 * kUnscale);
-                    }
-                }
+#ifdef SRU_TIMING
+        tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
+        // recurrence: 32 steps out of registers; x' of local step k from the wave's LDS tile (written above by the lanes that held those rows as A
+        // fragments: same wave, LDS operations of a wave complete in order - the fence keeps hipcc from moving the reads above the writes)
+        // (On gfx950 the fp32 MFMA executes on the SIMD's fp32 vector lanes - its rate IS the vector rate - and holds them for 64 cycles per instruction:
+        // next to the co-resident wave's MFMA phase every dependent VALU instruction of this chain waits for an MFMA to retire.  s_memtime stamps
+        // (tools/sru_timeline.py): 32 steps take ~19k cycles beside the partner's MFMAs, ~4.5k for two waves scanning together.  Locking the two waves'
+        // phases with workgroup barriers - MFMA phases together, recurrences together - measured the same 76-79 us as this free-running form: the
+        // vector lanes are busy either way, the barrier skew eats what the shorter scans save.  In the bf16 forms the matrix pipe is a separate unit.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#ifdef SRU_TIMING
+        tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
+        auto step = [&](int k) {
+            const int sl = sl0 + k;
+            const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
+            const float u0 = acc[sel][0][r], u1 = acc[sel][1][r], u2 = acc[sel][2][r];
+            const unsigned off = (unsigned)(off0 + sl * dstr);
+            const float x = xr[k * LDX] * scale_x;
+            const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
+            const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
+            c = u0 + (c - u0) * f;
+            st1_off(hob, off, x + (c - x) * rg);
+            if (SAVE_C) {
+                st1_off(cob, off, c);
+                const unsigned offu = (unsigned)(off0u + sl * (3 * dstr));
+                st1_off(uob, offu, u0), st1_off(uob, offu + 256, u1 * kUnscale), st1_off(uob, offu + 512, u2 * kUnscale);
             }
         };
-        load_x(xa, 0);
-        load_x(xb, 1);
-        steps(xa, 0, std::integral_constant<int, 0>{});
-        load_x(xa, 2);
-        steps(xb, 1, std::integral_constant<int, 1>{});
-        load_x(xb, 3);
-        steps(xa, 2, std::integral_constant<int, 2>{});
-        steps(xb, 3, std::integral_constant<int, 3>{});
+        if (sl0 + 32 <= L) {  // a full chunk: ONE basic block (a branch per step kept every x' read inside its step: LDS latency on the chain, 32 times)
+#pragma unroll
+            for (int k = 0; k < 32; ++k) step(k);
+        } else {  // the sequence's last chunk: steps past the end are skipped (wave-uniform branches)
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (sl0 + k < L) step(k);
+        }
+#ifdef SRU_TIMING
+        tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_wave_barrier();  // (the next chunk's x' writes stay behind this chunk's reads)
+#ifdef SRU_TIMING
+        tm[ntm++] = __builtin_amdgcn_s_memtime();
+#endif
     }
+#ifdef SRU_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(hob);
+        for (int k = 0; k < 24; ++k) o[k] = k < ntm ? tm[k] : 0ull;
+    }
+#endif
 }
 
 }  // namespace rtfs
@@ -1374,12 +1424,12 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
 int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                        float* Uout_or_null, int S, int L, void* stream) {
     if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
-    dim3 grid((S + 3) / 4);
+    dim3 grid((S + 7) / 8);
     if (Cout_or_null)
-        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
+        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
                            Uout_or_null, S, L);
     else
-        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
+        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
                            Uout_or_null, S, L);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
@@ -1389,9 +1439,9 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
 int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                             float* Uout_or_null, int S, int L, int terms, void* stream) {
     if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3 && terms != 6) || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
-    dim3 grid((S + 3) / 4);
+    dim3 grid((S + 7) / 8);
     hipStream_t st = (hipStream_t)stream;
-#define SRU_L(SAVE, NTV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV>), grid, dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
+#define SRU_L(SAVE, NTV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV>), grid, dim3(512), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
     if (Cout_or_null) {
         if (terms == 1) SRU_L(true, 1); else if (terms == 3) SRU_L(true, 3); else SRU_L(true, 6);
     } else {

@@ -5,8 +5,9 @@ tests/test_build_flags.py checks the instruction mix on the CPU, this file check
 
 The FORWARD has no order-dependent arithmetic (statistics are float64 slots whose sums are exact at these magnitudes; no fp32 atomics), so every
 repeat must give the SAME BITS - waveform and, in train mode, the BatchNorm running statistics.  The ADJOINT chain accumulates weight gradients
-with fp32 atomics into spread copies (csrc/spread.hip): run-to-run differences there are fp32 re-association noise, bounded here at 2e-6 of a
-tensor's norm - three orders of magnitude below the 2e-3 the rule-10 corruption produced."""
+with fp32 atomics into spread copies (csrc/spread.hip): run-to-run differences there are fp32 re-association noise (observed <= 3e-6 of a tensor's
+norm, 2e-5 on the scalar PReLU slopes - one heavily cancelling sum each), bounded here at 2e-5 / 2e-4 - ten to a hundred times below the 2e-3 the
+rule-10 corruption produced."""
 import pytest
 import torch
 
@@ -76,7 +77,7 @@ def test_split_bf16_training_step_is_bit_identical_run_to_run(training):
             out, g, s = step()
             assert torch.equal(out, out0), f"waveform of step {it + 1} differs"
             scale = max(float(v.norm()) for v in g0.values())
-            differ = [(n, e) for n in g0 if (e := float((g[n] - g0[n]).norm()) / (float(g0[n].norm()) + 1e-4 * scale)) > 2e-6]
+            differ = [(n, e) for n in g0 if (e := float((g[n] - g0[n]).norm()) / (float(g0[n].norm()) + 1e-3 * scale)) > (2e-4 if g0[n].numel() <= 12 else 2e-5)]  # (floor: analytically-zero gradients - conv biases in front of a batch-statistics BatchNorm - are pure residue)
             assert not differ, (it + 1, differ[:8])
             assert all(torch.equal(s[k], s0[k]) for k in s0), it + 1
     model.set_compute_dtype("f32")
