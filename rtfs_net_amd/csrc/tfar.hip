@@ -176,23 +176,27 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
 // (13 x 16 B per thread), applies the gLN / PReLU transform and the zero padding ONCE per element on the way into LDS, and the
 // sliding 4x4 window then walks LDS (100-cycle latency) instead of HBM.  53.5 KB of LDS: two workgroups per CU alternate
 // between their load and compute phases.   grid: (ceil(T/16), B, nseg); a workgroup walks its f segment in blocks of 8.
-template <int NCONV, int MODE>
-__global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
-    constexpr int TR = 16, TC = 8, R = TR + 3, CB = TC + 3;
+// Round 4: one or two convolutions take 4-column blocks (38-43 KB of LDS, <= 168 VGPRs: THREE workgroups per CU instead of two).  The kernel is bound by
+// the bytes it keeps in flight - a workgroup only has loads outstanding during its staging phase - and a third workgroup per CU measured -10 ... -12 %
+// on the full-resolution launches (same box: 149 -> 134 us, 186 -> 164 us); four workgroups (<= 128 VGPRs) spill the mix form and gain nothing more.
+// Four convolutions keep the 8-column block (their accumulators do not fit 168 registers).
+template <int NCONV, int MODE, int TC = (NCONV <= 2 ? 4 : 8)>
+__global__ __launch_bounds__(256, (NCONV <= 2 ? 3 : 2)) void dwconv_s1_kernel(DwArgs a, int fseg) {
+    constexpr int TR = 16, R = TR + 3, CB = TC + 3, RPI = 16 / TC;  // RPI: tile rows covered by one 256-thread pass over the new columns
     constexpr int RS = CB * 64;  // unpadded: ds_read_b128 serves lanes {0-3,12-15,20-27 | ...}, for which 256-byte rows at a multiple of
                                  // 64 floats are already conflict-free (a +16 pad was measured 20 % slower)
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
     __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
     __shared__ float red[8];
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, bx = blockIdx.x, bz = blockIdx.z;
     for (int i = threadIdx.x; i < NCONV * 256; i += 256) {
         const int j = i >> 8, o = (i & 255) * 4;
         st4(&ws[j][o], ld4(a.w[j] + o));
     }
     const int c4 = (threadIdx.x & 15) * 4, tr = threadIdx.x >> 4;
     const int T = a.Tin, F = a.Fin;  // stride 1: output size == input size
-    const int t0 = blockIdx.x * TR, to = t0 + tr;
-    const int f0 = blockIdx.z * fseg, f1 = min(F, f0 + fseg);
+    const int t0 = bx * TR, to = t0 + tr;
+    const int f0 = bz * fseg, f1 = min(F, f0 + fseg);
     float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
     if (MODE >= 1) {
         float mean, rstd;
@@ -226,15 +230,38 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
     for (int k = 0; k < NCONV; ++k) bias4[k] = a.bias[k] ? ld4(a.bias[k] + c4) : f4(0, 0, 0, 0);
     const size_t orow = (((size_t)b * T + (tvalid ? to : 0)) * F) * kH + c4;
 
+    constexpr int NN = (R * TC * 16 + 255) / 256, NH = (R * 3 * 16 + 255) / 256;
+    float4 vn[NN];  // the block's new columns, raw.  Modes 0-2: requested one block AHEAD (under the previous block's window pass)
+    auto is_interior = [&](int fb) { return t0 >= 1 && t0 + TR + 1 < T && fb >= 1 && fb + TC + 1 < F; };  // (workgroup-uniform)
+    auto issue_new = [&](int fb) {
+        // Blocks whose (16+3) x (TC+3) input window lies inside the tensor (3 of 4 at the headline shape) take a lean path: no clamping of the
+        // load addresses, no per-element zero-padding select, the transform in native 4-vectors (common.h) - the staging code was ~45 % of this
+        // kernel's VALU instructions (PMC, round 3: 44 M VALU per launch against 16.6 M for the convolution's FMAs; VALU 50 % busy).
+        if (is_interior(fb)) {
+            const unsigned boff = (((unsigned)(t0 - 1) * F + (fb - 1 + 3)) * kH) * 4u;
+#pragma unroll
+            for (int i = 0; i < NN; ++i) {
+                const int r = i == NN - 1 ? min((int)(threadIdx.x / (TC * 16)) + RPI * i, R - 1) : (int)(threadIdx.x / (TC * 16)) + RPI * i;
+                vn[i] = ld4_off(inb, boff + (((unsigned)r * F + ((threadIdx.x >> 4) % TC)) * kH + c4) * 4u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) {
+                const int idx = threadIdx.x + i * 256, r = min(idx / (TC * 16), R - 1), c = 3 + ((idx >> 4) % TC);
+                const int ti = t0 - 1 + r, fi = fb - 1 + c;
+                vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
+            }
+        }
+    };
+    if (MODE != 3) issue_new(f0);
 #pragma unroll 1
     for (int fb = f0; fb < f1; fb += TC) {
         // ---- stage input rows t0-1 .. t0+17, columns fb-1 .. fb+9 (transformed, zero outside the tensor).  Only the first block of
         // the segment fetches all 11 columns: afterwards the 3 halo columns fb-1 .. fb+1 are the previous block's last three, moved
         // inside LDS (read before the barrier, written after it), and 8 new columns come from HBM - 1.19x read amplification
         // (the t halo) instead of 1.63x.
-        constexpr int NN = (R * TC * 16 + 255) / 256, NH = (R * 3 * 16 + 255) / 256;
         const bool first = fb == f0;
-        float4 vn[NN], vh[NH];
+        float4 vh[NH];
         int moff = c4;
         asm volatile("" : "+v"(moff));  // opaque per block: the constants are re-read from LDS instead of living in 16 VGPRs
         auto xform = [&](float4 x, float4 g, float4 e, int ti, int fi) {
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
             float4 gn[MODE == 3 ? NN : 1], en[MODE == 3 ? NN : 1];
 #pragma unroll
             for (int i = i0; i < i1; ++i) {  // new columns: block columns 3 .. 10
-                const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+                const int idx = threadIdx.x + i * 256, r = min(idx / (TC * 16), R - 1), c = 3 + ((idx >> 4) % TC);
                 const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
                 vn[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);  // saddr + 32-bit offset
                 if (MODE == 3) {
@@ -261,14 +288,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
             }
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
-                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                const int idx = threadIdx.x + i * 256, r = idx / (TC * 16), c = 3 + ((idx >> 4) % TC);
                 vn[i] = xform(vn[i], gn[MODE == 3 ? i : 0], en[MODE == 3 ? i : 0], t0 - 1 + r, fb - 1 + c);
             }
         };
         auto store_new = [&](int i0, int i1) {
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
-                const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                const int idx = threadIdx.x + i * 256, r = idx / (TC * 16), c = 3 + ((idx >> 4) % TC);
                 if (idx < R * TC * 16) st4(tile + r * RS + c * 64 + c4, vn[i]);
             }
         };
@@ -298,27 +325,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                 vh[i] = ld4(tile + r * RS + (c + TC) * 64 + c4);
             }
         }
-        // Blocks whose (16+3) x (8+3) input window lies inside the tensor (3 of 4 at the headline shape) take a lean path: no clamping of the 10
-        // load addresses, no per-element zero-padding select, the transform in native 4-vectors (common.h) - the staging code was ~45 % of this
-        // kernel's VALU instructions (PMC, round 3: 44 M VALU per launch against 16.6 M for the convolution's FMAs; VALU 50 % busy).
-        const bool interior = t0 >= 1 && t0 + TR + 1 < T && fb >= 1 && fb + TC + 1 < F;  // (workgroup-uniform)
-        if (MODE != 3) {
-            if (interior) {
-                const unsigned boff = (((unsigned)(t0 - 1) * F + (fb - 1 + 3)) * kH) * 4u;
-#pragma unroll
-                for (int i = 0; i < NN; ++i) {
-                    const int r = i == NN - 1 ? min((int)(threadIdx.x >> 7) + 2 * i, R - 1) : (int)(threadIdx.x >> 7) + 2 * i;
-                    vn[i] = ld4_off(inb, boff + (((unsigned)r * F + ((threadIdx.x >> 4) & 7)) * kH + c4) * 4u);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NN; ++i) {
-                    const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
-                    const int ti = t0 - 1 + r, fi = fb - 1 + c;
-                    vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
-                }
-            }
-        }
+        const bool interior = is_interior(fb);
         __syncthreads();  // previous block's window reads are done
         if (MODE != 3) {
             if (interior) {
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
             } else {
 #pragma unroll
                 for (int i = 0; i < NN; ++i) {
-                    const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+                    const int idx = threadIdx.x + i * 256, r = idx / (TC * 16), c = 3 + ((idx >> 4) % TC);
                     vn[i] = xform(vn[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c);
                 }
             }
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_s1_kernel(DwArgs a, int fseg) {
                 st4(tile + r * RS + c * 64 + c4, (first && MODE != 3) ? xform(vh[i], f4(0, 0, 0, 0), f4(0, 0, 0, 0), t0 - 1 + r, fb - 1 + c) : vh[i]);
         }
         __syncthreads();
+        if (MODE != 3 && fb + TC < f1) issue_new(fb + TC);  // the next block's new columns travel while this block's window pass runs
         // ---- 8 output columns, OPS = 4 per step (round 3): for each of the four tap rows the step reads the OPS + 3 window columns of that row
         // once and every tap once, and feeds OPS outputs from them - 11 ds_read_b128 per output quad instead of 20 (16 taps + 4 new window
         // entries per single output before).  With one output per step the kernel read 80 bytes of LDS per output float against 8 bytes of
@@ -431,8 +439,8 @@ struct TrioArgs {
     float* pooled;  // [B][T2][64][64]
 };
 
-__global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fseg) {
-    constexpr int TR = 16, TC = 8, R = TR + 3, CB = TC + 3;
+__global__ __launch_bounds__(256, 3) void dwconv_trio_kernel(TrioArgs a, int fseg) {  // (4-column blocks, three workgroups per CU: see dwconv_s1_kernel)
+    constexpr int TR = 16, TC = 4, R = TR + 3, CB = TC + 3;
     constexpr int RS = CB * 64;
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
     __shared__ __attribute__((aligned(16))) float ws[2][16 * 64];
@@ -495,14 +503,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
         }
 #pragma unroll
         for (int i = 0; i < NN; ++i) {
-            const int idx = threadIdx.x + i * 256, r = min(idx >> 7, R - 1), c = 3 + ((idx >> 4) & 7);
+            const int idx = threadIdx.x + i * 256, r = min(idx / (TC * 16), R - 1), c = 3 + ((idx >> 4) % TC);
             const int ti = t0 - 1 + r, fi = fb - 1 + c;
             vn[i] = ld4_off(inb, (((unsigned)min(max(ti, 0), T - 1) * F + min(max(fi, 0), F - 1)) * kH + c4) * 4u);
         }
         __syncthreads();  // previous block's window reads are done
 #pragma unroll
         for (int i = 0; i < NN; ++i) {
-            const int idx = threadIdx.x + i * 256, r = idx >> 7, c = 3 + ((idx >> 4) & 7);
+            const int idx = threadIdx.x + i * 256, r = idx / (TC * 16), c = 3 + ((idx >> 4) % TC);
             if (idx < R * TC * 16) st4(tile + r * RS + c * 64 + c4, xform(vn[i], t0 - 1 + r, fb - 1 + c));
         }
 #pragma unroll
@@ -552,9 +560,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
         {
             int woff = c4;
             asm volatile("" : "+v"(woff));
-            const float* base = tile + (2 * lt) * RS + (4 * lp) * 64 + c4;
+            const float* base = tile + (2 * lt) * RS + ((TC / 2) * lp) * 64 + c4;
 #pragma unroll 1
-            for (int o = 0; o < 2; ++o) {  // (rolled: one 4 x 4 window of registers at a time)
+            for (int o = 0; o < TC / 4; ++o) {  // (rolled: one 4 x 4 window of registers at a time)
                 float4v x[4][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_trio_kernel(TrioArgs a, int fse
 #pragma unroll
                 for (int dt = 1; dt < 4; ++dt) rs[dt - 1] = x[1][dt] + x[2][dt] + x[3][dt];
                 const float4 acc = to_f4(accv), pool = to_f4((rs[0] + rs[1] + rs[2] * mt3) * pinv);
-                const int f2 = (fb >> 1) + 2 * lp + o;
+                const int f2 = (fb >> 1) + (TC / 4) * lp + o;
                 if (t2valid && f2 < kF2 && 2 * f2 < f1) {
                     st4(a.out2 + orow2 + (size_t)f2 * kH, acc);
                     st4(a.pooled + orow2 + (size_t)f2 * kH, pool);
@@ -944,8 +952,10 @@ static int caf_set_lds(const void* fn, bool* flags) {  // dynamic LDS beyond 64 
 template <int STRIDE, int MODE>
 static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
     if (STRIDE == 1) {  // LDS-staged kernel, f segments in multiples of its 8-column block
-        const int nseg = a.Fout >= 96 ? 4 : 2;
-        const int fseg = (((a.Fout + nseg - 1) / nseg) + 7) / 8 * 8;
+        // f segments per row tile: 4 at full resolution (2048 workgroups, 2.7 rounds of the 768 resident ones); at the compressed resolution 3 for the
+        // 4-column kernels (8 x 32 x 3 = 768 workgroups = one full round of three per CU; 2 left a third of the slots empty: 79 -> 71 us, 35 -> 31 us)
+        const int nseg = a.Fout >= 96 ? 4 : (a.nconv <= 2 ? 3 : 2);
+        const int fseg = (((a.Fout + nseg - 1) / nseg) + 7) / 8 * 8;  // (a multiple of the kernel's column block, 8 or 4)
         dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
         switch (a.nconv) {
             case 1: hipLaunchKernelGGL((dwconv_s1_kernel<1, MODE>), grid, dim3(256), 0, st, a, fseg); break;
