@@ -163,7 +163,19 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
                                                            float* __restrict__ O, float* __restrict__ LSE, int T2) {
     constexpr int LDS_S = MAXKT * 32 + 4;
     __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (query tile, head, utterance).  The query tiles of one (head, utterance) pair all read that pair's K and V (640 KB at 2 s): in
+    // launch order they would sit on different XCDs (workgroup l runs on XCD l % 8 - observed placement, a speed heuristic only) and every XCD would
+    // fetch K / V for itself (round 3: 344 MB fetched per launch against 96 MB of Q / K / V).  Consecutive workgroups OF ONE XCD take the query tiles
+    // of one pair instead: pair = (slot / nq) * 8 + xcd with slot = l / 8, so K / V come from HBM once per pair and from that XCD's L2 afterwards.
+    int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    {
+        const int nq = gridDim.x, npair = gridDim.y * gridDim.z;
+        if ((npair & 7) == 0) {
+            const int l = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z), slot = l >> 3;
+            const int pair = (slot / nq) * 8 + (l & 7);
+            qt = slot % nq, h = pair % gridDim.y, b = pair / gridDim.y;
+        }
+    }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int q0 = qt * 32;
     const int NT = (T2 + 31) / 32;
@@ -239,23 +251,34 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
         const float* pa = Ss + i * LDS_S + 4 * kh;
         if constexpr (PREC == 0) {
-            for (int kq = 0; kq < NT * 4; ++kq) {  // 8 keys per step: this lane's keys are 8kq + 4kh .. +3
-                const float4 p = ld4(pa + 8 * kq);
+            // 8 keys per step: this lane's keys are 8kq + 4kh .. +3.  The V fragments of step kq + 1 are requested before the 16 MFMAs of step kq
+            // (round 4: with the loads issued right in front of their MFMAs every step paid an L2 round trip with the matrix pipe idle)
+            float vb[2][4][4];
+            auto load_v = [&](float(&dst)[4][4], int kq) {
                 const int key = 8 * kq + 4 * kh;
-                float vb[4][4];
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float* vr = Vg + (size_t)min(key + r, T2 - 1) * 1024 + n0 + i;  // padded keys carry zero weight
-    #pragma unroll
-                    for (int n = 0; n < 4; ++n) vb[n][r] = vr[n * 32];
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) dst[n][r] = vr[n * 32];
                 }
-    #pragma unroll
+            };
+            auto step = [&](const float(&v)[4][4], int kq) {
+                const float4 p = ld4(pa + 8 * kq);
+#pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, vb[n][0], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, vb[n][1], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, vb[n][2], acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, vb[n][3], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.x, v[n][0], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.y, v[n][1], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.z, v[n][2], acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p.w, v[n][3], acc[n], 0, 0, 0);
                 }
+            };
+            load_v(vb[0], 0);
+            for (int kq = 0; kq < NT * 4; kq += 2) {  // (NT * 4 is even)
+                load_v(vb[1], kq + 1);
+                step(vb[0], kq);
+                load_v(vb[0], min(kq + 2, NT * 4 - 1));
+                step(vb[1], kq + 1);
             }
         } else {
             for (int kq2 = 0; kq2 < NT * 2; ++kq2) {  // 16 keys per step: this lane's keys are 16kq2 + 4kh .. +3 and 16kq2 + 8 + 4kh .. +3

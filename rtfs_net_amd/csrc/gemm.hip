@@ -651,6 +651,12 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
     }
     __syncthreads();
     float ps = 0.f, pq = 0.f;  // M: gLN partial sums of the projection output
+#ifdef RESID_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define RT_MARK(j) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[j] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define RT_MARK(j) do { } while (0)
+#endif
 
     if (mrole) {
         // ================================================ M waves ================================================
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
         int hb = 0;       // h % 3
 #pragma unroll 1
         for (int h = 0; h < H + 2; ++h) {
+            RT_MARK(5);
             if (h < H) {  // residual conv of half h
                 const float* E = Es[h & 1];
                 floatx16 acc[2];
@@ -705,6 +712,7 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
 #pragma unroll
                     for (int g = 0; g < 4; ++g) st4(O + i * LDO + 64 * w + 32 * nt + 8 * g + 4 * kh, acc_group(acc[nt], g));
             }
+            RT_MARK(0);
             if (h >= 2) {  // projection of half h - 2 (its gated tile was written by the X waves in phase h - 1)
                 const float* ap = Ot[hb == 2 ? 0 : hb + 1] + j * LDO + 64 * kk;
                 floatx4 pa[4];
@@ -751,7 +759,9 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
                 }
             }
             hb = hb == 2 ? 0 : hb + 1;
+            RT_MARK(1);
             __syncthreads();
+            RT_MARK(4);
         }
     } else {
         // ================================================ X waves ================================================
@@ -848,15 +858,21 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
         auto phase = [&](auto p_, int h) {
             constexpr int p = decltype(p_)::value;
             using Q = std::integral_constant<int, p ^ 1>;
+            RT_MARK(5);
             if (h >= 1 && h <= H) epilogue(Q{}, h - 1, Ot[hb == 0 ? 2 : hb - 1]);
             __builtin_amdgcn_sched_barrier(0);
+            RT_MARK(0);
             load_sv(Q{}, h + 1);
             __builtin_amdgcn_sched_barrier(0);
+            RT_MARK(1);
             xform_e(Q{}, Es[p ^ 1]);
+            RT_MARK(2);
             load_e(p_, h + 2);
             __builtin_amdgcn_sched_barrier(0);
             hb = hb == 2 ? 0 : hb + 1;
+            RT_MARK(3);
             __syncthreads();
+            RT_MARK(4);
         };
 #pragma unroll 1
         for (int h = 0; h < H + 2; h += 2) {
@@ -876,6 +892,16 @@ __global__ __launch_bounds__(512, 2) void resid_ws_kernel(ProExpanded pro, EpiRe
         atomicAdd(epi.pslot + kStatStride * b, (double)pred[0] + (double)pred[1] + (double)pred[2] + (double)pred[3]);
         atomicAdd(epi.pslot + kStatStride * b + 1, (double)pred[4] + (double)pred[5] + (double)pred[6] + (double)pred[7]);
     }
+#ifdef RESID_TIMING
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {  // this wave's segment sums over the workgroup's first output rows (the output is garbage in this build)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(epi.y + ((size_t)b * Mb + row0 + w) * kC);
+        for (int j = 0; j < 6; ++j) o[j] = tacc[j];
+        o[6] = (unsigned long long)H;
+    }
+#endif
+#undef RT_MARK
 }
 
 // ------------------------------------------------------------------------------------------------

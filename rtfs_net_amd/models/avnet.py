@@ -203,7 +203,11 @@ class AVNet(nn.Module):
                                   stacklevel=2)
                 return self._forward_autograd(x, mouth_embedding)
             if self.training:
-                raise NotImplementedError("training-mode forward without autograd is not supported: use torch.no_grad() with model.eval(), or enable grad")
+                # train() without autograd (torch.no_grad(), or every parameter frozen): BatchNorm batch statistics + running-statistics update and
+                # dropout / DropPath as in the reference's train-mode forward, nothing to differentiate - the training-step forward, its graph dropped
+                with torch.enable_grad():
+                    out = self._forward_autograd(x, mouth_embedding)
+                return out.detach()
             return self._hip(x, mouth_embedding)
 
     # names of the parameters whose gradients come from the HIP backward chain (everything but the video-side glue)

@@ -69,16 +69,30 @@ def test_edge_lengths_against_oracle():
         assert rel(out, ref) < WAVE_TOL, (L, Tv)
 
 
-def test_train_mode_runs_under_autograd_and_is_refused_without():
-    """train() + grad enabled = the HIP training step (tests/test_hip_backward.py checks its numbers); train() under no_grad
-    (BatchNorm batch statistics + dropout but nothing to differentiate) is not a path of the reference's train.py/test.py: refused loudly."""
-    model, _, _ = make_model(4, "cuda")
+def test_train_mode_runs_with_and_without_autograd():
+    """train() + grad enabled = the HIP training step (tests/test_hip_backward.py checks its numbers); train() under no_grad (BatchNorm batch
+    statistics + running-statistics update + dropout, nothing to differentiate - what the reference's modules do in that state) runs the same
+    forward and drops the graph: same waveform (dropout off so both calls see one function), same running statistics, no grad_fn."""
+    model, sd, _ = make_model(4, "cuda")
+    for mod in model.modules():
+        if isinstance(getattr(mod, "p", None), float):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
     model.train()
-    mix, _, emb = synth.synth_inputs(1, 8000, 12)
+    mix, _, emb = synth.synth_inputs(2, 8000, 12)
     out = model(mix.cuda(), emb.cuda())
     assert out.requires_grad and out.grad_fn is not None and torch.isfinite(out).all()
-    with torch.no_grad(), pytest.raises(NotImplementedError):
-        model(mix.cuda(), emb.cuda())
+    stats = {k: v.clone() for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    model.load_state_dict(sd)
+    model.train()
+    with torch.no_grad():
+        out2 = model(mix.cuda(), emb.cuda())
+    assert not out2.requires_grad and out2.grad_fn is None and torch.equal(out2, out.detach())
+    for k, v in model.state_dict().items():
+        if k in stats:
+            assert torch.equal(v, stats[k]), k
+    assert any(not torch.equal(stats[k], sd[k].to(stats[k].device)) for k in stats if k.endswith("running_mean"))  # (the step did move them)
     # a 10-s segment (625 compressed frames: the attention adjoint walks its keys in two blocks; round 2 refused > 8 s; Tv = 250: VP glue path)
     mix, _, emb = synth.synth_inputs(1, 160000, 250)
     model.zero_grad(set_to_none=True)
