@@ -4,10 +4,10 @@ the oracle restatement's autograd to 1e-7 of the reference's; the GPU box does n
 because the oracle has none), plus the BatchNorm running statistics the train-mode step leaves behind.
 
 Deterministic: one input seed per case, one tolerance per precision, no retries.
-  fp32 / bf16x6 step:  ||g - ref|| <= 3e-3 * (||ref|| + 1e-4 * largest gradient norm) per parameter tensor; 5e-2 for the 15 scalar PReLU
-                       slopes (ONE signed, heavily cancelling fp32 sum over 3e4 ... 2e6 activations each: observed up to 1.4e-2 at full
-                       length, 4e-3 on the short cases); median over the tensors < 1e-3.
-  bf16x3 step:         1.5e-3 per tensor, 1e-2 on the scalar slopes, median < 1e-3 - on the SMOOTH-REGIME weights of oracle/regimes.py smooth_regime
+  fp32 / bf16x6 step:  ||g - ref|| <= 3e-3 * (||ref|| + 1e-4 * largest gradient norm) per parameter tensor; 1e-2 for the 15 scalar PReLU
+                       slopes (ONE signed, heavily cancelling fp32 sum over 3e4 ... 2e6 activations each: observed up to 4.7e-3 over the seven
+                       cases, round 4); median over the tensors < 1e-3.
+  bf16x3 step:         1.5e-3 per tensor, 3e-3 on the scalar slopes (observed 1.1e-3), median < 1e-3 - on the SMOOTH-REGIME weights of oracle/regimes.py smooth_regime
                        (observed on MI355X: median 1e-5 ... 2e-5, worst tensor 2.8e-4).
 Activation kinks: an fp32 evaluation that lands on the other side of a PReLU / ReLU kink than float64 is off by O(1) in that element's
 derivative.  One element of an audio tensor is noise, one element of the 50-token video branch moves ~100 tensors by 1e-2 - so every case
@@ -78,10 +78,10 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None
     ref_stats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("stat.")}
     assert rel(out.detach(), ref_out) < 1e-3
     if tol is None:
-        tol, tol_scalar = (1.5e-3, 1e-2) if dtype == "bf16x3" else (3e-3, 5e-2)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
+        tol, tol_scalar = (1.5e-3, 3e-3) if dtype == "bf16x3" else (3e-3, 1e-2)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
     glue_video = training and Tv < 8  # the VP block as PyTorch glue on <= 7 tokens with batch statistics over B x (1 ... 6) positions: not a kernel of this build
     scale = max(float(g.norm()) for g in ref.values())
-    checked, errs, bad = 0, [], []
+    checked, errs, bad, errs_scalar, errs_tensor = 0, [], [], [], []
     for n, p in model.named_parameters():
         assert p.grad is not None, n
         if float(ref[n].norm()) < 1e-6 * scale:
@@ -95,10 +95,12 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None
         if err >= (tol_scalar if p.numel() <= 12 else tol):
             bad.append((round(err, 5), n))
         errs.append(err)
+        (errs_scalar if p.numel() <= 12 else errs_tensor).append(err)
         checked += 1
     assert checked > 150
     errs.sort()
-    print(f"{dtype} train={training} B={B} L={L} R={R} Tv={Tv}: median gradient error {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}, {checked} tensors")
+    print(f"{dtype} train={training} B={B} L={L} R={R} Tv={Tv}: median gradient error {errs[len(errs) // 2]:.2e}, worst tensor {max(errs_tensor):.2e}, "
+          f"worst scalar slope {max(errs_scalar):.2e}, {checked} tensors")
     assert not bad, sorted(bad, reverse=True)[:12]
     assert errs[len(errs) // 2] < tol_median
     if training:  # running statistics of the 26 VP BatchNorm1d + 2 CAF BatchNorm2d layers after one step (momentum 0.1, unbiased variance)
