@@ -543,6 +543,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ __attribute__((aligned(16))) float slab[2][(kFlatRows + 1) * kSlabLd + 2 * kSegSkew];  // (+ one scratch row)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     const int half = blockIdx.x & 1, slot = blockIdx.x >> 1, nslots = gridDim.x >> 1;
+#ifdef UW_TIMING
+    const unsigned long long uw_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int c4 = (threadIdx.x & 15) * 4;
     const int cst = NT == 0 ? c4 : (c4 >> 4) * 16 + ((c4 >> 2) & 1) * 4 + ((c4 >> 3) & 1) * 2;  // float offset of this thread's channel quad inside a slab row
     const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
@@ -808,6 +811,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int it = 0; it < 8; ++it) out1(accA, it, prev_base);
     }
+#ifdef UW_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(dst) + 2 * blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - uw_t0;
+        o[1] = (unsigned long long)(t1 - t0);
+    }
+#endif
 }
 
 // ConvTranspose kernel, weight-stationary (round 3, large batches, fp32): the structure of unfold_ws_kernel on the zero-padded SRU output.
