@@ -85,16 +85,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r0 = group * a.rows_per_wg;
     const int r1 = r0 + a.rows_per_wg < a.M ? r0 + a.rows_per_wg : a.M;
+#ifdef WG_TIMING
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int xoff = a.x_off + z;
 
-    float4 yr[NT], xr[KT], bs[NT];
+    // prefetch registers of the next stage (a second set, i.e. two stages of lead, measured no faster and spills the bf16 forms)
+    struct Pref {
+        float4 yr[NT], xr[KT];
+        unsigned xvalid;
+        int xb[KT];
+        bool lean;  // the stage came through the lean path
+    };
+    Pref pa;
+    float4 bs[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) bs[it] = f4(0, 0, 0, 0);
     const bool want_bias = a.dbias != nullptr && z == 0 && (blk % kblocks) == 0;  // uniform over the workgroup
-    unsigned xvalid = 0;
-    int xb[KT];
-    auto load = [&](int rb) {
-        xvalid = 0;
+    // Plain maps (one segment, no shift, whole tiles) take a lean path for every stage that lies inside the workgroup's row range: running row
+    // pointers, no clamps, no validity selects.  The general path spent ~140 VALU instructions per 32-row stage on address arithmetic (8 v_mul_lo_u32,
+    // 6 v_mad_i64, clamps) and zero-selects against 32 MFMAs - and an fp32 MFMA shares the SIMD's vector lanes with them.
+    const bool plain = P == 0 && a.seg_len == 0 && xoff == 0 && a.x_seg >= r1 && n0 + NW <= a.NOUT && k0 + KW <= a.KIN;
+    const float* yptr[NT];
+    const float* xptr[KT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+        const int idx = threadIdx.x + it * 256, lr = idx / (NW / 4), q4 = (idx % (NW / 4)) * 4;
+        yptr[it] = a.dY + (size_t)(r0 + lr) * a.ldy + n0 + q4;
+    }
+#pragma unroll
+    for (int it = 0; it < KT; ++it) {
+        const int idx = threadIdx.x + it * 256, lr = idx / (KW / 4), q4 = (idx % (KW / 4)) * 4;
+        xptr[it] = a.X + (size_t)(r0 + lr) * a.ldx + k0 + q4;
+    }
+    auto load = [&](Pref& pf, int rb) {
+        float4(&yr)[NT] = pf.yr;
+        float4(&xr)[KT] = pf.xr;
+        int(&xb)[KT] = pf.xb;
+        pf.lean = plain && rb + CH <= r1;
+        if (pf.lean) {
+            const size_t oy = (size_t)(rb - r0) * a.ldy, ox = (size_t)(rb - r0) * a.ldx;
+#pragma unroll
+            for (int it = 0; it < NT; ++it) yr[it] = ld4(yptr[it] + oy);
+#pragma unroll
+            for (int it = 0; it < KT; ++it) {
+                xr[it] = ld4(xptr[it] + ox);
+                if (PRO == 3) xb[it] = (rb + (int)((threadIdx.x + it * 256) / (KW / 4))) / a.rows_per_b;
+            }
+            return;
+        }
+        unsigned xvalid = 0;
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
             const int idx = threadIdx.x + it * 256, lr = idx / (NW / 4), q4 = (idx % (NW / 4)) * 4;
@@ -117,8 +157,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             xvalid |= (ok ? 1u : 0u) << it;
             if (PRO == 3) xb[it] = rc / a.rows_per_b;
         }
+        pf.xvalid = xvalid;
     };
-    auto store = [&](float* st) {
+    auto store = [&](const Pref& pf, float* st) {
+        const float4(&yr)[NT] = pf.yr;
+        const float4(&xr)[KT] = pf.xr;
+        const int(&xb)[KT] = pf.xb;
+        const unsigned xvalid = pf.xvalid;
+        const bool lean = pf.lean;
         float* Ys = st;
         float* Xs = st + CH * LDY;
 #pragma unroll
@@ -139,22 +185,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
                 stats_finalize(a.slot, xb[it], a.inv_n, mean, rstd);
                 x = relu4(norm4(x, mean, rstd, ld4(a.p0 + kc), ld4(a.p1 + kc)));
             }
-            if (!((xvalid >> it) & 1u)) x = f4(0, 0, 0, 0);
+            if (!lean && !((xvalid >> it) & 1u)) x = f4(0, 0, 0, 0);
             st4(Xs + lr * LDX + q4, x);
         }
     };
 
     floatx16 acc[NT][KT];
     acc_zero(acc);
-    load(r0);
-    store(lds);
+    load(pa, r0);
+    store(pa, lds);
     __syncthreads();
     const int i = lane & 31, kh = lane >> 5;
     int cur = 0;
-#pragma unroll 1
-    for (int rb = r0; rb < r1; rb += CH) {
-        const bool more = rb + CH < r1;
-        if (more) load(rb + CH);
+#ifdef WG_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define WT_MARK(j) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[j] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define WT_MARK(j) do { } while (0)
+#endif
+    auto stage = [&](int rb, Pref& pnext) {
+        if (rb + CH < r1) load(pnext, rb + CH);  // in flight during this stage's MFMAs
         if constexpr (P == 0) {
             const float* yp = lds + cur * STAGE + (w * 8 + kh * 4) * LDY + i;
             const float* xp = lds + cur * STAGE + CH * LDY + (w * 8 + kh * 4) * LDX + i;
@@ -167,12 +217,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
             for (int n = 0; n < KT; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[n][r] = xp[r * LDX + n * 32];
+#ifdef WG_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WT_MARK(0);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int m = 0; m < NT; ++m)
 #pragma unroll
                     for (int n = 0; n < KT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][r], bv[n][r], acc[m][n], 0, 0, 0);
+#ifdef WG_TIMING
+            WT_MARK(1);
+#endif
         } else {
             const float* yp = lds + cur * STAGE + (w * 8) * LDY + i;
             const float* xp = lds + cur * STAGE + CH * LDY + (w * 8) * LDX + i;
@@ -197,10 +254,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int n = 0; n < KT; ++n) mma32<P>(acc[m][n], fa[m], fb[n]);
         }
-        if (more) store(lds + (cur ^ 1) * STAGE);
+        if (rb + CH < r1) store(pnext, lds + (cur ^ 1) * STAGE);
+        WT_MARK(2);
         __syncthreads();
+        WT_MARK(4);
         cur ^= 1;
-    }
+    };
+#pragma unroll 1
+    for (int rb = r0; rb < r1; rb += CH) stage(rb, pa);
     if (want_bias) {
         constexpr int Q = NW / 4;  // column quads; thread t and stage slot `it` always hold quad t % Q
 #pragma unroll
@@ -214,28 +275,65 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
     }
-    // cross-wave sum of the 4 row-partials, then one atomic per element
+    // cross-wave sum of the 4 row-partials, then one atomic per element.  Round 4: the partials travel through LDS as register dumps ([tile][register
+    // quad][lane], one conflict-free ds_write_b128 / ds_read_b128 per quad) in a tree - wave 1 -> 0, wave 3 -> 2, wave 2 -> 0 - instead of four serial
+    // passes of 128 dependent LDS read-modify-writes per lane (~65k cycles per workgroup: as long as its 32 MFMA stages, s_memtime build).
+    constexpr int DUMP = NT * KT * 1024;
+    static_assert(DUMP <= 2 * STAGE, "register dump aliases the stages");
     float* red = lds;
-#pragma unroll 1
-    for (int w0 = 0; w0 < 4; ++w0) {
-        if (w == w0) {
+    auto dump = [&]() {
 #pragma unroll
-            for (int m = 0; m < NT; ++m)
+        for (int m = 0; m < NT; ++m)
 #pragma unroll
-                for (int n = 0; n < KT; ++n)
+            for (int n = 0; n < KT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* p = red + (m * 32 + acc_row(r)) * LDX + n * 32 + i;
-                        *p = w0 == 0 ? acc[m][n][r] : *p + acc[m][n][r];
-                    }
-        }
-        __syncthreads();
+                for (int g = 0; g < 4; ++g) st4(red + (((m * KT + n) * 4 + g) * 64 + lane) * 4, acc_group(acc[m][n], g));
+    };
+    auto add = [&]() {
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < KT; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = ld4(red + (((m * KT + n) * 4 + g) * 64 + lane) * 4);
+                    acc[m][n][4 * g] += v.x, acc[m][n][4 * g + 1] += v.y, acc[m][n][4 * g + 2] += v.z, acc[m][n][4 * g + 3] += v.w;
+                }
+    };
+    if (w == 1) dump();
+    __syncthreads();
+    if (w == 0) add();
+    __syncthreads();
+    if (w == 3) dump();
+    __syncthreads();
+    if (w == 2) add();
+    __syncthreads();
+    if (w == 2) dump();
+    __syncthreads();
+    if (w == 0) {
+        add();
+        dump();
     }
+    __syncthreads();
+    // dump element (tile t = m KT + n, register r, lane l) is dW[n0 + 32 m + (r & 3) + 8 (r >> 2) + 4 (l >> 5)][k0 + 32 n + (l & 31)]: consecutive threads
+    // take consecutive lanes of one register - 128-byte lines per half wave
     float* dWz = a.dW + (size_t)z * a.KIN;
-    for (int idx = threadIdx.x; idx < NW * KW; idx += 256) {
-        const int nn = idx / KW, kk = idx % KW;
-        if (n0 + nn < a.NOUT && k0 + kk < a.KIN) atomicAdd(dWz + (size_t)(n0 + nn) * a.ldw + k0 + kk, red[nn * LDX + kk]);
+    for (int idx = threadIdx.x; idx < DUMP; idx += 256) {
+        const int l = idx & 63, q = idx >> 6, comp = q & 3, g = (q >> 2) & 3, t = q >> 4;  // float4 slot (t, g) of lane l, component comp  ->  register 4 g + comp
+        const int r = 4 * g + comp, m = t / KT, n = t % KT;
+        const int nn = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), kk = 32 * n + (l & 31);
+        if (n0 + nn < a.NOUT && k0 + kk < a.KIN) atomicAdd(dWz + (size_t)(n0 + nn) * a.ldw + k0 + kk, red[((t * 4 + g) * 64 + l) * 4 + comp]);
     }
+#ifdef WG_TIMING
+    if (lane == 0 && a.dbias) {  // (timing build: the segment sums of wave w of workgroup blockIdx.x go to dbias - repurposed as a dump buffer)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(a.dbias) + (size_t)(blockIdx.x * 4 + w) * 8;
+        for (int j = 0; j < 5; ++j) o[j] = tacc[j];
+        o[5] = (unsigned long long)((r1 - r0 + CH - 1) / CH);
+        o[6] = __builtin_amdgcn_s_memtime() - t_entry;
+        o[7] = t_entry;
+    }
+#endif
+#undef WT_MARK
 }
 
 // Toeplitz weight gradient, all 8 taps in one workgroup:  dW[n][z*64 + k] += sum_r dY[r][n] * X[xrow(r) + z][k],  z = 0..7  (KIN = 64).
@@ -414,7 +512,10 @@ static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     const int nblk = ((a.NOUT + NT * 32 - 1) / (NT * 32)) * ((a.KIN + KT * 32 - 1) / (KT * 32)) * a.nshift;
     // ~2048 workgroups, but at least 1024 rows each: every workgroup ends with a cross-wave LDS sum and one atomic request per
     // line of its tile, and requests to one line are served serially (~27 ns) - a few hundred row groups keep that tail short
-    long long rpw = ((long long)a.M * nblk / 2048 + 31) / 32 * 32;
+    // (round 4: ~512 workgroups = one resident round for the full-resolution maps - a workgroup's prologue + cross-wave sum + atomics cost as much as
+    // ~9 of its 32-row stages, s_memtime build - the short SRU maps keep ~2048)
+    const long long wg_target = a.M >= 500000 ? 512 : 2048;
+    long long rpw = ((long long)a.M * nblk / wg_target + 31) / 32 * 32;
     a.rows_per_wg = (int)(rpw < 1024 ? 1024 : rpw);
     a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
     const dim3 grid((unsigned)((a.ngroups + 7) / 8 * 8 * nblk));
