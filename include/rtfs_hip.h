@@ -8,7 +8,8 @@
  *   - takes raw DEVICE pointers and sizes only (no torch types), caller-allocated outputs and workspaces,
  *   - enqueues on the given `hipStream_t` (passed as void*; NULL = default stream) and never synchronises,
  *   - keeps no global state and is re-entrant per stream (exception: the parameter-gradient reducers of the training step share
- *     one zeroed 2 MB scratch per device, csrc/spread.hip -- order their launches on one stream per device),
+ *     one zeroed 8 MB scratch per device and the deferred-finish state of rtfs_spread_defer, csrc/spread.hip -- order their launches on
+ *     one stream per device),
  *   - returns 0 on success, RTFS_EINVAL (-1) for unsupported shapes, RTFS_ELAUNCH (-2) if the launch failed.
  *
  * Tensor layout below the boundary is CHANNELS-LAST fp32:
@@ -165,6 +166,13 @@ int rtfs_istft_fwd(const float* taps, float* frames, float* out, int B, int L, v
  * ====================================================================================================================== */
 int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream);
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream);
+/* Deferred mode of the parameter-gradient reducers (every *_bwd / rtfs_wgrad-style entry point that adds per-workgroup partial sums into dgamma / dbeta / dW /
+ * dslope ... through the spread scratch): between rtfs_spread_defer(1) and rtfs_spread_defer(0) their small finish launches (219 per training step) are
+ * recorded and applied by one launch per ~20 producers, with fp32 atomic adds (two producers may name the same destination: the RTFS blocks share their
+ * weights).  Destinations are complete after rtfs_spread_flush / rtfs_spread_defer(0), stream-ordered.  Outside a deferred section every entry point finishes
+ * its own sums before it returns to the stream, as in rounds 1-3.  Reference: parameter-gradient accumulation of autograd over separators/tdanet.py:106-133. */
+int rtfs_spread_defer(int on, void* stream);
+int rtfs_spread_flush(void* stream);
 /* GroupNorm(1,C) adjoint; act: 0 none, 1 PReLU after the norm (C=64), 2 ReLU after the norm (C=256); red: double[B][16] (entries 0, 1 used) zeroed by caller */
 int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
                         float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream);

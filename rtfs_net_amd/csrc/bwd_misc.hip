@@ -283,7 +283,7 @@ int rtfs_caf_bwd_reduce(const float* dOut, const float* x, const float* ks, cons
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
     LAUNCH(caf_bwd_reduce_kernel, dim3(T, B), dOut, x, ks, kb, vs, vb, att, rsz, datt, drsz, scr, T, Tv);
-    return spread_finish(scr, SpreadOut{{R}, {1024}}, (hipStream_t)stream);
+    return spread_finish(scr, SpreadOut{{R}, {1024}}, (hipStream_t)stream, /*consumed_now=*/true);  // (the host side folds R into the BatchNorm adjoint next)
 }
 
 int rtfs_caf_bwd_apply(const float* dOut, const float* x, const float* ks, const float* kb, const float* att, const float* rsz, const float* coef,

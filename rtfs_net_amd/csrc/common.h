@@ -109,7 +109,7 @@ __device__ __forceinline__ void block_stats_commit(float s, float q, float* red,
 
 // ---- spread accumulators (spread.hip) ------------------------------------------------------------------------------
 constexpr int kSpread = 32;         // scratch copies; a workgroup adds into copy (its index % kSpread)
-constexpr int kSpreadCap = 16384;   // floats per copy
+constexpr int kSpreadCap = 65536;   // floats per copy (round 4: room for several pending regions, see spread.hip)
 constexpr int kSpreadSlots = 8;
 struct SpreadOut {                  // up to 8 accumulators of one kernel; region j starts at the 32-float-aligned running offset
     float* dst[kSpreadSlots];
@@ -122,8 +122,10 @@ struct SpreadOut {                  // up to 8 accumulators of one kernel; regio
 };
 // this workgroup's copy of the scratch
 __device__ __forceinline__ float* spread_copy(float* scr, unsigned wg) { return scr + (size_t)(wg & (kSpread - 1)) * kSpreadCap; }
-float* spread_scratch();                                             // zeroed [kSpread][kSpreadCap] floats of this device (nullptr on failure)
-int spread_finish(float* scr, const SpreadOut& o, hipStream_t st);   // dst[j][i] += sum over copies; re-zeroes the scratch
+float* spread_scratch();  // this device's zeroed scratch [kSpread][kSpreadCap], at the start of the next free region (nullptr on failure)
+// dst[j][i] += sum over copies of the region that starts at `scr`; re-zeroes it.  Immediately (one small launch), or - in deferred mode,
+// rtfs_spread_defer - recorded and applied by ONE launch for all pending regions at the next flush; `consumed_now`: the caller reads dst right away
+int spread_finish(float* scr, const SpreadOut& o, hipStream_t st, bool consumed_now = false);
 
 // 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each).  __frcp_rn expands to the full IEEE division sequence
 // (div_scale / rcp / 4 fma / div_fmas / div_fixup: 10 VALU instructions per gate), which dominated the recurrence kernels.

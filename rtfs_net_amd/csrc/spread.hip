@@ -34,31 +34,121 @@ __global__ __launch_bounds__(256) void spread_finish_kernel(float* __restrict__ 
     if (o.dst[j]) o.dst[j][i] += s;  // a region without destination (optional output the kernel still adds into) is only cleared
 }
 
-static float* g_scratch[16] = {};
-static std::mutex g_mu;
+// All pending regions of a deferred section in one launch.  Two regions may name the same destination (the R RTFS blocks share their weights, and a
+// block's adjoint adds into one gradient buffer per parameter): the sums are ADDED with fp32 atomics.
+constexpr int kMaxPend = 24;
+constexpr int kMaxRegion = 12352;  // largest region any producer asks for (attention QKV norm adjoint: 4 x 1024 + 2 x 4096 + 12, 32-float aligned)
+struct FlushArgs {
+    int n;
+    int off[kMaxPend], total[kMaxPend];
+    SpreadOut o[kMaxPend];
+};
+__global__ __launch_bounds__(256) void spread_flush_kernel(float* __restrict__ scr, FlushArgs fa) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    int p = 0;
+    while (p < fa.n && e >= fa.total[p]) e -= fa.total[p], ++p;
+    if (p >= fa.n) return;
+    const SpreadOut& o = fa.o[p];
+    int j = 0, base = 0;
+#pragma unroll
+    for (int k = 0; k < kSpreadSlots - 1; ++k) {
+        const int span = (o.n[j] + 31) & ~31;
+        if (j < kSpreadSlots - 1 && e >= base + span) base += span, ++j;
+    }
+    const int i = e - base;
+    if (i >= o.n[j]) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < kSpread; ++c) {
+        float* q = scr + (size_t)c * kSpreadCap + fa.off[p] + e;
+        s += *q;
+        *q = 0.f;
+    }
+    if (o.dst[j]) atomicAdd(o.dst[j] + i, s);
+}
 
-float* spread_scratch() {
+namespace {
+struct DevState {
+    float* scr = nullptr;
+    int cursor = 0;        // floats; start of the next free region (0 outside deferred sections)
+    bool deferred = false;
+    FlushArgs pend{};      // pend.n regions wait for the flush
+};
+DevState g_dev[16];
+std::mutex g_mu;
+
+DevState* dev_state() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_scratch[dev]) {
+    DevState& d = g_dev[dev];
+    if (!d.scr) {
         float* p = nullptr;
         const size_t bytes = (size_t)kSpread * kSpreadCap * sizeof(float);
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, bytes) != hipSuccess) return nullptr;
-        g_scratch[dev] = p;
+        d.scr = p;
     }
-    return g_scratch[dev];
+    return &d;
 }
 
-int spread_finish(float* scr, const SpreadOut& o, hipStream_t st) {
+int flush_locked(DevState& d, hipStream_t st) {
+    if (d.pend.n > 0) {
+        int total = 0;
+        for (int p = 0; p < d.pend.n; ++p) total += d.pend.total[p];
+        hipLaunchKernelGGL(spread_flush_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d.scr, d.pend);
+        d.pend.n = 0;
+        RTFS_LAUNCH_CHECK();
+    }
+    d.cursor = 0;
+    return RTFS_OK;
+}
+}  // namespace
+
+float* spread_scratch() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevState* d = dev_state();
+    return d ? d->scr + d->cursor : nullptr;
+}
+
+int spread_finish(float* scr, const SpreadOut& o, hipStream_t st, bool consumed_now) {
     int total = 0;
     for (int j = 0; j < kSpreadSlots; ++j) total += (o.n[j] + 31) & ~31;
     if (total <= 0) return RTFS_OK;
-    if (total > kSpreadCap) return RTFS_EINVAL;
-    hipLaunchKernelGGL(spread_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scr, o);
-    RTFS_LAUNCH_CHECK();
+    if (total > kMaxRegion) return RTFS_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevState* d = dev_state();
+    if (!d) return RTFS_ELAUNCH;
+    if (!d->deferred) {
+        hipLaunchKernelGGL(spread_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scr, o);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
+    }
+    const int p = d->pend.n++;
+    d->pend.off[p] = (int)(scr - d->scr), d->pend.total[p] = total, d->pend.o[p] = o;
+    d->cursor = d->pend.off[p] + total;
+    if (consumed_now || d->pend.n == kMaxPend || d->cursor + kMaxRegion > kSpreadCap) return flush_locked(*d, st);
     return RTFS_OK;
 }
 
 }  // namespace rtfs
+
+extern "C" {
+// Deferred mode of the parameter-gradient reducers (one stream per device, as for the scratch itself): between rtfs_spread_defer(1) and
+// rtfs_spread_defer(0) the per-kernel finish launches (219 per training step, ~5 us each + a launch gap) are recorded and applied by one launch per
+// ~20 producers; the destinations are complete after rtfs_spread_flush / rtfs_spread_defer(0), both stream-ordered.  Reference: the accumulation of
+// parameter gradients over the shared RTFS block, autograd of separators/tdanet.py:106-133.
+int rtfs_spread_defer(int on, void* stream) {
+    std::lock_guard<std::mutex> lk(rtfs::g_mu);
+    rtfs::DevState* d = rtfs::dev_state();
+    if (!d) return RTFS_ELAUNCH;
+    const int rc = rtfs::flush_locked(*d, (hipStream_t)stream);
+    d->deferred = on != 0;
+    return rc;
+}
+int rtfs_spread_flush(void* stream) {
+    std::lock_guard<std::mutex> lk(rtfs::g_mu);
+    rtfs::DevState* d = rtfs::dev_state();
+    if (!d) return RTFS_ELAUNCH;
+    return rtfs::flush_locked(*d, (hipStream_t)stream);
+}
+}

@@ -122,6 +122,8 @@ SIGNATURES = {
     "rtfs_gemm_rows_fwd_bf16": [P, P, P, P, I, I, I, I, P],
     "rtfs_gemm_rows_bf16": [P, P, P, P, I, I, I, I, I, P],
     "rtfs_wgrad_bf16": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, I, P],
+    "rtfs_spread_defer": [I, P],
+    "rtfs_spread_flush": [P],
     "rtfs_proj_gateway_bwd_bf16": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, I, P],
     "rtfs_fold_gemm_bwd_bf16": [P, P, P, I, I, I, I, P],
     "rtfs_convt_bwd_input_bf16": [P, P, P, I, I, I, I, P],
@@ -220,6 +222,16 @@ def call(name: str, *args):
         with torch.cuda.device(dev):
             return _launch(name, conv, args, dev)
     return _launch(name, conv, args, dev)
+
+
+def spread_defer(on: bool, device) -> None:
+    """rtfs_spread_defer on `device`'s current stream (no tensor argument to take the device from): the training step brackets each of its two
+    backward stages with it, so the parameter-gradient reducers' finish launches are batched (include/rtfs_hip.h)"""
+    device = torch.device(device)
+    with torch.cuda.device(device):
+        rc = load().rtfs_spread_defer(1 if on else 0, torch.cuda.current_stream(device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"rtfs_spread_defer failed with code {rc}")
 
 
 def _same_device(name, dev, t):

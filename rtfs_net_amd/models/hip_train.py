@@ -758,7 +758,11 @@ class AVNetHipStageA(torch.autograd.Function):
                 dx0 = torch.zeros(n, device=c.x0.device)
             if da_emb is None:
                 da_emb = torch.zeros(n, device=c.x0.device)
-            gr = trainer.backward_a(c, dx0, da0, da_emb)
+            lib.spread_defer(True, c.x0.device)
+            try:
+                gr = trainer.backward_a(c, dx0, da0, da_emb)
+            finally:
+                lib.spread_defer(False, c.x0.device)  # (flushes: every parameter gradient is complete, stream-ordered, before it is re-laid out)
             ref = grads_to_reference(trainer.model, c.pw, gr)
         grads = tuple(ref.get(name) for name in ctx.names)
         c.__dict__.clear()
@@ -779,7 +783,11 @@ class AVNetHipStageB(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         with torch.no_grad():
-            dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)
+            lib.spread_defer(True, dout.device)  # (the reducers' finish launches of this stage in a few batched launches, csrc/spread.hip)
+            try:
+                dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)
+            finally:
+                lib.spread_defer(False, dout.device)
         n = dx0.numel() // C
         return None, None, dx0.view(n, C), (None if da0 is None else da0.view(n, C)), da_emb.view(n, C), datt, drsz
 

@@ -14,6 +14,19 @@ for name, NOUT, KIN, rows in (("resid conv dW (64 -> 256)", 256, 64, M), ("SRU l
     for _ in range(2):
         lib.call("rtfs_wgrad", dY, NOUT, X, KIN, dW, KIN, dump, rows, 0, 0, 0, 1, NOUT, KIN, 0, None, None, 0.25, None, 0)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.call("rtfs_wgrad", dY, NOUT, X, KIN, dW, KIN, dump, rows, 0, 0, 0, 1, NOUT, KIN, 0, None, None, 0.25, None, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    wall_us = 1e3 * e0.elapsed_time(e1)
+    raw = dump.view(torch.int64)[: 4096 * 4 * 8].view(-1, 4, 8).cpu()
+    spans = []
+    for x in range(8):  # workgroup b runs on XCD b % 8 (observed): s_memtime bases differ per XCD
+        r = raw[x::8].reshape(-1, 8)
+        r = r[r[:, 5] > 0]
+        spans.append(int((r[:, 7] + r[:, 6]).max() - r[:, 7].min()))
+    print(f"  wall {wall_us:.1f} us; per-XCD span of s_memtime stamps {min(spans)} .. {max(spans)} ticks -> {max(spans) / wall_us:.0f} ticks per us")
     v = dump.view(torch.int64)[: 4096 * 4 * 8].view(-1, 8).cpu().double()
     v = v[v[:, 5] > 0]
     per = v[:, :5] / v[:, 5:6]
