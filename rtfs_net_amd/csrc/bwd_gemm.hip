@@ -808,7 +808,7 @@ static int wgrad_impl(const float* dY, int ldy, const float* X, int ldx, float* 
     hipStream_t st = (hipStream_t)stream;
     if (nshift == 8 && KIN == 64 && NOUT % 64 == 0 && pro == 0 && a.seg_len >= 32 && a.seg_len) {  // unfold / conv-transpose weights
         const int nblk = NOUT / 64;
-        long long rpw = ((long long)a.M * nblk / 1024 + 31) / 32 * 32;
+        long long rpw = ((long long)a.M * nblk / 512 + 31) / 32 * 32;  // ~512 workgroups = one resident round (round 4: 1024 -> 512, -3 %)
         a.rows_per_wg = (int)(rpw < 512 ? 512 : rpw);
         a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
         hipLaunchKernelGGL(toeplitz_wgrad_kernel<P>, dim3((unsigned)((a.ngroups + 7) / 8 * 8 * nblk)), dim3(256), 0, st, a);
