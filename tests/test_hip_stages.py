@@ -591,3 +591,40 @@ def test_unfold_gemm_bf16_weight_stationary_form(dim, terms, tol):
         assert rel(U.view(want.shape), want) < tol
         outs.append(U)
     assert rel(outs[0], outs[1]) < tol
+
+
+def test_deferred_finish_of_the_gradient_reducers():
+    """rtfs_spread_defer (csrc/spread.hip): inside a deferred section the reducers' finish launches are recorded and applied at the flush - with
+    atomic adds, because two producers may name the SAME destination (the RTFS blocks share their weights).  Thirty producers (more than one flush
+    batch of 24), two destinations used 15 times each, against the immediate mode; rtfs_colsum_add's wide regions exercise the region cursor."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(3)
+    n = 1 << 16
+    dy, x = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+    X = torch.randn(4096, 256, generator=g).cuda()
+    dx = torch.empty(n, device="cuda")
+
+    def run(deferred):
+        ds = [torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")]
+        cs = torch.zeros(256, device="cuda")
+        if deferred:
+            lib.spread_defer(True, "cuda:0")
+        for k in range(30):
+            lib.call("rtfs_prelu_bwd", dy, x, 0.25 + 0.01 * k, dx, 0, ds[k & 1], n)
+            if k % 5 == 0:
+                lib.call("rtfs_colsum_add", X, cs, 4096, 256)
+        if deferred:
+            assert float(ds[0].abs() + ds[1].abs()) >= 0  # (no flush forced here: the values are only complete after the section)
+            lib.spread_defer(False, "cuda:0")
+        torch.cuda.synchronize()
+        return ds[0].clone(), ds[1].clone(), cs.clone()
+
+    a0, a1, ac = run(False)
+    b0, b1, bc = run(True)
+    assert float(a0.abs()) > 0 and float(a1.abs()) > 0
+    assert rel(b0, a0) < 1e-5 and rel(b1, a1) < 1e-5 and rel(bc, ac) < 1e-5
+    ref = 6 * X.double().sum(0)
+    assert rel(bc, ref) < 1e-5
+    c0, c1, cc = run(False)  # immediate mode again after a deferred section: the scratch came back zeroed
+    assert rel(c0, a0) < 1e-5 and rel(cc, ac) < 1e-5
