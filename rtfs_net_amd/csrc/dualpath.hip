@@ -1122,27 +1122,30 @@ __global__ __launch_bounds__(256) void sru_scan_kernel(const float* __restrict__
 // 32 per-step stores in flight together every wait for a load is `s_waitcnt vmcnt(0)` (loads and stores complete out of order with respect to each
 // other, so hipcc cannot count past a store): four full drains of store acknowledgements + the next chunk's A prefetch per chunk.  Measured on the
 // bench shapes (tools/sru_bench.py, same box): see DESIGN.md section 5.
-template <bool SAVE_C, int NT = 0>  // SAVE_C (training): also stores the cell states and the pre-activations U (the adjoint's inputs); NT: common.h
-__global__ __launch_bounds__(512, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
+// NW = waves (= sequences) per workgroup: 8 at large batch; 4 below 2048 sequences, where the workgroups do not fill the chip anyway and two waves on a
+// SIMD only stretch each other's MFMA phases (batch 1: 33 -> 48 us per launch with 8, measured against the round-3 kernel).
+template <bool SAVE_C, int NT = 0, int NW = 8>  // SAVE_C (training): also stores the cell states and the pre-activations U (the adjoint's inputs); NT: common.h
+__global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
                                                            const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
                                                            float* __restrict__ Cout, float* __restrict__ Uout, int S, int L) {
     constexpr int LDW = 68, LDX = 36;  // LDX: ds_write_b128 of 8 consecutive rows (one lane group) covers 32 distinct banks; the per-step reads are consecutive floats
     __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
-    __shared__ __attribute__((aligned(16))) float Xs[8][2][32 * LDX];  // per wave: x' of the chunk's 32 steps, [dir][step][j]
+    __shared__ __attribute__((aligned(16))) float Xs[NW][2][32 * LDX];  // per wave: x' of the chunk's 32 steps, [dir][step][j]
     // the gate rows (m = 1, 2) are pre-scaled by -log2(e): the recurrence then needs fma, v_exp, add, v_rcp per gate and nothing else
     {
-        float4 stg[6];
+        constexpr int NS = 3072 / (NW * 64);
+        float4 stg[NS];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) stg[k] = ld4(Wt + (size_t)(threadIdx.x + 512 * k) * 4);  // (Wt is the plain fp32 weight for every NT: packed here, after the scaling)
+        for (int k = 0; k < NS; ++k) stg[k] = ld4(Wt + (size_t)(threadIdx.x + NW * 64 * k) * 4);  // (Wt is the plain fp32 weight for every NT: packed here, after the scaling)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int idx = threadIdx.x + 512 * k, n = idx >> 4, q4 = (idx & 15) * 4;
+        for (int k = 0; k < NS; ++k) {
+            const int idx = threadIdx.x + NW * 64 * k, n = idx >> 4, q4 = (idx & 15) * 4;
             st4(Ws + n * LDW + q4, pack4<NT>(stg[k] * (n >= 64 ? kNegLog2e : 1.0f)));
         }
     }
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.x * 8 + wv;  // wave-uniform: bases below live in SGPRs
+    const int s = blockIdx.x * NW + wv;  // wave-uniform: bases below live in SGPRs
     const int nch = (L + 31) >> 5;
     if (s >= S) return;
     const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
@@ -1435,13 +1438,14 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
 int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                        float* Uout_or_null, int S, int L, void* stream) {
     if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
-    dim3 grid((S + 7) / 8);
-    if (Cout_or_null)
-        hipLaunchKernelGGL((sru_layer_kernel<true>), grid, dim3(512), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
-                           Uout_or_null, S, L);
-    else
-        hipLaunchKernelGGL((sru_layer_kernel<false>), grid, dim3(512), 0, (hipStream_t)stream, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null,
-                           Uout_or_null, S, L);
+    hipStream_t st = (hipStream_t)stream;
+#define SRU_L(SAVE, NWV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, 0, NWV>), dim3((S + NWV - 1) / NWV), dim3(NWV * 64), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
+    if (S >= 2048) {
+        if (Cout_or_null) SRU_L(true, 8); else SRU_L(false, 8);
+    } else {
+        if (Cout_or_null) SRU_L(true, 4); else SRU_L(false, 4);
+    }
+#undef SRU_L
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -1450,14 +1454,15 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
 int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                             float* Uout_or_null, int S, int L, int terms, void* stream) {
     if (S <= 0 || L <= 0 || Hprev == Hout || (terms != 1 && terms != 3 && terms != 6) || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
-    dim3 grid((S + 7) / 8);
     hipStream_t st = (hipStream_t)stream;
-#define SRU_L(SAVE, NTV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV>), grid, dim3(512), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
+#define SRU_L(SAVE, NTV, NWV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, NTV, NWV>), dim3((S + NWV - 1) / NWV), dim3(NWV * 64), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
+#define SRU_LW(SAVE, NTV) do { if (S >= 2048) SRU_L(SAVE, NTV, 8); else SRU_L(SAVE, NTV, 4); } while (0)
     if (Cout_or_null) {
-        if (terms == 1) SRU_L(true, 1); else if (terms == 3) SRU_L(true, 3); else SRU_L(true, 6);
+        if (terms == 1) SRU_LW(true, 1); else if (terms == 3) SRU_LW(true, 3); else SRU_LW(true, 6);
     } else {
-        if (terms == 1) SRU_L(false, 1); else if (terms == 3) SRU_L(false, 3); else SRU_L(false, 6);
+        if (terms == 1) SRU_LW(false, 1); else if (terms == 3) SRU_LW(false, 3); else SRU_LW(false, 6);
     }
+#undef SRU_LW
 #undef SRU_L
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
