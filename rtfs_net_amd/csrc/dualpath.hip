@@ -1321,6 +1321,131 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
 #endif
 }
 
+// Small-batch form of the fused SRU layer (fp32, inference): ONE WAVE PER (sequence, direction).  sru_layer_kernel gives a sequence one wave, whose
+// per-chunk chain is 192 MFMAs (12.3k cycles) + 32 recurrence steps; below ~512 sequences most SIMDs idle while each sequence walks that chain (batch 1:
+// 64 / 125 sequences, 29 us per launch = 36 x 29 us = a quarter of the forward).  Here a wave owns one direction: 96 MFMAs per chunk (three 32 x 32 tiles
+// U_m[step][j]), then lanes 32-63 hand their 16 steps of every column to lanes 0-31 (v_permlane32_swap into a second register set) and lanes 0-31 run the
+// recurrence of their direction.  Same products in the same order per accumulator, same recurrence arithmetic: bit-identical to sru_layer_kernel.
+__global__ __launch_bounds__(256, 2) void sru_layer_dir_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
+                                                               const float* __restrict__ bias, float scale_x, float* __restrict__ Hout, int S, int L) {
+    constexpr int LDW = 68, LDX = 36;
+    __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
+    __shared__ __attribute__((aligned(16))) float Xs[4][32 * LDX];  // per wave: x' of the chunk's 32 steps of its direction, [step][j]
+    {
+        float4 stg[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) stg[k] = ld4(Wt + (size_t)(threadIdx.x + 256 * k) * 4);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int idx = threadIdx.x + 256 * k, n = idx >> 4, q4 = (idx & 15) * 4;
+            st4(Ws + n * LDW + q4, stg[k] * (n >= 64 ? kNegLog2e : 1.0f));
+        }
+    }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int unit = blockIdx.x * 4 + wv;  // (sequence, direction) pair, wave-uniform
+    const int s = unit >> 1, d = unit & 1;
+    if (s >= S) return;
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const float wf = wc[d * 32 + i] * kNegLog2e, wr = wc[64 + d * 32 + i] * kNegLog2e;
+    const float bf = bias[d * 32 + i] * kNegLog2e, br = bias[64 + d * 32 + i] * kNegLog2e;
+    const float* hp = Hprev + (size_t)s * L * 64;
+    float* hob = Hout + (size_t)s * L * 64;
+    const int dstr = d ? -256 : 256, off0 = (d ? (L - 1) * 256 : 0) + (d * 32 + i) * 4;  // byte offset of this column in the row of scan position 0
+    float* xw = &Xs[wv][i * LDX];    // row i of the tile this lane writes (lanes with kh == d hold columns 32 d .. 32 d + 31 of their A rows)
+    const float* xr = &Xs[wv][i];    // column i, local step k at + k * LDX
+    float c = 0.f;
+    const int nch = (L + 31) >> 5;
+    float4 a[8];
+    auto load_a = [&](int sl0) {
+        const int t = d ? max(L - 1 - (sl0 + i), 0) : min(sl0 + i, L - 1);  // rows past the end are clamped; their steps are never scanned
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = ld4(hp + (size_t)t * 64 + 32 * kh + 4 * q);
+    };
+    load_a(0);
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int sl0 = ch * 32;
+        floatx16 acc[3];
+        int woff = (d * 32 + i) * LDW + 32 * kh;
+        asm volatile("" : "+v"(woff));  // (see sru_layer_kernel)
+        const float* wp = Ws + woff;
+        float4 bb[2][3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) bb[0][m] = ld4(wp + (m * 64) * LDW);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) bb[(q + 1) & 1][m] = ld4(wp + (m * 64) * LDW + 4 * (q + 1));
+            }
+            if (kh == d) st4(xw + 4 * q, a[q]);  // x' tile: this direction's half of the A rows
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float4 b = bb[q & 1][m];
+                if (q == 0) {
+                    floatx16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b.x, z, 0, 0, 0);
+                } else {
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b.x, acc[m], 0, 0, 0);
+                }
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b.y, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b.z, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b.w, acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch + 1 < nch) load_a(sl0 + 32);
+        // lanes 32-63 -> lanes 0-31: after the swap oth[m][r] of lane i holds what lane i + 32 had in acc[m][r], i.e. local step rho(r) + 4 (own: rho(r)),
+        // rho(r) = (r & 3) + 8 (r >> 2)
+        // (the swap's operands must not have been written by a VALU instruction within two wait states - see sru_layer_kernel: the second set is
+        // zeroed BEFORE the scheduling barrier, and both registers are swapped in place so hipcc has no copy to insert in front of a swap)
+        floatx16 oth[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oth[m][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x0 = acc[m][r], y0 = oth[m][r];
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                acc[m][r] = x0;
+                oth[m][r] = y0;
+            }
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto step = [&](int k) {
+            const int sl = sl0 + k;
+            const int r = (k & 3) + 4 * (k >> 3), sel = (k >> 2) & 1;
+            const float u0 = sel ? oth[0][r] : acc[0][r], u1 = sel ? oth[1][r] : acc[1][r], u2 = sel ? oth[2][r] : acc[2][r];
+            const unsigned off = (unsigned)(off0 + sl * dstr);
+            const float x = xr[k * LDX] * scale_x;
+            const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
+            const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
+            c = u0 + (c - u0) * f;
+            if (kh == 0) st1_off(hob, off, x + (c - x) * rg);
+        };
+        if (sl0 + 32 <= L) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) step(k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (sl0 + k < L) step(k);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -1440,7 +1565,9 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
     if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define SRU_L(SAVE, NWV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, 0, NWV>), dim3((S + NWV - 1) / NWV), dim3(NWV * 64), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
-    if (S >= 2048) {
+    if (!Cout_or_null && S < 512) {  // small batches: one wave per (sequence, direction)
+        hipLaunchKernelGGL(sru_layer_dir_kernel, dim3((2 * S + 3) / 4), dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, S, L);
+    } else if (S >= 2048) {
         if (Cout_or_null) SRU_L(true, 8); else SRU_L(false, 8);
     } else {
         if (Cout_or_null) SRU_L(true, 4); else SRU_L(false, 4);
