@@ -11,6 +11,8 @@
 #include <type_traits>
 #include "common.h"
 
+#include <algorithm>
+
 namespace rtfs {
 
 constexpr int kMaxConv = 4;
@@ -954,7 +956,11 @@ static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
     if (STRIDE == 1) {  // LDS-staged kernel, f segments in multiples of its 8-column block
         // f segments per row tile: 4 at full resolution (2048 workgroups, 2.7 rounds of the 768 resident ones); at the compressed resolution 3 for the
         // 4-column kernels (8 x 32 x 3 = 768 workgroups = one full round of three per CU; 2 left a third of the slots empty: 79 -> 71 us, 35 -> 31 us)
-        const int nseg = a.Fout >= 96 ? 4 : (a.nconv <= 2 ? 3 : 2);
+        int nseg = a.Fout >= 96 ? 4 : (a.nconv <= 2 ? 3 : 2);
+        // small batches: a workgroup walks its segment's column blocks one after the other (a latency chain per block); with fewer than ~512
+        // workgroups the segments shrink to one 8-column piece at the least, which puts the chain's links side by side on idle CUs instead
+        const long long wg0 = (long long)((a.Tout + 15) / 16) * B;
+        if (wg0 * nseg < 512) nseg = (int)std::min<long long>((a.Fout + 7) / 8, (512 + wg0 - 1) / wg0);
         const int fseg = (((a.Fout + nseg - 1) / nseg) + 7) / 8 * 8;  // (a multiple of the kernel's column block, 8 or 4)
         dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
         switch (a.nconv) {
@@ -1053,7 +1059,10 @@ int rtfs_dwconv_trio_fwd(const float* d0, const double* d0_stats, const float* d
                          const float* w2, const float* bias2, float* out2, double* stats2, float* pooled, int B, int T, int T2, void* stream) {
     if (B <= 0 || T < 2 || T2 != (T - 2) / 2 + 1 || !bias2) return RTFS_EINVAL;
     TrioArgs a{d0, d0_stats, 1.0 / ((double)T * kF * kH), d0_g, d0_b, T, T2, w1, out1, stats1, w2, bias2, out2, stats2, pooled};
-    const int nseg = 4, fseg = (((kF + nseg - 1) / nseg) + 7) / 8 * 8;
+    int nseg = 4;
+    const long long wg0 = (long long)((T + 15) / 16) * B;
+    if (wg0 * nseg < 512) nseg = (int)std::min<long long>((kF + 7) / 8, (512 + wg0 - 1) / wg0);  // (small batches: see launch_dw)
+    const int fseg = (((kF + nseg - 1) / nseg) + 7) / 8 * 8;
     hipLaunchKernelGGL(dwconv_trio_kernel, dim3((T + 15) / 16, B, (kF + fseg - 1) / fseg), dim3(256), 0, (hipStream_t)stream, a, fseg);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
