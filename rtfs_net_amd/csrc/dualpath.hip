@@ -39,7 +39,9 @@ constexpr int kSlabLd = 68;
 
 // MODE 0: slab = LN4D(G) rows m0..m0+70;  out U0[S][L][256]
 // MODE 1: slab = zero-padded h3 rows (m0-7)..(m0+63);  out G[pos] = acc + bias + G[pos]  (in place)
-template <int N, int WM, int WN, int BK, int MODE, int NT = 0>  // NT != 0 (common.h): Wt host-PACKED, slab packed on store
+// LDO: row stride of the MODE 0 output.  LDO > N: the workgroup computes column block blockIdx.z (N of the LDO columns) - batch-1-sized launches put four
+// 64-column workgroups where one 256-column workgroup walked its 1024 MFMAs per wave alone (round 4).
+template <int N, int WM, int WN, int BK, int MODE, int NT = 0, int LDO = N>  // NT != 0 (common.h): Wt host-PACKED, slab packed on store
 __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const float* __restrict__ src, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, float* __restrict__ dst) {
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = w / WGN, wn = w % WGN;
     const size_t sbase = map.base(s);
+    if (LDO > N) Wt += (size_t)blockIdx.z * N * 512, dst += blockIdx.z * N;
 
     ChunkRegs<N, BK> breg;
     breg.load(Wt, 512, 0);
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void toeplitz_gemm_kernel(SeqMap map, const fl
                 const int col = (wn * WN + n) * 32 + 8 * g + 4 * (lane >> 5);
                 const float4 v = acc_group(acc[n][m], g);
                 if (MODE == 0) {
-                    if (row < map.L) st4(dst + ((size_t)s * map.L + row) * N + col, v);
+                    if (row < map.L) st4(dst + ((size_t)s * map.L + row) * LDO + col, v);
                 } else {
                     if (row < map.npos) {
                         float* o = dst + sbase + (size_t)row * map.pos_stride + col;
@@ -1471,7 +1474,10 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
     const int tps = (m.L + 63) / 64, total = S * tps;
     const int npairs = (total + 1) / 2, resident = 2 * 256;  // two 79.6 KB workgroups per CU
     if (npairs < 256 || (NT != 0 && m.L < 32)) {  // small batches: 64-row tiles put twice as many workgroups on the (otherwise half-empty) chip
-        hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0, NT>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+        if (total < 256)  // ... and below one workgroup per CU, four 64-column workgroups per row tile
+            hipLaunchKernelGGL((toeplitz_gemm_kernel<64, 1, 1, 16, 0, NT, 256>), dim3(tps, S, 4), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
+        else
+            hipLaunchKernelGGL((toeplitz_gemm_kernel<256, 2, 2, 16, 0, NT>), dim3(tps, S), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, nullptr, U0);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
