@@ -101,6 +101,10 @@ int rtfs_dwconv_trio_fwd(const float* d0, const double* d0_stats, const float* d
                          const float* w2, const float* bias2, float* out2, double* stats2, float* pooled, int B, int T, int T2, void* stream);
 int rtfs_pool_add_fwd(const float* pooled, const float* d1, const double* d1_stats, const float* d1_g, const float* d1_b, float* G, int B, int T2,
                       void* stream);
+/* rtfs_pool_add_fwd + rtfs_dwconv_fwd(mode 1, stride 1, one convolution, no bias) in ONE pass over `in` (D1): out = conv(gLN(in)) with its gLN partial
+ * sums (fusion_layers[1].local_embedding, layers/fusion.py:25-52) and G = pooled + gLN(in) (tdanet.py:117-118). */
+int rtfs_dwconv_gadd_fwd(const float* in, const double* stats_in, const float* gamma, const float* beta, const float* w /*[16][64]*/, float* out,
+                         double* stats_out, const float* pooled, float* G, int B, int T, int F, void* stream);
 
 /* ---- a5.6: TFAR, InjectionMultiSum.forward, layers/fusion.py:54-69 ------------------------------------------ */
 int rtfs_tfar_mix_fwd(const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,

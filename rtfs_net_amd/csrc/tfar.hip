@@ -48,6 +48,9 @@ struct DwArgs {
     // ^ = nearest up-sampling from (Tg, Fg)), formed on the way into LDS - the mixed tensor never exists in HBM
     NormRefLite gate, glob;
     int Tg, Fg;
+    // GADD (dwconv_s1_kernel<1, 1, 4, true>): addout[pixel] = addsrc[pixel] + gLN(in)[pixel] rides along (tdanet.py:117-118: G = pooled + gLN(D1))
+    const float* addsrc;
+    float* addout;
 };
 
 // Depth-wise 4x4 convolution, sliding-window form.
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(DwArgs a, int fseg) {
 // the bytes it keeps in flight - a workgroup only has loads outstanding during its staging phase - and a third workgroup per CU measured -10 ... -12 %
 // on the full-resolution launches (same box: 149 -> 134 us, 186 -> 164 us); four workgroups (<= 128 VGPRs) spill the mix form and gain nothing more.
 // Four convolutions keep the 8-column block (their accumulators do not fit 168 registers).
-template <int NCONV, int MODE, int TC = (NCONV <= 2 ? 4 : 8)>
+template <int NCONV, int MODE, int TC = (NCONV <= 2 ? 4 : 8), bool GADD = false>
 __global__ __launch_bounds__(256, (NCONV <= 2 ? 3 : 2)) void dwconv_s1_kernel(DwArgs a, int fseg) {
     constexpr int TR = 16, R = TR + 3, CB = TC + 3, RPI = 16 / TC;  // RPI: tile rows covered by one 256-thread pass over the new columns
     constexpr int RS = CB * 64;  // unpadded: ds_read_b128 serves lanes {0-3,12-15,20-27 | ...}, for which 256-byte rows at a multiple of
@@ -408,6 +411,8 @@ __global__ __launch_bounds__(256, (NCONV <= 2 ? 3 : 2)) void dwconv_s1_kernel(Dw
                         s[k] += acc[k][jj].x + acc[k][jj].y + acc[k][jj].z + acc[k][jj].w;
                         q[k] += acc[k][jj].x * acc[k][jj].x + acc[k][jj].y * acc[k][jj].y + acc[k][jj].z * acc[k][jj].z + acc[k][jj].w * acc[k][jj].w;
                     }
+                    if constexpr (GADD)  // the transformed input pixel itself (tile row tr + 1, column jb + jj + 1) + the pooled term
+                        st4(a.addout + orow + (size_t)fo * kH, ld4(trow + RS + (jb + jj + 1) * 64) + ld4(a.addsrc + orow + (size_t)fo * kH));
                 }
             }
         }
@@ -1008,6 +1013,7 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
     }
     a.gate = a.glob = NormRefLite{nullptr, nullptr, 0.0, nullptr, nullptr};
     a.Tg = a.Fg = 0;
+    a.addsrc = nullptr, a.addout = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
         if (mode == 0) return launch_dw<1, 0>(a, B, st);
@@ -1040,7 +1046,31 @@ int rtfs_dwconv_mix_fwd(const float* loc, const double* loc_stats, const float* 
     a.gate = NormRefLite{gate, gate_stats, ng, gate_g, gate_b};
     a.glob = NormRefLite{glob, glob_stats, ng, glob_g, glob_b};
     a.Tg = Tg, a.Fg = Fg;
+    a.addsrc = nullptr, a.addout = nullptr;
     return launch_dw<1, 3>(a, B, (hipStream_t)stream);
+}
+
+// rtfs_pool_add_fwd + rtfs_dwconv_fwd(mode 1, one convolution) in one pass over `in` (= D1, compressed resolution): out = conv(gLN(in)) with its gLN partial
+// sums (fusion_layers[1].local_embedding, fusion.py:25-52) AND G = pooled + gLN(in) (tdanet.py:117-118) - the normalised pixel is in the staged tile anyway.
+int rtfs_dwconv_gadd_fwd(const float* in, const double* stats_in, const float* gamma, const float* beta, const float* w, float* out, double* stats_out,
+                         const float* pooled, float* G, int B, int T, int F, void* stream) {
+    if (B <= 0 || T <= 0 || F <= 0 || !pooled || !G || !stats_in) return RTFS_EINVAL;
+    DwArgs a;
+    a.in = in, a.slot = stats_in, a.inv_n = 1.0 / ((double)T * F * kH), a.gamma = gamma, a.beta = beta, a.slope = 0.f;
+    a.Tin = a.Tout = T, a.Fin = a.Fout = F;
+    a.nconv = 1;
+    for (int j = 0; j < kMaxConv; ++j) a.w[j] = nullptr, a.bias[j] = nullptr, a.out[j] = nullptr, a.stats[j] = nullptr;
+    a.w[0] = w, a.out[0] = out, a.stats[0] = stats_out;
+    a.gate = a.glob = NormRefLite{nullptr, nullptr, 0.0, nullptr, nullptr};
+    a.Tg = a.Fg = 0;
+    a.addsrc = pooled, a.addout = G;
+    int nseg = F >= 96 ? 4 : 3;
+    const long long wg0 = (long long)((T + 15) / 16) * B;
+    if (wg0 * nseg < 512) nseg = (int)std::min<long long>((F + 7) / 8, (512 + wg0 - 1) / wg0);
+    const int fseg = (((F + nseg - 1) / nseg) + 7) / 8 * 8;
+    hipLaunchKernelGGL((dwconv_s1_kernel<1, 1, 4, true>), dim3((T + 15) / 16, B, (F + fseg - 1) / fseg), dim3(256), 0, (hipStream_t)stream, a, fseg);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
 }
 
 int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, const float* d0_b, const float* d1, const double* d1_stats,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
     "rtfs_dwconv_trio_fwd": [P] * 12 + [I, I, I, P],
     "rtfs_pool_add_fwd": [P] * 6 + [I, I, P],
+    "rtfs_dwconv_gadd_fwd": [P] * 9 + [I, I, I, P],
     "rtfs_resid_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, P],
     "rtfs_resid_proj_fwd": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, P],
     "rtfs_resid_caf_fwd": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, P],

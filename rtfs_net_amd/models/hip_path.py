@@ -255,7 +255,7 @@ class HipForward:
         # A/B switches of the host-side fusion choices, read from the environment ONCE here (not per forward); tests flip the attributes
         off = lambda name: os.environ.get(name, "0") == "1"  # noqa: E731
         self.fuse = {"trio": not off("RTFS_NO_TRIO_FUSION"), "mix": not off("RTFS_NO_MIX_FUSION"), "proj": not off("RTFS_NO_PROJ_FUSION"),
-                     "caf": not off("RTFS_NO_CAF_FUSION")}
+                     "caf": not off("RTFS_NO_CAF_FUSION"), "gadd": not off("RTFS_NO_GADD_FUSION")}
         self.vp_glue = off("RTFS_VP_GLUE")  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
         self.vp_side_stream = not off("RTFS_VP_NO_SIDE")
 
@@ -318,12 +318,17 @@ class HipForward:
         D1 = low()
         G = low()
         f0l = bw["fusion_layers.0.local_embedding"]
-        l0 = None
+        l0 = l1 = None
         if self.fuse["trio"]:
             # the three readers of gLN(D0) - D1's stride-2 conv, the pooling, fusion_layers[0]'s local embedding - in one pass over D0
             l0, pooled = full(), low()
             lib.call("rtfs_dwconv_trio_fwd", D0, st[1], d0g, d0be, f0l[0], l0, st[3], d1w, d1b, D1, st[2], pooled, B, T, T2)
-            lib.call("rtfs_pool_add_fwd", pooled, D1, st[2], d1g, d1be, G, B, T2)
+            if self.fuse["gadd"]:
+                # G = pooled + gLN(D1) rides in the pass that makes fusion_layers[1]'s local embedding of gLN(D1) (one read of D1 instead of two)
+                l1 = low()
+                lib.call("rtfs_dwconv_gadd_fwd", D1, st[2], d1g, d1be, bw["fusion_layers.1.local_embedding"][0], l1, st[4], pooled, G, B, T2, F2)
+            else:
+                lib.call("rtfs_pool_add_fwd", pooled, D1, st[2], d1g, d1be, G, B, T2)
             del pooled
         else:
             lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 2, 1, [d1w], [d1b], [D1], [st[2]], B, T, F_BINS)
@@ -350,11 +355,12 @@ class HipForward:
         f0g, f0gate = bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
-        l1 = low()
         if l0 is None:
             l0 = full()
             lib.call("rtfs_dwconv_fwd", D0, st[1], d0g, d0be, 0.0, 1, 1, 1, [f0l[0]], [None], [l0], [st[3]], B, T, F_BINS)
-        lib.call("rtfs_dwconv_fwd", D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [l1], [st[4]], B, T2, F2)
+        if l1 is None:
+            l1 = low()
+            lib.call("rtfs_dwconv_fwd", D1, st[2], d1g, d1be, 0.0, 1, 1, 1, [f1l[0]], [None], [l1], [st[4]], B, T2, F2)
         g0, gg0, g1, gg1 = low(), low(), low(), low()
         lib.call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [g0, gg0, g1, gg1],
                  [st[5], st[6], st[7], st[8]], B, T2, F2)

@@ -630,3 +630,16 @@ def test_deferred_finish_of_the_gradient_reducers():
     assert rel(bc, ref) < 1e-5
     c0, c1, cc = run(False)  # immediate mode again after a deferred section: the scratch came back zeroed
     assert rel(c0, a0) < 1e-5 and rel(cc, ac) < 1e-5
+
+
+@pytest.mark.parametrize("B,L", [(2, 16000 + 77), (1, 4096)])
+def test_gadd_fusion_matches_separate_calls(B, L):
+    """rtfs_dwconv_gadd_fwd (G = pooled + gLN(D1) formed inside the pass that computes fusion_layers[1]'s local embedding of gLN(D1)) against
+    rtfs_pool_add_fwd + rtfs_dwconv_fwd, end to end (even / odd frame counts, ragged tiles)"""
+    model, _, _ = make_model(2, "cuda")
+    mix, _, emb = synth.synth_inputs(B, L, max(8, L // 640))
+    with torch.no_grad():
+        fused = model(mix.cuda(), emb.cuda())
+        model._hip.fuse["gadd"] = False
+        plain = model(mix.cuda(), emb.cuda())
+    assert rel(fused, plain) < 2e-6
