@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
 
 // Small-batch form of the fused SRU layer (fp32, inference): ONE WAVE PER (sequence, direction).  sru_layer_kernel gives a sequence one wave, whose
 // per-chunk chain is 192 MFMAs (12.3k cycles) + 32 recurrence steps; below ~512 sequences most SIMDs idle while each sequence walks that chain (batch 1:
-// 64 / 125 sequences, 29 us per launch = 36 x 29 us = a quarter of the forward).  Here a wave owns one direction: 96 MFMAs per chunk (three 32 x 32 tiles
+// 64 / 125 sequences, 29 us per launch = 36 x 29 us = a quarter of the forward); used below 2048 sequences.  Here a wave owns one direction: 96 MFMAs per chunk (three 32 x 32 tiles
 // U_m[step][j]), then lanes 32-63 hand their 16 steps of every column to lanes 0-31 (v_permlane32_swap into a second register set) and lanes 0-31 run the
 // recurrence of their direction.  Same products in the same order per accumulator, same recurrence arithmetic: bit-identical to sru_layer_kernel.
 __global__ __launch_bounds__(256, 2) void sru_layer_dir_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
@@ -1571,7 +1571,7 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
     if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define SRU_L(SAVE, NWV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, 0, NWV>), dim3((S + NWV - 1) / NWV), dim3(NWV * 64), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
-    if (!Cout_or_null && S < 512) {  // small batches: one wave per (sequence, direction)
+    if (!Cout_or_null && S < 2048) {  // below 2048 sequences: one wave per (sequence, direction) (same-box A/B: batch 8 7.45 -> 7.23 ms, batch 16 equal; 4096: batch 32 slower)
         hipLaunchKernelGGL(sru_layer_dir_kernel, dim3((2 * S + 3) / 4), dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, S, L);
     } else if (S >= 2048) {
         if (Cout_or_null) SRU_L(true, 8); else SRU_L(false, 8);
