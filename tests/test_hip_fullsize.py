@@ -3,7 +3,7 @@
 * config 2 (RTFS-Net-4, batch 16, forward): batch invariance - an utterance separated alone equals its row of the batch.
 * config 3 (RTFS-Net-6, batch 32, forward + backward): the parameter gradients of one B = 32 step equal the SUM of the gradients of
   the two B = 16 half-batch steps (the loss is a sum over utterances and, in eval mode, nothing couples utterances), per tensor
-  <= 5e-3 of its norm - the B = 32 launch takes different kernels / tile schedules than any small gradient test (flattened 2- and
+  <= 3e-3 of its norm (1e-2 for the 15 scalar slopes) - the B = 32 launch takes different kernels / tile schedules than any small gradient test (flattened 2- and
   3-sequence tiles, row-split Toeplitz weight gradient, spread accumulators at 8096 workgroups).  One utterance's gradients at the
   full length are checked against float64 autograd of the oracle in tests/test_hip_backward.py (fifth case).
 * the SRU skip scaling `scale_x != 1` (a persistent buffer of the reference's state dict) through the whole path:
@@ -17,6 +17,7 @@ import torch
 from util import make_model, rel, synth
 
 pytestmark = pytest.mark.gpu
+SCALAR_TOL = 1e-2  # scalar PReLU slopes (round 3: error x 0.25 against 5e-3; round 4: observed 4.4e-3 here, worst tensor 1.0e-3)
 
 
 def test_config2_rtfs4_batch16_forward_batch_invariance():
@@ -54,15 +55,17 @@ def test_config3_rtfs6_batch32_training_step_is_sum_of_half_batches():
     assert torch.isfinite(out).all()
     assert rel(torch.cat([o_a, o_b]), out) < 1e-5
     scale = max(float(g.norm()) for g in g32.values())
-    worst = ("", 0.0)
+    worst, worst_scalar = ("", 0.0), ("", 0.0)
     for n, g in g32.items():
         s = g_a[n] + g_b[n]
         err = float((g - s).norm()) / (float(s.norm()) + 1e-4 * scale)
-        if g.numel() <= 12:
-            err *= 0.25  # scalar PReLU slopes: one signed fp32 sum over ~1e8 activations on both sides
-        worst = max(worst, (n, err), key=lambda kv: kv[1])
-    print("worst tensor:", worst)
-    assert worst[1] < 5e-3, worst
+        if g.numel() <= 12:  # scalar PReLU slopes: one signed fp32 sum over ~1e8 activations on both sides
+            worst_scalar = max(worst_scalar, (n, err), key=lambda kv: kv[1])
+        else:
+            worst = max(worst, (n, err), key=lambda kv: kv[1])
+    print("worst tensor:", worst, " worst scalar slope:", worst_scalar)
+    assert worst[1] < 3e-3, worst
+    assert worst_scalar[1] < SCALAR_TOL, worst_scalar
 
 
 def test_sru_scale_x_other_than_one_end_to_end():
