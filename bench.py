@@ -202,9 +202,12 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
     nranks, devs = 1.0, [torch.cuda.get_device_name(dev) + f" #{local_rank}"]
     if dist is not None:
         nranks = sum_over_ranks(1.0, dev, dist)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, devs[0])
-        devs = gathered
+        try:  # (evidence only: a failure of the object collective must not cost the measurement)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, devs[0])
+            devs = gathered
+        except Exception as e:  # noqa: BLE001
+            devs = devs + [f"all_gather_object failed: {type(e).__name__}"]
     handles = SimpleNamespace(model=model, sd=sd, cfg=cfg, L=L, T=T, Tv=Tv, dev=dev)
     if rank != 0:
         return None, handles
