@@ -8,6 +8,7 @@
 //   rtfs_dwconv_bwd_weight    tap / bias gradients of a depth-wise convolution, input re-normalised on read
 //   rtfs_pool_bwd             adjoint of adaptive_avg_pool2d + add            (tdanet.py:117-118)
 //   rtfs_mix_bwd              adjoint of InjectionMultiSum's gate/upsample mix (fusion.py:59-67)
+//   rtfs_mix_gln_bwd          the same fused with the gLN adjoint of the local branch (no dNloc tensor)
 //   rtfs_expand_fwd           materialise `expanded` (TFAR tail) for the residual_conv weight gradient
 //   rtfs_gateway_bwd          gateway (dw1x1 + PReLU) backward with parameter-gradient reductions
 //   rtfs_axpy                 y += a * x
@@ -407,6 +408,73 @@ __global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restri
     st4(dNglob + o, Bs);
 }
 
+// ---- mix backward fused with the gLN adjoint of its local branch ------------------------------------------------------
+// The local branch's incoming gradient is g[p] = dOut[p] * s[up(p)], s = sigmoid(n(gate)): CONSTANT over the footprint of a low-resolution
+// position q.  With Dx = sum_footprint dOut*xhat(loc) and Bs = sum_footprint dOut (what mix_bwd_glob_kernel forms anyway):
+//   A = gamma*Dx + beta*Bs;  dgamma_loc += s*Dx;  dbeta_loc += s*Bs;  S1 += sum_c gamma*s*Bs;  S2 += sum_c gamma*s*Dx
+// so the reduce pass of the local branch's gLN adjoint costs no extra read, and dNloc is never written: the apply pass re-forms it.
+__global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, float* __restrict__ dNgate,
+                                                                 float* __restrict__ dNglob, double* __restrict__ red, float* __restrict__ scr, int T,
+                                                                 int F, int Tg, int Fg) {
+    __shared__ __attribute__((aligned(16))) float lds[1024];
+    __shared__ float redl[8];
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c4 = (threadIdx.x & 15) * 4;
+    float4 dg = f4(0, 0, 0, 0), db = f4(0, 0, 0, 0);
+    float s1 = 0.f, s2 = 0.f;
+    if (q < Tg * Fg) {
+        const int tg = q / Fg, fg = q - tg * Fg;
+        const int t0 = (tg * T + Tg - 1) / Tg, t1 = min(T, ((tg + 1) * T + Tg - 1) / Tg);
+        const int f0 = (fg * F + Fg - 1) / Fg, f1 = min(F, ((fg + 1) * F + Fg - 1) / Fg);
+        float lm, lr, gm, gr;
+        stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
+        stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
+        const float4 lg = ld4(loc.gamma + c4), lb = ld4(loc.beta + c4);
+        float4 Dx = f4(0, 0, 0, 0), Bs = f4(0, 0, 0, 0);
+        for (int t = t0; t < t1; ++t)
+            for (int f = f0; f < f1; ++f) {
+                const size_t o = (((size_t)b * T + t) * F + f) * kH + c4;
+                const float4 d = ld4(dOut + o);
+                Dx = fma4(d, sub4(ld4(loc.x + o), lm) * lr, Dx);
+                Bs = Bs + d;
+            }
+        const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
+        const float4 s = sigmoid4(fma4(sub4(ld4(gate.x + o), gm) * gr, ld4(gate.gamma + c4), ld4(gate.beta + c4)));
+        const float4 A = fma4(lg, Dx, lb * Bs);
+        st4(dNgate + o, f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w)));
+        st4(dNglob + o, Bs);
+        dg = s * Dx;
+        db = s * Bs;
+        s1 = dot4(lg, db);
+        s2 = dot4(lg, dg);
+    }
+    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y);  // [dgamma 64 | dbeta 64]
+    quad_reduce_atomic<16>(dg, lds, mine);
+    quad_reduce_atomic<16>(db, lds, mine + kH);
+    block_stats_commit(s1, s2, redl, red, b);
+}
+
+// dLoc[p] = rstd * (a - S1/N - xhat*S2/N),  a = dOut[p] * s[up(p)] * gamma
+__global__ __launch_bounds__(256) void mix_gln_bwd_apply_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, const double* __restrict__ red,
+                                                                float* __restrict__ dLoc, int T, int F, int Tg, int Fg) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (p >= T * F) return;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const int t = p / F, f = p - t * F;
+    const int tg = nearest_src(t, Tg, T), fg = nearest_src(f, Fg, F);
+    float lm, lr, gm, gr;
+    stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
+    stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
+    const float m1 = (float)(red[kStatStride * b] * loc.inv_n), m2 = (float)(red[kStatStride * b + 1] * loc.inv_n);
+    const float4 s = sigmoid4(fma4(sub4(ld4(gate.x + (((size_t)b * Tg + tg) * Fg + fg) * kH + c4), gm) * gr, ld4(gate.gamma + c4), ld4(gate.beta + c4)));
+    const size_t o = ((size_t)b * T * F + p) * kH + c4;
+    const float4 xh = sub4(ld4(loc.x + o), lm) * lr;
+    const float4 a = ld4(dOut + o) * s * ld4(loc.gamma + c4);
+    st4(dLoc + o, f4((a.x - m1 - xh.x * m2) * lr, (a.y - m1 - xh.y * m2) * lr, (a.z - m1 - xh.z * m2) * lr, (a.w - m1 - xh.w * m2) * lr));
+}
+
 // ---- expanded (TFAR tail), materialised for the residual_conv weight gradient ---------------------------------------
 __global__ __launch_bounds__(256) void expand_kernel(NormArg cl, NormArg d0, NormArg cg, NormArg cgate, float* __restrict__ E, int T, int T2) {
     const int b = blockIdx.y;
@@ -588,6 +656,22 @@ int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, c
     NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b};
     LAUNCH(mix_bwd_glob_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, dNgate, dNglob, T, F, Tg, Fg);
     LAUNCH(mix_bwd_loc_kernel, dim3((T * F + 15) / 16, B), dOut, g, dNloc, T, F, Tg, Fg);
+    return RTFS_OK;
+}
+
+// rtfs_mix_bwd followed by the gLN adjoint of the local branch (rtfs_gln_bwd_reduce + rtfs_gln_bwd_apply on dNloc), without dNloc: dLoc is
+// the gradient w.r.t. the local conv's OUTPUT (pre-norm).  red: double[B][kStatStride], zeroed by the caller; dgamma / dbeta accumulate.
+int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                     const double* gate_stats, const float* gate_g, const float* gate_b, float* dLoc, float* dNgate, float* dNglob, double* red,
+                     float* dgamma, float* dbeta, int B, int T, int F, int Tg, int Fg, void* stream) {
+    if (B <= 0) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b};
+    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, dNgate, dNglob, red, scr, T, F, Tg, Fg);
+    const int rc = spread_finish(scr, SpreadOut{{dgamma, dbeta}, {kH, kH}}, (hipStream_t)stream);
+    if (rc != RTFS_OK) return rc;
+    LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);
     return RTFS_OK;
 }
 

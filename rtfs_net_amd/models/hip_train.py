@@ -350,6 +350,20 @@ class HipTrainer:
         self._call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         self._call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
+    def _mix_gln_bwd(self, dOut, loc, loc_st, loc_conv, gate, gate_st, gate_conv, dLoc, dNgate, dNglob, gr, key, B, T, F, Tg, Fg):
+        """adjoint of `n(loc) * sigmoid(n(gate))^ + n(glob)^` together with the gLN adjoint of its local branch: dLoc = gradient w.r.t. the
+        local conv's output; dNgate / dNglob = gradients w.r.t. the NORMALISED gate / global embeddings; gamma / beta grads into gr[key]."""
+        dev = dOut.device
+        dg, db = _acc(gr, key + ".g", H, dev), _acc(gr, key + ".b", H, dev)
+        if self.model._hip.fuse["mixgln"]:
+            red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
+            self._call("rtfs_mix_gln_bwd", dOut, loc, loc_st, loc_conv[2], loc_conv[3], gate, gate_st, gate_conv[2], gate_conv[3], dLoc, dNgate, dNglob, red,
+                       dg, db, B, T, F, Tg, Fg)
+            return
+        dNloc = torch.empty(B * T * F * H, device=dev)
+        self._call("rtfs_mix_bwd", dOut, loc, loc_st, loc_conv[2], loc_conv[3], gate, gate_st, gate_conv[2], gate_conv[3], dNloc, dNgate, dNglob, B, T, F, Tg, Fg)
+        self._gln_bwd(dNloc, loc, loc_st, loc_conv[2], loc_conv[3], dLoc, False, gr, key, B, T * F)
+
     def _dw_bwd(self, dOut, conv, inp, in_st, in_g, in_b, in_slope, mode, stride, dIn, accumulate, gr, key, B, Tin, Fin, has_bias):
         """depth-wise conv adjoint: input gradient (w.r.t. the transformed input) and tap/bias gradients."""
         dev = dOut.device
@@ -440,12 +454,11 @@ class HipTrainer:
         dE = full()
         self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
-        dN_cl, dN_cgate, dN_cg = full(), low(), low()
-        self._call("rtfs_mix_bwd", dE, k.cl, st[9], cl_[2], cl_[3], k.cgate, st[11], cgate_[2], cgate_[3], dN_cl, dN_cgate, dN_cg, B, T, F_BINS, T2, F2)
+        dN_cgate, dN_cg = low(), low()
         dN_D0 = dE
         # concat layer: gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
-        self._gln_bwd(dN_cl, k.cl, st[9], cl_[2], cl_[3], dcl, False, gr, "blk.cl", B, TF)
+        self._mix_gln_bwd(dE, k.cl, st[9], cl_, k.cgate, st[11], cgate_, dcl, dN_cgate, dN_cg, gr, "blk.cl", B, T, F_BINS, T2, F2)
         self._gln_bwd(dN_cg, k.cg, st[10], cg_[2], cg_[3], dcg, False, gr, "blk.cg", B, lo)
         self._gln_bwd(dN_cgate, k.cgate, st[11], cgate_[2], cgate_[3], dcgate, False, gr, "blk.cgate", B, lo)
         dF0, dF1 = full(), low()
@@ -453,13 +466,10 @@ class HipTrainer:
         self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, "blk.cg", B, T2, F2, False)
         self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, "blk.cgate", B, T2, F2, False)
         # fusion layers' mixes
-        dN_l0, dN_gg0, dN_g0 = full(), low(), low()
-        self._call("rtfs_mix_bwd", dF0, k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], dN_l0, dN_gg0, dN_g0, B, T, F_BINS, T2, F2)
-        dN_l1, dN_gg1, dN_g1 = low(), low(), low()
-        self._call("rtfs_mix_bwd", dF1, k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], dN_l1, dN_gg1, dN_g1, B, T2, F2, T2, F2)
+        dN_gg0, dN_g0, dN_gg1, dN_g1 = low(), low(), low(), low()
         dl0, dl1 = full(), low()
-        self._gln_bwd(dN_l0, k.l0, st[3], f0l[2], f0l[3], dl0, False, gr, "blk.f0l", B, TF)
-        self._gln_bwd(dN_l1, k.l1, st[4], f1l[2], f1l[3], dl1, False, gr, "blk.f1l", B, lo)
+        self._mix_gln_bwd(dF0, k.l0, st[3], f0l, k.gg0, st[6], f0gate, dl0, dN_gg0, dN_g0, gr, "blk.f0l", B, T, F_BINS, T2, F2)
+        self._mix_gln_bwd(dF1, k.l1, st[4], f1l, k.gg1, st[8], f1gate, dl1, dN_gg1, dN_g1, gr, "blk.f1l", B, T2, F2, T2, F2)
         dgs = [low() for _ in range(4)]
         for dN, X, sidx, conv, nm, dst in ((dN_g0, k.g0, 5, f0g, "f0g", dgs[0]), (dN_gg0, k.gg0, 6, f0gate, "f0gate", dgs[1]),
                                            (dN_g1, k.g1, 7, f1g, "f1g", dgs[2]), (dN_gg1, k.gg1, 8, f1gate, "f1gate", dgs[3])):
