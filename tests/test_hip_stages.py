@@ -702,3 +702,58 @@ def test_mix_gln_bwd_fusion_matches_separate_calls(B, T, F, Tg, Fg):
             assert rel(got.cpu().double(), want) < 2e-5, (fused, name, rel(got.cpu().double(), want))
     for a, b in zip(res[True], res[False]):
         assert rel(a, b) < 5e-6
+
+
+@pytest.mark.parametrize("B,T,F,stride,mode", [(2, 51, 129, 1, 0), (2, 37, 129, 1, 1), (1, 70, 129, 1, 2), (2, 13, 33, 1, 0), (3, 18, 129, 2, 1),
+                                               (2, 51, 129, 2, 2), (1, 33, 64, 1, 1)])
+def test_dwconv_adjoints_match_float64_autograd(B, T, F, stride, mode):
+    """rtfs_dwconv_bwd_weight (two output rows per thread at stride 1) and rtfs_dwconv_bwd_input against float64 autograd of the depth-wise 4x4
+    convolution as ConvNormAct builds it (conv_layers.py:104-113: 'same' padding 1 / 2 at stride 1, padding 1 at stride 2, applied to the
+    TRANSFORMED input: raw / gLN / PReLU(gLN)), ragged row counts (not multiples of the 32-row workgroup) and frequency segments."""
+    import torch.nn.functional as Fn
+
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(5)
+    H = 64
+    x = torch.randn(B, T, F, H, generator=g) * 1.3 + 0.2
+    w = torch.randn(16, H, generator=g) * 0.2
+    gam, bet = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g) * 0.2
+    slope = 0.25
+    To, Fo = (T, F) if stride == 1 else ((T - 2) // 2 + 1, (F - 2) // 2 + 1)
+    dOut = torch.randn(B, To, Fo, H, generator=g)
+
+    x64 = x.double()
+    if mode >= 1:
+        m, v = x64.flatten(1).mean(1).view(-1, 1, 1, 1), x64.flatten(1).var(1, unbiased=False).view(-1, 1, 1, 1)
+        xin = (x64 - m) / torch.sqrt(v + 1e-8) * gam.double() + bet.double()
+        if mode == 2:
+            xin = torch.where(xin >= 0, xin, slope * xin)
+    else:
+        xin = x64
+    xin = xin.detach().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    bias64 = torch.zeros(H, dtype=torch.float64, requires_grad=True)
+    xc = xin.permute(0, 3, 1, 2)
+    xc = Fn.pad(xc, (1, 2, 1, 2)) if stride == 1 else Fn.pad(xc, (1, 1, 1, 1))
+    out = Fn.conv2d(xc, w64.t().reshape(H, 1, 4, 4), bias64, stride=stride, groups=H).permute(0, 2, 3, 1)
+    assert out.shape == dOut.shape
+    (out * dOut.double()).sum().backward()
+
+    st = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64)
+    st[:, 0], st[:, 1] = x64.flatten(1).sum(1), x64.pow(2).flatten(1).sum(1)
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    dW, dbias = torch.zeros(16 * H, device="cuda"), torch.zeros(H, device="cuda")
+    if mode == 0:
+        lib.call("rtfs_dwconv_bwd_weight", d(dOut), d(x), None, None, None, 0.0, 0, stride, dW, dbias, B, T, F)
+    else:
+        lib.call("rtfs_dwconv_bwd_weight", d(dOut), d(x), d(st), d(gam), d(bet), slope, mode, stride, dW, dbias, B, T, F)
+    dIn = torch.empty(B, T, F, H, device="cuda")
+    lib.call("rtfs_dwconv_bwd_input", d(dOut), d(w), dIn, 0, stride, B, T, F)
+    dIn2 = torch.ones(B, T, F, H, device="cuda")
+    lib.call("rtfs_dwconv_bwd_input", d(dOut), d(w), dIn2, 1, stride, B, T, F)
+    torch.cuda.synchronize()
+    assert rel(dW.view(16, H).cpu().double(), w64.grad) < 1e-5
+    assert rel(dbias.cpu().double(), bias64.grad) < 1e-5
+    assert rel(dIn.cpu().double(), xin.grad) < 1e-5
+    assert rel((dIn2 - 1).cpu().double(), xin.grad) < 1e-5
