@@ -192,12 +192,16 @@ int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, c
                  const double* gate_stats, const float* gate_g, const float* gate_b, float* dNloc, float* dNgate, float* dNglob, int B, int T, int F, int Tg,
                  int Fg, void* stream);
 /* rtfs_mix_bwd + the gLN adjoint of the local branch (rtfs_gln_bwd_reduce / _apply on dNloc) in two passes over dOut and loc, dNloc never stored:
- * dLoc = gradient w.r.t. the local conv's output (pre-norm); red: double[B][16] zeroed by the caller; dgamma / dbeta [64] accumulate.
+ * dLoc = gradient w.r.t. the local conv's output (pre-norm).  The reduce passes of the gate / global branches' gLN adjoints ride in the first
+ * pass as well: red = double[3][B][16] (loc, gate, glob) zeroed by the caller - the caller finishes those two branches with
+ * rtfs_gln_bwd_apply(dNgate, ..., red + B*16, ...) / (dNglob, ..., red + 2*B*16, ...); dgb = host array of six device pointers to [64]
+ * accumulators (dgamma, dbeta of loc, gate, glob).
  * Replaces autograd over InjectionMultiSum.forward's `local_feat * sigmoid(gate) + global` (/root/reference/src/models/layers/fusion.py:59-67)
- * together with the GroupNorm of its local_embedding. */
+ * together with the GroupNorms of its three embeddings. */
 int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
-                     const double* gate_stats, const float* gate_g, const float* gate_b, float* dLoc, float* dNgate, float* dNglob, double* red,
-                     float* dgamma, float* dbeta, int B, int T, int F, int Tg, int Fg, void* stream);
+                     const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats, const float* glob_g,
+                     const float* glob_b, float* dLoc, float* dNgate, float* dNglob, double* red, float* const* dgb, int B, int T, int F, int Tg, int Fg,
+                     void* stream);
 int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                     const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b, const float* cgate,
                     const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream);

@@ -8,7 +8,7 @@
 //   rtfs_dwconv_bwd_weight    tap / bias gradients of a depth-wise convolution, input re-normalised on read
 //   rtfs_pool_bwd             adjoint of adaptive_avg_pool2d + add            (tdanet.py:117-118)
 //   rtfs_mix_bwd              adjoint of InjectionMultiSum's gate/upsample mix (fusion.py:59-67)
-//   rtfs_mix_gln_bwd          the same fused with the gLN adjoint of the local branch (no dNloc tensor)
+//   rtfs_mix_gln_bwd          the same fused with the gLN adjoint of the local branch (no dNloc tensor) and the gate / global branches' reduce passes
 //   rtfs_expand_fwd           materialise `expanded` (TFAR tail) for the residual_conv weight gradient
 //   rtfs_gateway_bwd          gateway (dw1x1 + PReLU) backward with parameter-gradient reductions
 //   rtfs_axpy                 y += a * x
@@ -408,51 +408,80 @@ __global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restri
     st4(dNglob + o, Bs);
 }
 
-// ---- mix backward fused with the gLN adjoint of its local branch ------------------------------------------------------
+// ---- mix backward fused with the gLN adjoint reductions of its three branches --------------------------------------------
 // The local branch's incoming gradient is g[p] = dOut[p] * s[up(p)], s = sigmoid(n(gate)): CONSTANT over the footprint of a low-resolution
 // position q.  With Dx = sum_footprint dOut*xhat(loc) and Bs = sum_footprint dOut (what mix_bwd_glob_kernel forms anyway):
 //   A = gamma*Dx + beta*Bs;  dgamma_loc += s*Dx;  dbeta_loc += s*Bs;  S1 += sum_c gamma*s*Bs;  S2 += sum_c gamma*s*Dx
 // so the reduce pass of the local branch's gLN adjoint costs no extra read, and dNloc is never written: the apply pass re-forms it.
-__global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, float* __restrict__ dNgate,
-                                                                 float* __restrict__ dNglob, double* __restrict__ red, float* __restrict__ scr, int T,
-                                                                 int F, int Tg, int Fg) {
-    __shared__ __attribute__((aligned(16))) float lds[1024];
-    __shared__ float redl[8];
+// The gate / global branches' incoming gradients dNgate = A s (1-s) and dNglob = Bs are in registers next to xhat(gate) (needed for s) and one
+// extra low-resolution read of glob: their gLN reduce passes ride along too (rtfs_gln_bwd_apply then runs on dNgate / dNglob as before).
+// Epilogue: the 4 position rows of a wave are summed with two xor shuffles, the 4 waves through LDS; 6 x 64 per-channel sums leave as one
+// coalesced atomic each, the 6 per-utterance sums as fp64 atomics.   red: [3][B][kStatStride] (loc, gate, glob)
+__global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, NormArg glob,
+                                                                 float* __restrict__ dNgate, float* __restrict__ dNglob, double* __restrict__ red,
+                                                                 float* __restrict__ scr, int T, int F, int Tg, int Fg, int B) {
+    __shared__ __attribute__((aligned(16))) float lds[4][6][64];
+    __shared__ float redl[4][6];
     const int b = blockIdx.y;
     const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c4 = (threadIdx.x & 15) * 4;
-    float4 dg = f4(0, 0, 0, 0), db = f4(0, 0, 0, 0);
-    float s1 = 0.f, s2 = 0.f;
+    float4 ch[6];  // dgamma_loc, dbeta_loc, dgamma_gate, dbeta_gate, dgamma_glob, dbeta_glob
+    float sm[6];   // (S1, S2) of loc, gate, glob
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ch[i] = f4(0, 0, 0, 0), sm[i] = 0.f;
     if (q < Tg * Fg) {
         const int tg = q / Fg, fg = q - tg * Fg;
         const int t0 = (tg * T + Tg - 1) / Tg, t1 = min(T, ((tg + 1) * T + Tg - 1) / Tg);
         const int f0 = (fg * F + Fg - 1) / Fg, f1 = min(F, ((fg + 1) * F + Fg - 1) / Fg);
-        float lm, lr, gm, gr;
+        float lm, lr, gm, gr, em, er;
         stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
         stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
+        stats_finalize(glob.slot, b, glob.inv_n, em, er);
         const float4 lg = ld4(loc.gamma + c4), lb = ld4(loc.beta + c4);
+        const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
+        const float4 xg = sub4(ld4(gate.x + o), gm) * gr, xe = sub4(ld4(glob.x + o), em) * er;
         float4 Dx = f4(0, 0, 0, 0), Bs = f4(0, 0, 0, 0);
         for (int t = t0; t < t1; ++t)
             for (int f = f0; f < f1; ++f) {
-                const size_t o = (((size_t)b * T + t) * F + f) * kH + c4;
-                const float4 d = ld4(dOut + o);
-                Dx = fma4(d, sub4(ld4(loc.x + o), lm) * lr, Dx);
+                const size_t oo = (((size_t)b * T + t) * F + f) * kH + c4;
+                const float4 d = ld4(dOut + oo);
+                Dx = fma4(d, sub4(ld4(loc.x + oo), lm) * lr, Dx);
                 Bs = Bs + d;
             }
-        const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
-        const float4 s = sigmoid4(fma4(sub4(ld4(gate.x + o), gm) * gr, ld4(gate.gamma + c4), ld4(gate.beta + c4)));
+        const float4 gg = ld4(gate.gamma + c4), eg = ld4(glob.gamma + c4);
+        const float4 s = sigmoid4(fma4(xg, gg, ld4(gate.beta + c4)));
         const float4 A = fma4(lg, Dx, lb * Bs);
-        st4(dNgate + o, f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w)));
+        const float4 dNg = f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w));
+        st4(dNgate + o, dNg);
         st4(dNglob + o, Bs);
-        dg = s * Dx;
-        db = s * Bs;
-        s1 = dot4(lg, db);
-        s2 = dot4(lg, dg);
+        ch[0] = s * Dx, ch[1] = s * Bs;
+        ch[2] = dNg * xg, ch[3] = dNg;
+        ch[4] = Bs * xe, ch[5] = Bs;
+        sm[0] = dot4(lg, ch[1]), sm[1] = dot4(lg, ch[0]);
+        sm[2] = dot4(gg, ch[3]), sm[3] = dot4(gg, ch[2]);
+        sm[4] = dot4(eg, ch[5]), sm[5] = dot4(eg, ch[4]);
     }
-    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y);  // [dgamma 64 | dbeta 64]
-    quad_reduce_atomic<16>(dg, lds, mine);
-    quad_reduce_atomic<16>(db, lds, mine + kH);
-    block_stats_commit(s1, s2, redl, red, b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float4 v = ch[i];
+        v = f4(v.x + __shfl_xor(v.x, 16, 64), v.y + __shfl_xor(v.y, 16, 64), v.z + __shfl_xor(v.z, 16, 64), v.w + __shfl_xor(v.w, 16, 64));
+        v = f4(v.x + __shfl_xor(v.x, 32, 64), v.y + __shfl_xor(v.y, 32, 64), v.z + __shfl_xor(v.z, 32, 64), v.w + __shfl_xor(v.w, 32, 64));
+        if (lane < 16) st4(&lds[wave][i][c4], v);
+        const float t = wave_sum(sm[i]);
+        if (lane == 0) redl[wave][i] = t;
+    }
+    __syncthreads();
+    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y);  // [6][64]
+    for (int idx = threadIdx.x; idx < 6 * 64; idx += 256) {
+        const int i = idx >> 6, c = idx & 63;
+        atomicAdd(mine + idx, lds[0][i][c] + lds[1][i][c] + lds[2][i][c] + lds[3][i][c]);
+    }
+    if (threadIdx.x < 6) {
+        const int i = threadIdx.x;
+        const double S = (double)redl[0][i] + (double)redl[1][i] + (double)redl[2][i] + (double)redl[3][i];
+        atomicAdd(red + ((size_t)(i >> 1) * B + b) * kStatStride + (i & 1), S);
+    }
 }
 
 // dLoc[p] = rstd * (a - S1/N - xhat*S2/N),  a = dOut[p] * s[up(p)] * gamma
@@ -659,17 +688,21 @@ int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, c
     return RTFS_OK;
 }
 
-// rtfs_mix_bwd followed by the gLN adjoint of the local branch (rtfs_gln_bwd_reduce + rtfs_gln_bwd_apply on dNloc), without dNloc: dLoc is
-// the gradient w.r.t. the local conv's OUTPUT (pre-norm).  red: double[B][kStatStride], zeroed by the caller; dgamma / dbeta accumulate.
+// rtfs_mix_bwd followed by the gLN adjoint of the local branch (rtfs_gln_bwd_reduce + rtfs_gln_bwd_apply on dNloc) without dNloc - dLoc is the
+// gradient w.r.t. the local conv's OUTPUT (pre-norm) - and by the REDUCE passes of the gate / global branches' gLN adjoints (the caller runs
+// rtfs_gln_bwd_apply on dNgate / dNglob with red + B*16 / red + 2*B*16).  red: double[3][B][kStatStride] zeroed by the caller;
+// dgb: six [64] accumulators (dgamma, dbeta of loc, gate, glob), all accumulate.
 int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
-                     const double* gate_stats, const float* gate_g, const float* gate_b, float* dLoc, float* dNgate, float* dNglob, double* red,
-                     float* dgamma, float* dbeta, int B, int T, int F, int Tg, int Fg, void* stream) {
-    if (B <= 0) return RTFS_EINVAL;
+                     const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats, const float* glob_g,
+                     const float* glob_b, float* dLoc, float* dNgate, float* dNglob, double* red, float* const* dgb, int B, int T, int F, int Tg, int Fg,
+                     void* stream) {
+    if (B <= 0 || !dgb) return RTFS_EINVAL;
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
-    NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b};
-    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, dNgate, dNglob, red, scr, T, F, Tg, Fg);
-    const int rc = spread_finish(scr, SpreadOut{{dgamma, dbeta}, {kH, kH}}, (hipStream_t)stream);
+    NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b},
+        e{glob, glob_stats, 1.0 / ((double)Tg * Fg * kH), glob_g, glob_b};
+    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, e, dNgate, dNglob, red, scr, T, F, Tg, Fg, B);
+    const int rc = spread_finish(scr, SpreadOut{{dgb[0], dgb[1], dgb[2], dgb[3], dgb[4], dgb[5]}, {kH, kH, kH, kH, kH, kH}}, (hipStream_t)stream);
     if (rc != RTFS_OK) return rc;
     LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);
     return RTFS_OK;

@@ -70,7 +70,7 @@ SIGNATURES = {
     "rtfs_dwconv_bwd_weight": [P, P, P, P, P, F, I, I, P, P, I, I, I, P],
     "rtfs_pool_bwd": [P, P, I, I, I, P],
     "rtfs_mix_bwd": [P] * 12 + [I, I, I, I, I, P],
-    "rtfs_mix_gln_bwd": [P] * 15 + [I, I, I, I, I, P],
+    "rtfs_mix_gln_bwd": [P] * 18 + [I, I, I, I, I, P],
     "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],
     "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
     "rtfs_proj_gateway_bwd": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, P],

@@ -350,19 +350,26 @@ class HipTrainer:
         self._call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         self._call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
-    def _mix_gln_bwd(self, dOut, loc, loc_st, loc_conv, gate, gate_st, gate_conv, dLoc, dNgate, dNglob, gr, key, B, T, F, Tg, Fg):
-        """adjoint of `n(loc) * sigmoid(n(gate))^ + n(glob)^` together with the gLN adjoint of its local branch: dLoc = gradient w.r.t. the
-        local conv's output; dNgate / dNglob = gradients w.r.t. the NORMALISED gate / global embeddings; gamma / beta grads into gr[key]."""
+    def _mix_gln_bwd(self, dOut, loc, gate, glob, dLoc, dGate, dGlob, gr, B, T, F, Tg, Fg):
+        """adjoint of `n(loc) * sigmoid(n(gate))^ + n(glob)^` (fusion.py:59-67) together with the gLN adjoints of its three embeddings.
+        loc / gate / glob: (pre-norm tensor, statistics slot, conv tuple (.., .., gamma, beta), gr key); dLoc / dGate / dGlob: gradients w.r.t.
+        the three convs' OUTPUTS; gamma / beta grads into gr[key]."""
         dev = dOut.device
-        dg, db = _acc(gr, key + ".g", H, dev), _acc(gr, key + ".b", H, dev)
+        dgb = [_acc(gr, br[3] + sfx, H, dev) for br in (loc, gate, glob) for sfx in (".g", ".b")]
+        low_rows = Tg * Fg
         if self.model._hip.fuse["mixgln"]:
-            red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
-            self._call("rtfs_mix_gln_bwd", dOut, loc, loc_st, loc_conv[2], loc_conv[3], gate, gate_st, gate_conv[2], gate_conv[3], dLoc, dNgate, dNglob, red,
-                       dg, db, B, T, F, Tg, Fg)
+            red = gr["_pool"].take(3 * B * lib.STAT_STRIDE, torch.float64).view(3, B, lib.STAT_STRIDE)
+            dNgate, dNglob = torch.empty_like(dGate), torch.empty_like(dGlob)
+            self._call("rtfs_mix_gln_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
+                       glob[2][3], dLoc, dNgate, dNglob, red, dgb, B, T, F, Tg, Fg)
+            self._call("rtfs_gln_bwd_apply", dNgate, gate[0], gate[1], gate[2][2], gate[2][3], 0, 0.0, red[1], dGate, 0, B, low_rows, H)
+            self._call("rtfs_gln_bwd_apply", dNglob, glob[0], glob[1], glob[2][2], glob[2][3], 0, 0.0, red[2], dGlob, 0, B, low_rows, H)
             return
-        dNloc = torch.empty(B * T * F * H, device=dev)
-        self._call("rtfs_mix_bwd", dOut, loc, loc_st, loc_conv[2], loc_conv[3], gate, gate_st, gate_conv[2], gate_conv[3], dNloc, dNgate, dNglob, B, T, F, Tg, Fg)
-        self._gln_bwd(dNloc, loc, loc_st, loc_conv[2], loc_conv[3], dLoc, False, gr, key, B, T * F)
+        dNloc, dNgate, dNglob = torch.empty(B * T * F * H, device=dev), torch.empty_like(dGate), torch.empty_like(dGlob)
+        self._call("rtfs_mix_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], dNloc, dNgate, dNglob, B, T, F, Tg, Fg)
+        self._gln_bwd(dNloc, loc[0], loc[1], loc[2][2], loc[2][3], dLoc, False, gr, loc[3], B, T * F)
+        self._gln_bwd(dNgate, gate[0], gate[1], gate[2][2], gate[2][3], dGate, False, gr, gate[3], B, low_rows)
+        self._gln_bwd(dNglob, glob[0], glob[1], glob[2][2], glob[2][3], dGlob, False, gr, glob[3], B, low_rows)
 
     def _dw_bwd(self, dOut, conv, inp, in_st, in_g, in_b, in_slope, mode, stride, dIn, accumulate, gr, key, B, Tin, Fin, has_bias):
         """depth-wise conv adjoint: input gradient (w.r.t. the transformed input) and tap/bias gradients."""
@@ -454,26 +461,22 @@ class HipTrainer:
         dE = full()
         self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
-        dN_cgate, dN_cg = low(), low()
         dN_D0 = dE
-        # concat layer: gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
+        # concat layer: mix + gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
-        self._mix_gln_bwd(dE, k.cl, st[9], cl_, k.cgate, st[11], cgate_, dcl, dN_cgate, dN_cg, gr, "blk.cl", B, T, F_BINS, T2, F2)
-        self._gln_bwd(dN_cg, k.cg, st[10], cg_[2], cg_[3], dcg, False, gr, "blk.cg", B, lo)
-        self._gln_bwd(dN_cgate, k.cgate, st[11], cgate_[2], cgate_[3], dcgate, False, gr, "blk.cgate", B, lo)
+        self._mix_gln_bwd(dE, (k.cl, st[9], cl_, "blk.cl"), (k.cgate, st[11], cgate_, "blk.cgate"), (k.cg, st[10], cg_, "blk.cg"), dcl, dcgate, dcg, gr,
+                          B, T, F_BINS, T2, F2)
         dF0, dF1 = full(), low()
         self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, "blk.cl", B, T, F_BINS, False)
         self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, "blk.cg", B, T2, F2, False)
         self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, "blk.cgate", B, T2, F2, False)
         # fusion layers' mixes
-        dN_gg0, dN_g0, dN_gg1, dN_g1 = low(), low(), low(), low()
         dl0, dl1 = full(), low()
-        self._mix_gln_bwd(dF0, k.l0, st[3], f0l, k.gg0, st[6], f0gate, dl0, dN_gg0, dN_g0, gr, "blk.f0l", B, T, F_BINS, T2, F2)
-        self._mix_gln_bwd(dF1, k.l1, st[4], f1l, k.gg1, st[8], f1gate, dl1, dN_gg1, dN_g1, gr, "blk.f1l", B, T2, F2, T2, F2)
-        dgs = [low() for _ in range(4)]
-        for dN, X, sidx, conv, nm, dst in ((dN_g0, k.g0, 5, f0g, "f0g", dgs[0]), (dN_gg0, k.gg0, 6, f0gate, "f0gate", dgs[1]),
-                                           (dN_g1, k.g1, 7, f1g, "f1g", dgs[2]), (dN_gg1, k.gg1, 8, f1gate, "f1gate", dgs[3])):
-            self._gln_bwd(dN, X, st[sidx], conv[2], conv[3], dst, False, gr, "blk." + nm, B, lo)
+        dgs = [low() for _ in range(4)]  # gradients w.r.t. the outputs of f0g, f0gate, f1g, f1gate
+        self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, "blk.f0l"), (k.gg0, st[6], f0gate, "blk.f0gate"), (k.g0, st[5], f0g, "blk.f0g"), dl0, dgs[1], dgs[0], gr,
+                          B, T, F_BINS, T2, F2)
+        self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, "blk.f1l"), (k.gg1, st[8], f1gate, "blk.f1gate"), (k.g1, st[7], f1g, "blk.f1g"), dl1, dgs[3], dgs[2], gr,
+                          B, T2, F2, T2, F2)
         # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
         dN_D1 = low()
         self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, "blk.f0l", B, T, F_BINS, False)

@@ -24,6 +24,9 @@ def main(B=32, T=251):
     la, lb, lc, ld = low(), low(), low(), low()
     sf, sl = st(T * F * 64), st(T2 * F2 * 64)
     red = torch.zeros(B, 16, dtype=torch.float64, device=dev)
+    red3 = torch.zeros(3, B, 16, dtype=torch.float64, device=dev)
+    dgb = [torch.zeros(64, device=dev) for _ in range(6)]
+    le, lf, lg_ = low(), low(), low()
     dg, db, dsl = torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(1, device=dev)
     dW, dbias = torch.zeros(1024, device=dev), torch.zeros(64, device=dev)
     FB, LB = 4 * nf, 4 * nl
@@ -38,9 +41,9 @@ def main(B=32, T=251):
     run("gln_bwd_apply  full act1", 3 * FB, lambda: lib.call("rtfs_gln_bwd_apply", a, b, sf, gam, bet, 1, 0.25, red, c, 0, B, T * F, 64))
     run("gln_bwd_reduce low", 2 * LB, lambda: lib.call("rtfs_gln_bwd_reduce", la, lb, sl, gam, bet, 0, 0.0, red, dg, db, None, B, T2 * F2, 64))
     run("gln_bwd_apply  low", 3 * LB, lambda: lib.call("rtfs_gln_bwd_apply", la, lb, sl, gam, bet, 0, 0.0, red, lc, 0, B, T2 * F2, 64))
-    run("mix_gln_bwd full", 5 * FB + 3 * LB, lambda: lib.call("rtfs_mix_gln_bwd", a, b, sf, gam, bet, la, sl, gam, bet, c, lb, lc, red, dg, db, B, T, F, T2, F2))
+    run("mix_gln_bwd full", 5 * FB + 3 * LB, lambda: lib.call("rtfs_mix_gln_bwd", a, b, sf, gam, bet, la, sl, gam, bet, ld, sl, gam, bet, c, lb, lc, red3, dgb, B, T, F, T2, F2))
     run("mix_bwd full (unfused part)", 4 * FB + 3 * LB, lambda: lib.call("rtfs_mix_bwd", a, b, sf, gam, bet, la, sl, gam, bet, c, lb, lc, B, T, F, T2, F2))
-    run("mix_gln_bwd low", 8 * LB, lambda: lib.call("rtfs_mix_gln_bwd", la, lb, sl, gam, bet, lc, sl, gam, bet, ld, lb, lc, red, dg, db, B, T2, F2, T2, F2))
+    run("mix_gln_bwd low", 8 * LB, lambda: lib.call("rtfs_mix_gln_bwd", la, lb, sl, gam, bet, lc, sl, gam, bet, ld, sl, gam, bet, le, lf, lg_, red3, dgb, B, T2, F2, T2, F2))
     run("dwconv_bwd_weight full mode0", 2 * FB, lambda: lib.call("rtfs_dwconv_bwd_weight", a, b, None, None, None, 0.0, 0, 1, dW, None, B, T, F))
     run("dwconv_bwd_weight full mode1", 2 * FB, lambda: lib.call("rtfs_dwconv_bwd_weight", a, b, sf, gam, bet, 0.0, 1, 1, dW, None, B, T, F))
     run("dwconv_bwd_weight full mode2", 2 * FB, lambda: lib.call("rtfs_dwconv_bwd_weight", a, b, sf, gam, bet, 0.25, 2, 1, dW, dbias, B, T, F))
