@@ -419,25 +419,26 @@ __global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restri
 // coalesced atomic each, the 6 per-utterance sums as fp64 atomics.   red: [3][B][kStatStride] (loc, gate, glob)
 __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, NormArg glob,
                                                                  float* __restrict__ dNgate, float* __restrict__ dNglob, double* __restrict__ red,
-                                                                 float* __restrict__ scr, int T, int F, int Tg, int Fg, int B) {
+                                                                 float* __restrict__ scr, int T, int F, int Tg, int Fg, int B, int qpt) {
     __shared__ __attribute__((aligned(16))) float lds[4][6][64];
     __shared__ float redl[4][6];
     const int b = blockIdx.y;
-    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c4 = (threadIdx.x & 15) * 4;
     float4 ch[6];  // dgamma_loc, dbeta_loc, dgamma_gate, dbeta_gate, dgamma_glob, dbeta_glob
     float sm[6];   // (S1, S2) of loc, gate, glob
 #pragma unroll
     for (int i = 0; i < 6; ++i) ch[i] = f4(0, 0, 0, 0), sm[i] = 0.f;
-    if (q < Tg * Fg) {
+    float lm, lr, gm, gr, em, er;
+    stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
+    stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
+    stats_finalize(glob.slot, b, glob.inv_n, em, er);
+    const float4 lg = ld4(loc.gamma + c4), lb = ld4(loc.beta + c4);
+    for (int it = 0; it < qpt; ++it) {  // qpt groups of 16 low-resolution positions per workgroup: one epilogue for all of them
+        const int q = (blockIdx.x * qpt + it) * 16 + (threadIdx.x >> 4);
+        if (q >= Tg * Fg) break;
         const int tg = q / Fg, fg = q - tg * Fg;
         const int t0 = (tg * T + Tg - 1) / Tg, t1 = min(T, ((tg + 1) * T + Tg - 1) / Tg);
         const int f0 = (fg * F + Fg - 1) / Fg, f1 = min(F, ((fg + 1) * F + Fg - 1) / Fg);
-        float lm, lr, gm, gr, em, er;
-        stats_finalize(loc.slot, b, loc.inv_n, lm, lr);
-        stats_finalize(gate.slot, b, gate.inv_n, gm, gr);
-        stats_finalize(glob.slot, b, glob.inv_n, em, er);
-        const float4 lg = ld4(loc.gamma + c4), lb = ld4(loc.beta + c4);
         const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
         const float4 xg = sub4(ld4(gate.x + o), gm) * gr, xe = sub4(ld4(glob.x + o), em) * er;
         float4 Dx = f4(0, 0, 0, 0), Bs = f4(0, 0, 0, 0);
@@ -454,12 +455,13 @@ __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __
         const float4 dNg = f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w));
         st4(dNgate + o, dNg);
         st4(dNglob + o, Bs);
-        ch[0] = s * Dx, ch[1] = s * Bs;
-        ch[2] = dNg * xg, ch[3] = dNg;
-        ch[4] = Bs * xe, ch[5] = Bs;
-        sm[0] = dot4(lg, ch[1]), sm[1] = dot4(lg, ch[0]);
-        sm[2] = dot4(gg, ch[3]), sm[3] = dot4(gg, ch[2]);
-        sm[4] = dot4(eg, ch[5]), sm[5] = dot4(eg, ch[4]);
+        const float4 c0 = s * Dx, c1 = s * Bs, c2 = dNg * xg, c4v = Bs * xe;
+        ch[0] = ch[0] + c0, ch[1] = ch[1] + c1;
+        ch[2] = ch[2] + c2, ch[3] = ch[3] + dNg;
+        ch[4] = ch[4] + c4v, ch[5] = ch[5] + Bs;
+        sm[0] += dot4(lg, c1), sm[1] += dot4(lg, c0);
+        sm[2] += dot4(gg, dNg), sm[3] += dot4(gg, c2);
+        sm[4] += dot4(eg, Bs), sm[5] += dot4(eg, c4v);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -701,7 +703,8 @@ int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stat
     if (!scr) return RTFS_ELAUNCH;
     NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b},
         e{glob, glob_stats, 1.0 / ((double)Tg * Fg * kH), glob_g, glob_b};
-    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 15) / 16, B), dOut, l, g, e, dNgate, dNglob, red, scr, T, F, Tg, Fg, B);
+    const int qpt = 8;  // 128 low-resolution positions per workgroup (measured 1 ... 16: the epilogue's 384 atomics stop showing from 4 up)
+    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 16 * qpt - 1) / (16 * qpt), B), dOut, l, g, e, dNgate, dNglob, red, scr, T, F, Tg, Fg, B, qpt);
     const int rc = spread_finish(scr, SpreadOut{{dgb[0], dgb[1], dgb[2], dgb[3], dgb[4], dgb[5]}, {kH, kH, kH, kH, kH, kH}}, (hipStream_t)stream);
     if (rc != RTFS_OK) return rc;
     LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);
