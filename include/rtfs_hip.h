@@ -188,6 +188,12 @@ int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* sta
                            int stride, float* dW, float* dbias_or_null, int B, int Tin, int Fin, void* stream);
 /* adjoints of rtfs_pool_fwd / rtfs_tfar_mix_fwd; rtfs_expand_fwd materialises the TFAR tail for d(residual_conv.weight) */
 int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* stream);
+/* the tail of an RTFS block's backward in one pass over d(gLN(D0)): dN0 += rtfs_dwconv_bwd_input(dD1, w, stride 2) + rtfs_pool_bwd(dG), then the
+ * reduce pass of rtfs_gln_bwd_reduce(dN0, D0, act 0) on the finished values (red: double[B][16] zeroed by the caller; dgamma / dbeta [64]
+ * accumulate).  Adjoint of /root/reference/src/models/separators/tdanet.py:112-118 (downsample_layers[1] and adaptive_avg_pool2d both read
+ * gLN(D0)).  F = 129 -> 64; T2 = (T - 2) / 2 + 1. */
+int rtfs_d0_tail_bwd(const float* dD1, const float* w, const float* dG, float* dN0, const float* D0, const double* d0_stats, const float* gamma,
+                     const float* beta, double* red, float* dgamma, float* dbeta, int B, int T, int T2, void* stream);
 int rtfs_mix_bwd(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
                  const double* gate_stats, const float* gate_g, const float* gate_b, float* dNloc, float* dNgate, float* dNglob, int B, int T, int F, int Tg,
                  int Fg, void* stream);

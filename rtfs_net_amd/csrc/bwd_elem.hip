@@ -7,6 +7,7 @@
 //   rtfs_dwconv_bwd_input     transposed depth-wise 4x4 convolution (stride 1 / 2)
 //   rtfs_dwconv_bwd_weight    tap / bias gradients of a depth-wise convolution, input re-normalised on read
 //   rtfs_pool_bwd             adjoint of adaptive_avg_pool2d + add            (tdanet.py:117-118)
+//   rtfs_d0_tail_bwd          stride-2 conv input gradient + rtfs_pool_bwd + the reduce pass of D0's gLN adjoint in one pass over d(gLN(D0))
 //   rtfs_mix_bwd              adjoint of InjectionMultiSum's gate/upsample mix (fusion.py:59-67)
 //   rtfs_mix_gln_bwd          the same fused with the gLN adjoint of the local branch (no dNloc tensor) and the gate / global branches' reduce passes
 //   rtfs_expand_fwd           materialise `expanded` (TFAR tail) for the residual_conv weight gradient
@@ -359,6 +360,91 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     st4(o, acc + ld4(o));
 }
 
+// ---- the last two contributions to d(gLN(D0)) + the reduce pass of D0's gLN adjoint, one pass over dN0 ------------------------
+// dN0[p] += (transposed stride-2 convolution of dD1: downsample_layers[1])[p] + (pooling adjoint of dG)[p]   -- dwconv_bwd_input_kernel<2, true>
+// and pool_bwd_kernel in one read-modify-write instead of two; the finished value v feeds D0's gLN reduce pass in registers
+// (dgamma += v*xhat, dbeta += v, S1 += v*gamma, S2 += v*gamma*xhat): rtfs_gln_bwd_reduce's two full-resolution reads are one read of D0.
+// `ppw` groups of 16 positions per workgroup share one reduction epilogue (mix_gln_bwd_reduce_kernel's).
+__global__ __launch_bounds__(256) void d0_tail_bwd_kernel(const float* __restrict__ dD1, const float* __restrict__ w, const float* __restrict__ dG,
+                                                          float* __restrict__ dN0, NormArg n, double* __restrict__ red, float* __restrict__ scr, int T,
+                                                          int T2, int ppw) {
+    __shared__ __attribute__((aligned(16))) float ws[16 * 64];
+    __shared__ __attribute__((aligned(16))) float lds[4][2][64];
+    __shared__ float redl[4][2];
+    st4(&ws[threadIdx.x * 4], ld4(w + threadIdx.x * 4));
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int c4 = (threadIdx.x & 15) * 4;
+    float mean, rstd;
+    stats_finalize(n.slot, b, n.inv_n, mean, rstd);
+    const float4 g4 = ld4(n.gamma + c4);
+    float4 dg = f4(0, 0, 0, 0), db = f4(0, 0, 0, 0);
+    float s1 = 0.f, s2 = 0.f;
+    const float* ob = dD1 + (size_t)b * T2 * kF2 * kH + c4;
+    const float* gb = dG + (size_t)b * T2 * kF2 * kH + c4;
+    for (int it = 0; it < ppw; ++it) {
+        const int p = (blockIdx.x * ppw + it) * 16 + (threadIdx.x >> 4);
+        if (p >= T * kF) break;
+        const int t = p / kF, f = p - t * kF;
+        float4 acc = f4(0, 0, 0, 0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {  // stride-2 transposed convolution (padding 1): to = (t + 1 - dt) / 2 where that is an integer in range
+            const int tn = t + 1 - dt;
+            if (tn < 0 || (tn & 1)) continue;
+            const int to = tn >> 1;
+            if (to >= T2) continue;
+#pragma unroll
+            for (int df = 0; df < 4; ++df) {
+                const int fn = f + 1 - df;
+                if (fn < 0 || (fn & 1)) continue;
+                const int fo = fn >> 1;
+                if (fo >= kF2) continue;
+                acc = fma4(ld4(&ws[(dt * 4 + df) * 64 + c4]), ld4(ob + ((size_t)to * kF2 + fo) * kH), acc);
+            }
+        }
+        const int tc = (t * T2) / T, fc = (f * kF2) / kF;  // pooling adjoint: the windows that contain (t, f)
+        for (int t2 = max(tc - 1, 0); t2 <= min(tc + 1, T2 - 1); ++t2) {
+            const int ts = (t2 * T) / T2, te = ((t2 + 1) * T + T2 - 1) / T2;
+            if (t < ts || t >= te) continue;
+            for (int f2 = max(fc - 1, 0); f2 <= min(fc + 1, kF2 - 1); ++f2) {
+                const int fs = (f2 * kF) / kF2, fe = ((f2 + 1) * kF + kF2 - 1) / kF2;
+                if (f < fs || f >= fe) continue;
+                const float inv = 1.0f / (float)((te - ts) * (fe - fs));
+                acc = fma4(ld4(gb + ((size_t)t2 * kF2 + f2) * kH), f4(inv, inv, inv, inv), acc);
+            }
+        }
+        const size_t o = ((size_t)b * T * kF + p) * kH + c4;
+        const float4 v = acc + ld4(dN0 + o);
+        st4(dN0 + o, v);
+        const float4 xh = sub4(ld4(n.x + o), mean) * rstd;
+        db = db + v;
+        dg = fma4(v, xh, dg);
+        const float4 a = v * g4;
+        s1 += hsum4(a);
+        s2 += dot4(a, xh);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float4 v = i ? db : dg;
+        v = f4(v.x + __shfl_xor(v.x, 16, 64), v.y + __shfl_xor(v.y, 16, 64), v.z + __shfl_xor(v.z, 16, 64), v.w + __shfl_xor(v.w, 16, 64));
+        v = f4(v.x + __shfl_xor(v.x, 32, 64), v.y + __shfl_xor(v.y, 32, 64), v.z + __shfl_xor(v.z, 32, 64), v.w + __shfl_xor(v.w, 32, 64));
+        if (lane < 16) st4(&lds[wave][i][c4], v);
+        const float tsum = wave_sum(i ? s2 : s1);
+        if (lane == 0) redl[wave][i] = tsum;
+    }
+    __syncthreads();
+    float* mine = spread_copy(scr, blockIdx.x + blockIdx.y);  // [dgamma 64 | dbeta 64]
+    if (threadIdx.x < 128) {
+        const int i = threadIdx.x >> 6, c = threadIdx.x & 63;
+        atomicAdd(mine + threadIdx.x, lds[0][i][c] + lds[1][i][c] + lds[2][i][c] + lds[3][i][c]);
+    }
+    if (threadIdx.x < 2) {
+        const int i = threadIdx.x;
+        atomicAdd(red + kStatStride * b + i, (double)redl[0][i] + (double)redl[1][i] + (double)redl[2][i] + (double)redl[3][i]);
+    }
+}
+
 // ---- mix backward -----------------------------------------------------------------------------------------------------
 // forward: out[p] = n(loc)[p] * sigmoid(n(gate)[up(p)]) + n(glob)[up(p)],  up = nearest (floor(dst*in/out)).
 // full-resolution part: dNloc[p] = dOut[p] * sigmoid(n(gate)[up(p)])
@@ -677,6 +763,20 @@ int rtfs_pool_bwd(const float* dG, float* dN0, int B, int T, int T2, void* strea
     if (B <= 0) return RTFS_EINVAL;
     LAUNCH(pool_bwd_kernel, dim3((T * kF + 15) / 16, B), dG, dN0, T, T2);
     return RTFS_OK;
+}
+
+// dN0 += stride-2 transposed conv of dD1 (taps w: downsample_layers[1]) + pooling adjoint of dG, then the reduce pass of D0's gLN adjoint on the
+// finished dN0 (red: double[B][kStatStride] zeroed by the caller; dgamma / dbeta accumulate): replaces rtfs_dwconv_bwd_input(stride 2,
+// accumulate) + rtfs_pool_bwd + rtfs_gln_bwd_reduce(act 0) of the block's tail.  T2 must be (T - 2) / 2 + 1.
+int rtfs_d0_tail_bwd(const float* dD1, const float* w, const float* dG, float* dN0, const float* D0, const double* d0_stats, const float* gamma,
+                     const float* beta, double* red, float* dgamma, float* dbeta, int B, int T, int T2, void* stream) {
+    if (B <= 0 || T2 != (T - 2) / 2 + 1) return RTFS_EINVAL;
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    NormArg n{D0, d0_stats, 1.0 / ((double)T * kF * kH), gamma, beta};
+    const int ppw = 8;
+    LAUNCH(d0_tail_bwd_kernel, dim3((T * kF + 16 * ppw - 1) / (16 * ppw), B), dD1, w, dG, dN0, n, red, scr, T, T2, ppw);
+    return spread_finish(scr, SpreadOut{{dgamma, dbeta}, {kH, kH}}, (hipStream_t)stream);
 }
 
 // loc at (T,F) with stats/gamma/beta; gate/glob at (Tg,Fg).  Outputs: dNloc [B][T][F][64], dNgate/dNglob [B][Tg][Fg][64].

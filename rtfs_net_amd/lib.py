@@ -69,6 +69,7 @@ SIGNATURES = {
     "rtfs_dwconv_bwd_input": [P, P, P, I, I, I, I, I, P],
     "rtfs_dwconv_bwd_weight": [P, P, P, P, P, F, I, I, P, P, I, I, I, P],
     "rtfs_pool_bwd": [P, P, I, I, I, P],
+    "rtfs_d0_tail_bwd": [P] * 11 + [I, I, I, P],
     "rtfs_mix_bwd": [P] * 12 + [I, I, I, I, I, P],
     "rtfs_mix_gln_bwd": [P] * 18 + [I, I, I, I, I, P],
     "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],

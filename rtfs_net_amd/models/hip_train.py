@@ -488,15 +488,20 @@ class HipTrainer:
         self._attn_bwd(dG, bw["attn"], k, B, T2, gr, "blk.attn")
         self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, "blk.dp1")
         self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, "blk.dp0")
-        # pooled = avgpool(D0n) + D1n
-        self._call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
+        # pooled = avgpool(D0n) + D1n; downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
         self._call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
-        # downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
-        dD1 = low()
+        dD1, dD0 = low(), full()
         self._gln_bwd(dN_D1, k.D1, st[2], d1g, d1be, dD1, False, gr, "blk.d1", B, lo)
-        self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, "blk.d1", B, T, F_BINS, True)
-        dD0 = full()
-        self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, "blk.d0", B, TF)
+        if self.model._hip.fuse["d0tail"]:
+            # the two remaining contributions to d(D0n) and the reduce pass of D0's gLN adjoint in one pass over dN_D0
+            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, None, False, gr, "blk.d1", B, T, F_BINS, True)  # (tap / bias gradients only)
+            red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
+            self._call("rtfs_d0_tail_bwd", dD1, d1w, dG, dN_D0, k.D0, st[1], d0g, d0be, red, _acc(gr, "blk.d0.g", H, dev), _acc(gr, "blk.d0.b", H, dev), B, T, T2)
+            self._call("rtfs_gln_bwd_apply", dN_D0, k.D0, st[1], d0g, d0be, 0, 0.0, red, dD0, 0, B, TF, H)
+        else:
+            self._call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
+            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, "blk.d1", B, T, F_BINS, True)
+            self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, "blk.d0", B, TF)
         dP = full()
         self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, "blk.d0", B, T, F_BINS, True)
         # projection: PReLU + gLN adjoint, then the 1x1 conv

@@ -760,3 +760,37 @@ def test_dwconv_adjoints_match_float64_autograd(B, T, F, stride, mode):
     assert rel(dbias.cpu().double(), bias64.grad) < 1e-5
     assert rel(dIn.cpu().double(), xin.grad) < 1e-5
     assert rel((dIn2 - 1).cpu().double(), xin.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(2, 51), (3, 18), (1, 126), (2, 33)])
+def test_d0_tail_bwd_matches_separate_calls(B, T):
+    """rtfs_d0_tail_bwd (stride-2 conv input gradient + pooling adjoint + the reduce pass of D0's gLN adjoint in one pass over d(gLN(D0)):
+    adjoint of tdanet.py:112-118) against rtfs_dwconv_bwd_input + rtfs_pool_bwd + rtfs_gln_bwd_reduce, odd / even frame counts."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(21)
+    H, F, F2 = 64, 129, 64
+    T2 = (T - 2) // 2 + 1
+    D0 = (torch.randn(B, T, F, H, generator=g) * 1.4 + 0.3).cuda()
+    dN0 = torch.randn(B, T, F, H, generator=g).cuda()
+    dD1, dG = torch.randn(B, T2, F2, H, generator=g).cuda(), torch.randn(B, T2, F2, H, generator=g).cuda()
+    w = (torch.randn(16, H, generator=g) * 0.2).cuda()
+    gam, bet = (torch.rand(H, generator=g) + 0.5).cuda(), (torch.randn(H, generator=g) * 0.2).cuda()
+    st = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device="cuda")
+    st[:, 0], st[:, 1] = D0.double().flatten(1).sum(1), D0.double().pow(2).flatten(1).sum(1)
+    res = {}
+    for fused in (True, False):
+        acc = dN0.clone()
+        red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device="cuda")
+        dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        if fused:
+            lib.call("rtfs_d0_tail_bwd", dD1, w, dG, acc, D0, st, gam, bet, red, dg, db, B, T, T2)
+        else:
+            lib.call("rtfs_pool_bwd", dG, acc, B, T, T2)
+            lib.call("rtfs_dwconv_bwd_input", dD1, w, acc, 1, 2, B, T, F)
+            lib.call("rtfs_gln_bwd_reduce", acc, D0, st, gam, bet, 0, 0.0, red, dg, db, None, B, T * F, H)
+        torch.cuda.synchronize()
+        res[fused] = (acc, red[:, :2].clone(), dg, db)
+    for a, b, name in zip(res[True], res[False], ("dN0", "S1/S2", "dgamma", "dbeta")):
+        assert rel(a, b) < 1e-5, (name, rel(a, b))
+    assert float((res[True][0] - dN0).abs().max()) > 0.1  # (something was added)
