@@ -794,3 +794,23 @@ def test_d0_tail_bwd_matches_separate_calls(B, T):
     for a, b, name in zip(res[True], res[False], ("dN0", "S1/S2", "dgamma", "dbeta")):
         assert rel(a, b) < 1e-5, (name, rel(a, b))
     assert float((res[True][0] - dN0).abs().max()) > 0.1  # (something was added)
+
+
+@pytest.mark.parametrize("switch", ["mixgln", "d0tail"])
+def test_training_step_fusion_switches_leave_the_gradients_alone(switch):
+    """The backward chain's host-side fusion choices (models/hip_train.py: rtfs_mix_gln_bwd, rtfs_d0_tail_bwd) against the separate launches they
+    replace, on a whole training step of RTFS-Net-3 (eval mode under autograd = the training-step path without dropout masks)."""
+    model, _, _ = make_model(3, "cuda")
+    model.eval()
+    mix, _, emb = synth.synth_inputs(2, 6000, 12)
+    wgt = torch.randn(2, 1, 6000, generator=torch.Generator().manual_seed(1)).cuda()
+    grads = {}
+    for on in (True, False):
+        model._hip.fuse[switch] = on
+        model.zero_grad(set_to_none=True)
+        (model(mix.cuda(), emb.cuda()) * wgt).sum().backward()
+        grads[on] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model._hip.fuse[switch] = True
+    scale = max(float(g.norm()) for g in grads[True].values())
+    for n, g in grads[True].items():
+        assert float((g - grads[False][n]).norm()) <= 2e-5 * float(g.norm()) + 1e-6 * scale, n
