@@ -177,6 +177,9 @@ int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream);
  * its own sums before it returns to the stream, as in rounds 1-3.  Reference: parameter-gradient accumulation of autograd over separators/tdanet.py:106-133. */
 int rtfs_spread_defer(int on, void* stream);
 int rtfs_spread_flush(void* stream);
+/* scratch lane (0 / 1) used by the following reducer launches and rtfs_spread_defer / _flush: lane 1 for launches on a second stream that may run
+ * concurrently with lane 0's (the training step's weight-gradient side stream); deferred sections are per lane */
+int rtfs_spread_lane(int lane);
 /* GroupNorm(1,C) adjoint; act: 0 none, 1 PReLU after the norm (C=64), 2 ReLU after the norm (C=256); red: double[B][16] (entries 0, 1 used) zeroed by caller */
 int rtfs_gln_bwd_reduce(const float* dY, const float* X, const double* stats, const float* gamma, const float* beta, int act, float slope, double* red,
                         float* dgamma, float* dbeta, float* dslope, int B, int rows, int C, void* stream);

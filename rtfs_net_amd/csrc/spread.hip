@@ -7,7 +7,9 @@
 // request per line - into copy (workgroup % kSpread) of a library-owned scratch buffer; a small finish kernel sums the
 // copies into the caller's accumulator (single writer, plain add) and re-zeroes the scratch for the next user.
 //
-// One scratch buffer per device; users are serialised by stream order (every training-step launch is on one stream).
+// One scratch buffer per device AND LANE; the users of a lane are serialised by stream order.  Lane 0 is the stream the training step runs on;
+// lane 1 (rtfs_spread_lane) belongs to the side stream that carries the step's weight-gradient launches underneath the bandwidth-bound adjoint
+// chain (models/hip_train.py): two producers that run concurrently must not share a scratch region.
 #include "common.h"
 
 #include <mutex>
@@ -74,13 +76,15 @@ struct DevState {
     bool deferred = false;
     FlushArgs pend{};      // pend.n regions wait for the flush
 };
-DevState g_dev[16];
+constexpr int kLanes = 2;
+DevState g_dev[16][kLanes];
+int g_lane = 0;  // the lane the calling (single) host thread currently issues for
 std::mutex g_mu;
 
 DevState* dev_state() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    DevState& d = g_dev[dev];
+    DevState& d = g_dev[dev][g_lane];
     if (!d.scr) {
         float* p = nullptr;
         const size_t bytes = (size_t)kSpread * kSpreadCap * sizeof(float);
@@ -144,6 +148,14 @@ int rtfs_spread_defer(int on, void* stream) {
     const int rc = rtfs::flush_locked(*d, (hipStream_t)stream);
     d->deferred = on != 0;
     return rc;
+}
+// Select the scratch lane (0 or 1) that the following reducer launches, rtfs_spread_defer and rtfs_spread_flush of this host thread use: lane 1 for
+// launches issued on a second stream that may run concurrently with lane 0's.  Deferred sections are per lane.
+int rtfs_spread_lane(int lane) {
+    if (lane < 0 || lane >= rtfs::kLanes) return RTFS_EINVAL;
+    std::lock_guard<std::mutex> lk(rtfs::g_mu);
+    rtfs::g_lane = lane;
+    return RTFS_OK;
 }
 int rtfs_spread_flush(void* stream) {
     std::lock_guard<std::mutex> lk(rtfs::g_mu);

@@ -127,6 +127,7 @@ SIGNATURES = {
     "rtfs_wgrad_bf16": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, I, P],
     "rtfs_spread_defer": [I, P],
     "rtfs_spread_flush": [P],
+    "rtfs_spread_lane": [I],
     "rtfs_proj_gateway_bwd_bf16": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, I, P],
     "rtfs_fold_gemm_bwd_bf16": [P, P, P, I, I, I, I, P],
     "rtfs_convt_bwd_input_bf16": [P, P, P, I, I, I, I, P],
@@ -235,6 +236,13 @@ def spread_defer(on: bool, device) -> None:
         rc = load().rtfs_spread_defer(1 if on else 0, torch.cuda.current_stream(device).cuda_stream)
     if rc != 0:
         raise RuntimeError(f"rtfs_spread_defer failed with code {rc}")
+
+
+def spread_lane(lane: int) -> None:
+    """rtfs_spread_lane: scratch lane of the following reducer launches (1 = the weight-gradient side stream of the training step)"""
+    rc = load().rtfs_spread_lane(int(lane))
+    if rc != 0:
+        raise RuntimeError(f"rtfs_spread_lane failed with code {rc}")
 
 
 def _same_device(name, dev, t):

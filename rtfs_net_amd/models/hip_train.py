@@ -139,6 +139,64 @@ class HipTrainer:
     def invalidate(self):
         self._prep = None
 
+    # ---- weight-gradient side stream ----------------------------------------------------------------------------------------------
+    # The weight / tap gradient launches (rtfs_wgrad: MFMA-bound; rtfs_dwconv_bwd_weight) produce nothing the adjoint chain reads: their
+    # results are needed when the stage ends.  They are issued on a second stream - scratch lane 1 of csrc/spread.hip - so that they run
+    # UNDERNEATH the bandwidth-bound elementwise / scan adjoints of the chain instead of in line with them.  Ordering: the side stream waits for
+    # the main stream at every launch (its operands were just produced there); operands are marked with record_stream (the caching allocator must
+    # not hand their memory to a later main-stream tensor while the side launch is pending); the stage end joins (end_stage).
+    def _side(self, dev):
+        if not self.model._hip.fuse["wgside"]:
+            return None
+        st = self.__dict__.setdefault("_side_streams", {})
+        if dev not in st:
+            st[dev] = torch.cuda.Stream(device=dev)
+        return st[dev]
+
+    def _wg(self, name, *args):
+        """a weight-gradient launch: on the side stream when enabled, else in line"""
+        dev = next(a.device for a in args if isinstance(a, torch.Tensor))
+        side = self._side(dev)
+        if side is None:
+            return self._call(name, *args)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                a.record_stream(side)
+        lib.spread_lane(1)
+        try:
+            with torch.cuda.stream(side):
+                self._call(name, *args)
+        finally:
+            lib.spread_lane(0)
+
+    def begin_stage(self, dev):
+        """deferred finish of the parameter-gradient reducers (csrc/spread.hip) on both lanes for one backward stage"""
+        lib.spread_defer(True, dev)
+        side = self._side(dev)
+        if side is not None:
+            lib.spread_lane(1)
+            try:
+                with torch.cuda.stream(side):
+                    lib.spread_defer(True, dev)
+            finally:
+                lib.spread_lane(0)
+
+    def end_stage(self, dev):
+        """flush both lanes; the main stream then waits for the side stream: every parameter gradient of the stage is complete, stream-ordered"""
+        side = self._side(dev)
+        try:
+            if side is not None:
+                lib.spread_lane(1)
+                try:
+                    with torch.cuda.stream(side):
+                        lib.spread_defer(False, dev)
+                finally:
+                    lib.spread_lane(0)
+                torch.cuda.current_stream(dev).wait_stream(side)
+        finally:
+            lib.spread_defer(False, dev)
+
     # ================================================= forward =================================================
     def _dual_path_fwd(self, G, d, B, T2, dim, save):
         S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
@@ -376,7 +434,7 @@ class HipTrainer:
         dev = dOut.device
         dW = _acc(gr, key + ".w", 16 * 64, dev)
         dbias = _acc(gr, key + ".bias", 64, dev) if has_bias else None
-        self._call("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
+        self._wg("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
         if dIn is not None:
             self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
 
@@ -390,7 +448,7 @@ class HipTrainer:
         dG_seq = torch.empty(S * npos * 64, device=dev)
         self._call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
         dct = g("ct_w", 64 * 512)
-        self._call("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
         self._call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
         # SRU layers 3..1
@@ -400,7 +458,7 @@ class HipTrainer:
             dx = torch.empty(S * L * 64, device=dev)
             self._call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
                      S, L, 3)
-            self._call("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
+            self._wg("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
             self._call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
             dh = dx
         l0 = d["layers"][0]
@@ -410,7 +468,7 @@ class HipTrainer:
         xn_seq = torch.empty(S * npos * 64, device=dev)
         self._call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
         dw0 = g("w0", 256 * 512)
-        self._call("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
         dxn = torch.empty(B * T2 * F2 * 64, device=dev)
         self._call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
         self._call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
@@ -425,7 +483,7 @@ class HipTrainer:
         self._call("rtfs_attn_out_norm_bwd", dG, k.Ypre_o, a["oslope"], a["og"], dYo, g("og", 4096), g("obe", 4096), g("oslope", 1), ntok)
         Ocl = torch.empty(rows * 64, device=dev)
         self._call("rtfs_transpose_tok", k.O, Ocl, ntok)  # [c][f] -> [f][c]
-        self._call("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, g("ob", 64), rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dYo, 64, Ocl, 64, g("ow", 64 * 64), 64, g("ob", 64), rows, 0, 0, 0, 1, 64, 64, 0, None, None, 0.0, None, 0)
         dOcl = torch.empty(rows * 64, device=dev)
         self._call("rtfs_gemm_rows", dYo, a["owT"], None, dOcl, rows, 64, 64, 0)
         dO = torch.empty(rows * 64, device=dev)
@@ -436,7 +494,7 @@ class HipTrainer:
         dY96 = torch.empty(rows * 96, device=dev)
         self._call("rtfs_attn_qkv_norm_bwd", dQ, dK, dV, k.Ypre96, a["slope"], a["gq"], a["gk"], a["gv"], dY96, g("gq", 1024), g("bq", 1024), g("gk", 1024),
                  g("bk", 1024), g("gv", 4096), g("bv", 4096), g("slope", 12), B, T2)
-        self._call("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
         self._call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
     def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode):
@@ -457,7 +515,7 @@ class HipTrainer:
         # residual_conv: bias, weight (needs `expanded`), input gradient
         E = full()
         self._call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
-        self._call("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
         self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
@@ -507,7 +565,7 @@ class HipTrainer:
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
-        self._call("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
+        self._wg("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
         # d(gateway out) = dx (residual path) + dy0 . Wp, formed inside the gateway adjoint
         if a0_mode >= 3:
             self._call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], da0, 1 if a0_mode == 3 else 0, None, 0,
@@ -538,14 +596,14 @@ class HipTrainer:
         dspec = torch.empty(B * TF * 2, device=dev)
         dtaps = torch.empty(B * TF * 32, device=dev)
         self._call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
-        self._call("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
         dmasked = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
         # S3 mask
         da_emb = _zeros(B * TF * C, dev)
         dz = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
-        self._call("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
+        self._wg("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dpre = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
@@ -581,14 +639,14 @@ class HipTrainer:
             da0 = torch.empty(B * TF * C, device=dev)
         self._block_bwd(dx0, c.blk[0], blocks[0], B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
-        self._call("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
+        self._wg("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
         self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
         self._call("rtfs_spec_patches", c.spec, patches, B, T)
-        self._call("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
+        self._wg("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
         return gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
@@ -743,7 +801,11 @@ class AVNetHipFunction(torch.autograd.Function):
     def backward(ctx, dout):
         trainer = ctx.trainer
         with torch.no_grad():
-            datt, drsz, gr = trainer.backward(ctx.saved, dout)
+            trainer.begin_stage(dout.device)
+            try:
+                datt, drsz, gr = trainer.backward(ctx.saved, dout)
+            finally:
+                trainer.end_stage(dout.device)
             ref = grads_to_reference(trainer.model, ctx.saved.pw, gr)
         grads = tuple(ref.get(n) for n in ctx.names)
         ctx.saved = None
@@ -776,11 +838,11 @@ class AVNetHipStageA(torch.autograd.Function):
                 dx0 = torch.zeros(n, device=c.x0.device)
             if da_emb is None:
                 da_emb = torch.zeros(n, device=c.x0.device)
-            lib.spread_defer(True, c.x0.device)
+            trainer.begin_stage(c.x0.device)
             try:
                 gr = trainer.backward_a(c, dx0, da0, da_emb)
             finally:
-                lib.spread_defer(False, c.x0.device)  # (flushes: every parameter gradient is complete, stream-ordered, before it is re-laid out)
+                trainer.end_stage(c.x0.device)  # (flushes + joins: every parameter gradient is complete, stream-ordered, before it is re-laid out)
             ref = grads_to_reference(trainer.model, c.pw, gr)
         grads = tuple(ref.get(name) for name in ctx.names)
         c.__dict__.clear()
@@ -801,11 +863,11 @@ class AVNetHipStageB(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         with torch.no_grad():
-            lib.spread_defer(True, dout.device)  # (the reducers' finish launches of this stage in a few batched launches, csrc/spread.hip)
+            ctx.trainer.begin_stage(dout.device)  # (the reducers' finish launches of this stage in a few batched launches, csrc/spread.hip)
             try:
                 dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)
             finally:
-                lib.spread_defer(False, dout.device)
+                ctx.trainer.end_stage(dout.device)
         n = dx0.numel() // C
         return None, None, dx0.view(n, C), (None if da0 is None else da0.view(n, C)), da_emb.view(n, C), datt, drsz
 
