@@ -155,6 +155,7 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
     kern = a.roofline_kernel or ("rtfs_dp_unfold_gemm_fwd" if a.mode == "infer" else "rtfs_wgrad")
     wgrad_l0 = (lambda ints: len(ints) >= 10 and ints[7] == 8 and ints[8] == 256) if kern == "rtfs_wgrad" else None
 
+    prof_overlapped = None
     if a.mode == "infer":
         with torch.no_grad():
             for _ in range(a.warmup):
@@ -192,7 +193,21 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         barrier()
         lib.profile_begin(kern, wgrad_l0)
         out, elapsed = timed(step)
-        prof = lib.profile_end()
+        prof_overlapped = lib.profile_end()
+        # In the timed steps the weight-gradient launches run on a second stream underneath the adjoint chain (models/hip_train.py: _wg): the events
+        # around them then bracket a kernel that shares the chip.  The roofline object prices the KERNEL: two more steps, outside the timed region,
+        # with those launches in line; the overlapped average is reported next to it.
+        side_on = model._hip.fuse.get("wgside", False)
+        if side_on:
+            model._hip.fuse["wgside"] = False
+            step()
+            lib.profile_begin(kern, wgrad_l0)
+            step()
+            step()
+            prof = lib.profile_end()
+            model._hip.fuse["wgside"] = True
+        else:
+            prof = prof_overlapped
     assert torch.isfinite(out).all()
     step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in step_events)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -268,6 +283,10 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                     "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
                     "peak": MFMA_BF16_PEAK_TF / terms if terms else MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None}
+            if prof_overlapped is not None and prof_overlapped is not prof:
+                roof["measured"] = ("two extra steps after the timed region with the weight-gradient launches in line; in the timed steps they run on a "
+                                    "second stream underneath the adjoint chain")
+                roof["avg_launch_ms_in_timed_steps_overlapped"] = sum(prof_overlapped) / max(1, len(prof_overlapped))
         else:
             km = kernel_models(a.batch, T, T2, Tv).get(kern)
             if km is not None:
