@@ -196,19 +196,19 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_input_s1_kernel(const float
         rmask[r] = (tvalid && to >= 0 && to < T) ? 1.f : 0.f;
         rowp[r] = dOut + (((size_t)b * T + min(max(to, 0), T - 1)) * F) * kH + c4;
     }
-    auto load_col = [&](int c, float4(&col)[4]) {
+    auto load_col = [&](int c, float4v(&col)[4]) {  // (native 4-vectors: packed FMAs, see dwconv_bwd_weight_kernel)
         const float cm = (c >= 0 && c < F) ? 1.f : 0.f;
         const size_t off = (size_t)min(max(c, 0), F - 1) * kH;
-        float4 x[4];
+        float4v x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = ld4(rowp[r] + off);
+        for (int r = 0; r < 4; ++r) x[r] = ld4v(rowp[r] + off);
 #pragma unroll
         for (int r = 0; r < 4; ++r) col[r] = x[r] * (cm * rmask[r]);
     };
-    float4 wreg[16];  // wreg[r*4+cc] = w[(3-r)*4 + (3-cc)]
+    float4v wreg[16];  // wreg[r*4+cc] = w[(3-r)*4 + (3-cc)]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) wreg[i] = ld4(w + (15 - i) * 64 + c4);
-    float4 win[4][4];
+    for (int i = 0; i < 16; ++i) wreg[i] = ld4v(w + (15 - i) * 64 + c4);
+    float4v win[4][4];
     load_col(f0 - 2, win[0]);
     load_col(f0 - 1, win[1]);
     load_col(f0, win[2]);
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_input_s1_kernel(const float
         for (int j = 0; j < 4; ++j) {
             const int fi = f + j;
             load_col(fi + 1, win[(j + 3) & 3]);
-            float4 old = f4(0, 0, 0, 0);
-            if (ACCUM) old = ld4(orow + (size_t)min(fi, F - 1) * kH);
-            float4 acc = f4(0, 0, 0, 0);
+            float4v old = float4v{0.f, 0.f, 0.f, 0.f};
+            if (ACCUM) old = ld4v(orow + (size_t)min(fi, F - 1) * kH);
+            float4v acc = old;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) acc = fma4(wreg[r * 4 + cc], win[(j + cc) & 3][r], acc);
-            if (tvalid && fi < f1) st4(orow + (size_t)fi * kH, ACCUM ? acc + old : acc);
+                for (int cc = 0; cc < 4; ++cc) acc = wreg[r * 4 + cc] * win[(j + cc) & 3][r] + acc;
+            if (tvalid && fi < f1) st4(orow + (size_t)fi * kH, to_f4(acc));
         }
     }
 }
@@ -731,7 +731,7 @@ int rtfs_dwconv_bwd_input(const float* dOut, const float* w, float* dIn, int acc
     const int Tout = stride == 1 ? Tin : (Tin - 2) / 2 + 1, Fout = stride == 1 ? Fin : (Fin - 2) / 2 + 1;
     dim3 grid((Tin * Fin + 15) / 16, B);
     if (stride == 1) {
-        const int nseg = Fin >= 96 ? 4 : 2, fseg = (((Fin + nseg - 1) / nseg) + 3) / 4 * 4;
+        const int nseg = Fin >= 96 ? 3 : 2, fseg = (((Fin + nseg - 1) / nseg) + 3) / 4 * 4;
         dim3 g1((Tin + 15) / 16, B, (Fin + fseg - 1) / fseg);
         if (accumulate) { LAUNCH((dwconv_bwd_input_s1_kernel<true>), g1, dOut, w, dIn, Tin, Fin, fseg); }
         else { LAUNCH((dwconv_bwd_input_s1_kernel<false>), g1, dOut, w, dIn, Tin, Fin, fseg); }
