@@ -235,13 +235,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_input_s1_kernel(const float
 // xin = transformed forward input (MODE 0 raw, 1 gLN, 2 PReLU(gLN)).  Same sliding-window walk as the forward kernel
 // (tfar.hip dwconv_kernel): thread = (output time row, channel quad) keeps a 4-column x 4-row register window of xin while
 // it walks a frequency segment, so xin is loaded once per overlapping time row instead of 16x; the 16 tap partials + the
-// bias partial stay in registers.  Lane = quad*4 + (row & 3): the 4 rows of a wave are summed with two quad_perm DPP adds,
+// bias partial stay in registers.  The 4 rows of a wave are summed with two xor shuffles (lanes 16 and 32 apart),
 // the 4 waves through LDS, and the workgroup leaves with one coalesced fp32 atomic per (tap, channel).
-__device__ __forceinline__ float quad_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // lanes [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));  // lanes [2,3,0,1]
-    return v;
-}
 
 template <int STRIDE, int MODE>
 __global__ __launch_bounds__(256, 2) void dwconv_bwd_weight_kernel(const float* __restrict__ dOut, NormArg n, float slope, float* __restrict__ scr,
@@ -249,8 +244,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_weight_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float red[4][17][64];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c4 = (lane >> 2) * 4;
-    const int to = blockIdx.x * 16 + wave * 4 + (lane & 3);
+    // lane = (row of the wave) * 16 + channel quad: 16 consecutive lanes read one row's 256 contiguous bytes.  (Until round 4 the row sat in the
+    // low two lane bits so that quad_perm DPP adds could sum the rows: every group of four lanes then touched four different cache lines, and
+    // the vector L1 - one line per cycle - made each load instruction cost 64 cycles instead of 16: the kernel ran at 3 TB/s on L1 issue.)
+    const int c4 = (lane & 15) * 4;
+    const int to = blockIdx.x * 16 + wave * 4 + (lane >> 4);
     const int f0 = blockIdx.z * fseg, f1 = min(Fout, f0 + fseg);
     float4 sc = f4(1, 1, 1, 1), sh = f4(0, 0, 0, 0);
     if (MODE >= 1) {
@@ -323,9 +321,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_bwd_weight_kernel(const float* 
     }
 #pragma unroll
     for (int i = 0; i < 17; ++i) {
-        const float4 v = i < 16 ? part[i] : pb;
-        const float4 t = f4(quad_sum(v.x), quad_sum(v.y), quad_sum(v.z), quad_sum(v.w));
-        if ((lane & 3) == 0) st4(&red[wave][i][c4], t);
+        float4 v = i < 16 ? part[i] : pb;
+        v = f4(v.x + __shfl_xor(v.x, 16, 64), v.y + __shfl_xor(v.y, 16, 64), v.z + __shfl_xor(v.z, 16, 64), v.w + __shfl_xor(v.w, 16, 64));
+        v = f4(v.x + __shfl_xor(v.x, 32, 64), v.y + __shfl_xor(v.y, 32, 64), v.z + __shfl_xor(v.z, 32, 64), v.w + __shfl_xor(v.w, 32, 64));
+        if (lane < 16) st4(&red[wave][i][c4], v);
     }
     __syncthreads();
     float* mine = spread_copy(scr, blockIdx.x + blockIdx.y + blockIdx.z);  // [dW 16*64 | dbias 64]
@@ -753,7 +752,10 @@ int rtfs_dwconv_bwd_weight(const float* dOut, const float* in, const double* sta
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
 #define DWW(S, M) LAUNCH((dwconv_bwd_weight_kernel<S, M>), grid, dOut, n, slope, scr, Tin, Fin, Tout, Fout, fseg)
-    if (stride == 1) { if (mode == 0) { DWW(1, 0); } else if (mode == 1) { DWW(1, 1); } else { DWW(1, 2); } }
+    // stride 1, gLN input: the PReLU instantiation with slope 1 (x >= 0 ? x : 1 * x - the same bits): hipcc schedules the <1, 1> instantiation's
+    // walk worse (same 247 VGPRs, 159 us against 123 at the headline shape)
+    if (stride == 1 && mode == 1) { mode = 2; slope = 1.0f; }
+    if (stride == 1) { if (mode == 0) { DWW(1, 0); } else { DWW(1, 2); } }
     else { if (mode == 0) { DWW(2, 0); } else if (mode == 1) { DWW(2, 1); } else { DWW(2, 2); } }
 #undef DWW
     return spread_finish(scr, SpreadOut{{dW, dbias}, {16 * 64, 64}}, (hipStream_t)stream);
