@@ -65,10 +65,13 @@ __device__ __forceinline__ void stats_finalize(const double* slot, int b, double
     rstd = (float)(1.0 / sqrt(v + (double)kEps));
 }
 
+__device__ __forceinline__ float row16_sum(float v);
+// xor butterfly 32, 16, 8, 4, 2, 1 over the wave, every lane gets the total; the four steps inside a 16-lane row run as DPP adds (row16_sum, same
+// operand pairs = same bits as four more __shfl_xor steps, a quarter of their cost: ds_bpermute goes through the LDS crossbar)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    return row16_sum(v);
 }
 // Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), every lane gets the total: the xor butterfly 8, 4, 2, 1 of
 //   for (o = 8; o; o >>= 1) v += __shfl_xor(v, o)
