@@ -244,6 +244,8 @@ int rtfs_attn_core_bwd(const float* Q, const float* K, const float* V, const flo
                        float* dK, float* dV, int B, int T2, void* stream);
 int rtfs_transpose_tok(const float* in, float* out, int ntok, void* stream);
 /* S3 mask, CAF (training-mode BatchNorm), decoder / encoder ends */
+/* rtfs_mask_bwd_elem: dz = gradient w.r.t. the mask pre-activation (ReLU gate from m), da_emb = gradient that reaches the encoder features through
+ * the complex product - WRITTEN (the first contribution; round 3 accumulated into a zeroed buffer) */
 int rtfs_mask_bwd_elem(const float* dmasked, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows, void* stream);
 int rtfs_prelu_bwd(const float* dy, const float* x, float slope, float* dx, int accumulate, float* dslope, long long n, void* stream);
 int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, void* stream);

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void mask_bwd_elem_kernel(const float* __restr
     st4(dz + o + 128, f4(gate(dmi.x, mi.x), gate(dmi.y, mi.y), gate(dmi.z, mi.z), gate(dmi.w, mi.w)));
     const float4 der = f4(dor.x * mr.x + doi.x * mi.x, dor.y * mr.y + doi.y * mi.y, dor.z * mr.z + doi.z * mi.z, dor.w * mr.w + doi.w * mi.w);
     const float4 dei = f4(doi.x * mr.x - dor.x * mi.x, doi.y * mr.y - dor.y * mi.y, doi.z * mr.z - dor.z * mi.z, doi.w * mr.w - dor.w * mi.w);
-    st4(de + o, der + ld4(de + o));
-    st4(de + o + 128, dei + ld4(de + o + 128));
+    st4(de + o, der);  // (plain store since round 4: this is the FIRST contribution to d(a_emb) - the += form cost a 1 GB memset and a 1 GB read per step)
+    st4(de + o + 128, dei);
 }
 
 template <bool ACCUM>

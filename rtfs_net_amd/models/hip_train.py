@@ -600,7 +600,7 @@ class HipTrainer:
         dmasked = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
         # S3 mask
-        da_emb = _zeros(B * TF * C, dev)
+        da_emb = torch.empty(B * TF * C, device=dev)  # (written by rtfs_mask_bwd_elem: the first contribution to d(a_emb))
         dz = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
         self._wg("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
