@@ -247,6 +247,11 @@ int rtfs_transpose_tok(const float* in, float* out, int ntok, void* stream);
 /* rtfs_mask_bwd_elem: dz = gradient w.r.t. the mask pre-activation (ReLU gate from m), da_emb = gradient that reaches the encoder features through
  * the complex product - WRITTEN (the first contribution; round 3 accumulated into a zeroed buffer) */
 int rtfs_mask_bwd_elem(const float* dmasked, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows, void* stream);
+/* rtfs_gemm_rows(dtaps, dec_wT, K = 32, N = 256) with rtfs_mask_bwd_elem in its epilogue: d(masked) never reaches HBM.  dtaps [rows][32] = the iSTFT /
+ * decoder adjoint's tap gradients (18 used), dec_wT [256][32].  Adjoint of /root/reference/src/models/TDAVNet/mask_generator.py:70-82 behind the decoder's
+ * ConvTranspose2d (decoder.py). */
+int rtfs_decoder_mask_bwd(const float* dtaps, const float* dec_wT, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
+                          void* stream);
 int rtfs_prelu_bwd(const float* dy, const float* x, float slope, float* dx, int accumulate, float* dslope, long long n, void* stream);
 int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, void* stream);
 int rtfs_caf_bwd_reduce(const float* dOut, const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att,
@@ -348,6 +353,8 @@ int rtfs_gemm_rows_bf16(const float* X, const void* Wpk, const float* bias_or_nu
 int rtfs_wgrad_bf16(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias, long long M, int seg_len, int x_seg, int x_off,
                     int nshift, int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, int terms,
                     void* stream);
+int rtfs_decoder_mask_bwd_bf16(const float* dtaps, const void* dec_wT_pk, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
+                               int terms, void* stream);
 int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float* dx, const float* s, const float* gw, const float* gb, float slope,
                                float* ds, int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, int terms,
                                void* stream);

@@ -171,6 +171,32 @@ struct EpiMask {
     }
 };
 
+// Adjoint of the S3 complex product + ReLU gate (mask_generator.py:70-82), applied to the decoder's input gradient d(masked) while its row is in the
+// epilogue registers (training step): dz = gradient w.r.t. the mask pre-activation, de = the part of d(a_emb) that arrives through the product.
+// Same arithmetic as mask_bwd_elem_kernel (bwd_misc.hip); d(masked) itself never exists in HBM.
+struct EpiMaskBwd {
+    static constexpr bool kAccum = false;
+    const float* __restrict__ emb;  // a_emb [rows][256]
+    const float* __restrict__ m;    // post-ReLU mask [rows][256]
+    float* __restrict__ dz;
+    float* __restrict__ de;
+    __device__ void store2(int b, int Mb, int row, int col, float4 vr, float4 vi) const {
+        const size_t o = ((size_t)b * Mb + row) * kC + col;
+        store2e(b, Mb, row, col, vr, vi, ld4(emb + o), ld4(emb + o + 128));
+    }
+    __device__ void store2e(int b, int Mb, int row, int col, float4 dor, float4 doi, float4 er, float4 ei) const {
+        const size_t o = ((size_t)b * Mb + row) * kC + col;
+        const float4 mr = ld4(m + o), mi = ld4(m + o + 128);
+        auto gate = [](float g, float mm) { return mm > 0.f ? g : 0.f; };
+        const float4 dmr = f4(dor.x * er.x + doi.x * ei.x, dor.y * er.y + doi.y * ei.y, dor.z * er.z + doi.z * ei.z, dor.w * er.w + doi.w * ei.w);
+        const float4 dmi = f4(doi.x * er.x - dor.x * ei.x, doi.y * er.y - dor.y * ei.y, doi.z * er.z - dor.z * ei.z, doi.w * er.w - dor.w * ei.w);
+        st4(dz + o, f4(gate(dmr.x, mr.x), gate(dmr.y, mr.y), gate(dmr.z, mr.z), gate(dmr.w, mr.w)));
+        st4(dz + o + 128, f4(gate(dmi.x, mi.x), gate(dmi.y, mi.y), gate(dmi.z, mi.z), gate(dmi.w, mi.w)));
+        st4(de + o, f4(dor.x * mr.x + doi.x * mi.x, dor.y * mr.y + doi.y * mi.y, dor.z * mr.z + doi.z * mi.z, dor.w * mr.w + doi.w * mi.w));
+        st4(de + o + 128, f4(doi.x * mr.x - dor.x * mi.x, doi.y * mr.y - dor.y * mi.y, doi.z * mr.z - dor.z * mi.z, doi.w * mr.w - dor.w * mi.w));
+    }
+};
+
 // sum and sum of squares of a float4 in scalar VALU instructions.  Left to hipcc, the SLP vectoriser turned the gLN partial sums of the MFMA waves of
 // resid_ws_kernel into v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1] - the packed form that returned wrong low halves next to bf16 MFMA traffic
 // (DESIGN.md rule 10), here issued BETWEEN the bf16 MFMAs of the same wave.
@@ -1383,6 +1409,17 @@ static int mask_impl(const float* x, float slope, const float* Wt, const float* 
     return launch<256, 256, 64, 2, 2, true, 16, NT>(pro, epi, Wt, B, TF, st);
 }
 
+// d(masked) = dtaps [rows][32] . dec_wT [256][32]^T (the decoder ConvTranspose's input gradient, rtfs_gemm_rows K = 32, N = 256) with the S3 mask's
+// element-wise adjoint (rtfs_mask_bwd_elem) in the epilogue: dz, da_emb written, d(masked) never stored.
+template <int NT>
+static int decoder_mask_bwd_impl(const float* dtaps, const float* dec_wT, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
+                                 hipStream_t st) {
+    if (rows <= 0 || rows * 1024 >= (1ll << 40)) return RTFS_EINVAL;
+    ProPlain pro{dtaps, 32};
+    EpiMaskBwd epi{a_emb, m, dz, da_emb};
+    return launch<32, 256, 64, 2, 2, true, 32, NT>(pro, epi, dec_wT, 1, (int)rows, st);
+}
+
 extern "C" {
 
 // a0 = Wt . relu(gLN(a_emb)) + bias.  a_emb, a0: [B][TF][256]; stats: [B][2] (sum, sumsq of a_emb).
@@ -1531,6 +1568,18 @@ int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, f
     RG(96, 64, 128, 2, 1)
 #undef RG
     return RTFS_EINVAL;
+}
+
+int rtfs_decoder_mask_bwd(const float* dtaps, const float* dec_wT, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
+                          void* stream) {
+    return decoder_mask_bwd_impl<0>(dtaps, dec_wT, a_emb, m, dz, da_emb, rows, (hipStream_t)stream);
+}
+int rtfs_decoder_mask_bwd_bf16(const float* dtaps, const void* dec_wT_pk, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
+                               int terms, void* stream) {
+    const float* W = (const float*)dec_wT_pk;
+    RTFS_TERMS_DISPATCH(terms, decoder_mask_bwd_impl<1>(dtaps, W, a_emb, m, dz, da_emb, rows, (hipStream_t)stream),
+                        decoder_mask_bwd_impl<3>(dtaps, W, a_emb, m, dz, da_emb, rows, (hipStream_t)stream),
+                        decoder_mask_bwd_impl<6>(dtaps, W, a_emb, m, dz, da_emb, rows, (hipStream_t)stream));
 }
 
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream) {

@@ -128,6 +128,8 @@ SIGNATURES = {
     "rtfs_spread_defer": [I, P],
     "rtfs_spread_flush": [P],
     "rtfs_spread_lane": [I],
+    "rtfs_decoder_mask_bwd": [P, P, P, P, P, P, LL, P],
+    "rtfs_decoder_mask_bwd_bf16": [P, P, P, P, P, P, LL, I, P],
     "rtfs_proj_gateway_bwd_bf16": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, I, P],
     "rtfs_fold_gemm_bwd_bf16": [P, P, P, I, I, I, I, P],
     "rtfs_convt_bwd_input_bf16": [P, P, P, I, I, I, I, P],

@@ -113,7 +113,7 @@ def _acc(gr, key, n, dev):
 # entry points whose contraction runs on MFMA and that have a *_bf16 sibling (include/rtfs_hip.h); everything else is fp32 in every mode
 _MFMA_ENTRY_POINTS = frozenset((
     "rtfs_bottleneck_fwd", "rtfs_proj_fwd", "rtfs_dp_unfold_gemm_fwd", "rtfs_sru_layer_fwd", "rtfs_dp_convt_fwd", "rtfs_attn_qkv_fwd", "rtfs_attn_core_fwd",
-    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_resid_proj_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_fold_gemm_bwd",
+    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_resid_proj_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_decoder_mask_bwd", "rtfs_fold_gemm_bwd",
     "rtfs_convt_bwd_input"))
 
 
@@ -597,12 +597,16 @@ class HipTrainer:
         dtaps = torch.empty(B * TF * 32, device=dev)
         self._call("rtfs_istft_bwd", dout, dspec, dtaps, B, L)
         self._wg("rtfs_wgrad", dtaps, 32, c.masked, C, g("dec_w", 32 * C), C, None, B * TF, 0, 0, 0, 1, 32, C, 0, None, None, 0.0, None, 0)
-        dmasked = torch.empty(B * TF * C, device=dev)
-        self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
-        # S3 mask
-        da_emb = torch.empty(B * TF * C, device=dev)  # (written by rtfs_mask_bwd_elem: the first contribution to d(a_emb))
+        # decoder input gradient + S3 mask's element-wise adjoint (da_emb: WRITTEN here, the first contribution to d(a_emb))
+        da_emb = torch.empty(B * TF * C, device=dev)
         dz = torch.empty(B * TF * C, device=dev)
-        self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
+        if m._hip.fuse["decmask"]:
+            self._call("rtfs_decoder_mask_bwd", dtaps, w["dec_wT"], c.a_emb, c.m, dz, da_emb, B * TF)  # d(masked) never stored
+        else:
+            dmasked = torch.empty(B * TF * C, device=dev)
+            self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
+            self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
+            del dmasked
         self._wg("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dpre = torch.empty(B * TF * C, device=dev)
         self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
