@@ -814,3 +814,56 @@ def test_training_step_fusion_switches_leave_the_gradients_alone(switch):
     scale = max(float(g.norm()) for g in grads[True].values())
     for n, g in grads[True].items():
         assert float((g - grads[False][n]).norm()) <= 2e-5 * float(g.norm()) + 1e-6 * scale, n
+
+
+def test_spread_lanes_keep_concurrent_reducers_apart():
+    """rtfs_spread_lane (csrc/spread.hip): reducers issued on a second stream with lane 1 run concurrently with lane 0's on the main stream - each lane has
+    its own scratch, cursor and deferred section.  Forty producers per stream, interleaved, immediate and deferred mode, against a serial run; without the
+    lanes the two streams' partial sums meet in one scratch region (the training step's weight-gradient side stream relies on this)."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(9)
+    n = 1 << 20
+    dy = [torch.randn(n, generator=g).cuda() for _ in range(2)]
+    x = [torch.randn(n, generator=g).cuda() for _ in range(2)]
+    side = torch.cuda.Stream()
+
+    def run(two_streams, deferred):
+        ds = [torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")]
+        dx = [torch.empty(n, device="cuda"), torch.empty(n, device="cuda")]
+        torch.cuda.synchronize()
+        main = torch.cuda.current_stream()
+        if deferred:
+            lib.spread_defer(True, "cuda:0")
+            if two_streams:
+                lib.spread_lane(1)
+                with torch.cuda.stream(side):
+                    lib.spread_defer(True, "cuda:0")
+                lib.spread_lane(0)
+        for k in range(40):
+            lib.call("rtfs_prelu_bwd", dy[0], x[0], 0.25, dx[0], 0, ds[0], n)
+            if two_streams:
+                lib.spread_lane(1)
+                with torch.cuda.stream(side):
+                    lib.call("rtfs_prelu_bwd", dy[1], x[1], 0.5, dx[1], 0, ds[1], n)
+                lib.spread_lane(0)
+            else:
+                lib.call("rtfs_prelu_bwd", dy[1], x[1], 0.5, dx[1], 0, ds[1], n)
+        if deferred:
+            if two_streams:
+                lib.spread_lane(1)
+                with torch.cuda.stream(side):
+                    lib.spread_defer(False, "cuda:0")
+                lib.spread_lane(0)
+            lib.spread_defer(False, "cuda:0")
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        return float(ds[0]), float(ds[1])
+
+    want = run(False, False)
+    assert abs(want[0]) > 1 and abs(want[1]) > 1
+    for deferred in (False, True):
+        got = run(True, deferred)
+        assert abs(got[0] - want[0]) <= 1e-4 * abs(want[0]) and abs(got[1] - want[1]) <= 1e-4 * abs(want[1]), (deferred, got, want)
+    again = run(False, True)  # both lanes came back clean
+    assert abs(again[0] - want[0]) <= 1e-4 * abs(want[0]) and abs(again[1] - want[1]) <= 1e-4 * abs(want[1])
