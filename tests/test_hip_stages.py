@@ -867,3 +867,28 @@ def test_spread_lanes_keep_concurrent_reducers_apart():
         assert abs(got[0] - want[0]) <= 1e-4 * abs(want[0]) and abs(got[1] - want[1]) <= 1e-4 * abs(want[1]), (deferred, got, want)
     again = run(False, True)  # both lanes came back clean
     assert abs(again[0] - want[0]) <= 1e-4 * abs(want[0]) and abs(again[1] - want[1]) <= 1e-4 * abs(want[1])
+
+
+@pytest.mark.parametrize("rows", [3 * 18 * 129, 64 * 129 + 7])
+def test_decoder_mask_bwd_matches_separate_calls(rows):
+    """rtfs_decoder_mask_bwd (the S3 mask's element-wise adjoint in the paired epilogue of the decoder input-gradient GEMM; mask_generator.py:70-82
+    behind decoder.py's ConvTranspose2d) against rtfs_gemm_rows + rtfs_mask_bwd_elem and against float64, ragged last tile."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator(device="cuda").manual_seed(12)
+    dtaps = torch.randn(rows, 32, device="cuda", generator=g)
+    wT = torch.randn(256, 32, device="cuda", generator=g) / 6
+    a_emb = torch.randn(rows, 256, device="cuda", generator=g)
+    m = torch.relu(torch.randn(rows, 256, device="cuda", generator=g))
+    dz, de = torch.empty(rows, 256, device="cuda"), torch.empty(rows, 256, device="cuda")
+    lib.call("rtfs_decoder_mask_bwd", dtaps, wT, a_emb, m, dz, de, rows)
+    dm, dz2, de2 = torch.empty(rows, 256, device="cuda"), torch.empty(rows, 256, device="cuda"), torch.empty(rows, 256, device="cuda")
+    lib.call("rtfs_gemm_rows", dtaps, wT, None, dm, rows, 32, 256, 0)
+    lib.call("rtfs_mask_bwd_elem", dm, a_emb, m, dz2, de2, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz2) and torch.equal(de, de2)  # same products, same order
+    d64 = dtaps.double() @ wT.double().t()
+    dor, doi, er, ei, mr, mi = d64[:, :128], d64[:, 128:], a_emb.double()[:, :128], a_emb.double()[:, 128:], m.double()[:, :128], m.double()[:, 128:]
+    want_dz = torch.cat([(dor * er + doi * ei) * (mr > 0), (doi * er - dor * ei) * (mi > 0)], 1)
+    want_de = torch.cat([dor * mr + doi * mi, doi * mr - dor * mi], 1)
+    assert rel(dz.double(), want_dz) < 1e-5 and rel(de.double(), want_de) < 1e-5
