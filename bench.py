@@ -89,6 +89,66 @@ def _free_port():
     return p
 
 
+class AllReduceTimer:
+    """State of `timed_allreduce_hook`: one (start, end) HIP-event pair per gradient bucket per step.  `start` is recorded on the compute
+    stream when DDP hands the bucket over (all 363 gradients of the HIP autograd node appear together, so that is the end of the backward),
+    `end` inside the collective's completion callback, i.e. on a stream ordered after the all-reduce."""
+
+    def __init__(self, dist, world):
+        self.dist, self.world, self.spans, self.bytes, self.phases, self.phase, self.kept, self.micro_ms = dist, world, [], [], [], "warmup", None, None
+
+    def freeze(self, steps):
+        """keep the spans recorded while `phase == "timed"` (warm-ups and the in-line roofline steps after the timed region are dropped)"""
+        torch.cuda.synchronize()
+        sel = [i for i, ph in enumerate(self.phases) if ph == "timed"]
+        per_step = max(1, len(sel) // max(1, steps))
+        self.kept = {"buckets_per_step": per_step, "bytes_per_step": int(sum(self.bytes[i] for i in sel[:per_step])),
+                     "ms": [self.spans[i][0].elapsed_time(self.spans[i][1]) for i in sel]}
+
+    def standalone(self, dev, nparam, reps=20):
+        """the same collective alone: all-reduce of a flat fp32 buffer of the model's parameter count, back to back"""
+        buf = torch.zeros(nparam, device=dev)
+        for _ in range(3):
+            self.dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        self.micro_ms = 1e3 * (time.perf_counter() - t0) / reps
+
+    def report(self):
+        k = self.kept or {"buckets_per_step": None, "bytes_per_step": None, "ms": []}
+        ms = sorted(k["ms"])
+        per_step = k["buckets_per_step"] or 1
+        return {"collective": "all-reduce (sum of grad / world), DistributedDataParallel bucket hook", "backend": self.dist.get_backend(),
+                "buckets_per_step": k["buckets_per_step"], "bytes_per_step": k["bytes_per_step"],
+                "ms_per_step_mean_in_step": (sum(ms) / len(ms) * per_step) if ms else None,
+                "ms_per_bucket_median_in_step": ms[len(ms) // 2] if ms else None,
+                "measured": "HIP events: bucket hand-over on the compute stream -> completion callback on the collective's stream (rank 0; "
+                            "includes the wait for the slowest rank's backward)",
+                "ms_standalone": self.micro_ms,
+                "standalone": "the same buffer size all-reduced back to back outside the step (wall clock / 20)"}
+
+
+def timed_allreduce_hook(state, bucket):
+    buf = bucket.buffer()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    buf.div_(state.world)
+    fut = state.dist.all_reduce(buf, async_op=True).get_future()
+
+    def done(f):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        state.spans.append((e0, e1))
+        state.bytes.append(buf.numel() * buf.element_size())
+        state.phases.append(state.phase)
+        return f.value()[0]
+
+    return fut.then(done)
+
+
 def measure(a, rank, world, local_rank, dist, one_gpu):
     """One measurement of configuration `a` (layers, batch, seconds, dtype, mode, lip, steps, warmup, roofline_kernel) -> (result dict or
     None on ranks > 0, handles for the CPU-baseline leg).  Inputs resident in HBM before the timed region; K steps between barriers."""
@@ -169,9 +229,12 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         # DDP gradient all-reduce (one 2.96 MB bucket) and SyncBatchNorm over RCCL when N > 1
         model.train()
         net = model
+        ar = None
         if dist is not None:
             net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
             net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
+            ar = AllReduceTimer(dist, world)
+            net.register_comm_hook(ar, timed_allreduce_hook)  # the default hook's arithmetic (grad / world, sum) with HIP events around it
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
 
         from rtfs_net_amd.losses import PITLossWrapper, pairwise_neg_snr
@@ -192,7 +255,11 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
             out = step()
         barrier()
         lib.profile_begin(kern, wgrad_l0)
+        if ar is not None:
+            ar.phase = "timed"
         out, elapsed = timed(step)
+        if ar is not None:
+            ar.phase = "after"
         prof_overlapped = lib.profile_end()
         # In the timed steps the weight-gradient launches run on a second stream underneath the adjoint chain (models/hip_train.py: _wg): the events
         # around them then bracket a kernel that shares the chip.  The roofline object prices the KERNEL: two more steps, outside the timed region,
@@ -200,14 +267,19 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         side_on = model._hip.fuse.get("wgside", False)
         if side_on:
             model._hip.fuse["wgside"] = False
-            step()
-            lib.profile_begin(kern, wgrad_l0)
-            step()
-            step()
-            prof = lib.profile_end()
-            model._hip.fuse["wgside"] = True
+            try:
+                step()
+                lib.profile_begin(kern, wgrad_l0)
+                step()
+                step()
+                prof = lib.profile_end()
+            finally:
+                model._hip.fuse["wgside"] = True
         else:
             prof = prof_overlapped
+        if ar is not None:
+            ar.freeze(a.steps)
+            ar.standalone(dev, sum(p.numel() for p in model.parameters() if p.requires_grad))
     assert torch.isfinite(out).all()
     step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in step_events)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -224,6 +296,7 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         except Exception as e:  # noqa: BLE001
             devs = devs + [f"all_gather_object failed: {type(e).__name__}"]
     handles = SimpleNamespace(model=model, sd=sd, cfg=cfg, L=L, T=T, Tv=Tv, dev=dev)
+    ar_report = ar.report() if (a.mode == "train" and ar is not None) else None
     if rank != 0:
         return None, handles
     res = {
@@ -248,10 +321,14 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                         + f"{a.seconds:g} s @16 kHz, batch {a.batch} per GPU, " + DTYPE_TEXT[a.dtype] + ", random-init weights",
             "mode": a.mode + ("+lip-encoder" if a.lip else ""),
             "global_batch": world * a.batch, "frames_per_utt": T, "utt_per_s": world * a.batch * a.steps / elapsed,
-            "parallelism": f"utterance-sharded x{world} (contiguous shards of one global batch), no data-path collective"
+            "parallelism": (f"utterance-sharded x{world} (contiguous shards of one global batch), no data-path collective" if a.mode == "infer" else
+                            f"dp{world}: DistributedDataParallel (one gradient bucket, all-reduce over " + ("RCCL" if not one_gpu else "gloo")
+                            + ") + SyncBatchNorm, train.py:135-146" if world > 1 else "dp1 (single process, no collective)")
                            + (" [RTFS_BENCH_ONE_GPU test mode: ranks share one GPU]" if one_gpu else ""),
         },
     }
+    if ar_report is not None:
+        res["grad_allreduce"] = ar_report
     # ---- roofline of the dominant kernel (live HIP-event timing on the launch stream) ----
     roof = None
     if prof:
@@ -496,9 +573,52 @@ def main():
             nt = str(max(2, min(20, args.steps)))
             res["training_step"] = brief(child(["--mode", "train", "--steps", nt, "--warmup", "3"]))
             res["training_step_split_bf16"] = brief(child(["--mode", "train", "--dtype", "bf16x3", "--steps", nt, "--warmup", "3"]))
-        print(json.dumps(res), flush=True)
+    # N > 1, default (inference) line: BASELINE config 4 rides along as `training_step_dp` - the training step under SyncBatchNorm +
+    # DistributedDataParallel on the same N GPUs, `--batch` utterances per rank (global batch N x batch), measured by a CHILD
+    # `torch.distributed.run` of this script in `--mode train` once every rank of this run has released its GPU: a hang or a failure over there costs
+    # the rider, not the headline line.  The inference `value` stays the headline (utterance shards, no collective).
+    dp_rider = world > 1 and args.mode == "infer" and not args.lip and not args.no_train_line
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if dp_rider:
+        del h
+        torch.cuda.empty_cache()
+    if rank == 0:
+        if dp_rider:
+            res["training_step_dp"] = dp_training_rider(args, world)
+            res["scaling_note"] = ("`value` = inference frames/s over utterance shards (no collective); `training_step_dp` = BASELINE.json configs[3] "
+                                   "(DDP + SyncBatchNorm step, global batch n_gpus x batch, one gradient all-reduce per step).  The builder has no N > 1 hardware: "
+                                   "no scaling curve exists until the driver runs N = 1, 2, 4, 8 on one node.")
+        print(json.dumps(res), flush=True)
+
+
+def dp_training_rider(args, world):
+    """child launch of `bench.py --gpus N --mode train` (rank 0 of the parent run only); returns the brief form + the collective evidence, or a
+    dict with the reason it is missing"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
+                        "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    nt = str(max(2, min(10, args.steps)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), "--gpus", str(world), "--mode", "train", "--steps", nt, "--warmup", "3",
+           "--layers", str(args.layers), "--batch", str(args.batch), "--seconds", str(args.seconds), "--dtype", args.dtype, "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": "child torch.distributed.run did not finish within 600 s"}
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"value": None, "error": f"child torch.distributed.run rc {r.returncode}: " + (r.stderr or "")[-400:]}
+    t = json.loads(line[-1])
+    out = brief(t)
+    out.update(n_gpus=t["n_gpus"], global_batch=t["config"]["global_batch"], parallelism=t["config"]["parallelism"], dist=t.get("dist"),
+               grad_allreduce=t.get("grad_allreduce"), baseline_config="BASELINE.json configs[3] (RTFS-Net-6, 8 x MI355X DP, RCCL grad all-reduce, global batch 256) "
+                                                                       "when run with --gpus 8 --layers 6 --batch 32")
+    return out
 
 
 if __name__ == "__main__":

@@ -31,6 +31,18 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_stale(src_path: str, obj: str) -> bool:
+    """an object is rebuilt when its source, any header of csrc/ or include/, or this file (the flags) is newer"""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    deps = [src_path, os.path.abspath(__file__)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if os.path.isdir(inc):
+        deps += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
@@ -40,6 +52,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
+        if not force and not _obj_stale(os.path.join(CSRC, src), obj):
+            continue
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

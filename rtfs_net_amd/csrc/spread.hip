@@ -78,7 +78,7 @@ struct DevState {
 };
 constexpr int kLanes = 2;
 DevState g_dev[16][kLanes];
-int g_lane = 0;  // the lane the calling (single) host thread currently issues for
+thread_local int g_lane = 0;  // the lane the CALLING host thread currently issues for (per thread: one host thread per device may drive its own step)
 std::mutex g_mu;
 
 DevState* dev_state() {
@@ -118,15 +118,18 @@ int spread_finish(float* scr, const SpreadOut& o, hipStream_t st, bool consumed_
     int total = 0;
     for (int j = 0; j < kSpreadSlots; ++j) total += (o.n[j] + 31) & ~31;
     if (total <= 0) return RTFS_OK;
-    if (total > kMaxRegion) return RTFS_EINVAL;
+    if (total > kSpreadCap) return RTFS_EINVAL;
     std::lock_guard<std::mutex> lk(g_mu);
     DevState* d = dev_state();
     if (!d) return RTFS_ELAUNCH;
-    if (!d->deferred) {
+    if (!d->deferred) {  // immediate mode: the region starts at the scratch base, any size up to a copy's capacity
         hipLaunchKernelGGL(spread_finish_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scr, o);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
+    // deferred sections pack regions behind one another and keep kMaxRegion floats free behind the cursor: a producer that outgrows it must
+    // raise the constant (the request fails here, loudly, instead of running past the copy)
+    if (total > kMaxRegion) return RTFS_EINVAL;
     const int p = d->pend.n++;
     d->pend.off[p] = (int)(scr - d->scr), d->pend.total[p] = total, d->pend.o[p] = o;
     d->cursor = d->pend.off[p] + total;
@@ -149,8 +152,10 @@ int rtfs_spread_defer(int on, void* stream) {
     d->deferred = on != 0;
     return rc;
 }
-// Select the scratch lane (0 or 1) that the following reducer launches, rtfs_spread_defer and rtfs_spread_flush of this host thread use: lane 1 for
-// launches issued on a second stream that may run concurrently with lane 0's.  Deferred sections are per lane.
+// Select the scratch lane (0 or 1) that the following reducer launches, rtfs_spread_defer and rtfs_spread_flush of THIS host thread use: lane 1 for
+// launches issued on a second stream that may run concurrently with lane 0's.  Deferred sections are per (device, lane); the selection is per host
+// thread (thread_local), so a second host thread driving another device is not redirected by this thread's lane window.  Two host threads that
+// drive the SAME device concurrently are outside the contract (as for the scratch itself: its users are serialised by stream order).
 int rtfs_spread_lane(int lane) {
     if (lane < 0 || lane >= rtfs::kLanes) return RTFS_EINVAL;
     std::lock_guard<std::mutex> lk(rtfs::g_mu);

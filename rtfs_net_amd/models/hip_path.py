@@ -23,6 +23,7 @@ F_BINS = 129
 F2 = 64
 H = 64
 C = 256
+MAX_FRAMES = 15001  # longest utterance the inference path is tested at (120 s, tests/test_hip_e2e.py); 32-bit in-utterance byte offsets end at 16256
 
 
 def _f32(t):
@@ -421,11 +422,11 @@ class HipForward:
             # nn.Unfold((8, 1)) raises on fewer than 8 compressed frames (RuntimeError; tests/test_oracle_golden.py pins that)
             raise ValueError("input too short: fewer than 8 compressed frames (16 STFT frames, L >= 1920 samples) - the 8-tap unfold of the "
                              "time-path DualPathRNN has no window, exactly as in the reference (which raises from nn.Unfold)")
-        if T * F_BINS * C * 4 >= 2 ** 31:
-            # kernels address inside an utterance with 32-bit byte offsets (2 GiB).  tests/test_hip_e2e.py runs 120 s (1.98e9 bytes) against the
-            # reference's waveform and a batch whose B x T x 129 x 256 passes 2^31 elements
-            raise ValueError(f"input too long for the HIP path: {L} samples - one utterance's [T][129][256] fp32 activation must stay within 2 GiB "
-                             "(about 130 s at 16 kHz); split longer recordings into segments")
+        if T > MAX_FRAMES:
+            # kernels address inside an utterance with 32-bit byte offsets (2 GiB = T 16256).  The guard sits at the TESTED envelope: tests/test_hip_e2e.py
+            # runs 120 s (T = 15001, 1.98e9 bytes per [T][129][256] activation) against the reference's waveform (T 15002..16256 was never run)
+            raise ValueError(f"input too long for the HIP path: {L} samples - at most {MAX_FRAMES} STFT frames ({(MAX_FRAMES - 1) * 128 / 16000:.0f} s at 16 kHz) per "
+                             "utterance; split longer recordings into segments")
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats

@@ -117,6 +117,27 @@ _MFMA_ENTRY_POINTS = frozenset((
     "rtfs_convt_bwd_input"))
 
 
+class _Stage:
+    """one backward stage of HipTrainer: begin_stage on entry of the outermost `with`, end_stage (flush + side-stream join) on its exit"""
+
+    def __init__(self, trainer, dev):
+        self.t, self.dev = trainer, dev
+
+    def __enter__(self):
+        depth = self.t.__dict__.setdefault("_stage_depth", {})
+        depth[self.dev] = depth.get(self.dev, 0) + 1
+        if depth[self.dev] == 1:
+            self.t.begin_stage(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        depth = self.t._stage_depth
+        depth[self.dev] -= 1
+        if depth[self.dev] == 0:
+            self.t.end_stage(self.dev)
+        return False
+
+
 class HipTrainer:
     def __init__(self, model):
         self.model = model
@@ -581,7 +602,21 @@ class HipTrainer:
         dx0, da0, da_emb, datt, drsz = self.backward_b(c, dout)
         return datt, drsz, self.backward_a(c, dx0, da0, da_emb)
 
+    # The public adjoints open and close their own reducer stage (deferred finishes on both scratch lanes, side-stream join): on return every
+    # parameter gradient they produced is complete in stream order, whoever the caller is (autograd nodes, tools, tests).  Stages nest: an outer
+    # stage (`with trainer.stage(dev)`) keeps the section open across both calls.
+    def stage(self, dev):
+        return _Stage(self, dev)
+
     def backward_b(self, c, dout):
+        with self.stage(dout.device):
+            return self._backward_b(c, dout)
+
+    def backward_a(self, c, dx0, da0, da_emb):
+        with self.stage(dx0.device):
+            return self._backward_a(c, dx0, da0, da_emb)
+
+    def _backward_b(self, c, dout):
         """adjoint of forward_b: dout [B,1,L] -> (d x0, d a0 or None, d a_emb, datt, drsz); parameter gradients go to c.gr."""
         m = self.model
         pw = c.pw
@@ -628,7 +663,7 @@ class HipTrainer:
         self._call("rtfs_caf_bwd_apply", dx, c.x0, cf["ks"], cf["kb"], c.att, c.rsz, coef, dx0, 0, B, T, Tv)
         return dx0, (da0 if R > 1 else None), da_emb, datt.view(B, Tv, C), drsz.view(B, Tv, C)
 
-    def backward_a(self, c, dx0, da0, da_emb):
+    def _backward_a(self, c, dx0, da0, da_emb):
         """adjoint of forward_a.  dx0: gradient of block 0's output (overwritten); da0: running d(a0) sum of the later blocks (updated in
         place) or None; da_emb: gradient that reached a_emb through the S3 mask (updated in place).  -> grads dict in kernel layout."""
         pw = c.pw
@@ -805,11 +840,8 @@ class AVNetHipFunction(torch.autograd.Function):
     def backward(ctx, dout):
         trainer = ctx.trainer
         with torch.no_grad():
-            trainer.begin_stage(dout.device)
-            try:
+            with trainer.stage(dout.device):
                 datt, drsz, gr = trainer.backward(ctx.saved, dout)
-            finally:
-                trainer.end_stage(dout.device)
             ref = grads_to_reference(trainer.model, ctx.saved.pw, gr)
         grads = tuple(ref.get(n) for n in ctx.names)
         ctx.saved = None
@@ -842,11 +874,7 @@ class AVNetHipStageA(torch.autograd.Function):
                 dx0 = torch.zeros(n, device=c.x0.device)
             if da_emb is None:
                 da_emb = torch.zeros(n, device=c.x0.device)
-            trainer.begin_stage(c.x0.device)
-            try:
-                gr = trainer.backward_a(c, dx0, da0, da_emb)
-            finally:
-                trainer.end_stage(c.x0.device)  # (flushes + joins: every parameter gradient is complete, stream-ordered, before it is re-laid out)
+            gr = trainer.backward_a(c, dx0, da0, da_emb)  # (own reducer stage: flushed + joined, every parameter gradient complete in stream order)
             ref = grads_to_reference(trainer.model, c.pw, gr)
         grads = tuple(ref.get(name) for name in ctx.names)
         c.__dict__.clear()
@@ -867,11 +895,7 @@ class AVNetHipStageB(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         with torch.no_grad():
-            ctx.trainer.begin_stage(dout.device)  # (the reducers' finish launches of this stage in a few batched launches, csrc/spread.hip)
-            try:
-                dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)
-            finally:
-                ctx.trainer.end_stage(dout.device)
+            dx0, da0, da_emb, datt, drsz = ctx.trainer.backward_b(ctx.step.c, dout)  # (own reducer stage, csrc/spread.hip)
         n = dx0.numel() // C
         return None, None, dx0.view(n, C), (None if da0 is None else da0.view(n, C)), da_emb.view(n, C), datt, drsz
 

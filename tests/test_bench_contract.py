@@ -19,6 +19,27 @@ def _last_json(out):
     return json.loads(lines[0])
 
 
+DP_KEYS = {"metric", "value", "unit", "dtype", "ms_per_step", "ms_per_step_median", "steps", "warmup", "workload", "roofline", "n_gpus", "global_batch",
+           "parallelism", "dist", "grad_allreduce", "baseline_config"}
+AR_KEYS = {"collective", "backend", "buckets_per_step", "bytes_per_step", "ms_per_step_mean_in_step", "ms_per_bucket_median_in_step", "ms_standalone"}
+
+
+def _check_allreduce(ar):
+    assert AR_KEYS <= set(ar), ar
+    # every trainable parameter of RTFS-Net (740,210 floats = 2.96 MB) crosses the collective once per step, in ONE bucket (train.py:135-146: DDP defaults)
+    assert ar["buckets_per_step"] == 1 and ar["bytes_per_step"] == 4 * 740210, ar
+    assert ar["ms_per_step_mean_in_step"] > 0 and ar["ms_standalone"] > 0
+
+
+def _check_dp_rider(dp):
+    assert dp is not None and dp.get("value"), dp
+    assert DP_KEYS <= set(dp), sorted(DP_KEYS - set(dp))
+    assert dp["n_gpus"] == 2 and dp["global_batch"] == 4 and "training step" in dp["workload"] and dp["ms_per_step"] > 0
+    assert dp["parallelism"].startswith("dp2: DistributedDataParallel") and "SyncBatchNorm" in dp["parallelism"]
+    assert dp["dist"]["world_size"] == 2 and dp["dist"]["ranks_reporting"] == 2
+    _check_allreduce(dp["grad_allreduce"])
+
+
 def test_single_process_line():
     r = subprocess.run([sys.executable, "bench.py", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1", "--cpu-budget-s", "2"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
@@ -64,6 +85,8 @@ def test_plain_launch_with_gpus_2_spawns_its_own_ranks():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     res = _last_json(r.stdout)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
+    assert "no data-path collective" in res["config"]["parallelism"]  # the headline stays the inference line
+    _check_dp_rider(res["training_step_dp"])
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])
@@ -77,3 +100,11 @@ def test_two_rank_launch(mode):
     res = _last_json(r.stdout)
     assert KEYS <= set(res) and "cpu_baseline" not in res  # the CPU baseline is a rank-0, N = 1 measurement
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
+    assert res["dist"]["world_size"] == 2 and res["dist"]["ranks_reporting"] == 2
+    if mode == "infer":
+        # BASELINE config 4 rides along on the N > 1 inference line: the DDP + SyncBatchNorm training step on the same ranks
+        _check_dp_rider(res["training_step_dp"])
+        assert "no scaling curve" in res["scaling_note"]
+    else:
+        assert res["config"]["parallelism"].startswith("dp2: DistributedDataParallel")
+        _check_allreduce(res["grad_allreduce"])

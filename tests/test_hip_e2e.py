@@ -148,6 +148,8 @@ def test_120s_utterance_at_the_length_guard():
     mix, emb = _against_long_fixture(model, "long_120s_R1", 1920000, 3000)
     with torch.no_grad(), pytest.raises(ValueError):
         model(torch.cat([mix, mix[:, :177152]], 1).cuda(), emb.cuda())
+    with torch.no_grad(), pytest.raises(ValueError):  # the guard is the tested envelope itself: one frame more (T = 15002) is refused as well
+        model(torch.cat([mix, mix[:, :128]], 1).cuda(), emb.cuda())
 
 
 def test_batch_offsets_past_2_31_elements():
