@@ -81,6 +81,19 @@ def dp_gemm_flops(B, T2):
     return {4: 2.0 * B * T2 * (F2 - 7) * 512 * 256, 3: 2.0 * B * F2 * (T2 - 7) * 512 * 256}
 
 
+def dp_gemm_executed_flops(B, T2):
+    """MFMA flops the fast-FIR layer-0 kernel issues per launch (csrc/dualpath.hip unfold_ffa_kernel: 64-row tiles advancing by 63 virtual rows, Lv = (L + 2) // 2
+    pair rows per sequence, 3 x 256 k-products x 256 columns per row), or None where the launcher keeps the direct kernels (below 512 tiles / Lv < 21)"""
+    out = {}
+    for dim, (S, L) in {4: (B * T2, F2 - 7), 3: (B * F2, T2 - 7)}.items():
+        Lv = (L + 2) // 2
+        tiles = (S * Lv + 62) // 63
+        if tiles < 512 or Lv < 21:
+            return None
+        out[dim] = 2.0 * tiles * 64 * 768 * 256
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -346,12 +359,24 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                     "mfma_tflops_algorithmic": (fl[4] + fl[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12}
         elif kern == "rtfs_dp_unfold_gemm_fwd":
             tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)  # launches alternate dim 4 (freq), dim 3 (time)
-            roof = {"kernel": "rtfs::unfold_ws_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA, weight-stationary form at "
-                              "large batch; rtfs::unfold_gemm128f_kernel / toeplitz_gemm_kernel below 1024 row tiles)",
+            ex = dp_gemm_executed_flops(a.batch, T2)
+            fast_fir = ex is not None
+            roof = {"kernel": ("rtfs::unfold_ffa_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA, weight-stationary 2-parallel fast-FIR form at "
+                               "large batch: three half-rate 4-tap correlations per output pair; rtfs::unfold_gemm128f_kernel / toeplitz_gemm_kernel below 512 tiles)") if fast_fir else
+                              ("rtfs::unfold_gemm128f_kernel / toeplitz_gemm_kernel (rtfs_dp_unfold_gemm_fwd: LN4D + unfold + SRU layer-0 GEMM, fp32 MFMA, LDS-staged forms below "
+                               "512 tiles)"),
                     "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
-                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_ws" if a.batch * T2 * 57 >= 1024 * 64 else "unfold_gemm128", a),
+                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_ffa" if fast_fir else "unfold_gemm128", a),
                     "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
+            if fast_fir:
+                # ALGORITHMIC flops (2 x 512 x 256 per window) price the direct form; the kernel EXECUTES 0.775x of them (0.75 from the fast-FIR identity,
+                # x 64/63 tile overlap x one extra pair row per even-length sequence) - `frac` is the algorithmic rate over the MFMA peak and may pass the pipe's
+                # own busy fraction; `frac_executed` is what the matrix pipe actually sustains
+                ex_tot = (ex[4] + ex[3]) * (len(prof) // 2)
+                roof.update(executed_flop_per_launch=(ex[4] + ex[3]) / 2, achieved_executed=ex_tot / (tot_ms * 1e-3) / 1e12,
+                            frac_executed=ex_tot / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                            flops="achieved / frac: algorithmic flops (direct 8-tap form, SURVEY 8d) per second; *_executed: the MFMAs the fast-FIR kernel issues")
         elif kern == "rtfs_wgrad":
             # dW0[256][512] += dU0[S*L][256]^T . X_unfold[S*L][512]: the same 2*S*L*512*256 flop as the forward layer-0 GEMM
             tot_fl = (fl[4] + fl[3]) * (len(prof) // 2)

@@ -69,9 +69,10 @@ int rtfs_pool_fwd(const float* d0, const double* d0_stats, const float* d0_g, co
 
 /* ---- a6-a7: DualPathRNN.forward, layers/rnn_layers.py:136-162; sru.SRU (external, oracle/sru_ref.py) --------- */
 /* dim 4: sequences along F (one per (b,t2)); dim 3: along T (one per (b,f2)).  S sequences of L = npos-7 windows. */
-/* variant: 0 = the library's choice (fp32 at >= 1024 flattened 64-row tiles: weight-stationary kernel, W0 resident in registers; else LDS-staged
+/* variant: 0 = the library's choice (fp32 at >= 512 tiles of 63 pair rows: weight-stationary 2-parallel fast-FIR kernel - three half-rate 4-tap correlations, 0.775x the MFMAs, sums re-ordered; else LDS-staged
  * kernels on tiles cut from the flattened (sequence, window) row index), 1 = tiles padded per sequence, 2 = LDS-staged flattened tiles (A/B: 1 and 2
- * give the same bits; the weight-stationary kernel's LayerNorm uses v_rsq_f32 and agrees to 1 ulp of rstd).  The bf16 entry takes the same range (0 .. 2). */
+ * give the same bits), 3 = the direct weight-stationary kernel (W0 resident in registers, >= 1024 flattened 64-row tiles; its LayerNorm uses v_rsq_f32 and
+ * agrees with 1 / 2 to 1 ulp of rstd).  The bf16 entry takes the same range (its 0 and 3 are the direct weight-stationary kernel). */
 int rtfs_dp_unfold_gemm_fwd(const float* G, const float* gamma, const float* beta, const float* Wt /*[256][512]*/, float* U0, int B, int T2, int dim,
                             int variant, void* stream);
 int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, int S, int L, int km,

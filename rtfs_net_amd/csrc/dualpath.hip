@@ -824,6 +824,253 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #endif
 }
 
+// Layer-0 kernel, fifth generation (round 5), large batches, fp32: WEIGHT-STATIONARY 2-PARALLEL FAST FIR - 0.75x the MFMAs of the direct form.
+// U[l] = sum_{k<8} W_k x[l + k] is a stride-1 correlation over the sequence with 64 x 256 matrix taps.  With the input phases e[m] = x[2m],
+// o[m] = x[2m + 1] and the even / odd taps We[j] = W_{2j}, Wo[j] = W_{2j+1} (j < 4):
+//      A[m] = sum_j We[j] e[m + j],   B[m] = sum_j Wo[j] o[m + j],   Z[m] = sum_j (We[j] + Wo[j]) (o[m + j] + e[m + j + 1])
+//      U[2m] = A[m] + B[m],           U[2m + 1] = Z[m] - A[m + 1] - B[m]
+// - three 4-tap correlations over half-rate sequences per PAIR of outputs (768 k-products) instead of two 8-tap ones (1024).  Rows of the GEMM
+// are "virtual rows" (sequence s, pair index v), Lv = (L + 2) / 2 per sequence (the last one of an even-length sequence only supplies A[m + 1]),
+// flattened over the sequences and cut into 64-row tiles that advance by 63 rows: row 63 of a tile supplies A[m + 1] to row 62 and is computed
+// again as row 0 of the next tile (1.6 % of the MFMAs; with the per-sequence extra row 0.775x the direct form's count in total).
+// Three weight sets = 768 KB: FOUR workgroups (one XCD) share a range of tiles, 64 output columns each; wave w owns 16 columns x all 768 k =
+// 192 registers per lane, bound to the accumulation half of the register file, and runs v_mfma_f32_16x16x4_f32 (A = weights: lane (n, kg) holds
+// column n, k = 4 kg + step; B = 16 virtual rows; a lane ends up with 4 consecutive output channels of one row).  LDS holds, double-buffered, three
+// planes of LayerNorm-ed rows per tile - E (even positions), O (odd), Z' = O + next E - as "unit" rows u = (positions 2(v + u) - 1, 2(v + u)) with 4
+// halo units per sequence segment (a tile spans up to four sequences); segment g is skewed by 12 g sixteen-byte slots so that the +4-row jump
+// at a sequence boundary keeps a wave's ds_read_b128 conflict-free.  As in unfold_ws_kernel the K loop (768 MFMAs per wave and tile) never stops:
+// staging of the next tile, write-back of the previous one (two accumulator sets; A[m + 1] arrives through two DPP row shifts) and the global
+// loads of the tile after next ride between its MFMAs, one piece per 16-MFMA group.  Not bit-compatible with the direct form: (We + Wo) is rounded
+// once and Z - A - B cancels a little (fp32 error of U against float64 2.2e-7 against 1.6e-7, tools/ffa_prototype.py).
+// Reference: rnn_layers.py:97,146-150 (LayerNormalization4D + nn.Unfold((8, 1)) + the SRU's layer-0 projection).
+constexpr int kFfaUnits = 80;                                        // 64 rows + 4 segments x 4 halo units
+constexpr int kFfaSkew = 48;                                         // floats (12 slots) per segment index: 4 rows x 17 slots + 12 = 80 = 0 (mod 16)
+constexpr int kFfaPlane = kFfaUnits * kSlabLd + 3 * kFfaSkew + 16;   // floats per plane
+struct FfaTile {  // geometry of one 64-row tile (wave-uniform): first virtual row r0 = (s0, v0); n0 rows in segment 0
+    int s0, v0, n0;
+};
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ffa_kernel(SeqMap map, const float* __restrict__ src,
+                                                                                                       const float* __restrict__ gamma,
+                                                                                                       const float* __restrict__ beta,
+                                                                                                       const float* __restrict__ Wt, float* __restrict__ dst,
+                                                                                                       int S, int Lv, unsigned magicLv, int total_tiles) {
+    constexpr int NIT = kFfaUnits * 16 / 256;  // 5 staging iterations of (unit row, channel quad) items
+    __shared__ __attribute__((aligned(16))) float slab[2][3][kFfaPlane];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
+    // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) hold the four 64-column quarters of one tile range
+    const int xcd = blockIdx.x & 7, qd = (blockIdx.x >> 3) & 3, slot = xcd + 8 * (blockIdx.x >> 5), nslots = gridDim.x >> 2;
+    const int col0 = 64 * qd + 16 * w;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
+    const int L = map.L;
+
+    // weights: lane (n = j, kg) holds W[col0 + n][64 tap + 16 cg + 4 kg .. + 3] for q = 4 j' + cg; We: tap 2 j', Wo: tap 2 j' + 1
+    float4 wA[16], wB[16], wS[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float* wp = Wt + (size_t)(col0 + j) * 512 + 128 * (q >> 2) + 16 * (q & 3) + 4 * kg;
+        wA[q] = ld4(wp), wB[q] = ld4(wp + 64);
+    }
+    const int t0 = (int)((long long)total_tiles * slot / nslots), t1 = (int)((long long)total_tiles * (slot + 1) / nslots);
+    if (t0 >= t1) return;
+    auto tile_of = [&](int t) {
+        FfaTile g;
+        const unsigned r0 = 63u * (unsigned)t;
+        g.s0 = (int)__umulhi(r0, magicLv);  // = r0 / Lv (exact: checked by the launcher)
+        g.v0 = (int)r0 - g.s0 * Lv;
+        g.n0 = min(Lv - g.v0, 64);
+        return g;
+    };
+    // ---- staging: unit row ur = (t >> 4) + 16 it of the tile being fetched: positions (2 (v + u) - 1, 2 (v + u)) of its segment's sequence ----
+    float4 rawo[NIT], rawe[NIT];
+    int sinfo[NIT];  // float offset of this thread's quad inside a plane of the fetched tile's slab: unit row * ld + segment skew + channel
+    FfaTile tf;
+    auto fetch1 = [&](int it) {
+        const int ur = (int)(threadIdx.x >> 4) + 16 * it;
+        const int b1 = tf.n0 + 4, b2 = b1 + Lv + 4, b3 = b2 + Lv + 4;
+        const int g = (ur >= b1) + (ur >= b2) + (ur >= b3);
+        const int u = ur - (g == 0 ? 0 : (g == 1 ? b1 : (g == 2 ? b2 : b3)));
+        const int sq = min(tf.s0 + g, S - 1);
+        const int pe = 2 * ((g == 0 ? tf.v0 : 0) + u);
+        const unsigned lane16 = (threadIdx.x & 15) * 16u;
+        rawe[it] = ld4_off(src, map.off32(sq, min(pe, map.npos - 1)) + lane16);
+        rawo[it] = ld4_off(src, map.off32(sq, min(max(pe - 1, 0), map.npos - 1)) + lane16);
+        sinfo[it] = ur * kSlabLd + g * kFfaSkew + c4;
+    };
+    // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37); 16 lanes = one position (v_rsq_f32 as in unfold_ws_kernel)
+    float4 de, dod;
+    float se, so;
+    auto ln_a = [&](const float4 v, float4& d, float& sq) {
+        const float mean = row16_sum(v.x + v.y + v.z + v.w) * (1.f / 64.f);
+        d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    };
+    auto ln_b = [&](float& sq) { sq = __builtin_amdgcn_rsqf(row16_sum(sq) * (1.f / 64.f) + kEps); };
+    auto ln_c = [&](float* sl, int off) {
+        const float4 ye = fma4(de * se, g4, b4), yo = fma4(dod * so, g4, b4);
+        st4(sl + off, ye);
+        st4(sl + kFfaPlane + off, yo);
+        st4(sl + 2 * kFfaPlane + off, ye + yo);
+    };
+    // ---- output rows: virtual row r = 63 tile + 16 rt + j -> U0 rows (s L + 2 v) and (+ 1), through a buffer descriptor (invalid rows dropped) ----
+    const long long R = (long long)S * L;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
+    constexpr unsigned kDrop = 0xC0000000u;
+    auto out_offset = [&](int tile, int rt, bool odd) {  // tile < 0 (no previous tile yet): dropped
+        const unsigned r = 63u * (unsigned)max(tile, 0) + 16u * rt + j;
+        const int sq = (int)__umulhi(r, magicLv), v = (int)r - sq * Lv;
+        const bool ok = tile >= 0 && (16 * rt + j < 63) && sq < S && 2 * v + (odd ? 1 : 0) < L;
+        const unsigned off = ((unsigned)(sq * L + 2 * v + (odd ? 1 : 0)) * 256u + (unsigned)(col0 + 4 * kg)) * 4u;
+        return ok ? off : kDrop;
+    };
+    // slab offset (floats, E plane) of this lane's row in the four 16-row tiles: unit row (16 rt + j) + 4 g, skewed by its segment g
+    auto rows_in = [&](const FfaTile& t, const float* sl, const float* (&bp)[4]) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const int ri = 16 * rt + j, g = (ri >= t.n0) + (ri >= t.n0 + Lv) + (ri >= t.n0 + 2 * Lv);
+            bp[rt] = sl + (ri + 4 * g) * kSlabLd + g * kFfaSkew + 4 * kg;
+        }
+    };
+    // B fragment of step q = 4 j' + cg of sub-GEMM sub (0 A: plane E, unit row + j'; 1 B: plane O, + j' + 1; 2 Z: plane Z', + j' + 1)
+    auto frag_off = [](int sub, int q) { return sub * kFfaPlane + ((q >> 2) + (sub != 0)) * kSlabLd + (q & 3) * 16; };
+
+    // ---- prologue: first tile staged directly, second tile's rows requested ----
+    tf = tile_of(t0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wS[q] = wA[q] + wB[q];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        ln_a(rawe[it], de, se);
+        ln_a(rawo[it], dod, so);
+        ln_b(se);
+        ln_b(so);
+        ln_c(&slab[0][0][0], sinfo[it]);
+    }
+    tf = tile_of(min(t0 + 1, t1 - 1));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        asm volatile("" : "+a"(wA[q].x), "+a"(wA[q].y), "+a"(wA[q].z), "+a"(wA[q].w));
+        asm volatile("" : "+a"(wB[q].x), "+a"(wB[q].y), "+a"(wB[q].z), "+a"(wB[q].w));
+        asm volatile("" : "+a"(wS[q].x), "+a"(wS[q].y), "+a"(wS[q].z), "+a"(wS[q].w));
+    }
+    __syncthreads();
+
+    floatx4 accA[3][4], accB[3][4];  // [sub-GEMM][16-row tile], two sets: even / odd tiles
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) accA[sb][rt] = floatx4{0.f, 0.f, 0.f, 0.f}, accB[sb][rt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const float* bp[4];
+    float4 eb[2][4];  // [buffer][16-row tile]
+    rows_in(tile_of(t0), &slab[0][0][0], bp);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) eb[0][rt] = ld4(bp[rt] + frag_off(0, 0));
+
+    auto shl1 = [](float lo, float nxt) {  // lane j <- lane j + 1 of `lo` inside its 16-lane row; lane 15 <- lane 0 of `nxt`
+        int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, lo), 0x101, 0xf, 0xf, false);   // row_shl:1
+        t = __builtin_amdgcn_update_dpp(t, __builtin_bit_cast(int, nxt), 0x11f, 0xf, 0xf, false);      // row_shr:15 (only lane 15 has a source)
+        return __builtin_bit_cast(float, t);
+    };
+    floatx4 aps;  // A[m + 1] of the row tile being written back
+    auto out1 = [&](const floatx4 (&h)[3][4], int k, int ptile) {
+        const int rt = k >> 1;
+        if ((k & 1) == 0) {
+            const floatx4 nx = rt < 3 ? h[0][rt + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) aps[c] = shl1(h[0][rt][c], nx[c]);
+            const floatx4 ue = h[0][rt] + h[1][rt];
+            __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(ue[0]), __float_as_uint(ue[1]), __float_as_uint(ue[2]), __float_as_uint(ue[3])}, ru,
+                                                   (int)out_offset(ptile, rt, false), 0, 0);
+        } else {
+            const floatx4 uo = h[2][rt] - (aps + h[1][rt]);
+            __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(uo[0]), __float_as_uint(uo[1]), __float_as_uint(uo[2]), __float_as_uint(uo[3])}, ru,
+                                                   (int)out_offset(ptile, rt, true), 0, 0);
+        }
+    };
+    auto body = [&](auto par, int tile, floatx4 (&acc)[3][4], const floatx4 (&accp)[3][4]) {
+        constexpr int PAR = decltype(par)::value;
+        float* sn = &slab[PAR ^ 1][0][0];
+        const float* bpn[4];
+        FfaTile tn;
+#pragma unroll
+        for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[sb][rt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // the tile's other work as 48 slots, one per 16-MFMA group:
+        //   1 barrier (previous tile left: its slab may be overwritten) | 2-21 next tile's raw rows -> LayerNorm -> that slab | 22-29 previous tile's
+        //   accumulators -> U0 (8 stores) | 30-40 loads of the tile after next | 42 barrier (next slab complete) | 44 next tile's row geometry
+        auto piece = [&](int sl_) {
+            if (sl_ == 0) tn = tile_of(min(tile + 1, t1 - 1));
+            if (sl_ == 1) __syncthreads();
+            if (sl_ >= 2 && sl_ < 22) {
+                const int it = (sl_ - 2) >> 2, ph = (sl_ - 2) & 3;
+                if (ph == 0) ln_a(rawe[it], de, se);
+                if (ph == 1) ln_a(rawo[it], dod, so);
+                if (ph == 2) ln_b(se), ln_b(so);
+                if (ph == 3) ln_c(sn, sinfo[it]);
+            }
+            if (sl_ >= 22 && sl_ < 30) out1(accp, sl_ - 22, tile > t0 ? tile - 1 : -1);
+            if (sl_ == 30) tf = tile_of(min(tile + 2, t1 - 1));
+            if (sl_ >= 31 && sl_ < 31 + NIT) fetch1(sl_ - 31);
+            if (sl_ == 42) __syncthreads();
+            if (sl_ == 44) rows_in(tn, sn, bpn);
+        };
+        auto sub_loop = [&](auto sub_, const float4 (&wq)[16]) {
+            constexpr int SUB = decltype(sub_)::value;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int lin = 16 * SUB + q;
+                if (lin + 1 < 48) {
+                    const int o = frag_off((lin + 1) >> 4, (lin + 1) & 15);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) eb[(lin + 1) & 1][rt] = ld4(bp[rt] + o);
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) eb[0][rt] = ld4(bpn[rt] + frag_off(0, 0));  // step 0 of the next tile
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4(&e)[4] = eb[lin & 1];
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].x, e[rt].x, acc[SUB][rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                piece(lin);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].y, e[rt].y, acc[SUB][rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].z, e[rt].z, acc[SUB][rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].w, e[rt].w, acc[SUB][rt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        sub_loop(std::integral_constant<int, 0>{}, wA);
+        sub_loop(std::integral_constant<int, 1>{}, wB);
+        sub_loop(std::integral_constant<int, 2>{}, wS);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) bp[rt] = bpn[rt];
+    };
+    bool last_is_b = false;
+#pragma unroll 1
+    for (int tile = t0; tile < t1; tile += 2) {
+        body(std::integral_constant<int, 0>{}, tile, accA, accB);
+        last_is_b = tile + 1 < t1;
+        if (!last_is_b) break;
+        body(std::integral_constant<int, 1>{}, tile + 1, accB, accA);
+    }
+    if (last_is_b) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out1(accB, k, t1 - 1);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out1(accA, k, t1 - 1);
+    }
+}
+
 // ConvTranspose kernel, weight-stationary (round 3, large batches, fp32): the structure of unfold_ws_kernel on the zero-padded SRU output.
 // W' (64 x 512 = 128 KB) lives in registers - wave (wn, wm): output channels 32 wn .. + 31 x all 512 k = 256 registers per lane, the MFMA A
 // operand; the two waves of a column half hold the same fragments and own one 64-row tile each (wm) - and a workgroup walks pairs of 64-row
@@ -1468,7 +1715,7 @@ static SeqMap make_map(int dim, int B, int T2) {
 
 template <int NT>
 static int unfold_gemm_impl(const float* G, const float* gamma, const float* beta, const float* Wt, float* U0, int B, int T2, int dim, int variant, void* stream) {
-    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || variant < 0 || variant > 2) return RTFS_EINVAL;
+    if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8 || variant < 0 || variant > 3) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.L + 63) / 64, total = S * tps;
@@ -1481,8 +1728,20 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
-    // fp32 / bf16 / split-bf16, large batch: the weight-stationary kernel (variant 2 keeps the LDS-staged flattened-tile kernel selectable for A/B)
-    if ((NT == 0 || NT == 1 || NT == 3) && variant == 0 && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
+    // fp32, large batch: the weight-stationary fast-FIR kernel (three half-rate 4-tap correlations, 0.775x the MFMAs; variant 3 = the direct form)
+    if constexpr (NT == 0) {
+        const int Lv = (m.L + 2) / 2;
+        const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
+        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (Rv + 64) * Lv < (1LL << 32) && (long long)S * m.L * 1024 < (1LL << 31) &&
+            ftiles >= 8 * 64) {  // (>= 8 tiles per tile range to pay for the 192 KB weight read of each of its four workgroups)
+            const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
+            hipLaunchKernelGGL(unfold_ffa_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
+            RTFS_LAUNCH_CHECK();
+            return RTFS_OK;
+        }
+    }
+    // fp32 (variant 3) / bf16 / split-bf16, large batch: the direct weight-stationary kernel (variant 2 keeps the LDS-staged flattened-tile kernel selectable for A/B)
+    if ((NT == 0 || NT == 1 || NT == 3) && (variant == 0 || variant == 3) && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
         (long long)S * m.L * 1024 < (1LL << 31) && ((long long)S * m.L + 63) / 64 >= 8 * 128) {  // (>= 8 tiles per workgroup to pay for its 256 KB weight read)
         const int ftiles = (int)(((long long)S * m.L + 63) / 64);
         hipLaunchKernelGGL(unfold_ws_kernel<(NT == 6 ? 0 : NT)>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, ftiles);

@@ -213,13 +213,15 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
 
 
-@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70)])
+@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70), (23, 50)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     """rtfs_dp_unfold_gemm_fwd in isolation (LN4D over channels + 8-tap unfold + layer-0 GEMM, rnn_layers.py:146-150) against float64 on
     the CPU, at sizes that take the large-batch kernel (tiles cut from the flattened row index: 2- and 3-sequence tiles, ragged end)
-    a few that take the small-batch one, and two that take the weight-stationary kernel (>= 1024 flattened 64-row tiles; its LayerNorm uses
-    v_rsq_f32, so it agrees with the LDS-staged kernels to 1 ulp of rstd, not bit for bit)."""
+    a few that take the small-batch one, and three that take the weight-stationary kernels: variant 0 = the fast-FIR form (>= 512 tiles of 63 virtual
+    rows; pair rows per sequence Lv = 29 / 60 / 32 / 22: two-, three- and four-sequence tiles, odd and even window counts; three half-rate 4-tap
+    correlations, so its sums are ordered differently: agreement to round-off, not bit for bit), variant 3 = the direct form (>= 1024 flattened 64-row
+    tiles; its LayerNorm uses v_rsq_f32, so it agrees with the LDS-staged kernels to 1 ulp of rstd, not bit for bit)."""
     from rtfs_net_amd import lib
 
     g = torch.Generator().manual_seed(100 * B + T2 + dim)
@@ -241,7 +243,14 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U2, B, T2, dim, 2)  # LDS-staged flattened tiles: the same bits
     assert torch.equal(U2, U1)
     weight_stationary = (seqs.shape[0] * L + 63) // 64 >= 1024 and L >= 32
-    assert rel(U, U2) < 1e-6 and (weight_stationary or torch.equal(U, U2))
+    fast_fir = (seqs.shape[0] * ((L + 2) // 2) + 62) // 63 >= 512 and (L + 2) // 2 >= 21
+    assert rel(U, U2) < 1e-6 and (weight_stationary or fast_fir or torch.equal(U, U2))
+    U3 = torch.full_like(U, float("nan"))
+    lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U3, B, T2, dim, 3)  # direct weight-stationary form where eligible
+    assert rel(U3.view(want.shape), want) < 2e-6 and rel(U3, U2) < 1e-6 and (weight_stationary or torch.equal(U3, U2))
+    if fast_fir:  # every output ROW on its own (a mis-addressed halo unit or pair row shows in single rows long before it shows in the norm)
+        rows = (U.view(want.shape).double().cpu() - want).norm(dim=-1) / want.norm(dim=-1)
+        assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
     with pytest.raises(RuntimeError):
         lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 7)
 
