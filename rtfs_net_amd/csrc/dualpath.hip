@@ -849,6 +849,7 @@ constexpr int kFfaPlane = kFfaUnits * kSlabLd + 3 * kFfaSkew + 16;   // floats p
 struct FfaTile {  // geometry of one 64-row tile (wave-uniform): first virtual row r0 = (s0, v0); n0 rows in segment 0
     int s0, v0, n0;
 };
+template <int DIM>  // 4: sequences along F (one per (b, t2)), 3: along T (one per (b, f2)) - the row address is shifts and one 24-bit multiply
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ffa_kernel(SeqMap map, const float* __restrict__ src,
                                                                                                        const float* __restrict__ gamma,
                                                                                                        const float* __restrict__ beta,
@@ -885,29 +886,45 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     float4 rawo[NIT], rawe[NIT];
     int sinfo[NIT];  // float offset of this thread's quad inside a plane of the fetched tile's slab: unit row * ld + segment skew + channel
     FfaTile tf;
+    const unsigned lane16 = (threadIdx.x & 15) * 16u;
+    const unsigned t2rows = (unsigned)(map.stride_hi >> 12);  // dim 3: T2 (stride_hi = T2 x F2 x 64 floats)
     auto fetch1 = [&](int it) {
         const int ur = (int)(threadIdx.x >> 4) + 16 * it;
         const int b1 = tf.n0 + 4, b2 = b1 + Lv + 4, b3 = b2 + Lv + 4;
         const int g = (ur >= b1) + (ur >= b2) + (ur >= b3);
         const int u = ur - (g == 0 ? 0 : (g == 1 ? b1 : (g == 2 ? b2 : b3)));
-        const int sq = min(tf.s0 + g, S - 1);
+        const unsigned sq = (unsigned)min(tf.s0 + g, S - 1);
         const int pe = 2 * ((g == 0 ? tf.v0 : 0) + u);
-        const unsigned lane16 = (threadIdx.x & 15) * 16u;
-        rawe[it] = ld4_off(src, map.off32(sq, min(pe, map.npos - 1)) + lane16);
-        rawo[it] = ld4_off(src, map.off32(sq, min(max(pe - 1, 0), map.npos - 1)) + lane16);
+        const unsigned p1 = (unsigned)min(pe, map.npos - 1), p0 = (unsigned)min(max(pe - 1, 0), map.npos - 1);
+        // byte offset of (sequence, position): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
+        const unsigned sb = DIM == 4 ? (sq << 14) + lane16 : (__umul24(sq >> 6, t2rows) << 14) + ((sq & 63u) << 8) + lane16;
+        constexpr int PS = DIM == 4 ? 8 : 14;
+        rawe[it] = ld4_off(src, sb + (p1 << PS));
+        rawo[it] = ld4_off(src, sb + (p0 << PS));
         sinfo[it] = ur * kSlabLd + g * kFfaSkew + c4;
     };
     // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37); 16 lanes = one position (v_rsq_f32 as in unfold_ws_kernel)
     float4 de, dod;
     float se, so;
-    auto ln_a = [&](const float4 v, float4& d, float& sq) {
-        const float mean = row16_sum(v.x + v.y + v.z + v.w) * (1.f / 64.f);
-        d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
-        sq = d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+    auto ln_mean = [&](int it) {  // the two rows of a unit side by side: their DPP chains interleave
+        const float4 ve = rawe[it], vo = rawo[it];
+        const float me = row16_sum(ve.x + ve.y + ve.z + ve.w) * (1.f / 64.f), mo = row16_sum(vo.x + vo.y + vo.z + vo.w) * (1.f / 64.f);
+        de = f4(ve.x - me, ve.y - me, ve.z - me, ve.w - me);
+        dod = f4(vo.x - mo, vo.y - mo, vo.z - mo, vo.w - mo);
     };
-    auto ln_b = [&](float& sq) { sq = __builtin_amdgcn_rsqf(row16_sum(sq) * (1.f / 64.f) + kEps); };
+    auto ln_rstd = [&]() {
+        se = __builtin_amdgcn_rsqf(row16_sum(de.x * de.x + de.y * de.y + de.z * de.z + de.w * de.w) * (1.f / 64.f) + kEps);
+        so = __builtin_amdgcn_rsqf(row16_sum(dod.x * dod.x + dod.y * dod.y + dod.z * dod.z + dod.w * dod.w) * (1.f / 64.f) + kEps);
+    };
+#ifndef FFA_ABL
+#define FFA_ABL 0  // ablation builds (tools/ffa_ablate.sh), wrong results, timing only: 1 no staging, 2 no write-back, 4 no fetch, 8 no barriers,
+#endif             // 16 staging without its LDS stores, 32 staging without the LayerNorm arithmetic, 64 write-back without stores, 128 without its arithmetic
     auto ln_c = [&](float* sl, int off) {
         const float4 ye = fma4(de * se, g4, b4), yo = fma4(dod * so, g4, b4);
+        if (FFA_ABL & 16) {
+            asm volatile("" ::"v"(ye.x + yo.x), "v"(ye.y + yo.y), "v"(ye.z + yo.z), "v"(ye.w + yo.w));
+            return;
+        }
         st4(sl + off, ye);
         st4(sl + kFfaPlane + off, yo);
         st4(sl + 2 * kFfaPlane + off, ye + yo);
@@ -916,12 +933,21 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const long long R = (long long)S * L;
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
     constexpr unsigned kDrop = 0xC0000000u;
-    auto out_offset = [&](int tile, int rt, bool odd) {  // tile < 0 (no previous tile yet): dropped
-        const unsigned r = 63u * (unsigned)max(tile, 0) + 16u * rt + j;
-        const int sq = (int)__umulhi(r, magicLv), v = (int)r - sq * Lv;
-        const bool ok = tile >= 0 && (16 * rt + j < 63) && sq < S && 2 * v + (odd ? 1 : 0) < L;
-        const unsigned off = ((unsigned)(sq * L + 2 * v + (odd ? 1 : 0)) * 256u + (unsigned)(col0 + 4 * kg)) * 4u;
-        return ok ? off : kDrop;
+    // byte offsets of the even / odd U0 rows of virtual rows 63 tile + 16 rt + j, rt = 0..3: one division for rt = 0, then + 16 rows with at most one
+    // sequence wrap each (Lv >= 21)
+    unsigned oe[4], oo[4];
+    auto out_offsets = [&](int tile) {  // tile < 0 (no previous tile yet): everything dropped
+        const unsigned r = 63u * (unsigned)max(tile, 0) + j;
+        int sq = (int)__umulhi(r, magicLv), v = (int)r - (int)__umul24((unsigned)sq, (unsigned)Lv);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const bool ok = tile >= 0 && (16 * rt + j < 63) && sq < S && 2 * v < L;
+            const unsigned off = ((__umul24((unsigned)sq, (unsigned)L) + 2u * (unsigned)v) << 10) + (unsigned)(col0 + 4 * kg) * 4u;
+            oe[rt] = ok ? off : kDrop;
+            oo[rt] = (ok && 2 * v + 1 < L) ? off + 1024u : kDrop;
+            v += 16;
+            if (v >= Lv) v -= Lv, ++sq;
+        }
     };
     // slab offset (floats, E plane) of this lane's row in the four 16-row tiles: unit row (16 rt + j) + 4 g, skewed by its segment g
     auto rows_in = [&](const FfaTile& t, const float* sl, const float* (&bp)[4]) {
@@ -942,10 +968,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int q = 0; q < 16; ++q) wS[q] = wA[q] + wB[q];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        ln_a(rawe[it], de, se);
-        ln_a(rawo[it], dod, so);
-        ln_b(se);
-        ln_b(so);
+        ln_mean(it);
+        ln_rstd();
         ln_c(&slab[0][0][0], sinfo[it]);
     }
     tf = tile_of(min(t0 + 1, t1 - 1));
@@ -976,19 +1000,26 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         return __builtin_bit_cast(float, t);
     };
     floatx4 aps;  // A[m + 1] of the row tile being written back
-    auto out1 = [&](const floatx4 (&h)[3][4], int k, int ptile) {
+    auto store_u = [&](floatx4 u, unsigned off) {
+        if (FFA_ABL & 64) {
+            asm volatile("" ::"v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(off));
+            return;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(u[0]), __float_as_uint(u[1]), __float_as_uint(u[2]), __float_as_uint(u[3])}, ru, (int)off, 0, 0);
+    };
+    auto out1 = [&](const floatx4 (&h)[3][4], int k) {
         const int rt = k >> 1;
+        if (FFA_ABL & 128) {
+            store_u(h[k & 1][rt], (k & 1) ? oo[rt] : oe[rt]);
+            return;
+        }
         if ((k & 1) == 0) {
             const floatx4 nx = rt < 3 ? h[0][rt + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) aps[c] = shl1(h[0][rt][c], nx[c]);
-            const floatx4 ue = h[0][rt] + h[1][rt];
-            __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(ue[0]), __float_as_uint(ue[1]), __float_as_uint(ue[2]), __float_as_uint(ue[3])}, ru,
-                                                   (int)out_offset(ptile, rt, false), 0, 0);
+            store_u(h[0][rt] + h[1][rt], oe[rt]);
         } else {
-            const floatx4 uo = h[2][rt] - (aps + h[1][rt]);
-            __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(uo[0]), __float_as_uint(uo[1]), __float_as_uint(uo[2]), __float_as_uint(uo[3])}, ru,
-                                                   (int)out_offset(ptile, rt, true), 0, 0);
+            store_u(h[2][rt] - (aps + h[1][rt]), oo[rt]);
         }
     };
     auto body = [&](auto par, int tile, floatx4 (&acc)[3][4], const floatx4 (&accp)[3][4]) {
@@ -996,27 +1027,27 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         float* sn = &slab[PAR ^ 1][0][0];
         const float* bpn[4];
         FfaTile tn;
-#pragma unroll
-        for (int sb = 0; sb < 3; ++sb)
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) acc[sb][rt] = floatx4{0.f, 0.f, 0.f, 0.f};
         // the tile's other work as 48 slots, one per 16-MFMA group:
         //   1 barrier (previous tile left: its slab may be overwritten) | 2-21 next tile's raw rows -> LayerNorm -> that slab | 22-29 previous tile's
         //   accumulators -> U0 (8 stores) | 30-40 loads of the tile after next | 42 barrier (next slab complete) | 44 next tile's row geometry
         auto piece = [&](int sl_) {
             if (sl_ == 0) tn = tile_of(min(tile + 1, t1 - 1));
-            if (sl_ == 1) __syncthreads();
-            if (sl_ >= 2 && sl_ < 22) {
+            if (sl_ == 1 && !(FFA_ABL & 8)) __syncthreads();
+            if (sl_ >= 2 && sl_ < 22 && !(FFA_ABL & 1)) {
                 const int it = (sl_ - 2) >> 2, ph = (sl_ - 2) & 3;
-                if (ph == 0) ln_a(rawe[it], de, se);
-                if (ph == 1) ln_a(rawo[it], dod, so);
-                if (ph == 2) ln_b(se), ln_b(so);
-                if (ph == 3) ln_c(sn, sinfo[it]);
+                if (FFA_ABL & 32) {
+                    if (ph == 2) st4(sn + sinfo[it], rawe[it]), st4(sn + kFfaPlane + sinfo[it], rawo[it]), st4(sn + 2 * kFfaPlane + sinfo[it], rawo[it]);
+                } else {
+                    if (ph == 0) ln_mean(it);
+                    if (ph == 1) ln_rstd();
+                    if (ph == 2) ln_c(sn, sinfo[it]);
+                }
             }
-            if (sl_ >= 22 && sl_ < 30) out1(accp, sl_ - 22, tile > t0 ? tile - 1 : -1);
+            if (sl_ == 18 && !(FFA_ABL & 2)) out_offsets(tile > t0 ? tile - 1 : -1);
+            if (sl_ >= 22 && sl_ < 30 && !(FFA_ABL & 2)) out1(accp, sl_ - 22);
             if (sl_ == 30) tf = tile_of(min(tile + 2, t1 - 1));
-            if (sl_ >= 31 && sl_ < 31 + NIT) fetch1(sl_ - 31);
-            if (sl_ == 42) __syncthreads();
+            if (sl_ >= 31 && sl_ < 31 + NIT && !(FFA_ABL & 4)) fetch1(sl_ - 31);
+            if (sl_ == 42 && !(FFA_ABL & 8)) __syncthreads();
             if (sl_ == 44) rows_in(tn, sn, bpn);
         };
         auto sub_loop = [&](auto sub_, const float4 (&wq)[16]) {
@@ -1035,10 +1066,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 __builtin_amdgcn_sched_barrier(0);
                 const float4(&e)[4] = eb[lin & 1];
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].x, e[rt].x, acc[SUB][rt], 0, 0, 0);
+                for (int rt = 0; rt < 4; ++rt)  // (the chain starts from an inline-constant zero C operand: no register clearing)
+                    acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].x, e[rt].x, q == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[SUB][rt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 piece(lin);
+#if !(FFA_ABL & 256)
                 __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) acc[SUB][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].y, e[rt].y, acc[SUB][rt], 0, 0, 0);
 #pragma unroll
@@ -1062,12 +1096,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         if (!last_is_b) break;
         body(std::integral_constant<int, 1>{}, tile + 1, accB, accA);
     }
+    out_offsets(t1 - 1);
     if (last_is_b) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) out1(accB, k, t1 - 1);
+        for (int k = 0; k < 8; ++k) out1(accB, k);
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) out1(accA, k, t1 - 1);
+        for (int k = 0; k < 8; ++k) out1(accA, k);
     }
 }
 
@@ -1735,7 +1770,10 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
         if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (Rv + 64) * Lv < (1LL << 32) && (long long)S * m.L * 1024 < (1LL << 31) &&
             ftiles >= 8 * 64) {  // (>= 8 tiles per tile range to pay for the 192 KB weight read of each of its four workgroups)
             const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
-            hipLaunchKernelGGL(unfold_ffa_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
+            if (dim == 4)
+                hipLaunchKernelGGL(unfold_ffa_kernel<4>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
+            else
+                hipLaunchKernelGGL(unfold_ffa_kernel<3>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
             RTFS_LAUNCH_CHECK();
             return RTFS_OK;
         }
