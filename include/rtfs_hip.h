@@ -86,6 +86,10 @@ int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_nul
 /* generic row GEMM Y (= or +=) X . Wt^T (+bias): also every input-gradient GEMM of the backward pass (Wt = transposed weight) */
 int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream);
 int rtfs_dp_convt_fwd(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, void* stream);
+/* the same with the kernel form named: 0 = the library's choice (fp32 at >= 1024 tiles of 63 pair rows: the fast-FIR kernel of rtfs_dp_unfold_gemm_fwd in its
+ * ConvTranspose mode - three half-rate 4-tap correlations over the zero-padded rows, sums re-ordered), 1 = the direct 8-tap kernels (A/B and tests) */
+int rtfs_dp_convt_fwd_form(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, int variant,
+                           void* stream);
 
 /* ---- a8: MultiHeadSelfAttention2D.forward, layers/attention.py:149-189 ------------------------------------- */
 int rtfs_attn_qkv_fwd(const float* G, const float* Wt /*[96][64]*/, const float* bias, const float* slope, const float* gq, const float* bq,

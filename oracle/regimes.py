@@ -17,6 +17,7 @@ GRAD_CASES = [
     (False, 1, 12100, 1, 19),   # T2 = 47: 40-step time sequences (all-taps Toeplitz weight gradient, 2-tile fold kernel on both dual paths); odd L
     (False, 1, 4096, 3, 6),     # R = 3: a MIDDLE block (rtfs_proj_gateway_bwd with da0 += ds)
     (False, 1, 32000, 2, 50),   # one full-length utterance (T2 = 125, 57- / 118-step sequences): the shapes of BASELINE config 3
+    (False, 1, 32000, 6, 50),   # RTFS-Net-6 itself (BASELINE configs[2] / [3]: six passes through the shared block, five middle / last blocks), full length
 ]
 SMOOTH_CASES = [GRAD_CASES[1], GRAD_CASES[2], GRAD_CASES[5], GRAD_CASES[6]]  # the split-bf16 step's cases, on smooth_regime weights
 GRAD_WEIGHT_SEED = 7  # seed of the output weighting of the scalar loss (out * wgt).sum()

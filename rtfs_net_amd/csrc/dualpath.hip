@@ -849,7 +849,11 @@ constexpr int kFfaPlane = kFfaUnits * kSlabLd + 3 * kFfaSkew + 16;   // floats p
 struct FfaTile {  // geometry of one 64-row tile (wave-uniform): first virtual row r0 = (s0, v0); n0 rows in segment 0
     int s0, v0, n0;
 };
-template <int DIM>  // 4: sequences along F (one per (b, t2)), 3: along T (one per (b, f2)) - the row address is shifts and one 24-bit multiply
+// MODE 1 (round 5): the same machinery for the ConvTranspose1d that closes a DualPathRNN (rnn_layers.py:129,153-156): y[n] = sum_k' W'[k'] x[n + k'] over the
+// zero-padded SRU output x[p] = h3[p - 7] is the same 8-tap correlation with 64-channel taps and 64 output channels - one workgroup holds all three weight
+// sets (192 KB), there is no LayerNorm in the staging (rows outside the sequence come back as zeros from the buffer range check), and the write-back adds bias
+// and the residual row of G (fetched earlier in the same tile) and stores in place.
+template <int DIM, int MODE = 0>  // DIM 4: sequences along F (one per (b, t2)), 3: along T (one per (b, f2)) - the row address is shifts and one 24-bit multiply
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ffa_kernel(SeqMap map, const float* __restrict__ src,
                                                                                                        const float* __restrict__ gamma,
                                                                                                        const float* __restrict__ beta,
@@ -859,11 +863,14 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ __attribute__((aligned(16))) float slab[2][3][kFfaPlane];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
     // workgroups b, b + 8, b + 16, b + 24 (one XCD under round-robin dispatch) hold the four 64-column quarters of one tile range
-    const int xcd = blockIdx.x & 7, qd = (blockIdx.x >> 3) & 3, slot = xcd + 8 * (blockIdx.x >> 5), nslots = gridDim.x >> 2;
+    const int xcd = blockIdx.x & 7, qd = MODE == 0 ? (blockIdx.x >> 3) & 3 : 0, slot = MODE == 0 ? xcd + 8 * (blockIdx.x >> 5) : blockIdx.x,
+              nslots = MODE == 0 ? gridDim.x >> 2 : gridDim.x;
     const int col0 = 64 * qd + 16 * w;
     const int c4 = (threadIdx.x & 15) * 4;
-    const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
-    const int L = map.L;
+    const float4 g4 = MODE == 0 ? ld4(gamma + c4) : f4(0, 0, 0, 0), b4 = MODE == 0 ? ld4(beta + c4) : f4(0, 0, 0, 0);
+    const floatx4 bias4 = MODE == 1 ? *reinterpret_cast<const floatx4*>(gamma + col0 + 4 * kg) : floatx4{0.f, 0.f, 0.f, 0.f};  // (MODE 1: `gamma` is the bias)
+    const int L = MODE == 0 ? map.L : map.npos;  // outputs per sequence
+    const int Lh = map.L;                        // MODE 1: rows of h3 per sequence
 
     // weights: lane (n = j, kg) holds W[col0 + n][64 tap + 16 cg + 4 kg .. + 3] for q = 4 j' + cg; We: tap 2 j', Wo: tap 2 j' + 1
     float4 wA[16], wB[16], wS[16];
@@ -888,19 +895,32 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     FfaTile tf;
     const unsigned lane16 = (threadIdx.x & 15) * 16u;
     const unsigned t2rows = (unsigned)(map.stride_hi >> 12);  // dim 3: T2 (stride_hi = T2 x F2 x 64 floats)
+    constexpr unsigned kNowhere = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, MODE == 1 ? (int)((long long)S * Lh * 256) : 0, 0x00020000);
+    auto bld = [](const __amdgpu_buffer_rsrc_t& r, unsigned off) {
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return f4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    };
     auto fetch1 = [&](int it) {
         const int ur = (int)(threadIdx.x >> 4) + 16 * it;
         const int b1 = tf.n0 + 4, b2 = b1 + Lv + 4, b3 = b2 + Lv + 4;
         const int g = (ur >= b1) + (ur >= b2) + (ur >= b3);
         const int u = ur - (g == 0 ? 0 : (g == 1 ? b1 : (g == 2 ? b2 : b3)));
-        const unsigned sq = (unsigned)min(tf.s0 + g, S - 1);
         const int pe = 2 * ((g == 0 ? tf.v0 : 0) + u);
-        const unsigned p1 = (unsigned)min(pe, map.npos - 1), p0 = (unsigned)min(max(pe - 1, 0), map.npos - 1);
-        // byte offset of (sequence, position): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
-        const unsigned sb = DIM == 4 ? (sq << 14) + lane16 : (__umul24(sq >> 6, t2rows) << 14) + ((sq & 63u) << 8) + lane16;
-        constexpr int PS = DIM == 4 ? 8 : 14;
-        rawe[it] = ld4_off(src, sb + (p1 << PS));
-        rawo[it] = ld4_off(src, sb + (p0 << PS));
+        if constexpr (MODE == 0) {
+            const unsigned sq = (unsigned)min(tf.s0 + g, S - 1);
+            const unsigned p1 = (unsigned)min(pe, map.npos - 1), p0 = (unsigned)min(max(pe - 1, 0), map.npos - 1);
+            // byte offset of (sequence, position): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
+            const unsigned sb = DIM == 4 ? (sq << 14) + lane16 : (__umul24(sq >> 6, t2rows) << 14) + ((sq & 63u) << 8) + lane16;
+            constexpr int PS = DIM == 4 ? 8 : 14;
+            rawe[it] = ld4_off(src, sb + (p1 << PS));
+            rawo[it] = ld4_off(src, sb + (p0 << PS));
+        } else {  // x[p] = h3[s][p - 7] (contiguous [S][Lh][64]); zero outside the sequence / past the last one
+            const int sq = tf.s0 + g, h1 = pe - 7, h0 = pe - 8;
+            const unsigned sb = (__umul24((unsigned)min(sq, S - 1), (unsigned)Lh) << 8) + lane16;
+            rawe[it] = bld(rh, (sq < S && (unsigned)h1 < (unsigned)Lh) ? sb + ((unsigned)h1 << 8) : kNowhere);
+            rawo[it] = bld(rh, (sq < S && (unsigned)h0 < (unsigned)Lh) ? sb + ((unsigned)h0 << 8) : kNowhere);
+        }
         sinfo[it] = ur * kSlabLd + g * kFfaSkew + c4;
     };
     // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37); 16 lanes = one position (v_rsq_f32 as in unfold_ws_kernel)
@@ -919,6 +939,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #ifndef FFA_ABL
 #define FFA_ABL 0  // ablation builds (tools/ffa_ablate.sh), wrong results, timing only: 1 no staging, 2 no write-back, 4 no fetch, 8 no barriers,
 #endif             // 16 staging without its LDS stores, 32 staging without the LayerNorm arithmetic, 64 write-back without stores, 128 without its arithmetic
+    auto raw_c = [&](float* sl, int off, int it) {  // MODE 1: the rows as they are
+        st4(sl + off, rawe[it]);
+        st4(sl + kFfaPlane + off, rawo[it]);
+        st4(sl + 2 * kFfaPlane + off, rawe[it] + rawo[it]);
+    };
     auto ln_c = [&](float* sl, int off) {
         const float4 ye = fma4(de * se, g4, b4), yo = fma4(dod * so, g4, b4);
         if (FFA_ABL & 16) {
@@ -931,7 +956,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
     // ---- output rows: virtual row r = 63 tile + 16 rt + j -> U0 rows (s L + 2 v) and (+ 1), through a buffer descriptor (invalid rows dropped) ----
     const long long R = (long long)S * L;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, MODE == 0 ? (int)(R * 1024) : (int)(((long long)(S >> map.seq_shift) * map.stride_hi) * 4), 0x00020000);
     constexpr unsigned kDrop = 0xC0000000u;
     // byte offsets of the even / odd U0 rows of virtual rows 63 tile + 16 rt + j, rt = 0..3: one division for rt = 0, then + 16 rows with at most one
     // sequence wrap each (Lv >= 21)
@@ -942,9 +967,17 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const bool ok = tile >= 0 && (16 * rt + j < 63) && sq < S && 2 * v < L;
-            const unsigned off = ((__umul24((unsigned)sq, (unsigned)L) + 2u * (unsigned)v) << 10) + (unsigned)(col0 + 4 * kg) * 4u;
+            unsigned off, step;
+            if constexpr (MODE == 0) {
+                off = ((__umul24((unsigned)sq, (unsigned)L) + 2u * (unsigned)v) << 10) + (unsigned)(col0 + 4 * kg) * 4u, step = 1024u;
+            } else {  // G row (sequence sq, position 2 v): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
+                constexpr int PS = DIM == 4 ? 8 : 14;
+                const unsigned usq = (unsigned)sq;
+                off = (DIM == 4 ? (usq << 14) : (__umul24(usq >> 6, t2rows) << 14) + ((usq & 63u) << 8)) + ((2u * (unsigned)v) << PS) + (unsigned)(col0 + 4 * kg) * 4u;
+                step = 1u << PS;
+            }
             oe[rt] = ok ? off : kDrop;
-            oo[rt] = (ok && 2 * v + 1 < L) ? off + 1024u : kDrop;
+            oo[rt] = (ok && 2 * v + 1 < L) ? off + step : kDrop;
             v += 16;
             if (v >= Lv) v -= Lv, ++sq;
         }
@@ -968,9 +1001,13 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     for (int q = 0; q < 16; ++q) wS[q] = wA[q] + wB[q];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        ln_mean(it);
-        ln_rstd();
-        ln_c(&slab[0][0][0], sinfo[it]);
+        if constexpr (MODE == 0) {
+            ln_mean(it);
+            ln_rstd();
+            ln_c(&slab[0][0][0], sinfo[it]);
+        } else {
+            raw_c(&slab[0][0][0], sinfo[it], it);
+        }
     }
     tf = tile_of(min(t0 + 1, t1 - 1));
 #pragma unroll
@@ -1007,6 +1044,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(u[0]), __float_as_uint(u[1]), __float_as_uint(u[2]), __float_as_uint(u[3])}, ru, (int)off, 0, 0);
     };
+    floatx4 res[MODE == 1 ? 8 : 1];  // MODE 1: residual rows of G for the previous tile's 8 stores
+    auto res1 = [&](int k) {
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(ru, (int)((k & 1) ? oo[k >> 1] : oe[k >> 1]), 0, 0);
+        res[MODE == 1 ? k : 0] = floatx4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+    };
     auto out1 = [&](const floatx4 (&h)[3][4], int k) {
         const int rt = k >> 1;
         if (FFA_ABL & 128) {
@@ -1017,9 +1059,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const floatx4 nx = rt < 3 ? h[0][rt + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) aps[c] = shl1(h[0][rt][c], nx[c]);
-            store_u(h[0][rt] + h[1][rt], oe[rt]);
+            if constexpr (MODE == 0) store_u(h[0][rt] + h[1][rt], oe[rt]);
+            else store_u((h[0][rt] + h[1][rt]) + (bias4 + res[MODE == 1 ? k : 0]), oe[rt]);
         } else {
-            store_u(h[2][rt] - (aps + h[1][rt]), oo[rt]);
+            if constexpr (MODE == 0) store_u(h[2][rt] - (aps + h[1][rt]), oo[rt]);
+            else store_u((h[2][rt] - (aps + h[1][rt])) + (bias4 + res[MODE == 1 ? k : 0]), oo[rt]);
         }
     };
     auto body = [&](auto par, int tile, floatx4 (&acc)[3][4], const floatx4 (&accp)[3][4]) {
@@ -1035,7 +1079,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             if (sl_ == 1 && !(FFA_ABL & 8)) __syncthreads();
             if (sl_ >= 2 && sl_ < 22 && !(FFA_ABL & 1)) {
                 const int it = (sl_ - 2) >> 2, ph = (sl_ - 2) & 3;
-                if (FFA_ABL & 32) {
+                if (MODE == 1) {
+                    if (ph == 2) raw_c(sn, sinfo[it], it);
+                    if (it >= 1 && ph < 2) res1(2 * (it - 1) + ph);  // slots 6, 7, 10, 11, 14, 15, 18, 19: the residual rows of the previous tile's outputs
+                } else if (FFA_ABL & 32) {
                     if (ph == 2) st4(sn + sinfo[it], rawe[it]), st4(sn + kFfaPlane + sinfo[it], rawo[it]), st4(sn + 2 * kFfaPlane + sinfo[it], rawo[it]);
                 } else {
                     if (ph == 0) ln_mean(it);
@@ -1043,7 +1090,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     if (ph == 2) ln_c(sn, sinfo[it]);
                 }
             }
-            if (sl_ == 18 && !(FFA_ABL & 2)) out_offsets(tile > t0 ? tile - 1 : -1);
+            if (sl_ == (MODE == 0 ? 18 : 2) && !(FFA_ABL & 2)) out_offsets(tile > t0 ? tile - 1 : -1);
             if (sl_ >= 22 && sl_ < 30 && !(FFA_ABL & 2)) out1(accp, sl_ - 22);
             if (sl_ == 30) tf = tile_of(min(tile + 2, t1 - 1));
             if (sl_ >= 31 && sl_ < 31 + NIT && !(FFA_ABL & 4)) fetch1(sl_ - 31);
@@ -1097,6 +1144,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         body(std::integral_constant<int, 1>{}, tile + 1, accB, accA);
     }
     out_offsets(t1 - 1);
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) res1(k);
+    }
     if (last_is_b) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) out1(accB, k);
@@ -1803,12 +1854,27 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
 }
 
 template <int NT>
-static int convt_impl(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
+static int convt_impl(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream, int variant = 0) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.npos + 63) / 64, total = S * tps;
-    // fp32, large batch (>= 3 tile pairs per CU - measured: 84.6 vs 90.5 us at 3.9 pairs, 49.4 vs 47.6 us at 2; 32-bit offsets): the weight-stationary kernel
+    // fp32, large batch: the weight-stationary fast-FIR kernel in its ConvTranspose mode (unfold_ffa_kernel<DIM, 1>: 0.775x the MFMAs of the direct form)
+    if constexpr (NT == 0) {
+        const int Lv = (m.npos + 2) / 2;
+        const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
+        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 64) * Lv < (1LL << 32) &&
+            ftiles >= 4 * 256) {
+            const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
+            if (dim == 4)
+                hipLaunchKernelGGL((unfold_ffa_kernel<4, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, nullptr, Wt, G, S, Lv, magicLv, (int)ftiles);
+            else
+                hipLaunchKernelGGL((unfold_ffa_kernel<3, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, nullptr, Wt, G, S, Lv, magicLv, (int)ftiles);
+            RTFS_LAUNCH_CHECK();
+            return RTFS_OK;
+        }
+    }
+    // fp32 (variant 1), bf16 modes; large batch (>= 3 tile pairs per CU - measured: 84.6 vs 90.5 us at 3.9 pairs, 49.4 vs 47.6 us at 2; 32-bit offsets): the direct weight-stationary kernel
     if ((NT == 0 || NT == 1 || NT == 3) && total >= 2 * 3 * 256 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31)) {
         hipLaunchKernelGGL(convt_ws_kernel<(NT == 6 ? 0 : NT)>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, S, tps, total);
         RTFS_LAUNCH_CHECK();
@@ -1839,6 +1905,11 @@ int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float
 // H3: [S][L][64] -> G[pos] += convT(H3)[pos] + bias  (in place on G).  Wt: [64][512], k index = k'*64 + j, k' = 7-k.
 int rtfs_dp_convt_fwd(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream) {
     return convt_impl<0>(H3, Wt, bias, G, B, T2, dim, stream);
+}
+// variant: 0 = the library's choice (the fast-FIR kernel at large batch), 1 = the direct 8-tap forms (weight-stationary / LDS-staged: the same bits as each other)
+int rtfs_dp_convt_fwd_form(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, int variant, void* stream) {
+    if (variant < 0 || variant > 1) return RTFS_EINVAL;
+    return convt_impl<0>(H3, Wt, bias, G, B, T2, dim, stream, variant);
 }
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rtfs_lip_roi_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
+    "rtfs_dp_convt_fwd_form": [P, P, P, P, I, I, I, I, P],
     "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],
     "rtfs_attn_core_fwd": [P, P, P, P, P, I, I, P],
     "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, P, I, I, P],

@@ -550,6 +550,17 @@ def test_convt_entry_isolated(B, T2, dim, terms, tol):
     y = win @ W.double().t() + bias.double()
     y = y.view(B, T2, 64, 64) if dim == 4 else y.view(B, 64, T2, 64).permute(0, 2, 1, 3)
     assert rel(G.cpu(), y + G0.double()) < tol
+    if terms == 0:
+        # the two larger sizes take the fast-FIR kernel (pair rows per sequence 33 / 63 / 126: odd and even position counts, two- and three-sequence
+        # tiles); form 1 = the direct 8-tap kernels.  Every output ROW on its own as well (a mis-addressed halo unit shows in single rows first)
+        G1 = G0.clone().cuda()
+        lib.call("rtfs_dp_convt_fwd_form", H3.cuda(), W.cuda(), bias.cuda(), G1, B, T2, dim, 1)
+        assert rel(G1.cpu(), y + G0.double()) < tol and rel(G, G1) < 1e-6
+        want = (y + G0.double()).reshape(-1, 64)
+        rows = (G.double().cpu().reshape(-1, 64) - want).norm(dim=-1) / want.norm(dim=-1)
+        assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
+        with pytest.raises(RuntimeError):
+            lib.call("rtfs_dp_convt_fwd_form", H3.cuda(), W.cuda(), bias.cuda(), G1, B, T2, dim, 2)
 
 
 def test_weight_stationary_kernels_in_the_model():

@@ -40,8 +40,9 @@ def main(dtype="f32", B=32, T2=125, variant=0):
         print(f"{dtype} variant {variant} dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {float(U.double().sum()):.10e} {float(U.double().abs().sum()):.10e}")
 
 
-def convt(B=32, T2=125):
-    """rtfs_dp_convt_fwd (ConvTranspose1d + bias + residual, in place on G) at the bench shape: time + checksum of one application"""
+def convt(B=32, T2=125, form=0):
+    """rtfs_dp_convt_fwd_form (ConvTranspose1d + bias + residual, in place on G; form 0 = library's choice, 1 = direct 8-tap kernels) at the bench shape:
+    time + checksum of one application"""
     g = torch.Generator().manual_seed(1)
     for dim in (4, 3):
         S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
@@ -51,7 +52,7 @@ def convt(B=32, T2=125):
         bias = (torch.randn(64, generator=g) * 0.1).cuda()
         G0 = torch.randn(B, T2, 64, 64, generator=g).cuda()
         G = G0.clone()
-        lib.call("rtfs_dp_convt_fwd", H3, W, bias, G, B, T2, dim)
+        lib.call("rtfs_dp_convt_fwd_form", H3, W, bias, G, B, T2, dim, form)
         chk = (float(G.double().sum()), float(G.double().abs().sum()))
         # float64 check of a few sequences: y[n] = sum_k' hpad[n + k'] . W'[k'] + bias + G0[n], k index = k' * 64 + channel
         Gs = (G if dim == 4 else G.permute(0, 2, 1, 3)).reshape(S, npos, 64)
@@ -66,16 +67,16 @@ def convt(B=32, T2=125):
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
         for a, b in ev:
             a.record()
-            lib.call("rtfs_dp_convt_fwd", H3, W, bias, G, B, T2, dim)
+            lib.call("rtfs_dp_convt_fwd_form", H3, W, bias, G, B, T2, dim, form)
             b.record()
         torch.cuda.synchronize()
         t = sorted(a.elapsed_time(b) for a, b in ev)
         fl = 2.0 * S * npos * 512 * 64
-        print(f"convt dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {chk[0]:.10e} {chk[1]:.10e}   max rel err vs float64 (4 sequences) {err:.2e}")
+        print(f"convt form {form} dim {dim}: median {1e3 * t[len(t) // 2]:.1f} us  min {1e3 * t[0]:.1f} us  {fl / (t[len(t) // 2] * 1e-3) / 1e12:.1f} TFLOP/s   checksum {chk[0]:.10e} {chk[1]:.10e}   max rel err vs float64 (4 sequences) {err:.2e}")
 
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["convt"]:
-        convt(*[int(a) for a in sys.argv[2:4]])
+        convt(*[int(a) for a in sys.argv[2:5]])
         sys.exit(0)
     main(*(sys.argv[1:2] or ["f32"]), *[int(a) for a in sys.argv[2:5]])

@@ -37,3 +37,7 @@ for case in [GRAD_CASES[int(i)] for i in (args or range(len(GRAD_CASES)))]:
     print(f"== {case}: {len(rows)} tensors, median {rows[len(rows)//2][0]:.1e}")
     for e, n, k, rn in rows[:40]:
         print(f"   {e:.2e}  numel {k:7d}  |ref|/max {rn:.1e}  {n}")
+    print("   -- scalar parameters (numel <= 12):")
+    for e, n, k, rn in rows:
+        if k <= 12 and e > 2e-4:
+            print(f"   {e:.2e}  numel {k:3d}  |ref|/max {rn:.1e}  {n}")
