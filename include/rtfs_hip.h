@@ -232,6 +232,8 @@ int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int
 /* adjoints of rtfs_dp_unfold_gemm_fwd (input side) and rtfs_dp_convt_fwd */
 int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt /*[64][2048]*/, float* dxn, int B, int T2, int dim, void* stream);
 int rtfs_convt_bwd_input(const float* dG, const float* Wt /*[64][512]*/, float* dH3, int B, int T2, int dim, void* stream);
+/* the same with the kernel form named: 0 = the library's choice (fp32 at >= 1024 tiles of 63 pair rows: the fast-FIR kernel), 1 = the direct 8-tap kernel */
+int rtfs_convt_bwd_input_form(const float* dG, const float* Wt /*[64][512]*/, float* dH3, int B, int T2, int dim, int variant, void* stream);
 /* SRU recurrence: training forward (stores the cell state) and adjoint */
 int rtfs_sru_scan_train_fwd(const float* U, const float* X, const float* wc, const float* bias, float scale_x, float* H, float* C, int S, int L,
                             int km, void* stream);

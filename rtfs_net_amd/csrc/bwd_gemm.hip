@@ -869,10 +869,14 @@ static int fold_impl(const float* dU0, const float* Wt, float* dxn, int B, int T
 }
 
 template <int P>
-static int convt_bwd_impl(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
+static int convt_bwd_impl(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream, int variant = 0) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
     SeqMapB m = make_map(dim, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
+    if (P == 0 && variant == 0) {  // fp32, large batch: the weight-stationary fast-FIR kernel (dualpath.hip)
+        const int rc = convt_bwd_input_ffa(dG, Wt, dH3, B, T2, dim, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     hipLaunchKernelGGL((toeplitz_bwd_kernel<2, P>), dim3((m.L + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, m, dG, Wt, dH3);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
@@ -925,6 +929,11 @@ int rtfs_fold_gemm_bwd_bf16(const float* dU0, const void* Wpk, float* dxn, int B
 // dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
 int rtfs_convt_bwd_input(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, void* stream) {
     return convt_bwd_impl<0>(dG, Wt, dH3, B, T2, dim, stream);
+}
+// variant: 0 = the library's choice (the fast-FIR kernel at large batch), 1 = the direct 8-tap kernel
+int rtfs_convt_bwd_input_form(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, int variant, void* stream) {
+    if (variant < 0 || variant > 1) return RTFS_EINVAL;
+    return convt_bwd_impl<0>(dG, Wt, dH3, B, T2, dim, stream, variant);
 }
 int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;

@@ -130,6 +130,9 @@ float* spread_scratch();  // this device's zeroed scratch [kSpread][kSpreadCap],
 // rtfs_spread_defer - recorded and applied by ONE launch for all pending regions at the next flush; `consumed_now`: the caller reads dst right away
 int spread_finish(float* scr, const SpreadOut& o, hipStream_t st, bool consumed_now = false);
 
+// dualpath.hip: the fast-FIR weight-stationary kernel in its ConvTranspose-input-gradient mode (bwd_gemm.hip calls it); 1 = size not eligible
+int convt_bwd_input_ffa(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, hipStream_t stream);
+
 // 1 / (1 + 2^(-x log2 e)) on v_exp_f32 + v_rcp_f32 (1 ulp each).  __frcp_rn expands to the full IEEE division sequence
 // (div_scale / rcp / 4 fma / div_fmas / div_fixup: 10 VALU instructions per gate), which dominated the recurrence kernels.
 constexpr float kNegLog2e = -1.4426950408889634f;

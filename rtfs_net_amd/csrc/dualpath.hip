@@ -853,6 +853,8 @@ struct FfaTile {  // geometry of one 64-row tile (wave-uniform): first virtual r
 // zero-padded SRU output x[p] = h3[p - 7] is the same 8-tap correlation with 64-channel taps and 64 output channels - one workgroup holds all three weight
 // sets (192 KB), there is no LayerNorm in the staging (rows outside the sequence come back as zeros from the buffer range check), and the write-back adds bias
 // and the residual row of G (fetched earlier in the same tile) and stores in place.
+// MODE 2: the input gradient of that ConvTranspose1d (training step; adjoint of rtfs_dp_convt_fwd): dH3[l] = sum_k W[k] dG[l + k] - the unfold correlation on
+// the rows of dG without the LayerNorm, 64 output channels, plain stores into [S][L][64].
 template <int DIM, int MODE = 0>  // DIM 4: sequences along F (one per (b, t2)), 3: along T (one per (b, f2)) - the row address is shifts and one 24-bit multiply
 __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ffa_kernel(SeqMap map, const float* __restrict__ src,
                                                                                                        const float* __restrict__ gamma,
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int c4 = (threadIdx.x & 15) * 4;
     const float4 g4 = MODE == 0 ? ld4(gamma + c4) : f4(0, 0, 0, 0), b4 = MODE == 0 ? ld4(beta + c4) : f4(0, 0, 0, 0);
     const floatx4 bias4 = MODE == 1 ? *reinterpret_cast<const floatx4*>(gamma + col0 + 4 * kg) : floatx4{0.f, 0.f, 0.f, 0.f};  // (MODE 1: `gamma` is the bias)
-    const int L = MODE == 0 ? map.L : map.npos;  // outputs per sequence
+    const int L = MODE == 1 ? map.npos : map.L;  // outputs per sequence
     const int Lh = map.L;                        // MODE 1: rows of h3 per sequence
 
     // weights: lane (n = j, kg) holds W[col0 + n][64 tap + 16 cg + 4 kg .. + 3] for q = 4 j' + cg; We: tap 2 j', Wo: tap 2 j' + 1
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const int g = (ur >= b1) + (ur >= b2) + (ur >= b3);
         const int u = ur - (g == 0 ? 0 : (g == 1 ? b1 : (g == 2 ? b2 : b3)));
         const int pe = 2 * ((g == 0 ? tf.v0 : 0) + u);
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             const unsigned sq = (unsigned)min(tf.s0 + g, S - 1);
             const unsigned p1 = (unsigned)min(pe, map.npos - 1), p0 = (unsigned)min(max(pe - 1, 0), map.npos - 1);
             // byte offset of (sequence, position): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     };
     // ---- output rows: virtual row r = 63 tile + 16 rt + j -> U0 rows (s L + 2 v) and (+ 1), through a buffer descriptor (invalid rows dropped) ----
     const long long R = (long long)S * L;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, MODE == 0 ? (int)(R * 1024) : (int)(((long long)(S >> map.seq_shift) * map.stride_hi) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, MODE == 0 ? (int)(R * 1024) : (MODE == 2 ? (int)(R * 256) : (int)(((long long)(S >> map.seq_shift) * map.stride_hi) * 4)), 0x00020000);
     constexpr unsigned kDrop = 0xC0000000u;
     // byte offsets of the even / odd U0 rows of virtual rows 63 tile + 16 rt + j, rt = 0..3: one division for rt = 0, then + 16 rows with at most one
     // sequence wrap each (Lv >= 21)
@@ -970,6 +972,8 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             unsigned off, step;
             if constexpr (MODE == 0) {
                 off = ((__umul24((unsigned)sq, (unsigned)L) + 2u * (unsigned)v) << 10) + (unsigned)(col0 + 4 * kg) * 4u, step = 1024u;
+            } else if constexpr (MODE == 2) {
+                off = ((__umul24((unsigned)sq, (unsigned)L) + 2u * (unsigned)v) << 8) + (unsigned)(col0 + 4 * kg) * 4u, step = 256u;
             } else {  // G row (sequence sq, position 2 v): dim 4: [s][pos][64]; dim 3: [s >> 6][pos][s & 63][64]
                 constexpr int PS = DIM == 4 ? 8 : 14;
                 const unsigned usq = (unsigned)sq;
@@ -1059,10 +1063,10 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const floatx4 nx = rt < 3 ? h[0][rt + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 4; ++c) aps[c] = shl1(h[0][rt][c], nx[c]);
-            if constexpr (MODE == 0) store_u(h[0][rt] + h[1][rt], oe[rt]);
+            if constexpr (MODE != 1) store_u(h[0][rt] + h[1][rt], oe[rt]);
             else store_u((h[0][rt] + h[1][rt]) + (bias4 + res[MODE == 1 ? k : 0]), oe[rt]);
         } else {
-            if constexpr (MODE == 0) store_u(h[2][rt] - (aps + h[1][rt]), oo[rt]);
+            if constexpr (MODE != 1) store_u(h[2][rt] - (aps + h[1][rt]), oo[rt]);
             else store_u((h[2][rt] - (aps + h[1][rt])) + (bias4 + res[MODE == 1 ? k : 0]), oo[rt]);
         }
     };
@@ -1079,9 +1083,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             if (sl_ == 1 && !(FFA_ABL & 8)) __syncthreads();
             if (sl_ >= 2 && sl_ < 22 && !(FFA_ABL & 1)) {
                 const int it = (sl_ - 2) >> 2, ph = (sl_ - 2) & 3;
-                if (MODE == 1) {
+                if (MODE != 0) {
                     if (ph == 2) raw_c(sn, sinfo[it], it);
-                    if (it >= 1 && ph < 2) res1(2 * (it - 1) + ph);  // slots 6, 7, 10, 11, 14, 15, 18, 19: the residual rows of the previous tile's outputs
+                    if (MODE == 1 && it >= 1 && ph < 2) res1(2 * (it - 1) + ph);  // slots 6, 7, 10, 11, 14, 15, 18, 19: the residual rows of the previous tile's outputs
                 } else if (FFA_ABL & 32) {
                     if (ph == 2) st4(sn + sinfo[it], rawe[it]), st4(sn + kFfaPlane + sinfo[it], rawo[it]), st4(sn + 2 * kFfaPlane + sinfo[it], rawo[it]);
                 } else {
@@ -1090,7 +1094,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     if (ph == 2) ln_c(sn, sinfo[it]);
                 }
             }
-            if (sl_ == (MODE == 0 ? 18 : 2) && !(FFA_ABL & 2)) out_offsets(tile > t0 ? tile - 1 : -1);
+            if (sl_ == (MODE == 1 ? 2 : 18) && !(FFA_ABL & 2)) out_offsets(tile > t0 ? tile - 1 : -1);
             if (sl_ >= 22 && sl_ < 30 && !(FFA_ABL & 2)) out1(accp, sl_ - 22);
             if (sl_ == 30) tf = tile_of(min(tile + 2, t1 - 1));
             if (sl_ >= 31 && sl_ < 31 + NIT && !(FFA_ABL & 4)) fetch1(sl_ - 31);
@@ -1849,6 +1853,22 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
     if (NT != 0) return RTFS_EINVAL;  // (not reached: the bf16 paths are served by the two kernels above)
     hipLaunchKernelGGL(unfold_gemm128_kernel, dim3(npairs < resident ? npairs : resident), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0,
                        tps, total);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// rtfs_convt_bwd_input at large batch (fp32): unfold_ffa_kernel<DIM, 2>.  Returns 1 when the size is not eligible (the caller launches the direct kernel).
+int rtfs::convt_bwd_input_ffa(const float* dG, const float* Wt, float* dH3, int B, int T2, int dim, hipStream_t stream) {
+    SeqMap m = make_map(dim, B, T2);
+    const int S = dim == 4 ? B * T2 : B * kF2;
+    const int Lv = (m.L + 2) / 2;
+    const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
+    if (!(Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 64) * Lv < (1LL << 32) && ftiles >= 4 * 256)) return 1;
+    const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
+    if (dim == 4)
+        hipLaunchKernelGGL((unfold_ffa_kernel<4, 2>), dim3(256), dim3(256), 0, stream, m, dG, nullptr, nullptr, Wt, dH3, S, Lv, magicLv, (int)ftiles);
+    else
+        hipLaunchKernelGGL((unfold_ffa_kernel<3, 2>), dim3(256), dim3(256), 0, stream, m, dG, nullptr, nullptr, Wt, dH3, S, Lv, magicLv, (int)ftiles);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

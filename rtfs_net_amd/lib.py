@@ -79,6 +79,7 @@ SIGNATURES = {
     "rtfs_wgrad": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, P],
     "rtfs_fold_gemm_bwd": [P, P, P, I, I, I, P],
     "rtfs_convt_bwd_input": [P, P, P, I, I, I, P],
+    "rtfs_convt_bwd_input_form": [P, P, P, I, I, I, I, P],
     "rtfs_sru_scan_train_fwd": [P, P, P, P, F, P, P, I, I, I, P],
     "rtfs_sru_scan_bwd": [P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_ln4d_c_bwd": [P, P, P, P, P, P, LL, P],

@@ -563,6 +563,35 @@ def test_convt_entry_isolated(B, T2, dim, terms, tol):
             lib.call("rtfs_dp_convt_fwd_form", H3.cuda(), W.cuda(), bias.cuda(), G1, B, T2, dim, 2)
 
 
+@pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_convt_bwd_input_entry_isolated(B, T2, dim):
+    """rtfs_convt_bwd_input in isolation (input gradient of ConvTranspose1d(64 -> 64, k = 8): dH3[l][j] = sum_{k, c} dG[l + k][c] Wt[j][64 k + c]; autograd of
+    rnn_layers.py:153) against float64: two sizes that take the fast-FIR kernel (unfold_ffa_kernel<DIM, 2>, >= 1024 tiles of 63 pair rows) and one that takes the
+    direct kernel; form 1 names the direct kernel at every size."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(11 * B + T2 + dim)
+    S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
+    L = npos - 7
+    dG = torch.randn(B, T2, 64, 64, generator=g)
+    W = torch.randn(64, 512, generator=g) * 0.05
+    seqs = (dG if dim == 4 else dG.permute(0, 2, 1, 3)).reshape(S, npos, 64).double()
+    win = torch.stack([seqs[:, k:k + L] for k in range(8)], dim=2).reshape(S, L, 512)
+    want = win @ W.double().t()
+    out = torch.full((S * L * 64,), float("nan"), device="cuda")
+    lib.call("rtfs_convt_bwd_input", dG.cuda(), W.cuda(), out, B, T2, dim)
+    out1 = torch.full_like(out, float("nan"))
+    lib.call("rtfs_convt_bwd_input_form", dG.cuda(), W.cuda(), out1, B, T2, dim, 1)
+    assert rel(out.view(want.shape), want) < 2e-6 and rel(out1.view(want.shape), want) < 2e-6 and rel(out, out1) < 1e-6
+    rows = (out.view(want.shape).double().cpu() - want).norm(dim=-1) / want.norm(dim=-1)
+    assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
+    fast_fir = (S * ((L + 2) // 2) + 62) // 63 >= 1024
+    assert fast_fir or torch.equal(out, out1)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_convt_bwd_input_form", dG.cuda(), W.cuda(), out1, B, T2, dim, 2)
+
+
 def test_weight_stationary_kernels_in_the_model():
     """RTFS-Net-2 at the bench shape (batch 32, 2 s): the forward takes the weight-stationary kernels (256 -> 256 pixel GEMMs, layer-0 GEMM,
     ConvTranspose GEMM) and the one-workgroup residual kernels.  (1) with the layer-0 GEMM forced to the LDS-staged kernel (variant 2) the
