@@ -9,4 +9,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd /root/repo
 python tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) gpurun_out/${tag}_pmc_hbm_traffic.txt
+cp gpurun_out/${tag}_pmc_hbm_traffic.json gpurun_out/pmc_traffic.json  # (bench.py reads the roofline kernel's `traffic` from profiles/pmc_traffic.json)
 head -12 gpurun_out/${tag}_pmc_hbm_traffic.txt | cut -c1-60,100-150

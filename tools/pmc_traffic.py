@@ -32,6 +32,10 @@ def main(fetch_csv, write_csv, out=None):
              f"{'kernel':100s} {'launches':>8s} {'read_MB':>10s} {'write_MB':>10s} {'total_MB':>10s}"]
     for tot, k, c, rd, wr in rows[:40]:
         lines.append(f"{k[:100]:100s} {c:8d} {rd / 1e6:10.1f} {wr / 1e6:10.1f} {tot / 1e6:10.1f}")
+    passes = [c for _, k, c, _, _ in rows if "stft_kernel" in k and "istft" not in k]  # rtfs::stft_kernel runs once per forward / step
+    total = sum(tot * c for tot, _, c, _, _ in rows)
+    lines.append(f"# all {len(rows)} kernels, launches x bytes: {total / 1e9:.1f} GB over {passes[0] if passes else '?'} passes"
+                 + (f" = {total / 1e9 / passes[0]:.1f} GB per forward / step" if passes else ""))
     text = "\n".join(lines) + "\n"
     (open(out, "w") if out else sys.stdout).write(text)
     if out:
@@ -39,7 +43,7 @@ def main(fetch_csv, write_csv, out=None):
         import os
 
         js = {k: {"bytes_per_launch": tot, "read_bytes": rd, "write_bytes": wr, "launches": c} for tot, k, c, rd, wr in rows}
-        json.dump(js, open(os.path.join(os.path.dirname(out), "pmc_traffic.json"), "w"), indent=0)
+        json.dump(js, open(os.path.splitext(out)[0] + ".json", "w"), indent=0)  # every kernel; tools/pmc_hbm.sh copies the forward one to pmc_traffic.json
 
 
 if __name__ == "__main__":
