@@ -390,7 +390,9 @@ def avnet_forward(sd: dict, audionet: dict, wav: torch.Tensor, emb: torch.Tensor
         raise ValueError("oracle supports video repeats == 1 (RTFS-Net configs)")
     if taps is not None:
         taps["a_emb"], taps["a0"] = a_emb, a0
-    ablk, vblk = rm.sub("audio_net.blocks"), rm.sub("video_net.blocks")
+    shared = bool(cfg["audio"].get("shared", False))  # tdanet.py:170-181: one block applied R times, or R blocks (state-dict prefix blocks.<i>.)
+    ablk_of = lambda i: rm.sub("audio_net.blocks") if shared else rm.sub(f"audio_net.blocks.{i}")  # noqa: E731
+    ablk, vblk = ablk_of(0), rm.sub("video_net.blocks")
     btaps = {} if taps is not None else None
     a = tdanet_block(a0, ablk, cfg["audio"], training=training, taps=btaps)
     if taps is not None:
@@ -402,7 +404,7 @@ def avnet_forward(sd: dict, audionet: dict, wav: torch.Tensor, emb: torch.Tensor
         taps["vp"], taps["caf"] = v1, a
     for i in range(1, R):
         btaps = {} if taps is not None else None
-        a = tdanet_block(a + a0, ablk, cfg["audio"], training=training, taps=btaps)
+        a = tdanet_block(a + a0, ablk_of(i), cfg["audio"], training=training, taps=btaps)
         if taps is not None:
             taps[f"block{i}"] = a
             taps.update({f"block{i}.{k}": v for k, v in btaps.items()})

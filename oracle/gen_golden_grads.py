@@ -89,11 +89,13 @@ def full_model_case(AVNet, kind, training, B, L, R, Tv):
     name = regimes.case_name(kind, training, B, L, R, Tv)
     t0 = time.time()
     cfg = synth.rtfs_audionet(R)
+    if kind == "nonshared":
+        cfg["audio_params"]["shared"] = False
     torch.manual_seed(0)
     template = AVNet(print_macs=False, **copy.deepcopy(cfg)).state_dict()
     sd0 = synth.synth_state_dict(template)
     mix, _, emb = synth.synth_inputs(B, L, Tv)
-    sd = regimes.smooth_regime(sd0, cfg, mix, emb, training) if kind == "smooth" else sd0
+    sd = regimes.smooth_regime(sd0, cfg, mix, emb, training) if kind in ("smooth", "nonshared") else sd0  # (nonshared: see regimes.NONSHARED_CASES)
     emb = regimes.stable_emb(sd, cfg, emb, training)
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(regimes.GRAD_WEIGHT_SEED))
     out, grads, stats = reference_step(AVNet, cfg, sd, mix, emb, wgt, training)
@@ -110,7 +112,7 @@ def full_model_case(AVNet, kind, training, B, L, R, Tv):
     arrays.update({f"grad.{k}": v.numpy().astype(np.float32) for k, v in grads.items()})
     if training:
         arrays.update({f"stat.{k}": v.numpy().astype(np.float64) for k, v in stats.items()})
-    if kind == "smooth":
+    if kind in ("smooth", "nonshared"):
         arrays.update({f"sd.{k}": v.numpy() for k, v in sd.items() if not torch.equal(v, sd0[k])})
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
 
@@ -168,7 +170,7 @@ def main():
         for B, Tv in VP_CASES:
             if args.only in f"vpgrads_{'train' if train else 'eval'}_B{B}_Tv{Tv}":
                 vp_case(AVNet, train, B, Tv)
-    for kind, cases in (("plain", regimes.GRAD_CASES), ("smooth", regimes.SMOOTH_CASES)):
+    for kind, cases in (("plain", regimes.GRAD_CASES), ("smooth", regimes.SMOOTH_CASES), ("nonshared", regimes.NONSHARED_CASES)):
         for case in cases:
             if args.only in regimes.case_name(kind, *case):
                 full_model_case(AVNet, kind, *case)

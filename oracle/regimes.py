@@ -20,6 +20,10 @@ GRAD_CASES = [
     (False, 1, 32000, 6, 50),   # RTFS-Net-6 itself (BASELINE configs[2] / [3]: six passes through the shared block, five middle / last blocks), full length
 ]
 SMOOTH_CASES = [GRAD_CASES[1], GRAD_CASES[2], GRAD_CASES[5], GRAD_CASES[6]]  # the split-bf16 step's cases, on smooth_regime weights
+# audio_params.shared = False: two RTFS blocks with their own weights (tdanet.py:170-181; no shipped config).  On the SMOOTH-REGIME weights: the case checks the
+# per-block weight / gradient plumbing of the step, and on ordinary weights a single flipped element of the S3 mask's PReLU input (-1.1e-6 / -1.7e-6 in float64,
+# positive in fp32) carried 100 % / 93 % of a 6e-3 / 1e-3 deviation of d(refined) at the two input sizes tried (tools/nonshared_bisect.py) - the forward agrees to 7e-7
+NONSHARED_CASES = [(False, 2, 8192, 2, 12)]
 GRAD_WEIGHT_SEED = 7  # seed of the output weighting of the scalar loss (out * wgt).sum()
 
 

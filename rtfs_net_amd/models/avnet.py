@@ -231,8 +231,6 @@ class AVNet(nn.Module):
 
         if not x.is_cuda:
             raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
-        if not self.refinement_module.audio_net.shared:
-            raise NotImplementedError("the HIP backward accumulates into ONE shared RTFS block (audio_params.shared: true)")
         if getattr(self, "_trainer", None) is None:
             self._trainer = HipTrainer(self)
             self._trainer.prec = getattr(self, "_compute_prec", self._hip.prec)

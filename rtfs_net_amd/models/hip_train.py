@@ -518,8 +518,9 @@ class HipTrainer:
         self._wg("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
         self._call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
-    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode):
+    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode, tag="blk."):
         """dx: gradient w.r.t. the block output [B,TF,256] (overwritten).  Returns ds (gradient w.r.t. the block input).
+        tag: prefix of this block's gradient accumulators in `gr` ("blk." for the shared block, "blk<i>." for block i of a non-shared stack).
         a0_mode: how ds also enters the running d(a0) sum `da0` -- 1: da0 = ds, 2: da0 += ds (blocks whose input was
         `previous + a0`), 3: block 0, whose input IS a0: ds is accumulated straight into da0, 4: same but da0 is empty (R = 1)."""
         dev = dx.device
@@ -527,7 +528,7 @@ class HipTrainer:
         st = k.st
         full = lambda: torch.empty(B * TF * H, device=dev)  # noqa: E731
         low = lambda: torch.empty(B * lo * H, device=dev)  # noqa: E731
-        g = lambda name, n: _acc(gr, f"blk.{name}", n, dev)  # noqa: E731
+        g = lambda name, n: _acc(gr, f"{tag}{name}", n, dev)  # noqa: E731
         d0w, d0b, d0g, d0be = bw["d0"]
         d1w, d1b, d1g, d1be = bw["d1"]
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
@@ -543,49 +544,49 @@ class HipTrainer:
         dN_D0 = dE
         # concat layer: mix + gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
-        self._mix_gln_bwd(dE, (k.cl, st[9], cl_, "blk.cl"), (k.cgate, st[11], cgate_, "blk.cgate"), (k.cg, st[10], cg_, "blk.cg"), dcl, dcgate, dcg, gr,
+        self._mix_gln_bwd(dE, (k.cl, st[9], cl_, tag + "cl"), (k.cgate, st[11], cgate_, tag + "cgate"), (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr,
                           B, T, F_BINS, T2, F2)
         dF0, dF1 = full(), low()
-        self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, "blk.cl", B, T, F_BINS, False)
-        self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, "blk.cg", B, T2, F2, False)
-        self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, "blk.cgate", B, T2, F2, False)
+        self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, tag + "cl", B, T, F_BINS, False)
+        self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, tag + "cg", B, T2, F2, False)
+        self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, tag + "cgate", B, T2, F2, False)
         # fusion layers' mixes
         dl0, dl1 = full(), low()
         dgs = [low() for _ in range(4)]  # gradients w.r.t. the outputs of f0g, f0gate, f1g, f1gate
-        self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, "blk.f0l"), (k.gg0, st[6], f0gate, "blk.f0gate"), (k.g0, st[5], f0g, "blk.f0g"), dl0, dgs[1], dgs[0], gr,
+        self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, tag + "f0l"), (k.gg0, st[6], f0gate, tag + "f0gate"), (k.g0, st[5], f0g, tag + "f0g"), dl0, dgs[1], dgs[0], gr,
                           B, T, F_BINS, T2, F2)
-        self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, "blk.f1l"), (k.gg1, st[8], f1gate, "blk.f1gate"), (k.g1, st[7], f1g, "blk.f1g"), dl1, dgs[3], dgs[2], gr,
+        self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, tag + "f1l"), (k.gg1, st[8], f1gate, tag + "f1gate"), (k.g1, st[7], f1g, tag + "f1g"), dl1, dgs[3], dgs[2], gr,
                           B, T2, F2, T2, F2)
         # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
         dN_D1 = low()
-        self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, "blk.f0l", B, T, F_BINS, False)
-        self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, "blk.f1l", B, T2, F2, False)
+        self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, tag + "f0l", B, T, F_BINS, False)
+        self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, tag + "f1l", B, T2, F2, False)
         dG = low()  # gradient w.r.t. G3 (attention output)
         for j, (conv, nm) in enumerate(((f0g, "f0g"), (f0gate, "f0gate"), (f1g, "f1g"), (f1gate, "f1gate"))):
-            self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, "blk." + nm, B, T2, F2, False)
+            self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, tag + nm, B, T2, F2, False)
         # attention, dual paths (each updates dG in place to the gradient w.r.t. its input)
-        self._attn_bwd(dG, bw["attn"], k, B, T2, gr, "blk.attn")
-        self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, "blk.dp1")
-        self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, "blk.dp0")
+        self._attn_bwd(dG, bw["attn"], k, B, T2, gr, tag + "attn")
+        self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, tag + "dp1")
+        self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, tag + "dp0")
         # pooled = avgpool(D0n) + D1n; downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
         self._call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
         dD1, dD0 = low(), full()
-        self._gln_bwd(dN_D1, k.D1, st[2], d1g, d1be, dD1, False, gr, "blk.d1", B, lo)
+        self._gln_bwd(dN_D1, k.D1, st[2], d1g, d1be, dD1, False, gr, tag + "d1", B, lo)
         if self.model._hip.fuse["d0tail"]:
             # the two remaining contributions to d(D0n) and the reduce pass of D0's gLN adjoint in one pass over dN_D0
-            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, None, False, gr, "blk.d1", B, T, F_BINS, True)  # (tap / bias gradients only)
+            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, None, False, gr, tag + "d1", B, T, F_BINS, True)  # (tap / bias gradients only)
             red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
-            self._call("rtfs_d0_tail_bwd", dD1, d1w, dG, dN_D0, k.D0, st[1], d0g, d0be, red, _acc(gr, "blk.d0.g", H, dev), _acc(gr, "blk.d0.b", H, dev), B, T, T2)
+            self._call("rtfs_d0_tail_bwd", dD1, d1w, dG, dN_D0, k.D0, st[1], d0g, d0be, red, _acc(gr, tag + "d0.g", H, dev), _acc(gr, tag + "d0.b", H, dev), B, T, T2)
             self._call("rtfs_gln_bwd_apply", dN_D0, k.D0, st[1], d0g, d0be, 0, 0.0, red, dD0, 0, B, TF, H)
         else:
             self._call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
-            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, "blk.d1", B, T, F_BINS, True)
-            self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, "blk.d0", B, TF)
+            self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, tag + "d1", B, T, F_BINS, True)
+            self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, tag + "d0", B, TF)
         dP = full()
-        self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, "blk.d0", B, T, F_BINS, True)
+        self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, tag + "d0", B, T, F_BINS, True)
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
-        self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, "blk.p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
+        self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, tag + "p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
         self._wg("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
         # d(gateway out) = dx (residual path) + dy0 . Wp, formed inside the gateway adjoint
         if a0_mode >= 3:
@@ -596,6 +597,11 @@ class HipTrainer:
         self._call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C),
                  g("gslope", 1), B * TF)
         return ds
+
+    @staticmethod
+    def _tag(n_blocks, i):
+        """prefix of block i's gradient accumulators: one shared block -> "blk.", a stack of R blocks with their own weights (tdanet.py:170-181) -> "blk<i>." """
+        return "blk." if n_blocks == 1 else f"blk{i}."
 
     def backward(self, c, dout):
         """dout [B,1,L] -> (datt, drsz, grads dict in kernel layout)."""
@@ -652,7 +658,7 @@ class HipTrainer:
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         for i in range(R - 1, 0, -1):
-            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0, 1 if i == R - 1 else 2)
+            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0, 1 if i == R - 1 else 2, tag=self._tag(len(blocks), i))
         # CAF: out = key*rsz^ + att^*val (+ a0)
         datt, drsz = _zeros(B * Tv * C, dev), _zeros(B * Tv * C, dev)
         Rr = _zeros(4 * C, dev)
@@ -676,7 +682,7 @@ class HipTrainer:
         blocks = pw.blocks
         if da0 is None:
             da0 = torch.empty(B * TF * C, device=dev)
-        self._block_bwd(dx0, c.blk[0], blocks[0], B, T, T2, gr, da0, 3 if R > 1 else 4)  # block 0's input is a0 itself
+        self._block_bwd(dx0, c.blk[0], blocks[0], B, T, T2, gr, da0, 3 if R > 1 else 4, tag=self._tag(len(blocks), 0))  # block 0's input is a0 itself
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
         self._wg("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
@@ -758,62 +764,65 @@ def grads_to_reference(model, pw: TrainWeights, gr: dict) -> dict:
     put("audio_bottleneck.full_layer.0.norm.bias", gr["bn.b"], (C,))
     put("audio_bottleneck.full_layer.2.weight", gr["bn_w"], (C, C, 1, 1))
     put("audio_bottleneck.full_layer.2.bias", gr["bn_bias"], (C,))
-    p = "refinement_module.audio_net.blocks."
-    b = "blk."
-    put(p + "gateway.full_layer.2.weight", gr[b + "gw"], (C, 1, 1, 1))
-    put(p + "gateway.full_layer.2.bias", gr[b + "gb"], (C,))
-    put(p + "gateway.full_layer.4.weight", gr[b + "gslope"], (1,))
-    put(p + "projection.full_layer.2.weight", gr[b + "pw"], (H, C, 1, 1))
-    put(p + "projection.full_layer.2.bias", gr[b + "pb"], (H,))
-    put(p + "projection.full_layer.3.norm.weight", gr[b + "p.g"], (H,))
-    put(p + "projection.full_layer.3.norm.bias", gr[b + "p.b"], (H,))
-    put(p + "projection.full_layer.4.weight", gr[b + "pslope"], (1,))
+    n_blocks = len(pw.blocks)
+    shared = model.refinement_module.audio_net.shared
+    for bi in range(n_blocks):  # one shared block, or R blocks with their own parameters (state-dict prefix blocks.<i>.)
+        p = "refinement_module.audio_net.blocks." + ("" if shared else f"{bi}.")
+        b = HipTrainer._tag(n_blocks, bi)
+        put(p + "gateway.full_layer.2.weight", gr[b + "gw"], (C, 1, 1, 1))
+        put(p + "gateway.full_layer.2.bias", gr[b + "gb"], (C,))
+        put(p + "gateway.full_layer.4.weight", gr[b + "gslope"], (1,))
+        put(p + "projection.full_layer.2.weight", gr[b + "pw"], (H, C, 1, 1))
+        put(p + "projection.full_layer.2.bias", gr[b + "pb"], (H,))
+        put(p + "projection.full_layer.3.norm.weight", gr[b + "p.g"], (H,))
+        put(p + "projection.full_layer.3.norm.bias", gr[b + "p.b"], (H,))
+        put(p + "projection.full_layer.4.weight", gr[b + "pslope"], (1,))
 
-    def dw(prefix, key, bias):
-        put(prefix + "full_layer.2.weight", gr[key + ".w"].view(16, 64).t(), (64, 1, 4, 4))
-        if bias:
-            put(prefix + "full_layer.2.bias", gr[key + ".bias"], (64,))
-        put(prefix + "full_layer.3.norm.weight", gr[key + ".g"], (64,))
-        put(prefix + "full_layer.3.norm.bias", gr[key + ".b"], (64,))
+        def dw(prefix, key, bias):
+            put(prefix + "full_layer.2.weight", gr[key + ".w"].view(16, 64).t(), (64, 1, 4, 4))
+            if bias:
+                put(prefix + "full_layer.2.bias", gr[key + ".bias"], (64,))
+            put(prefix + "full_layer.3.norm.weight", gr[key + ".g"], (64,))
+            put(prefix + "full_layer.3.norm.bias", gr[key + ".b"], (64,))
 
-    dw(p + "downsample_layers.0.", b + "d0", True)
-    dw(p + "downsample_layers.1.", b + "d1", True)
-    for name, key in (("fusion_layers.0.local_embedding", "f0l"), ("fusion_layers.0.global_embedding", "f0g"), ("fusion_layers.0.global_gate", "f0gate"),
-                      ("fusion_layers.1.local_embedding", "f1l"), ("fusion_layers.1.global_embedding", "f1g"), ("fusion_layers.1.global_gate", "f1gate"),
-                      ("concat_layers.0.local_embedding", "cl"), ("concat_layers.0.global_embedding", "cg"), ("concat_layers.0.global_gate", "cgate")):
-        dw(f"{p}{name}.", b + key, False)
-    put(p + "residual_conv.full_layer.2.weight", gr[b + "rw"], (C, H, 1, 1))
-    put(p + "residual_conv.full_layer.2.bias", gr[b + "rb"], (C,))
-    for j in (0, 1):
-        q, k = f"{p}globalatt.{j}.", f"{b}dp{j}."
-        put(q + "norm.gamma", gr[k + "g"], (1, 64, 1, 1))
-        put(q + "norm.beta", gr[k + "b"], (1, 64, 1, 1))
-        put(q + "rnn.rnn_lst.0.weight", gr[k + "w0"].view(256, 8, 64).permute(2, 1, 0), (512, 256))
-        for l in range(4):
-            put(q + f"rnn.rnn_lst.{l}.weight_c", gr[k + f"l{l}.wc"], (128,))
-            put(q + f"rnn.rnn_lst.{l}.bias", gr[k + f"l{l}.bias"], (128,))
-            if l > 0:
-                put(q + f"rnn.rnn_lst.{l}.weight", gr[k + f"l{l}.w"].view(3, 64, 64).permute(2, 1, 0), (64, 192))
-        put(q + "linear.weight", gr[k + "ct_w"].view(64, 8, 64).permute(2, 0, 1).flip(2), (64, 64, 8))
-        put(q + "linear.bias", gr[k + "ct_b"], (64,))
-    q, k = p + "globalatt.2.", b + "attn."
-    wq = gr[k + "w"].view(96, 64)
-    bq = gr[k + "bias"]
-    sl = gr[k + "slope"]
-    off = 0
-    for mi, (name, nch, gk, bk) in enumerate((("Queries", 4, "gq", "bq"), ("Keys", 4, "gk", "bk"), ("Values", 16, "gv", "bv"))):
-        for h in range(4):
-            put(f"{q}{name}.{h}.conv.weight", wq[off:off + nch], (nch, 64, 1, 1))
-            put(f"{q}{name}.{h}.conv.bias", bq[off:off + nch], (nch,))
-            put(f"{q}{name}.{h}.act.weight", sl[mi * 4 + h:mi * 4 + h + 1], (1,))
-            put(f"{q}{name}.{h}.norm.gamma", gr[k + gk].view(4, -1)[h], (1, nch, 1, 64))
-            put(f"{q}{name}.{h}.norm.beta", gr[k + bk].view(4, -1)[h], (1, nch, 1, 64))
-            off += nch
-    put(q + "attn_concat_proj.conv.weight", gr[k + "ow"], (64, 64, 1, 1))
-    put(q + "attn_concat_proj.conv.bias", gr[k + "ob"], (64,))
-    put(q + "attn_concat_proj.act.weight", gr[k + "oslope"], (1,))
-    put(q + "attn_concat_proj.norm.gamma", gr[k + "og"].view(64, 64).t(), (1, 64, 1, 64))
-    put(q + "attn_concat_proj.norm.beta", gr[k + "obe"].view(64, 64).t(), (1, 64, 1, 64))
+        dw(p + "downsample_layers.0.", b + "d0", True)
+        dw(p + "downsample_layers.1.", b + "d1", True)
+        for name, key in (("fusion_layers.0.local_embedding", "f0l"), ("fusion_layers.0.global_embedding", "f0g"), ("fusion_layers.0.global_gate", "f0gate"),
+                          ("fusion_layers.1.local_embedding", "f1l"), ("fusion_layers.1.global_embedding", "f1g"), ("fusion_layers.1.global_gate", "f1gate"),
+                          ("concat_layers.0.local_embedding", "cl"), ("concat_layers.0.global_embedding", "cg"), ("concat_layers.0.global_gate", "cgate")):
+            dw(f"{p}{name}.", b + key, False)
+        put(p + "residual_conv.full_layer.2.weight", gr[b + "rw"], (C, H, 1, 1))
+        put(p + "residual_conv.full_layer.2.bias", gr[b + "rb"], (C,))
+        for j in (0, 1):
+            q, k = f"{p}globalatt.{j}.", f"{b}dp{j}."
+            put(q + "norm.gamma", gr[k + "g"], (1, 64, 1, 1))
+            put(q + "norm.beta", gr[k + "b"], (1, 64, 1, 1))
+            put(q + "rnn.rnn_lst.0.weight", gr[k + "w0"].view(256, 8, 64).permute(2, 1, 0), (512, 256))
+            for l in range(4):
+                put(q + f"rnn.rnn_lst.{l}.weight_c", gr[k + f"l{l}.wc"], (128,))
+                put(q + f"rnn.rnn_lst.{l}.bias", gr[k + f"l{l}.bias"], (128,))
+                if l > 0:
+                    put(q + f"rnn.rnn_lst.{l}.weight", gr[k + f"l{l}.w"].view(3, 64, 64).permute(2, 1, 0), (64, 192))
+            put(q + "linear.weight", gr[k + "ct_w"].view(64, 8, 64).permute(2, 0, 1).flip(2), (64, 64, 8))
+            put(q + "linear.bias", gr[k + "ct_b"], (64,))
+        q, k = p + "globalatt.2.", b + "attn."
+        wq = gr[k + "w"].view(96, 64)
+        bq = gr[k + "bias"]
+        sl = gr[k + "slope"]
+        off = 0
+        for mi, (name, nch, gk, bk) in enumerate((("Queries", 4, "gq", "bq"), ("Keys", 4, "gk", "bk"), ("Values", 16, "gv", "bv"))):
+            for h in range(4):
+                put(f"{q}{name}.{h}.conv.weight", wq[off:off + nch], (nch, 64, 1, 1))
+                put(f"{q}{name}.{h}.conv.bias", bq[off:off + nch], (nch,))
+                put(f"{q}{name}.{h}.act.weight", sl[mi * 4 + h:mi * 4 + h + 1], (1,))
+                put(f"{q}{name}.{h}.norm.gamma", gr[k + gk].view(4, -1)[h], (1, nch, 1, 64))
+                put(f"{q}{name}.{h}.norm.beta", gr[k + bk].view(4, -1)[h], (1, nch, 1, 64))
+                off += nch
+        put(q + "attn_concat_proj.conv.weight", gr[k + "ow"], (64, 64, 1, 1))
+        put(q + "attn_concat_proj.conv.bias", gr[k + "ob"], (64,))
+        put(q + "attn_concat_proj.act.weight", gr[k + "oslope"], (1,))
+        put(q + "attn_concat_proj.norm.gamma", gr[k + "og"].view(64, 64).t(), (1, 64, 1, 64))
+        put(q + "attn_concat_proj.norm.beta", gr[k + "obe"].view(64, 64).t(), (1, 64, 1, 64))
     caf = pw.caf_prefix
     for tag in ("key", "value"):
         put(f"{caf}{tag}_embed.full_layer.2.weight", gr[f"caf_{tag}_dw"], (C, 1, 1, 1))

@@ -213,7 +213,7 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
 
 
-@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70), (23, 50)])
+@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70), (23, 50), (5, 250)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
     """rtfs_dp_unfold_gemm_fwd in isolation (LN4D over channels + 8-tap unfold + layer-0 GEMM, rnn_layers.py:146-150) against float64 on
