@@ -70,10 +70,9 @@ def pmc_traffic(kernel_substr, a):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path) or (a.layers, a.batch, a.seconds, a.dtype, a.mode) != (6, 32, 2.0, "f32", "infer"):
         return None
-    for k, v in json.load(open(path)).items():
-        if kernel_substr in k:
-            return v["bytes_per_launch"]
-    return None
+    hits = [v for k, v in json.load(open(path)).items() if any(sub in k for sub in kernel_substr.split("|"))]  # (the freq and the time launch are two instantiations: launch-weighted mean)
+    n = sum(v["launches"] for v in hits)
+    return sum(v["bytes_per_launch"] * v["launches"] for v in hits) / n if n else None
 
 
 def dp_gemm_flops(B, T2):
@@ -368,7 +367,7 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                                "512 tiles)"),
                     "bound": "mfma", "achieved": tot_fl / (tot_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
-                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_ffa" if fast_fir else "unfold_gemm128", a),
+                    "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": pmc_traffic("unfold_ffa_kernel<3, 0>|unfold_ffa_kernel<4, 0>" if fast_fir else "unfold_gemm128", a),
                     "traffic_source": "committed PMC passes of this command line (profiles/pmc_traffic.json), not a live counter"}
             if fast_fir:
                 # ALGORITHMIC flops (2 x 512 x 256 per window) price the direct form; the kernel EXECUTES 0.775x of them (0.75 from the fast-FIR identity,

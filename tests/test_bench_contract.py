@@ -80,34 +80,30 @@ def test_lip_encoder_in_the_timed_step():
 
 def test_plain_launch_with_gpus_2_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without torch.distributed.run in front (the form the driver uses for N = 1): the script re-executes itself
-    under torch.distributed.run instead of exiting"""
+    under torch.distributed.run instead of exiting.  (`--no-train-line`: the DDP rider of the N > 1 line is test_two_rank_launch's subject.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["RTFS_BENCH_ONE_GPU"] = "1"
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1", "--no-train-line"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     res = _last_json(r.stdout)
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
-    assert "no data-path collective" in res["config"]["parallelism"]  # the headline stays the inference line
-    _check_dp_rider(res["training_step_dp"])
+    assert "no data-path collective" in res["config"]["parallelism"] and "training_step_dp" not in res
 
 
-@pytest.mark.parametrize("mode", ["infer", "train"])
-def test_two_rank_launch(mode):
+def test_two_rank_launch():
+    """the driver's N > 1 launch form (two ranks sharing the test GPU over gloo): the headline stays the inference line over utterance shards, and BASELINE
+    config 4 rides along as `training_step_dp` - a CHILD torch.distributed.run of `bench.py --mode train` on the same ranks (DDP + SyncBatchNorm step, one
+    gradient bucket, all-reduce timed), whose own JSON line this test therefore covers as well"""
     env = dict(os.environ, RTFS_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           "29531" if mode == "infer" else "29532", "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1",
-           "--mode", mode]
+           "29531", "bench.py", "--gpus", "2", "--layers", "2", "--batch", "2", "--steps", "2", "--warmup", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     res = _last_json(r.stdout)
     assert KEYS <= set(res) and "cpu_baseline" not in res  # the CPU baseline is a rank-0, N = 1 measurement
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["value"] > 0
     assert res["dist"]["world_size"] == 2 and res["dist"]["ranks_reporting"] == 2
-    if mode == "infer":
-        # BASELINE config 4 rides along on the N > 1 inference line: the DDP + SyncBatchNorm training step on the same ranks
-        _check_dp_rider(res["training_step_dp"])
-        assert "no scaling curve" in res["scaling_note"]
-    else:
-        assert res["config"]["parallelism"].startswith("dp2: DistributedDataParallel")
-        _check_allreduce(res["grad_allreduce"])
+    assert "no data-path collective" in res["config"]["parallelism"]
+    _check_dp_rider(res["training_step_dp"])
+    assert "no scaling curve" in res["scaling_note"]
