@@ -408,8 +408,11 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
 def cpu_baseline(res, h, a):
     """the oracle on the host cores, bounded sample + SI-SDRi parity of the HIP estimate (rank 0, N = 1 only)"""
     from oracle.avnet_ref import avnet_forward
+    from oracle.sru_ref import _c_scan
     from rtfs_net_amd import synthetic as synth
     from rtfs_net_amd.metrics import separation_metrics
+
+    sru_c = _c_scan() is not None
 
     cmix, ctgt, cemb = synth.synth_inputs(1, h.L, h.Tv)
     # the many small ops of this model do not scale to every host core: probe a few thread counts (one run each,
@@ -445,7 +448,8 @@ def cpu_baseline(res, h, a):
                              "note": "random-init weights: the value itself is meaningless, the agreement is the check (<= 0.01 dB)"}
     res["cpu_baseline"] = {"value": h.T / dt, "unit": "frames/s", "cores": n, "kind": "port", "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
                            "sample": f"oracle/avnet_ref.py, RTFS-Net-{a.layers}, batch 1 x {a.seconds:g} s, {runs} runs of {dt:.2f} s (torch CPU, {n} threads)",
-                           "sru": "python time loop (oracle/sru_ref.py:72-76): pessimistic for the SRU share of the CPU time - the reference's CPU path runs sru's C++ loop"}
+                           "sru": ("C loop (oracle/csrc/sru_scan.c, gcc -O3 -fopenmp, the oracle's restatement of the recurrence: the reference's CPU path runs the sru package's "
+                                   "compiled loop)" if sru_c else "python time loop (oracle/sru_ref.py; no gcc on this box): pessimistic for the SRU share of the CPU time")}
     # BASELINE.json configs[0] (the reference's own CPU-runnable case): RTFS-Net-4, batch 1, 2 s, forward only, on the same thread count
     # and on ONE thread (per-core figure); median of 3 after one warm-up each - a couple of seconds
     try:

@@ -47,13 +47,55 @@ import torch
 import torch.nn as nn
 
 
-def sru_cell_forward(x, weight, weight_c, bias, scale_x, hidden_size, bidirectional=True, c0=None):
-    """One SRU layer, time-major. x: [L, B, d_in] -> (h [L, B, D*d], c_last [B, D*d])."""
+_C_SCAN = None  # ctypes handle of oracle/_build/libsru_scan.so (False: unavailable)
+
+
+def _c_scan():
+    """the C restatement of the recurrence (oracle/csrc/sru_scan.c), built on first use; None without gcc"""
+    global _C_SCAN
+    if _C_SCAN is None:
+        try:
+            import ctypes
+
+            from .build_c import build
+
+            path = build()
+            lib = ctypes.CDLL(path) if path else None
+            if lib is not None:
+                for fn in (lib.sru_scan_f32, lib.sru_scan_f64):
+                    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2 + [ctypes.c_int]
+                    fn.restype = None
+            _C_SCAN = lib or False
+        except Exception:  # noqa: BLE001  (the Python loop below is the same arithmetic)
+            _C_SCAN = False
+    return _C_SCAN or None
+
+
+def _scan_in_c(U, xp, weight_c, bias, L, B, D, d, k):
+    """h [L,B,D,d], c_last [B,D,d] from the C loop; inference only (no autograd), CPU float32 / float64"""
+    lib = _c_scan()
+    fn = lib.sru_scan_f32 if U.dtype == torch.float32 else lib.sru_scan_f64
+    U, wc, bs = U.contiguous(), weight_c.detach().to(U.dtype).contiguous(), bias.detach().to(U.dtype).contiguous()
+    xpc = None if xp is None else xp.contiguous()
+    h = torch.empty(L, B, D, d, dtype=U.dtype)
+    c_last = torch.empty(B, D, d, dtype=U.dtype)
+    fn(U.data_ptr(), 0 if xpc is None else xpc.data_ptr(), wc.data_ptr(), bs.data_ptr(), L, B, D, d, k, h.data_ptr(), c_last.data_ptr(), max(1, min(torch.get_num_threads(), B * D)))
+    return h, c_last
+
+
+def sru_cell_forward(x, weight, weight_c, bias, scale_x, hidden_size, bidirectional=True, c0=None, use_c=True):
+    """One SRU layer, time-major. x: [L, B, d_in] -> (h [L, B, D*d], c_last [B, D*d]).  Without autograd (forward parity checks, bench.py's CPU baseline) the
+    recurrence runs in the C restatement (oracle/csrc/sru_scan.c: same formulas, same order); under autograd, or without gcc, in the Python loop below."""
     L, B, d_in = x.shape
     D = 2 if bidirectional else 1
     d = hidden_size
     k = weight.shape[1] // (D * d)
     U = (x.reshape(L * B, d_in) @ weight).view(L, B, D, d, k)
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (x, weight, weight_c, bias))
+    if (use_c and not needs_grad and c0 is None and x.device.type == "cpu" and U.dtype in (torch.float32, torch.float64) and d <= 256 and _c_scan() is not None):
+        xp_c = (x.view(L, B, D, d) * scale_x).to(U.dtype) if k == 3 else None
+        h, c_last = _scan_in_c(U.detach(), None if xp_c is None else xp_c.detach(), weight_c, bias, L, B, D, d, k)
+        return h.view(L, B, D * d), c_last.reshape(B, D * d)
     wf, wr = weight_c.view(2, D, d)
     bf, br = bias.view(2, D, d)
     if k == 3:

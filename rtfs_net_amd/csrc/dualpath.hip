@@ -1822,7 +1822,7 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
     if constexpr (NT == 0) {
         const int Lv = (m.L + 2) / 2;
         const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
-        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (Rv + 64) * Lv < (1LL << 32) && (long long)S * m.L * 1024 < (1LL << 31) &&
+        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (Rv + 256) * Lv < (1LL << 32) && (long long)S * m.L * 1024 < (1LL << 31) &&
             ftiles >= 8 * 64) {  // (>= 8 tiles per tile range to pay for the 192 KB weight read of each of its four workgroups)
             const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
             if (dim == 4)
@@ -1863,7 +1863,7 @@ int rtfs::convt_bwd_input_ffa(const float* dG, const float* Wt, float* dH3, int 
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int Lv = (m.L + 2) / 2;
     const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
-    if (!(Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 64) * Lv < (1LL << 32) && ftiles >= 4 * 256)) return 1;
+    if (!(Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 256) * Lv < (1LL << 32) && ftiles >= 4 * 256)) return 1;
     const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
     if (dim == 4)
         hipLaunchKernelGGL((unfold_ffa_kernel<4, 2>), dim3(256), dim3(256), 0, stream, m, dG, nullptr, nullptr, Wt, dH3, S, Lv, magicLv, (int)ftiles);
@@ -1883,7 +1883,7 @@ static int convt_impl(const float* H3, const float* Wt, const float* bias, float
     if constexpr (NT == 0) {
         const int Lv = (m.npos + 2) / 2;
         const long long Rv = (long long)S * Lv, ftiles = (Rv + 62) / 63;
-        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 64) * Lv < (1LL << 32) &&
+        if (variant == 0 && Lv >= 21 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31) && (Rv + 256) * Lv < (1LL << 32) &&
             ftiles >= 4 * 256) {
             const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
             if (dim == 4)

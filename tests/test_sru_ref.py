@@ -39,3 +39,32 @@ def test_single_step_closed_form():
     c1 = U[..., 0] * (1 - f)
     h1 = x.view(1, 2, d) * (1 - r) + c1 * r
     assert torch.allclose(h.view(1, 2, d), h1, atol=1e-6) and torch.allclose(c.view(1, 2, d), c1, atol=1e-6)
+
+
+def test_c_restatement_of_the_recurrence_matches_the_python_loop():
+    """oracle/csrc/sru_scan.c (what the oracle runs without autograd: forward parity checks, bench.py's CPU baseline) against the Python loop, k = 3 and k = 4,
+    float32 and float64, both directions, scale_x != 1"""
+    import pytest
+
+    from oracle.sru_ref import _c_scan
+
+    if _c_scan() is None:
+        pytest.skip("no gcc: the oracle keeps its Python loop")
+    g = torch.Generator().manual_seed(3)
+    for d_in, dtype, tol in ((64, torch.float32, 2e-6), (512, torch.float32, 2e-6), (64, torch.float64, 1e-14), (512, torch.float64, 1e-14)):
+        L, B, d = 23, 5, 32
+        k = 3 if d_in == 2 * d else 4
+        x = torch.randn(L, B, d_in, generator=g).to(dtype)
+        W = (torch.randn(d_in, 2 * d * k, generator=g) * 0.1).to(dtype)
+        wc, b = torch.randn(4 * d, generator=g).to(dtype), torch.randn(4 * d, generator=g).to(dtype)
+        sx = torch.tensor([0.7], dtype=dtype)
+        with torch.no_grad():
+            h_c, c_c = sru_cell_forward(x, W, wc, b, sx, d, True)
+            h_p, c_p = sru_cell_forward(x, W, wc, b, sx, d, True, use_c=False)
+        assert float((h_c - h_p).abs().max()) < tol and float((c_c - c_p).abs().max()) < tol, (d_in, dtype)
+    # under autograd the Python loop runs (gradients flow)
+    x = torch.randn(5, 2, 64, generator=g).requires_grad_(True)
+    W = torch.randn(64, 192, generator=g) * 0.1
+    h, _ = sru_cell_forward(x, W, torch.randn(128, generator=g), torch.randn(128, generator=g), torch.ones(1), 32, True)
+    h.sum().backward()
+    assert x.grad is not None and float(x.grad.abs().max()) > 0
