@@ -592,6 +592,37 @@ def test_convt_bwd_input_entry_isolated(B, T2, dim):
         lib.call("rtfs_convt_bwd_input_form", dG.cuda(), W.cuda(), out1, B, T2, dim, 2)
 
 
+@pytest.mark.parametrize("kind,B,T2,dim", [("l0", 20, 125, 4), ("l0", 20, 125, 3), ("l0", 9, 250, 3), ("ct", 20, 125, 4), ("ct", 20, 125, 3), ("l0", 23, 50, 3), ("l0", 2, 125, 4)])
+def test_toeplitz_wgrad_entry_isolated(kind, B, T2, dim):
+    """rtfs_wgrad on the two Toeplitz maps of a DualPathRNN in isolation against float64 (round 5: until then these launches were only covered end to end):
+    "l0" = the weight gradient of LN4D + unfold + SRU layer-0 GEMM (dW0[n][64 z + k] = sum_l dU0[l][n] xn[l + z][k], autograd of rnn_layers.py:146-150),
+    "ct" = the ConvTranspose1d weight + bias gradient (x_off = -7, zero rows outside the sequence; rnn_layers.py:153).  Every (output channel, tap) row on its own."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(13 * B + T2 + dim + (kind == "ct"))
+    S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
+    L = npos - 7
+    if kind == "l0":
+        nout, seg, xseg, xoff = 256, L, npos, 0
+    else:
+        nout, seg, xseg, xoff = 64, npos, L, -7
+    dY = torch.randn(S * seg, nout, generator=g)
+    X = torch.randn(S * xseg, 64, generator=g)
+    Xs = torch.zeros(S, xseg + 16, 64, dtype=torch.float64)  # padded by 8 on both sides: X[seq][p] at index p + 8
+    Xs[:, 8:8 + xseg] = X.view(S, xseg, 64).double()
+    dYs = dY.view(S, seg, nout).double()
+    want = torch.stack([torch.einsum("sln,slk->nk", dYs, Xs[:, 8 + xoff + z:8 + xoff + z + seg]) for z in range(8)], 1).reshape(nout, 512)
+    want_b = dYs.sum((0, 1))
+    dW = torch.zeros(nout, 512, device="cuda")
+    db = torch.zeros(nout, device="cuda") if kind == "ct" else None
+    lib.call("rtfs_wgrad", dY.cuda(), nout, X.cuda(), 64, dW, 512, db, S * seg, seg, xseg, xoff, 8, nout, 64, 0, None, None, 0.0, None, 0)
+    assert rel(dW, want) < 3e-6, rel(dW, want)
+    rows = (dW.double().cpu() - want).view(nout, 8, 64).norm(dim=-1) / want.view(nout, 8, 64).norm(dim=-1)
+    assert float(rows.max()) < 2e-5, float(rows.max())
+    if db is not None:
+        assert rel(db, want_b) < 3e-6, rel(db, want_b)
+
+
 def test_weight_stationary_kernels_in_the_model():
     """RTFS-Net-2 at the bench shape (batch 32, 2 s): the forward takes the weight-stationary kernels (256 -> 256 pixel GEMMs, layer-0 GEMM,
     ConvTranspose GEMM) and the one-workgroup residual kernels.  (1) with the layer-0 GEMM forced to the LDS-staged kernel (variant 2) the

@@ -49,14 +49,20 @@ def main():
         err = float((dW2.double() - ref).norm() / ref.norm())
         fl = 2.0 * rows * NOUT * KIN
         print(f"  {name:40s} {t:8.1f} us  {fl / (t * 1e-6) / 1e12:6.1f} TFLOP/s = {fl / (t * 1e-6) / 157.3e12:.3f} of peak   rel err vs float64 (200k rows) {err:.1e}")
-    # layer-0 Toeplitz weight gradient (nshift 8): dW0[256][512]
+    # layer-0 Toeplitz weight gradient (nshift 8): dW0[256][512]; ConvTranspose1d weight gradient dWct[64][512] (+ bias)
     for S, npos in ((4000, 64), (2048, 125)):
         L = npos - 7
         dU, X = R(S * L, 256), R(S * npos, 64)
-        dW = torch.zeros(256, 512, device="cuda")
-        t = timeit(lambda: lib.call("rtfs_wgrad", dU, 256, X, 64, dW, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0))
-        fl = 2.0 * S * L * 256 * 512
-        print(f"  Toeplitz dW0, S {S} npos {npos}:               {t:8.1f} us  {fl / (t * 1e-6) / 1e12:6.1f} TFLOP/s = {fl / (t * 1e-6) / 157.3e12:.3f} of peak")
+        dG, H3 = R(S * npos, 64), R(S * L, 64)
+        for form in (0,):
+            dW = torch.zeros(256, 512, device="cuda")
+            t = timeit(lambda: lib.call("rtfs_wgrad", dU, 256, X, 64, dW, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0))
+            fl = 2.0 * S * L * 256 * 512
+            print(f"  Toeplitz dW0, S {S} npos {npos}:        {t:8.1f} us  {fl / (t * 1e-6) / 1e12:6.1f} TFLOP/s (algorithmic) = {fl / (t * 1e-6) / 157.3e12:.3f} of peak")
+            dWc, db = torch.zeros(64, 512, device="cuda"), torch.zeros(64, device="cuda")
+            t = timeit(lambda: lib.call("rtfs_wgrad", dG, 64, H3, 64, dWc, 512, db, S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0))
+            fl = 2.0 * S * npos * 64 * 512
+            print(f"  Toeplitz dWct, S {S} npos {npos}:       {t:8.1f} us  {fl / (t * 1e-6) / 1e12:6.1f} TFLOP/s (algorithmic) = {fl / (t * 1e-6) / 157.3e12:.3f} of peak")
 
 
 if __name__ == "__main__":
