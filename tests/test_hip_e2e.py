@@ -27,6 +27,32 @@ def test_against_reference_golden(name, R, B, L):
     assert rel(out, torch.from_numpy(z["out"])) < WAVE_TOL
 
 
+def test_bench_shape_against_reference_golden():
+    """BASELINE configs[2] shape (RTFS-Net-6, batch 32, 2 s): at this batch the layer-0 GEMM and the ConvTranspose1d run on the fast-FIR weight-stationary
+    kernels (csrc/dualpath.hip unfold_ffa_kernel, round 5) and every 256-wide GEMM on its weight-stationary form.  The first two utterances of the batch are
+    the inputs of the reference's own fixture (tests/golden/rtfs6_b2.npz, written by oracle/gen_golden.py from /root/reference): their rows must be the
+    reference's waveforms, whatever the other 30 utterances are (utterances are independent)."""
+    z = load_npz("rtfs6_b2.npz")
+    model, _, _ = make_model(6, "cuda")
+    mix2, _, emb2 = synth.synth_inputs(2, 32000, 50)
+    assert np.array_equal(mix2[:, :256].numpy(), z["mix_head"])
+    mix30, _, emb30 = synth.synth_inputs(30, 32000, 50, seed=synth.INPUT_SEED + 17)
+    mix, emb = torch.cat([mix2, mix30], 0), torch.cat([emb2, emb30], 0)
+    with torch.no_grad():
+        out = model(mix.cuda(), emb.cuda())
+        direct = None
+        model._hip.variants["unfold"] = 3  # the direct weight-stationary layer-0 kernel of round 4 for comparison
+        try:
+            direct = model(mix.cuda(), emb.cuda())
+        finally:
+            model._hip.variants["unfold"] = 0
+    ref = torch.from_numpy(z["out"])
+    e_ffa, e_dir = rel(out[:2], ref), rel(direct[:2], ref)
+    print(f"bench shape vs the reference's waveform: fast-FIR kernels {e_ffa:.2e}, direct layer-0 kernel {e_dir:.2e}")
+    assert e_ffa < 2e-5 and e_dir < 2e-5  # (bound 1e-3; the batch-2 forward of the same utterances sits at ~1e-6)
+    assert torch.isfinite(out).all() and rel(out, direct) < 1e-5
+
+
 def test_batch_invariance_and_sisdr_parity():
     from oracle.avnet_ref import avnet_forward, si_sdr
 
