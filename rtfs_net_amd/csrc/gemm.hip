@@ -1294,6 +1294,94 @@ static int launch(const Pro& pro, const Epi& epi, const float* Wt, int B, int Mb
 }
 
 
+// Row GEMM onto 64 output columns with the weight in registers (round 5; training step, fp32, large M): Y[M][64] (= or +=) X[M][K] . Wt[64][K]^T.
+// The generic pixel_gemm_kernel re-stages the weight through LDS for every row tile and streams these narrow maps - dx += dU . W of the SRU layers (K = 192),
+// the residual conv's input gradient (K = 256) - at 3.8 TB/s.  Here wave w keeps its 16 output columns x all K (K / 4 registers per lane, v_mfma_f32_16x16x4_f32:
+// lane (n, kg) holds W[16 w + n][16 Q + 4 kg .. + 3]) for a contiguous range of 32-row tiles; only the rows go through LDS (double-buffered, the next tile's rows in
+// flight under the MFMAs), a lane ends with 4 consecutive columns of one row (16-byte accumulate / store).  Two to three workgroups per CU overlap each other's phases.
+template <int K, bool ACC>
+__global__ __launch_bounds__(256, 2) void rows_ws64_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y, int M, int tiles_per_wg) {
+    constexpr int BM = 32, LDX = K + 4, NQ = K / 16, XIT = BM * (K / 4) / 256;
+    __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDX];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, kg = lane >> 4;
+    float4 wq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) wq[q] = ld4(Wt + (size_t)(16 * w + j) * K + 16 * q + 4 * kg);
+    const int ntiles = (M + BM - 1) / BM;
+    const int t0 = blockIdx.x * tiles_per_wg, t1 = min(ntiles, t0 + tiles_per_wg);
+    if (t0 >= t1) return;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)((long long)M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((long long)M * 256), 0x00020000);
+    float4 xr[XIT];
+    auto fetch = [&](int t) {  // rows past M come back as zeros from the range check
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int idx = threadIdx.x + it * 256, r = idx / (K / 4), c4 = (idx % (K / 4)) * 4;
+            const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(((unsigned)(t * BM + r) * (unsigned)K + (unsigned)c4) * 4u), 0, 0);
+            xr[it] = f4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int idx = threadIdx.x + it * 256, r = idx / (K / 4), c4 = (idx % (K / 4)) * 4;
+            st4(&Xs[buf][r * LDX + c4], xr[it]);
+        }
+    };
+    fetch(t0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) fetch(t + 1);
+        const unsigned yoff = ((unsigned)(t * BM + j) * 64u + (unsigned)(16 * w + 4 * kg)) * 4u;  // this lane's row j of row tile 0, its 4 columns
+        floatx4 yold[2];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)(yoff + (unsigned)rt * 16u * 256u), 0, 0);
+                yold[rt] = floatx4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+            }
+        }
+        const float* xp = &Xs[cur][j * LDX + 4 * kg];
+        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float4 e0 = ld4(xp + 16 * q), e1 = ld4(xp + 16 * LDX + 16 * q);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].x, e0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].x, e1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].y, e0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].y, e1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].z, e0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].z, e1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].w, e0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[q].w, e1.w, acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            floatx4 v = acc[rt];
+            if constexpr (ACC) v = v + yold[rt];
+            __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, ry,
+                                                   (int)(yoff + (unsigned)rt * 16u * 256u), 0, 0);  // (rows past M are dropped by the range check)
+        }
+        if (t + 1 < t1) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int K>
+static int rows_ws64(const float* X, const float* Wt, float* Y, int M, int accumulate, hipStream_t st) {
+    const int ntiles = (M + 31) / 32;
+    const int per = (ntiles + 767) / 768 < 4 ? 4 : (ntiles + 767) / 768;  // ~768 workgroups (three per CU), at least 4 tiles each to pay for the weight read
+    const dim3 grid((ntiles + per - 1) / per);
+    if (accumulate) hipLaunchKernelGGL((rows_ws64_kernel<K, true>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
+    else hipLaunchKernelGGL((rows_ws64_kernel<K, false>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -1554,6 +1642,11 @@ int rtfs_mask_fwd_bf16(const float* x, float slope, const void* Wpk, const float
 // the attention projections in training mode and every input-gradient GEMM of the backward pass (Wt = transposed weight).
 int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    // narrow maps at large M (training step): the weight-stationary 64-column kernel (32-bit byte offsets: M K 4 < 2^31)
+    if (N == 64 && bias_or_null == nullptr && M >= 65536 && (long long)M * K * 4 < (1LL << 31)) {
+        if (K == 192) return rows_ws64<192>(X, Wt, Y, M, accumulate, st);
+        if (K == 256 && !accumulate) return rows_ws64<256>(X, Wt, Y, M, accumulate, st);  // (accumulating, the generic kernel measured faster: 431 vs 453 us)
+    }
 #define RG(KK, NN, BM, WM, WN) \
     if (K == KK && N == NN) return rows_gemm<KK, NN, BM, WM, WN>(X, Wt, bias_or_null, Y, M, accumulate, st);
     RG(64, 192, 64, 1, 3)

@@ -623,6 +623,24 @@ def test_toeplitz_wgrad_entry_isolated(kind, B, T2, dim):
         assert rel(db, want_b) < 3e-6, rel(db, want_b)
 
 
+@pytest.mark.parametrize("M,K,acc", [(228000, 192, 1), (65537, 192, 1), (70001, 192, 0), (200000, 256, 0), (65536 + 31, 256, 0), (40000, 192, 1)])
+def test_gemm_rows_narrow_maps_isolated(M, K, acc):
+    """rtfs_gemm_rows onto 64 columns at the training step's sizes (dx += dU . W of the SRU layers: K = 192, accumulating; the residual conv's input gradient:
+    K = 256) against float64: from 65536 rows up the weight-stationary 64-column kernel (rows_ws64_kernel, round 5; ragged last 32-row tile), below it the generic one."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(M + K + acc)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(64, K, generator=g) * 0.1
+    Y0 = torch.randn(M, 64, generator=g)
+    Y = torch.cat([Y0, torch.full((64, 64), 7.0)], 0).cuda()  # 64 guard rows behind the matrix: a store past row M would show
+    lib.call("rtfs_gemm_rows", X.cuda(), W.cuda(), None, Y, M, K, 64, acc)
+    want = X.double() @ W.double().t() + (Y0.double() if acc else 0)
+    assert rel(Y[:M], want) < 1e-6
+    rows = (Y[:M].double().cpu() - want).norm(dim=-1) / want.norm(dim=-1)
+    assert float(rows.max()) < 1e-5 and bool((Y[M:] == 7.0).all())
+
+
 def test_weight_stationary_kernels_in_the_model():
     """RTFS-Net-2 at the bench shape (batch 32, 2 s): the forward takes the weight-stationary kernels (256 -> 256 pixel GEMMs, layer-0 GEMM,
     ConvTranspose GEMM) and the one-workgroup residual kernels.  (1) with the layer-0 GEMM forced to the LDS-staged kernel (variant 2) the
