@@ -1645,6 +1645,8 @@ int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, f
     // narrow maps at large M (training step): the weight-stationary 64-column kernel (32-bit byte offsets: M K 4 < 2^31)
     if (N == 64 && bias_or_null == nullptr && M >= 65536 && (long long)M * K * 4 < (1LL << 31)) {
         if (K == 192) return rows_ws64<192>(X, Wt, Y, M, accumulate, st);
+        if (K == 96) return rows_ws64<96>(X, Wt, Y, M, accumulate, st);
+        if (K == 64) return rows_ws64<64>(X, Wt, Y, M, accumulate, st);
         if (K == 256 && !accumulate) return rows_ws64<256>(X, Wt, Y, M, accumulate, st);  // (accumulating, the generic kernel measured faster: 431 vs 453 us)
     }
 #define RG(KK, NN, BM, WM, WN) \

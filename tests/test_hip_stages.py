@@ -623,7 +623,7 @@ def test_toeplitz_wgrad_entry_isolated(kind, B, T2, dim):
         assert rel(db, want_b) < 3e-6, rel(db, want_b)
 
 
-@pytest.mark.parametrize("M,K,acc", [(228000, 192, 1), (65537, 192, 1), (70001, 192, 0), (200000, 256, 0), (65536 + 31, 256, 0), (40000, 192, 1)])
+@pytest.mark.parametrize("M,K,acc", [(228000, 192, 1), (65537, 192, 1), (70001, 192, 0), (200000, 256, 0), (65536 + 31, 256, 0), (40000, 192, 1), (100003, 96, 1), (100003, 64, 0)])
 def test_gemm_rows_narrow_maps_isolated(M, K, acc):
     """rtfs_gemm_rows onto 64 columns at the training step's sizes (dx += dU . W of the SRU layers: K = 192, accumulating; the residual conv's input gradient:
     K = 256) against float64: from 65536 rows up the weight-stationary 64-column kernel (rows_ws64_kernel, round 5; ragged last 32-row tile), below it the generic one."""
