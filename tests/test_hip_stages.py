@@ -623,6 +623,25 @@ def test_toeplitz_wgrad_entry_isolated(kind, B, T2, dim):
         assert rel(db, want_b) < 3e-6, rel(db, want_b)
 
 
+@pytest.mark.parametrize("M", [228000, 241664, 65536 + 13, 40000])
+def test_wgrad_sru_layer_map_isolated(M):
+    """rtfs_wgrad on the SRU layer 1-3 map (dW[192][64] += dU^T . h: 36 launches per training step) in isolation against float64 (ragged row counts; dW is
+    ACCUMULATED into).  (Round 5 built a one-workgroup-per-output kernel for this map and measured it no faster than the generic one - 81 against 77 us: with the
+    row index as contraction both sides are read 4 bytes at a time from LDS and the MFMA and memory phases do not overlap - so it is not in the library.)"""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(M)
+    dU = torch.randn(M, 192, generator=g)
+    h = torch.randn(M, 64, generator=g)
+    dW0 = torch.randn(192, 64, generator=g)
+    dW = dW0.clone().cuda()
+    lib.call("rtfs_wgrad", dU.cuda(), 192, h.cuda(), 64, dW, 64, None, M, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
+    want = dU.double().t() @ h.double()
+    assert rel(dW.double().cpu() - dW0.double(), want) < 3e-6
+    rows = (dW.double().cpu() - dW0.double() - want).norm(dim=-1) / want.norm(dim=-1)
+    assert float(rows.max()) < 2e-5
+
+
 @pytest.mark.parametrize("M,K,acc", [(228000, 192, 1), (65537, 192, 1), (70001, 192, 0), (200000, 256, 0), (65536 + 31, 256, 0), (40000, 192, 1), (100003, 96, 1), (100003, 64, 0)])
 def test_gemm_rows_narrow_maps_isolated(M, K, acc):
     """rtfs_gemm_rows onto 64 columns at the training step's sizes (dx += dU . W of the SRU layers: K = 192, accumulating; the residual conv's input gradient:
