@@ -824,6 +824,267 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #endif
 }
 
+// Layer-0 kernel for the six-term split (NT = 6: fp32-equivalent arithmetic on the bf16 pipe, common.h), large batches: WEIGHT-STATIONARY.
+// The LDS-staged kernel splits every fp32 fragment it reads into three bf16 planes in registers (~56 VALU instructions per ds_read_b128) and is
+// bound by that; here every operand is split ONCE.  Four workgroups of one XCD share a range of 64-row tiles (same flattened tile geometry as
+// unfold_ws_kernel), 64 output columns each.  Wave (cn = w & 1, kp = w >> 1) owns columns 32 cn .. + 31 and the taps 4 kp .. 4 kp + 3: 32 x 256
+// weights split three ways = 16 steps x (hi, mid, lo) operand tuples of v_mfma_f32_32x32x16_bf16 = 192 registers per lane, bound to the
+// accumulation half of the register file.  The slab holds the LayerNorm-ed rows as THREE bf16 planes per row (hi | mid | lo, 128 bytes each,
+// row stride 25 sixteen-byte slots, segment skew 1 slot: the 7-row jump at a sequence boundary becomes 176 slots = 0 mod 16), written by the
+// staging threads - a lane's ds_read_b128 is a finished operand tuple.  Per tile and wave: 2 row tiles x 16 steps x 6 products = 192 MFMAs of
+// 32 cycles (the fp32 fast-FIR kernel: 768 of 32) and 96 fragment reads; the two tap halves of a column block are added through LDS in the
+// write-back (each wave of a pair hands one row tile over and stores the other).  Product order per accumulator as mma32<6>.
+#ifndef WS6_ABL
+#define WS6_ABL 0  // ablation builds (tools/ffa_ablate.sh ws6; wrong results, timing only): 1 no staging, 2 no write-back, 4 no fetch, 8 no barriers, 16 no fragment reads
+#endif
+constexpr int kW6Row = 100;  // floats per slab row
+constexpr int kW6Skew = 4;   // floats per segment index
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void unfold_ws6_kernel(SeqMap map, const float* __restrict__ src,
+                                                                                                        const float* __restrict__ gamma,
+                                                                                                        const float* __restrict__ beta,
+                                                                                                        const float* __restrict__ Wt, float* __restrict__ dst,
+                                                                                                        int S, int total_tiles) {
+    constexpr int NIT = (kFlatRows * 16 + 255) / 256;  // 6
+    __shared__ __attribute__((aligned(16))) float slab[2][(kFlatRows + 1) * kW6Row + 2 * kW6Skew];  // (+ one scratch row)
+    __shared__ __attribute__((aligned(16))) float red[4][4 * 64 * 4];  // per wave: the row tile it hands to its partner, [register group][lane]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int cn = w & 1, kp = w >> 1;
+    const int xcd = blockIdx.x & 7, qd = (blockIdx.x >> 3) & 3, slot = xcd + 8 * (blockIdx.x >> 5), nslots = gridDim.x >> 2;
+    const int c4 = (threadIdx.x & 15) * 4;
+    const float4 g4 = ld4(gamma + c4), b4 = ld4(beta + c4);
+    const int L = map.L;
+#ifdef UW_TIMING
+    const unsigned long long uw_t0 = __builtin_amdgcn_s_memtime();
+#endif
+
+    // step s = tap 4 kp + s / 4, channels 16 (s % 4) + 8 kh .. + 7 of column 64 qd + 32 cn + i
+    bf16x8 whi[16], wmid[16], wlo[16];
+    {
+        const float* wp = Wt + (size_t)(64 * qd + 32 * cn + i) * 512 + 256 * kp + 8 * kh;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const Frag f = frag_split3(ld4(wp + 16 * s), ld4(wp + 16 * s + 4));
+            whi[s] = f.hi, wmid[s] = f.mid, wlo[s] = f.lo;
+        }
+    }
+
+    const int t0 = (int)((long long)total_tiles * slot / nslots), t1 = (int)((long long)total_tiles * (slot + 1) / nslots);
+    if (t0 >= t1) return;
+    auto tile_of = [&](int gt) {
+        FlatTile t;
+        t.r0 = gt * 64;
+        t.s0 = (int)__umulhi((unsigned)t.r0, map.magicL);  // = r0 / L (exact: S L^2 < 2^32, checked by the launcher)
+        t.l0 = t.r0 - t.s0 * L;
+        t.n0 = min(L - t.l0, 64);
+        t.n1 = min(L, 64 - t.n0);
+        return t;
+    };
+    auto slab_row = [&](const FlatTile& t, int j, int& sq, int& pos, int& g) {  // slab row j of a tile -> (sequence, position, segment)
+        const int e0 = t.n0 + 7, e1 = e0 + t.n1 + 7;
+        g = (j >= e0) + (j >= e1);
+        const int jj = j - (g == 0 ? 0 : (g == 1 ? e0 : e1));
+        sq = t.s0 + g;
+        pos = (g == 0 ? t.l0 : 0) + jj;
+    };
+    float4 sraw[NIT];
+    unsigned sinfo[NIT];  // float offset of this thread's 8 hi bytes in the slab (scratch row behind the slab for rows past it)
+    FlatTile tf;
+    auto fetch_begin = [&](int tile) { tf = tile_of(min(tile, t1 - 1)); };  // (tiles past the end re-fetch the last one: L2 hits, never used)
+    auto fetch1 = [&](int it) {
+        const int j = (int)(threadIdx.x >> 4) + 16 * it;
+        const bool inr = j < kFlatRows;
+        int sq, pos, g;
+        slab_row(tf, min(j, kFlatRows - 1), sq, pos, g);
+        sraw[it] = ld4_off(src, map.off32(min(sq, S - 1), min(pos, map.npos - 1)) + (threadIdx.x & 15) * 16u);
+        sinfo[it] = (unsigned)((inr ? j * kW6Row + g * kW6Skew : kFlatRows * kW6Row + 2 * kW6Skew) + (c4 >> 1));
+    };
+    // LayerNormalization4D over the 64 channels of a position (normalizations.py:33-37) and the three-way split (residues exact in fp32), in four
+    // pieces of <= ~15 instructions.  Each piece ends by passing its results through an empty volatile asm: sched_barrier only binds the machine
+    // scheduler, the instruction selector is free to sink pure arithmetic to its first use - it merged three pieces into one MFMA gap otherwise.
+    float4 ln_d, sp_r;
+    float ln_s;
+    auto pin4 = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+    auto stage_a = [&](int it) {
+        const float4 v = sraw[it];
+        const float mean = row16_sum(((v.x + v.y) + v.z) + v.w) * (1.f / 64.f);
+        ln_d = f4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+        pin4(ln_d);
+    };
+    auto stage_b = [&]() {
+        ln_s = __builtin_amdgcn_rsqf(row16_sum(fmaf(ln_d.w, ln_d.w, fmaf(ln_d.z, ln_d.z, fmaf(ln_d.y, ln_d.y, ln_d.x * ln_d.x)))) * (1.f / 64.f) + kEps);
+        asm volatile("" : "+v"(ln_s));
+    };
+    auto stage_c = [&](float* sl, int it) {
+        const float4 y = f4(fmaf(ln_d.x * ln_s, g4.x, b4.x), fmaf(ln_d.y * ln_s, g4.y, b4.y), fmaf(ln_d.z * ln_s, g4.z, b4.z), fmaf(ln_d.w * ln_s, g4.w, b4.w));
+        const unsigned h0 = pk_bf16(y.x, y.y), h1 = pk_bf16(y.z, y.w);
+        sp_r = f4(y.x - __uint_as_float(h0 << 16), y.y - __uint_as_float(h0 & 0xffff0000u), y.z - __uint_as_float(h1 << 16),
+                  y.w - __uint_as_float(h1 & 0xffff0000u));
+        *reinterpret_cast<float2*>(sl + sinfo[it]) = make_float2(__uint_as_float(h0), __uint_as_float(h1));
+        pin4(sp_r);
+    };
+    auto stage_d = [&](float* sl, int it) {
+        const float4 r = sp_r;
+        const unsigned m0 = pk_bf16(r.x, r.y), m1 = pk_bf16(r.z, r.w);
+        const unsigned l0 = pk_bf16(r.x - __uint_as_float(m0 << 16), r.y - __uint_as_float(m0 & 0xffff0000u));
+        const unsigned l1 = pk_bf16(r.z - __uint_as_float(m1 << 16), r.w - __uint_as_float(m1 & 0xffff0000u));
+        float* o = sl + sinfo[it];
+        *reinterpret_cast<float2*>(o + 32) = make_float2(__uint_as_float(m0), __uint_as_float(m1));
+        *reinterpret_cast<float2*>(o + 64) = make_float2(__uint_as_float(l0), __uint_as_float(l1));
+    };
+    const long long R = (long long)S * L;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(R * 1024), 0x00020000);
+    // a wave's two row tiles: local 0 = rows 32 kp + i (kept and stored), local 1 = rows 32 (kp ^ 1) + i (handed to the partner wave w ^ 2)
+    const unsigned ocol = (unsigned)((32 * kp + i) * 256 + 64 * qd + 32 * cn + 4 * kh) * 4u;
+    fetch_begin(t0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        stage_a(it);
+        stage_b();
+        stage_c(slab[0], it);
+        stage_d(slab[0], it);
+    }
+    fetch_begin(t0 + 1);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) fetch1(it);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) asm volatile("" : "+a"(whi[s]), "+a"(wmid[s]), "+a"(wlo[s]));  // (see unfold_ws_kernel)
+    __syncthreads();
+    unsigned prev_base = 0xC0000000u;  // no previous tile yet: its stores are dropped by the range check (U0 stays below 2^31 bytes)
+    // slab offset of this lane's output row in its two row tiles, at this wave's first tap
+    auto rows_in = [&](const FlatTile& t, const float* sl, const float* (&bp)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ri = 32 * (m ^ kp) + i, g = (ri >= t.n0) + (ri >= t.n0 + t.n1);
+            bp[m] = sl + (ri + 7 * g + 4 * kp) * kW6Row + g * kW6Skew + 4 * kh;
+        }
+    };
+    // Tile loop unrolled by two (slab / accumulator set A, B) with the other work of a tile in 64 slots between the MFMAs, four per step:
+    //   slots 0-1    the PREVIOUS tile's hand-over row tile -> red;   slot 2: barrier (red complete, every wave has left the previous slab);
+    //   slots 3-26   the NEXT tile's raw rows -> LayerNormalization4D -> three planes -> that slab (four pieces per 16-row group);
+    //   slots 27-31  partner's partial sums (read one slot ahead) + own -> U0 (4 stores);   slots 32-38: the global loads of the tile after next;
+    //   slot  44     barrier: the next slab is complete, red may be overwritten;   slot 58: the next tile's row geometry.
+    floatx16 accA[2], accB[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accA[m][r] = 0.f, accB[m][r] = 0.f;
+    const float* bp[2];
+    float4 eb[2][2][3];  // [buffer][row tile][plane]
+    rows_in(tile_of(t0), slab[0], bp);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) eb[0][m][pl] = ld4(bp[m] + 32 * pl);
+    float* rmine = red[w] + lane * 4;
+    const float* rpart = red[w ^ 2] + lane * 4;
+    auto hand1 = [&](const floatx16 (&h)[2], int g) { st4(rmine + g * 256, acc_group(h[1], g)); };
+    float4 rv;  // the partner's register group, read one slot before it is used
+    auto out0 = [&](int g) { rv = ld4(rpart + g * 256); };
+    auto out1 = [&](const floatx16 (&h)[2], int g, unsigned base) {
+        const float4 v = acc_group(h[0], g) + rv;
+        __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ru,
+                                               (int)(ocol + (base + (unsigned)(g * 32))), 0, 0);
+    };
+    auto tuple = [](float4 v) { return __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}); };
+    auto body = [&](auto par, int tile, floatx16 (&acc)[2], const floatx16 (&accp)[2]) {
+        constexpr int PAR = decltype(par)::value;
+        float* sn = slab[PAR ^ 1];
+        const float* bpn[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        auto piece = [&](int sl_) {
+            if (sl_ == 0 && !(WS6_ABL & 2)) hand1(accp, 0), hand1(accp, 1);
+            if (sl_ == 1 && !(WS6_ABL & 2)) hand1(accp, 2), hand1(accp, 3);
+            if (sl_ == 2 && !(WS6_ABL & 8)) __syncthreads();
+            if (sl_ >= 3 && sl_ < 27 && !(WS6_ABL & 1)) {
+                if ((sl_ - 3) % 4 == 0) stage_a((sl_ - 3) / 4);
+                if ((sl_ - 3) % 4 == 1) stage_b();
+                if ((sl_ - 3) % 4 == 2) stage_c(sn, (sl_ - 3) / 4);
+                if ((sl_ - 3) % 4 == 3) stage_d(sn, (sl_ - 3) / 4);
+            }
+            if (sl_ >= 28 && sl_ < 32 && !(WS6_ABL & 2)) out1(accp, sl_ - 28, prev_base);
+            if (sl_ >= 27 && sl_ < 31 && !(WS6_ABL & 2)) out0(sl_ - 27);
+            if (sl_ == 32) fetch_begin(tile + 2);
+            if (sl_ >= 33 && sl_ < 33 + NIT && !(WS6_ABL & 4)) fetch1(sl_ - 33);
+            if (sl_ == 44 && !(WS6_ABL & 8)) __syncthreads();
+            if (sl_ == 58) rows_in(tile_of(min(tile + 1, t1 - 1)), sn, bpn);
+        };
+        // One step = 12 MFMAs of 32 cycles in four regions of three, each region with one slot of the other work and two of the six fragment reads
+        // of the next step.  A wave issues in order: whatever follows an MFMA hides only under THAT MFMA (~6 instructions), so inside a region the
+        // scheduler is asked (sched_group_barrier) for the pattern MFMA, <= 6 others, MFMA, <= 6 others, MFMA, rest - a block of 15-20 instructions
+        // behind three back-to-back MFMAs cost two thirds of its own issue time (s_memtime build: 9.5k cycles per tile against 6.1k of MFMAs).
+#define WS6_REGION(SLOT)                                         \
+    piece(SLOT);                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x496, 6, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x496, 6, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x496, 8, 0);           \
+    __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float4(&nx)[2][3] = eb[(s + 1) & 1];
+            const float* bn[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) bn[m] = s + 1 < 16 ? bp[m] + ((s + 1) >> 2) * kW6Row + ((s + 1) & 3) * 8 : bpn[m];  // (step 0 of the next tile after the last step)
+            const bool rd = !(WS6_ABL & 16) || s == 15;
+            const bf16x8 h0 = tuple(eb[s & 1][0][0]), m0 = tuple(eb[s & 1][0][1]), l0 = tuple(eb[s & 1][0][2]);
+            const bf16x8 h1 = tuple(eb[s & 1][1][0]), m1 = tuple(eb[s & 1][1][1]), l1 = tuple(eb[s & 1][1][2]);
+            // the two accumulator chains alternate; per accumulator the order of mma32<6>: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+            if (rd) nx[0][0] = ld4(bn[0]), nx[1][0] = ld4(bn[1]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[s], h0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[s], h1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], l0, acc[0], 0, 0, 0);
+            WS6_REGION(4 * s);
+            if (rd) nx[0][2] = ld4(bn[0] + 64), nx[1][2] = ld4(bn[1] + 64);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], l1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wmid[s], m0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wmid[s], m1, acc[1], 0, 0, 0);
+            WS6_REGION(4 * s + 1);
+            if (rd) nx[0][1] = ld4(bn[0] + 32), nx[1][1] = ld4(bn[1] + 32);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wmid[s], h0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wmid[s], h1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], m0, acc[0], 0, 0, 0);
+            WS6_REGION(4 * s + 2);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], m1, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], h0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[s], h1, acc[1], 0, 0, 0);
+            WS6_REGION(4 * s + 3);
+        }
+#undef WS6_REGION
+        bp[0] = bpn[0], bp[1] = bpn[1];
+        prev_base = tile < t1 ? (unsigned)(tile * 64) * 1024u : 0xC0000000u;
+    };
+    // Always whole pairs, without a branch between the two bodies: a range with an odd number of tiles runs its last tile once more as a dummy whose
+    // stores are dropped (<= 1 tile in ~56).  With `if (...) break` in between, the bodies are two basic blocks and hipcc sinks everything the
+    // first one prepares for the second - the global loads of the tile after next, the row geometry, ~200 instructions - to the top of the
+    // second block, in front of its first MFMA.
+#pragma unroll 1
+    for (int tile = t0; tile < t1; tile += 2) {
+        body(std::integral_constant<int, 0>{}, tile, accA, accB);
+        body(std::integral_constant<int, 1>{}, tile + 1, accB, accA);
+    }
+    // the last tile: hand over, barrier, add and store
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hand1(accB, g);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out0(g), out1(accB, g, prev_base);
+#ifdef UW_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(dst) + 2 * blockIdx.x;
+        o[0] = __builtin_amdgcn_s_memtime() - uw_t0;
+        o[1] = (unsigned long long)(t1 - t0);
+    }
+#endif
+}
+
 // Layer-0 kernel, fifth generation (round 5), large batches, fp32: WEIGHT-STATIONARY 2-PARALLEL FAST FIR - 0.75x the MFMAs of the direct form.
 // U[l] = sum_{k<8} W_k x[l + k] is a stride-1 correlation over the sequence with 64 x 256 matrix taps.  With the input phases e[m] = x[2m],
 // o[m] = x[2m + 1] and the even / odd taps We[j] = W_{2j}, Wo[j] = W_{2j+1} (j < 4):
@@ -1829,6 +2090,16 @@ static int unfold_gemm_impl(const float* G, const float* gamma, const float* bet
                 hipLaunchKernelGGL(unfold_ffa_kernel<4>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
             else
                 hipLaunchKernelGGL(unfold_ffa_kernel<3>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, Lv, magicLv, (int)ftiles);
+            RTFS_LAUNCH_CHECK();
+            return RTFS_OK;
+        }
+    }
+    // six-term split, large batch: its own weight-stationary kernel (variant 2 keeps the LDS-staged kernel selectable for A/B)
+    if constexpr (NT == 6) {
+        if ((variant == 0 || variant == 3) && m.L >= 32 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 32) && (long long)S * m.L * m.L < (1LL << 32) &&
+            (long long)S * m.L * 1024 < (1LL << 31) && ((long long)S * m.L + 63) / 64 >= 8 * 64) {
+            const int ftiles = (int)(((long long)S * m.L + 63) / 64);
+            hipLaunchKernelGGL(unfold_ws6_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, m, G, gamma, beta, Wt, U0, S, ftiles);
             RTFS_LAUNCH_CHECK();
             return RTFS_OK;
         }

@@ -255,6 +255,38 @@ def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):
         lib.call("rtfs_dp_unfold_gemm_fwd", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U1, B, T2, dim, 7)
 
 
+@pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (17, 70), (23, 50), (5, 250), (10, 125)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_unfold_gemm_entry_six_term_split(B, T2, dim):
+    """rtfs_dp_unfold_gemm_fwd_bf16 with terms = 6 (fp32 operands split into three bfloat16 values, six MFMAs per product) in isolation against
+    float64 on the CPU.  From 512 flattened 64-row tiles on (and windows per sequence L >= 32) variant 0 is the weight-stationary kernel of this
+    split (unfold_ws6_kernel: operands split once, two tap halves of a column block added through LDS; tiles over two and three sequences, ragged
+    ends, tile ranges with an odd count = the dummy tile); below that and as variant 2, the LDS-staged kernel that splits in registers.  The split
+    keeps all 24 mantissa bits of both operands: same bound as the fp32 kernels, every output row on its own as well."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(100 * B + T2 + dim + 6)
+    G = torch.randn(B, T2, 64, 64, generator=g)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    Wt = torch.randn(256, 512, generator=g) * 0.05
+    x = G.double()
+    xn = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    seqs = xn.reshape(B * T2, 64, 64) if dim == 4 else xn.permute(0, 2, 1, 3).reshape(B * 64, T2, 64)  # [S][npos][64]
+    L = seqs.shape[1] - 7
+    win = torch.stack([seqs[:, k:k + L] for k in range(8)], dim=2).reshape(seqs.shape[0], L, 512)  # k index = tap * 64 + channel
+    want = win @ Wt.double().t()
+    out = {}
+    for variant in (0, 2):
+        U = torch.full((seqs.shape[0] * L * 256,), float("nan"), device="cuda")
+        lib.call("rtfs_dp_unfold_gemm_fwd_bf16", G.cuda(), gamma.cuda(), beta.cuda(), Wt.cuda(), U, B, T2, dim, variant, 6)
+        out[variant] = U
+        assert rel(U.view(want.shape), want) < 1e-6
+        rows = (U.view(want.shape).double().cpu() - want).norm(dim=-1) / want.norm(dim=-1)
+        assert float(rows.max()) < 3e-6, (variant, float(rows.max()), int(rows.argmax()))
+    weight_stationary = (seqs.shape[0] * L + 63) // 64 >= 512 and L >= 32
+    assert rel(out[0], out[2]) < 1e-6 and (weight_stationary != torch.equal(out[0], out[2]))
+
+
 def test_resid_proj_fusion_matches_separate_calls():
     """Blocks 1..R-2 compute the next block's projection inside the residual kernel: same waveform as the separate kernels (the only
     difference is the summation order of the 256-term projection dot products)."""

@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from rtfs_net_amd import lib
 from rtfs_net_amd.models.hip_path import COMPUTE_DTYPES, pack_bf16
-for dtype in ("f32", "bf16x3", "bf16"):
+for dtype in (sys.argv[1:] or ("f32", "bf16x3", "bf16")):
     prec = COMPUTE_DTYPES[dtype]
     g = torch.Generator().manual_seed(0)
     B, T2 = 32, 125
