@@ -347,12 +347,22 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
         terms = {"bf16": 1, "bf16x3": 3, "bf16x6": 6}.get(a.dtype, 0)
         fl = dp_gemm_flops(a.batch, T2)
         tot_ms = sum(prof)
-        if kern == "rtfs_dp_unfold_gemm_fwd" and terms:
+        if kern == "rtfs_dp_unfold_gemm_fwd" and terms == 6:
+            # six products per fp32-equivalent product: the layer-0 GEMM stays bound by the matrix pipe (and, measured, by the chip's power limit: the
+            # kernel sustains ~1.45 GHz), priced against the bf16 peak / 6
+            ws6 = (a.batch * T2 * (F2 - 7) + 63) // 64 >= 512 and T2 - 7 >= 32
+            roof = {"kernel": ("rtfs::unfold_ws6_kernel (rtfs_dp_unfold_gemm_fwd_bf16, terms 6: LN4D + unfold + SRU layer-0 GEMM, every fp32 operand split once into three "
+                               "bf16 planes, six v_mfma_f32_32x32x16_bf16 per product, weight-stationary, two tap halves of a column block added through LDS)") if ws6 else
+                              "rtfs::unfold_gemm128f_kernel<6> / toeplitz_gemm_kernel (terms 6, LDS-staged forms below 512 row tiles: fragments split in registers)",
+                    "bound": "mfma", "achieved": (fl[4] + fl[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TF / 6, "unit": "TFLOP/s",
+                    "launches": len(prof), "avg_launch_ms": tot_ms / len(prof), "flop_per_launch": (fl[4] + fl[3]) / 2, "traffic": None,
+                    "flops": "algorithmic fp32-equivalent flops (SURVEY 8d) over the dense bf16 MFMA peak / 6"}
+        elif kern == "rtfs_dp_unfold_gemm_fwd" and terms:
             # on the bf16 pipe the layer-0 GEMM is bound by its stage-boundary traffic: read G [B][T2][F2][64], write U0 [S][L][256] (fp32)
             by = {4: 4.0 * (a.batch * T2 * F2 * H + a.batch * T2 * (F2 - 7) * 256), 3: 4.0 * (a.batch * T2 * F2 * H + a.batch * F2 * (T2 - 7) * 256)}
-            roof = {"kernel": (f"rtfs::unfold_ws_kernel<{terms}>" if terms != 6 else "rtfs::unfold_gemm128f_kernel<6>")
+            roof = {"kernel": f"rtfs::unfold_ws_kernel<{terms}>"
                               + " (rtfs_dp_unfold_gemm_fwd_bf16: LN4D + unfold + SRU layer-0 GEMM on v_mfma_f32_32x32x16_bf16, "
-                              "weight-stationary form at large batch; unfold_gemm128f_kernel for the six-term split and below 1024 row tiles)",
+                              "weight-stationary form at large batch; unfold_gemm128f_kernel below 1024 row tiles)",
                     "bound": "hbm", "achieved": (by[4] + by[3]) * (len(prof) // 2) / (tot_ms * 1e-3) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": len(prof), "avg_launch_ms": tot_ms / len(prof),
                     "bytes_per_launch": (by[4] + by[3]) / 2, "traffic": None,

@@ -1729,7 +1729,10 @@ template <bool SAVE_C, int NT = 0, int NW = 8>  // SAVE_C (training): also store
 __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
                                                            const float* __restrict__ bias, float scale_x, float* __restrict__ Hout,
                                                            float* __restrict__ Cout, float* __restrict__ Uout, int S, int L) {
-    constexpr int LDW = 68, LDX = 36;  // LDX: ds_write_b128 of 8 consecutive rows (one lane group) covers 32 distinct banks; the per-step reads are consecutive floats
+    // LDX: ds_write_b128 of 8 consecutive rows (one lane group) covers 32 distinct banks; the per-step reads are consecutive floats
+    // LDW, NT = 6: a weight row is split ONCE, here, into three bf16 planes (hi | mid | lo, 128 bytes each, + 16: 25 sixteen-byte slots) - a lane's
+    // ds_read_b128 is a finished operand tuple (round 5; splitting every fragment read in registers cost ~1300 VALU instructions per 32-step chunk)
+    constexpr int LDW = NT == 6 ? 100 : 68, LDX = 36;
     __shared__ __attribute__((aligned(16))) float Ws[192 * LDW];
     __shared__ __attribute__((aligned(16))) float Xs[NW][2][32 * LDX];  // per wave: x' of the chunk's 32 steps, [dir][step][j]
     // the gate rows (m = 1, 2) are pre-scaled by -log2(e): the recurrence then needs fma, v_exp, add, v_rcp per gate and nothing else
@@ -1741,6 +1744,19 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int idx = threadIdx.x + NW * 64 * k, n = idx >> 4, q4 = (idx & 15) * 4;
+            if constexpr (NT == 6) {
+                const float4 y = stg[k] * (n >= 64 ? kNegLog2e : 1.0f);
+                const unsigned h0 = pk_bf16(y.x, y.y), h1 = pk_bf16(y.z, y.w);
+                const float4 r = f4(y.x - __uint_as_float(h0 << 16), y.y - __uint_as_float(h0 & 0xffff0000u), y.z - __uint_as_float(h1 << 16),
+                                    y.w - __uint_as_float(h1 & 0xffff0000u));
+                const unsigned m0 = pk_bf16(r.x, r.y), m1 = pk_bf16(r.z, r.w);
+                const unsigned l0 = pk_bf16(r.x - __uint_as_float(m0 << 16), r.y - __uint_as_float(m0 & 0xffff0000u));
+                const unsigned l1 = pk_bf16(r.z - __uint_as_float(m1 << 16), r.w - __uint_as_float(m1 & 0xffff0000u));
+                float* o = Ws + n * LDW + (q4 >> 1);
+                *reinterpret_cast<float2*>(o) = make_float2(__uint_as_float(h0), __uint_as_float(h1));
+                *reinterpret_cast<float2*>(o + 32) = make_float2(__uint_as_float(m0), __uint_as_float(m1));
+                *reinterpret_cast<float2*>(o + 64) = make_float2(__uint_as_float(l0), __uint_as_float(l1));
+            } else
             st4(Ws + n * LDW + q4, pack4<NT>(stg[k] * (n >= 64 ? kNegLog2e : 1.0f)));
         }
     }
@@ -1786,7 +1802,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
     for (int ch = 0; ch < nch; ++ch) {
         const int sl0 = ch * 32;
         floatx16 acc[2][3];
-        int woff = i * LDW + 32 * kh;
+        int woff = i * LDW + (NT == 6 ? 16 : 32) * kh;
         asm volatile("" : "+v"(woff));  // opaque per chunk: keeps hipcc from hoisting all 48 weight reads (192 VGPRs) out of the chunk
                                         // loop (the OFFSET is laundered, not the pointer, so the reads stay ds_read_b128)
         const float* wp = Ws + woff;
@@ -1806,8 +1822,36 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tm[ntm++] = __builtin_amdgcn_s_memtime();
 #endif
-        read_group(bb[0], 0);
         Frag fa0, fa1;
+        if constexpr (NT == 6) {
+            // 24 half groups (k octet qq, gate m, direction half hf): three plane reads one half group ahead, six MFMAs; 12 registers of fragments
+            // per buffer (whole groups double-buffered spilled); the x' tile goes out during the first eight
+            auto tuple = [](float4 v) { return __builtin_bit_cast(bf16x8, uint4v{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}); };
+            float4 b6[2][3];
+            auto read_half = [&](float4(&dst)[3], int hg) {
+                const int g = hg >> 1, hf = hg & 1, qq = g / 3, m = g % 3;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[pl] = ld4(wp + (m * 64 + 32 * hf) * LDW + 4 * qq + 32 * pl);
+            };
+            read_half(b6[0], 0);
+#pragma unroll
+            for (int hg = 0; hg < 24; ++hg) {
+                const int g = hg >> 1, hf = hg & 1, qq = g / 3, m = g % 3;
+                if (hg + 1 < 24) read_half(b6[(hg + 1) & 1], hg + 1);
+                if (hg < 8) st4(xw + 4 * hg, kh ? a1[hg] : a0[hg]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 0 && hf == 0) fa0 = frag_split3(a0[2 * qq], a0[2 * qq + 1]);
+                if (m == 0 && hf == 1) fa1 = frag_split3(a1[2 * qq], a1[2 * qq + 1]);
+                const float4(&b)[3] = b6[hg & 1];
+                const Frag bf{tuple(b[0]), tuple(b[2]), tuple(b[1])};  // (hi, lo, mid)
+                if (qq == 0)
+                    acc[hf][m] = mma32_first<6>(hf ? fa1 : fa0, bf);
+                else
+                    mma32<6>(acc[hf][m], hf ? fa1 : fa0, bf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+        read_group(bb[0], 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int qq = g / 3, m = g % 3;
@@ -1844,6 +1888,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sru_layer_kernel(const float* __re
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         if (ch + 1 < nch) load_a(sl0 + 32);
         // Half exchange: v_permlane32_swap X, Y swaps lanes 32-63 of X with lanes 0-31 of Y.  With X = a dir-0 accumulator register and

@@ -213,6 +213,29 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
 
 
+@pytest.mark.parametrize("S,L", [(37, 57), (2100, 57), (130, 118), (9, 33)])
+def test_sru_layer_six_term_split_matches_fp32(S, L):
+    """rtfs_sru_layer_fwd_bf16 with terms = 6 (the 64 -> 192 projection as six bf16 MFMAs per product, weight rows split once into three planes in
+    LDS, h_prev fragments split in registers; recurrence in fp32) against the fp32 entry point: h, and in the training form the cell states and
+    pre-activations, to round-off; both workgroup sizes (8 waves from 2048 sequences), ragged last chunks."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(S + L)
+    h = torch.randn(S, L, 64, generator=g).cuda()
+    W = (torch.randn(192, 64, generator=g) * 0.2).cuda()
+    wc, bias = (torch.randn(128, generator=g) * 0.5).cuda(), (torch.randn(128, generator=g) * 0.5).cuda()
+    ref, cref, uref = torch.empty_like(h), torch.empty_like(h), torch.empty(S * L * 192, device="cuda")
+    lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, ref, cref, uref, S, L)
+    out, out2, cst, U2 = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h), torch.empty_like(uref)
+    lib.call("rtfs_sru_layer_fwd_bf16", h, W, wc, bias, 0.7, out, None, None, S, L, 6)
+    lib.call("rtfs_sru_layer_fwd_bf16", h, W, wc, bias, 0.7, out2, cst, U2, S, L, 6)
+    assert torch.equal(out, out2)
+    # (two fp32-accurate projections that round differently, carried through the recurrence: the relative L2 bound is the check; the largest single element
+    # among 7.7M - a cell state of magnitude ~5 after a run of open forget gates - was 5.3e-5 off at S = 2100)
+    assert float((out - ref).abs().max()) < 2e-4 and float((cst - cref).abs().max()) < 2e-4 and float((U2 - uref).abs().max()) < 2e-5
+    assert rel(out, ref) < 2e-6 and rel(U2, uref) < 2e-6
+
+
 @pytest.mark.parametrize("B,T2", [(5, 125), (13, 40), (8, 40), (5, 77), (9, 16), (10, 125), (17, 70), (23, 50), (5, 250)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_unfold_gemm_entry_flattened_tiles(B, T2, dim):

@@ -1,7 +1,7 @@
 """GPU micro-benchmark of the fused SRU layer entry point (rtfs_sru_layer_fwd: input projection on MFMA inside the recurrence) at the two shapes of the
 bench workload (freq path S = B x 125 sequences of 57 steps, time path S = B x 64 sequences of 118 steps) + an output checksum for A/B runs.
 
-    python tools/sru_bench.py [dtype: f32|bf16|bf16x3] [B]
+    python tools/sru_bench.py [dtype: f32|bf16|bf16x3|bf16x6] [B]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ from rtfs_net_amd import lib  # noqa: E402
 
 
 def main(dtype="f32", B=32):
-    terms = {"f32": 0, "bf16": 1, "bf16x3": 3}[dtype]
+    terms = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}[dtype]
     g = torch.Generator().manual_seed(0)
     W = (torch.randn(192, 64, generator=g) * 0.1).cuda()
     wc = (torch.rand(128, generator=g) * 2 - 1).cuda()
