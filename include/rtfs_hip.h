@@ -90,6 +90,9 @@ int rtfs_dp_convt_fwd(const float* H3, const float* Wt /*[64][512]*/, const floa
  * ConvTranspose mode - three half-rate 4-tap correlations over the zero-padded rows, sums re-ordered), 1 = the direct 8-tap kernels (A/B and tests) */
 int rtfs_dp_convt_fwd_form(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, int variant,
                            void* stream);
+/* out of place: Gout = Gin + ConvTranspose1d(H3) + bias (the training step keeps Gin - the stage's input - for the adjoint: rnn_layers.py:146-156 under autograd);
+ * Gin == Gout is rtfs_dp_convt_fwd.  The fast-FIR kernel reads Gin directly, the other forms copy it to Gout on the stream first. */
+int rtfs_dp_convt_fwd_to(const float* H3, const float* Wt /*[64][512]*/, const float* bias, const float* Gin, float* Gout, int B, int T2, int dim, void* stream);
 
 /* ---- a8: MultiHeadSelfAttention2D.forward, layers/attention.py:149-189 ------------------------------------- */
 int rtfs_attn_qkv_fwd(const float* G, const float* Wt /*[96][64]*/, const float* bias, const float* slope, const float* gq, const float* bq,
@@ -98,6 +101,9 @@ int rtfs_attn_qkv_fwd(const float* G, const float* Wt /*[96][64]*/, const float*
 int rtfs_attn_core_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null /*[B][4][T2], training*/, int B, int T2, void* stream);
 int rtfs_attn_out_fwd(const float* O, const float* W /*[64][64] out,in*/, const float* bias, float slope, const float* gamma_fc, const float* beta_fc,
                       float* G /*in place*/, float* Ypre_or_null /*[B*T2][64 f][64 co], training*/, int B, int T2, void* stream);
+/* out of place: Gout = Gin + LN4D(PReLU(out-projection of O)) (attention.py:183-189; the training step keeps Gin, the attention's input); Gin == Gout is the call above */
+int rtfs_attn_out_fwd_to(const float* O, const float* W /*[64][64] out,in*/, const float* bias, float slope, const float* gamma_fc, const float* beta_fc,
+                         const float* Gin, float* Gout, float* Ypre_or_null, int B, int T2, void* stream);
 
 /* The three readers of gLN(D0) in one pass: rtfs_dwconv_fwd(mode 1, stride 1, w1 -> out1: fusion_layers[0].local_embedding, fusion.py:25-52),
  * rtfs_dwconv_fwd(mode 1, stride 2, w2 + bias2 -> out2: downsample_layers[1], tdanet.py:112-114) and the adaptive_avg_pool2d(gLN(D0)) term of
@@ -327,12 +333,15 @@ int rtfs_dp_unfold_gemm_fwd_bf16(const float* G, const float* gamma, const float
 int rtfs_sru_layer_fwd_bf16(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout,
                             float* Cout_or_null, float* Uout_or_null, int S, int L, int terms, void* stream);
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream);
+int rtfs_dp_convt_fwd_to_bf16(const float* H3, const void* Wpk, const float* bias, const float* Gin, float* Gout, int B, int T2, int dim, int terms, void* stream);
 int rtfs_attn_qkv_fwd_bf16(const float* G, const void* Wpk, const float* bias, const float* slope, const float* gq, const float* bq, const float* gk,
                            const float* bk, const float* gv, const float* bv, float* Q, float* K, float* V, float* Ypre_or_null, int B, int T2, int terms,
                            void* stream);
 int rtfs_attn_core_fwd_bf16(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, int terms, void* stream);
 int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
                            float* Ypre_or_null, int B, int T2, int terms, void* stream);
+int rtfs_attn_out_fwd_to_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, const float* Gin,
+                              float* Gout, float* Ypre_or_null, int B, int T2, int terms, void* stream);
 int rtfs_resid_fwd_bf16(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                         const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b,
                         const float* cgate, const double* cgate_stats, const float* cgate_g, const float* cgate_b, const void* Wpk, const float* bias,

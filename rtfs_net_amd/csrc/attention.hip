@@ -455,14 +455,15 @@ __global__ __launch_bounds__(256) void attn_core_long_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// out-projection + PReLU + LN4D over (64, F) + residual, one token per workgroup, in place on G.
+// out-projection + PReLU + LN4D over (64, F) + residual, one token per workgroup: G = Gres + LN(...) (Gres == G: in place; the two may alias exactly, hence
+// no __restrict__ on them).
 // Computes Y^T[co][f] = W[co][c] . X[c][f] so the O layout [c][f] is consumed without a transpose.
 // gamma/beta are host-permuted to [f][c].
 // ------------------------------------------------------------------------------------------------
 template <int NT = 0>  // NT != 0: W host-PACKED
 __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__ O, const float* __restrict__ W, const float* __restrict__ bias,
                                                        float slope, const float* __restrict__ gamma_fc, const float* __restrict__ beta_fc,
-                                                       float* __restrict__ G, float* __restrict__ Ypre) {
+                                                       const float* Gres, float* G, float* __restrict__ Ypre) {
     constexpr int LD = 68, LDY = 65;
     __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
     __shared__ __attribute__((aligned(16))) float Xs[64 * LD];
@@ -515,13 +516,14 @@ __global__ __launch_bounds__(256) void attn_out_kernel(const float* __restrict__
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) * (1.f / 4096.f) + kEps);
     float* g = G + tok * 4096;
+    const float* gr = Gres + tok * 4096;
     // residual update in 16-byte pieces: a thread owns 4 consecutive channels of one frequency bin (gamma / beta / G are [f][c])
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int i = (threadIdx.x + it * 256) * 4;
         const int f = i >> 6, c = i & 63;
         const float4 y = f4(Ys[c * LDY + f], Ys[(c + 1) * LDY + f], Ys[(c + 2) * LDY + f], Ys[(c + 3) * LDY + f]);
-        const float4 ga = ld4(gamma_fc + i), be = ld4(beta_fc + i), g0 = ld4(g + i);
+        const float4 ga = ld4(gamma_fc + i), be = ld4(beta_fc + i), g0 = ld4(gr + i);
         st4(g + i, f4(fmaf((y.x - mean) * rstd, ga.x, be.x) + g0.x, fmaf((y.y - mean) * rstd, ga.y, be.y) + g0.y, fmaf((y.z - mean) * rstd, ga.z, be.z) + g0.z,
                       fmaf((y.w - mean) * rstd, ga.w, be.w) + g0.w));
     }
@@ -565,9 +567,9 @@ static int attn_core_impl(const float* Q, const float* K, const float* V, float*
 
 template <int NT>
 static int attn_out_impl(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, float* G,
-                         float* Ypre_or_null, int B, int T2, void* stream) {
+                         float* Ypre_or_null, int B, int T2, void* stream, const float* Gres = nullptr) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
-    hipLaunchKernelGGL(attn_out_kernel<NT>, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null);
+    hipLaunchKernelGGL(attn_out_kernel<NT>, dim3(B * T2), dim3(256), 0, (hipStream_t)stream, O, W, bias, slope, gamma_fc, beta_fc, Gres ? Gres : G, G, Ypre_or_null);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -606,6 +608,18 @@ int rtfs_attn_out_fwd_bf16(const float* O, const void* Wpk, const float* bias, f
     RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream),
                         attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream),
                         attn_out_impl<6>(O, W, bias, slope, gamma_fc, beta_fc, G, Ypre_or_null, B, T2, stream));
+}
+// Gout = Gin + LN(PReLU(out-projection)): the out-of-place form (training step: Gin is the attention's input, kept for the adjoint).  Gin == Gout is the in-place call.
+int rtfs_attn_out_fwd_to(const float* O, const float* W, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, const float* Gin, float* Gout,
+                         float* Ypre_or_null, int B, int T2, void* stream) {
+    return attn_out_impl<0>(O, W, bias, slope, gamma_fc, beta_fc, Gout, Ypre_or_null, B, T2, stream, Gin);
+}
+int rtfs_attn_out_fwd_to_bf16(const float* O, const void* Wpk, const float* bias, float slope, const float* gamma_fc, const float* beta_fc, const float* Gin, float* Gout,
+                              float* Ypre_or_null, int B, int T2, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, attn_out_impl<1>(O, W, bias, slope, gamma_fc, beta_fc, Gout, Ypre_or_null, B, T2, stream, Gin),
+                        attn_out_impl<3>(O, W, bias, slope, gamma_fc, beta_fc, Gout, Ypre_or_null, B, T2, stream, Gin),
+                        attn_out_impl<6>(O, W, bias, slope, gamma_fc, beta_fc, Gout, Ypre_or_null, B, T2, stream, Gin));
 }
 
 }  // extern "C"

@@ -1310,8 +1310,11 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         __builtin_amdgcn_raw_buffer_store_b128(uint4v{__float_as_uint(u[0]), __float_as_uint(u[1]), __float_as_uint(u[2]), __float_as_uint(u[3])}, ru, (int)off, 0, 0);
     };
     floatx4 res[MODE == 1 ? 8 : 1];  // MODE 1: residual rows of G for the previous tile's 8 stores
+    // MODE 1: `beta` carries the tensor the residual rows are read from when the output goes to a different buffer (rtfs_dp_convt_fwd_to: the training
+    // step keeps the input of a dual-path stage for the adjoint - in place it had to copy G first); nullptr = in place
+    const __amdgpu_buffer_rsrc_t rres = MODE == 1 && beta != nullptr ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(beta), 0, (int)(((long long)(S >> map.seq_shift) * map.stride_hi) * 4), 0x00020000) : ru;
     auto res1 = [&](int k) {
-        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(ru, (int)((k & 1) ? oo[k >> 1] : oe[k >> 1]), 0, 0);
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(rres, (int)((k & 1) ? oo[k >> 1] : oe[k >> 1]), 0, 0);
         res[MODE == 1 ? k : 0] = floatx4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
     };
     auto out1 = [&](const floatx4 (&h)[3][4], int k) {
@@ -2190,8 +2193,10 @@ int rtfs::convt_bwd_input_ffa(const float* dG, const float* Wt, float* dH3, int 
 }
 
 template <int NT>
-static int convt_impl(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream, int variant = 0) {
+// Gres: the tensor the residual is read from (nullptr or G: in place).  Only the fast-FIR kernel reads it directly; every other form copies it to G first.
+static int convt_impl(const float* H3, const float* Wt, const float* bias, float* G, int B, int T2, int dim, void* stream, int variant = 0, const float* Gres = nullptr) {
     if ((dim != 3 && dim != 4) || B <= 0 || T2 < 8) return RTFS_EINVAL;
+    if (Gres == G) Gres = nullptr;
     SeqMap m = make_map(dim, B, T2);
     const int S = dim == 4 ? B * T2 : B * kF2;
     const int tps = (m.npos + 63) / 64, total = S * tps;
@@ -2203,13 +2208,14 @@ static int convt_impl(const float* H3, const float* Wt, const float* bias, float
             ftiles >= 4 * 256) {
             const unsigned magicLv = (unsigned)((1ULL << 32) / (unsigned)Lv) + 1u;
             if (dim == 4)
-                hipLaunchKernelGGL((unfold_ffa_kernel<4, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, nullptr, Wt, G, S, Lv, magicLv, (int)ftiles);
+                hipLaunchKernelGGL((unfold_ffa_kernel<4, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, Gres, Wt, G, S, Lv, magicLv, (int)ftiles);
             else
-                hipLaunchKernelGGL((unfold_ffa_kernel<3, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, nullptr, Wt, G, S, Lv, magicLv, (int)ftiles);
+                hipLaunchKernelGGL((unfold_ffa_kernel<3, 1>), dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, bias, Gres, Wt, G, S, Lv, magicLv, (int)ftiles);
             RTFS_LAUNCH_CHECK();
             return RTFS_OK;
         }
     }
+    if (Gres != nullptr && hipMemcpyAsync(G, Gres, (size_t)B * T2 * kF2 * kH * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return RTFS_ELAUNCH;
     // fp32 (variant 1), bf16 modes; large batch (>= 3 tile pairs per CU - measured: 84.6 vs 90.5 us at 3.9 pairs, 49.4 vs 47.6 us at 2; 32-bit offsets): the direct weight-stationary kernel
     if ((NT == 0 || NT == 1 || NT == 3) && total >= 2 * 3 * 256 && (long long)B * T2 * kF2 * kH * 4 < (1LL << 31) && (long long)S * m.L * 256 < (1LL << 31)) {
         hipLaunchKernelGGL(convt_ws_kernel<(NT == 6 ? 0 : NT)>, dim3(256), dim3(256), 0, (hipStream_t)stream, m, H3, Wt, bias, G, S, tps, total);
@@ -2250,6 +2256,16 @@ int rtfs_dp_convt_fwd_form(const float* H3, const float* Wt, const float* bias, 
 int rtfs_dp_convt_fwd_bf16(const float* H3, const void* Wpk, const float* bias, float* G, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
     RTFS_TERMS_DISPATCH(terms, convt_impl<1>(H3, W, bias, G, B, T2, dim, stream), convt_impl<3>(H3, W, bias, G, B, T2, dim, stream), convt_impl<6>(H3, W, bias, G, B, T2, dim, stream));
+}
+// Gout = Gin + convT(H3) + bias: the out-of-place form (training step: Gin is kept for the adjoint; no copy of G in front of an in-place launch).  Gin == Gout
+// is the in-place call.  The fp32 fast-FIR kernel reads Gin directly; every other form copies Gin to Gout on the stream and runs in place.
+int rtfs_dp_convt_fwd_to(const float* H3, const float* Wt, const float* bias, const float* Gin, float* Gout, int B, int T2, int dim, void* stream) {
+    return convt_impl<0>(H3, Wt, bias, Gout, B, T2, dim, stream, 0, Gin);
+}
+int rtfs_dp_convt_fwd_to_bf16(const float* H3, const void* Wpk, const float* bias, const float* Gin, float* Gout, int B, int T2, int dim, int terms, void* stream) {
+    const float* W = (const float*)Wpk;
+    RTFS_TERMS_DISPATCH(terms, convt_impl<1>(H3, W, bias, Gout, B, T2, dim, stream, 0, Gin), convt_impl<3>(H3, W, bias, Gout, B, T2, dim, stream, 0, Gin),
+                        convt_impl<6>(H3, W, bias, Gout, B, T2, dim, stream, 0, Gin));
 }
 
 // km = 4: U [S][L][64][4];  km = 3: U [S][L][3][64] and X [S][L][64].  wc, bias: [2][64] (forget | reset).  H: [S][L][64].

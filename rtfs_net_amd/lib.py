@@ -46,9 +46,11 @@ SIGNATURES = {
     "rtfs_gemm_rows_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd": [P, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd_form": [P, P, P, P, I, I, I, I, P],
+    "rtfs_dp_convt_fwd_to": [P, P, P, P, P, I, I, I, P],
     "rtfs_attn_qkv_fwd": [P] * 14 + [I, I, P],
     "rtfs_attn_core_fwd": [P, P, P, P, P, I, I, P],
     "rtfs_attn_out_fwd": [P, P, P, F, P, P, P, P, I, I, P],
+    "rtfs_attn_out_fwd_to": [P, P, P, F, P, P, P, P, P, I, I, P],
     "rtfs_tfar_mix_fwd": [P] * 13 + [I, I, I, I, I, P],
     "rtfs_dwconv_trio_fwd": [P] * 12 + [I, I, I, P],
     "rtfs_pool_add_fwd": [P] * 6 + [I, I, P],
@@ -117,9 +119,11 @@ SIGNATURES = {
     "rtfs_dp_unfold_gemm_fwd_bf16": [P, P, P, P, P, I, I, I, I, I, P],
     "rtfs_sru_layer_fwd_bf16": [P, P, P, P, F, P, P, P, I, I, I, P],
     "rtfs_dp_convt_fwd_bf16": [P, P, P, P, I, I, I, I, P],
+    "rtfs_dp_convt_fwd_to_bf16": [P, P, P, P, P, I, I, I, I, P],
     "rtfs_attn_qkv_fwd_bf16": [P] * 14 + [I, I, I, P],
     "rtfs_attn_core_fwd_bf16": [P, P, P, P, P, I, I, I, P],
     "rtfs_attn_out_fwd_bf16": [P, P, P, F, P, P, P, P, I, I, I, P],
+    "rtfs_attn_out_fwd_to_bf16": [P, P, P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_resid_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, I, I, I, I, P],
     "rtfs_resid_proj_fwd_bf16": [P] * 16 + [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, I, I, P],
     "rtfs_resid_caf_fwd_bf16": [P] * 16 + [P, P, P, P, P, F] + [P] * 6 + [I, I, P, P, P, P, P, I, I, I, I, I, P],

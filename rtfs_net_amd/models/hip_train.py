@@ -112,8 +112,8 @@ def _acc(gr, key, n, dev):
 
 # entry points whose contraction runs on MFMA and that have a *_bf16 sibling (include/rtfs_hip.h); everything else is fp32 in every mode
 _MFMA_ENTRY_POINTS = frozenset((
-    "rtfs_bottleneck_fwd", "rtfs_proj_fwd", "rtfs_dp_unfold_gemm_fwd", "rtfs_sru_layer_fwd", "rtfs_dp_convt_fwd", "rtfs_attn_qkv_fwd", "rtfs_attn_core_fwd",
-    "rtfs_attn_out_fwd", "rtfs_resid_fwd", "rtfs_resid_proj_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_decoder_mask_bwd", "rtfs_fold_gemm_bwd",
+    "rtfs_bottleneck_fwd", "rtfs_proj_fwd", "rtfs_dp_unfold_gemm_fwd", "rtfs_sru_layer_fwd", "rtfs_dp_convt_fwd", "rtfs_dp_convt_fwd_to", "rtfs_attn_qkv_fwd", "rtfs_attn_core_fwd",
+    "rtfs_attn_out_fwd", "rtfs_attn_out_fwd_to", "rtfs_resid_fwd", "rtfs_resid_proj_fwd", "rtfs_mask_fwd", "rtfs_gemm_rows", "rtfs_wgrad", "rtfs_proj_gateway_bwd", "rtfs_decoder_mask_bwd", "rtfs_fold_gemm_bwd",
     "rtfs_convt_bwd_input"))
 
 
@@ -223,7 +223,7 @@ class HipTrainer:
         S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
         L = npos - 7
         dev = G.device
-        save.G_in = G.clone()
+        save.G_in = G  # kept for the adjoint: the stage's output goes to a new buffer (rtfs_dp_convt_fwd_to; in place, G had to be copied first)
         save.U, save.h, save.c = [], [], []
         U0 = torch.empty(S * L * 256, device=dev)
         self._call("rtfs_dp_unfold_gemm_fwd", G, d["g"], d["b"], d["w0"], U0, B, T2, dim, 0)
@@ -238,7 +238,9 @@ class HipTrainer:
             self._call("rtfs_sru_layer_fwd", h, lw["w"], lw["wc"], lw["bias"], lw["scale_x"], h2, c2, U, S, L)  # projection fused, U / c saved
             save.U.append(U), save.h.append(h2), save.c.append(c2)
             h = h2
-        self._call("rtfs_dp_convt_fwd", h, d["ct_w"], d["ct_b"], G, B, T2, dim)
+        Gout = torch.empty_like(G)
+        self._call("rtfs_dp_convt_fwd_to", h, d["ct_w"], d["ct_b"], G, Gout, B, T2, dim)
+        return Gout
 
     def _block_fwd(self, s_in, out, a0_or_none, bw, st, B, T, T2, y0=None, next_proj=None):
         """`y0`: this block's projection output when the previous block's residual kernel already produced it; `next_proj` = (y0 buffer,
@@ -266,10 +268,10 @@ class HipTrainer:
         self._call("rtfs_pool_add_fwd", pooled, k.D1, st[2], d1g, d1be, G, B, T2)
         del pooled
         k.dp = [Ctx(), Ctx()]
-        self._dual_path_fwd(G, bw["dp0"], B, T2, 4, k.dp[0])
-        self._dual_path_fwd(G, bw["dp1"], B, T2, 3, k.dp[1])
+        G = self._dual_path_fwd(G, bw["dp0"], B, T2, 4, k.dp[0])
+        G = self._dual_path_fwd(G, bw["dp1"], B, T2, 3, k.dp[1])
         a = bw["attn"]
-        k.G2 = G.clone()
+        k.G2 = G  # the attention's input, kept for the adjoint (rtfs_attn_out_fwd_to writes a new buffer)
         k.Q = torch.empty(B * 4 * T2 * 256, device=dev)
         k.K = torch.empty_like(k.Q)
         k.V = torch.empty(B * 4 * T2 * 1024, device=dev)
@@ -279,7 +281,8 @@ class HipTrainer:
         k.LSE = torch.empty(B * 4 * T2, device=dev)
         self._call("rtfs_attn_core_fwd", k.Q, k.K, k.V, k.O, k.LSE, B, T2)
         k.Ypre_o = torch.empty(B * T2 * 4096, device=dev)
-        self._call("rtfs_attn_out_fwd", k.O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], G, k.Ypre_o, B, T2)
+        G = torch.empty_like(k.G2)
+        self._call("rtfs_attn_out_fwd_to", k.O, a["ow"], a["ob"], a["oslope"], a["og"], a["obe"], k.G2, G, k.Ypre_o, B, T2)
         k.G3 = G
         f0l, f0g, f0gate = bw["fusion_layers.0.local_embedding"], bw["fusion_layers.0.global_embedding"], bw["fusion_layers.0.global_gate"]
         f1l, f1g, f1gate = bw["fusion_layers.1.local_embedding"], bw["fusion_layers.1.global_embedding"], bw["fusion_layers.1.global_gate"]

@@ -616,6 +616,36 @@ def test_convt_entry_isolated(B, T2, dim, terms, tol):
         assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
         with pytest.raises(RuntimeError):
             lib.call("rtfs_dp_convt_fwd_form", H3.cuda(), W.cuda(), bias.cuda(), G1, B, T2, dim, 2)
+    # the out-of-place form (training step: the stage's input survives for the adjoint): the same bits as the in-place call, the input untouched
+    Gin, Gout = G0.clone().cuda(), torch.full_like(G, float("nan"))
+    if terms:
+        lib.call("rtfs_dp_convt_fwd_to_bf16", H3.cuda(), pack_bf16(W.cuda()), bias.cuda(), Gin, Gout, B, T2, dim, terms)
+    else:
+        lib.call("rtfs_dp_convt_fwd_to", H3.cuda(), W.cuda(), bias.cuda(), Gin, Gout, B, T2, dim)
+    assert torch.equal(Gout, G) and torch.equal(Gin.cpu(), G0)
+
+
+def test_attn_out_entry_in_place_and_out_of_place():
+    """rtfs_attn_out_fwd (out-projection 64 -> 64 over the channels of every (token, frequency) + PReLU + LayerNorm over (64, F) + residual, attention.py:183-189)
+    against float64, and its out-of-place form rtfs_attn_out_fwd_to (training step: the attention's input survives for the adjoint): the same bits, input untouched."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(5)
+    B, T2 = 3, 21
+    O = torch.randn(B * T2, 64, 64, generator=g)  # [token][c][f]
+    W, bias, slope = torch.randn(64, 64, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1, 0.3
+    gamma_fc, beta_fc = torch.rand(64, 64, generator=g) + 0.5, torch.randn(64, 64, generator=g) * 0.1  # [f][c]
+    G0 = torch.randn(B * T2, 64, 64, generator=g)  # [token][f][c]
+    y = torch.einsum("oc,tcf->tof", W.double(), O.double()) + bias.double()[None, :, None]
+    y = torch.where(y >= 0, y, slope * y)
+    mean, var = y.mean(dim=(1, 2), keepdim=True), y.var(dim=(1, 2), unbiased=False, keepdim=True)
+    want = ((y - mean) / torch.sqrt(var + 1e-5)).permute(0, 2, 1) * gamma_fc.double() + beta_fc.double() + G0.double()
+    G, ypre = G0.clone().cuda(), torch.empty(B * T2 * 4096, device="cuda")
+    lib.call("rtfs_attn_out_fwd", O.cuda(), W.cuda(), bias.cuda(), slope, gamma_fc.cuda(), beta_fc.cuda(), G, ypre, B, T2)
+    assert rel(G.cpu(), want) < 2e-6
+    Gin, Gout, ypre2 = G0.clone().cuda(), torch.full_like(G, float("nan")), torch.empty_like(ypre)
+    lib.call("rtfs_attn_out_fwd_to", O.cuda(), W.cuda(), bias.cuda(), slope, gamma_fc.cuda(), beta_fc.cuda(), Gin, Gout, ypre2, B, T2)
+    assert torch.equal(Gout, G) and torch.equal(ypre2, ypre) and torch.equal(Gin.cpu(), G0)
 
 
 @pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125)])
