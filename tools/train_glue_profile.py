@@ -20,12 +20,13 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-ka = prof.key_averages(group_by_stack_n=4)
-rows = [(e.count, e.device_time_total, e.key, e.stack) for e in ka if e.key.startswith("aten::") and e.device_time_total > 0]
+ka = prof.key_averages(group_by_stack_n=14)
+LEAF = ("aten::copy_", "aten::mul", "aten::fill_", "aten::div", "aten::sub", "aten::cat", "aten::add", "aten::add_", "aten::neg", "aten::flip", "aten::clamp_min", "aten::mul_", "aten::stack")
+rows = [(e.count, e.device_time_total, e.key, e.stack) for e in ka if e.key in LEAF and e.device_time_total > 0]
 rows.sort(key=lambda r: -r[1])
 tot = 0
-for c, t, k, st in rows[:45]:
+for c, t, k, st in rows[:60]:
     tot += t
-    s = [x for x in st if "rtfs_net_amd" in x or "bench" in x or "optim" in x]
-    print(f"{c:5d} {t:9.1f} us  {k:28s} {' <- '.join(x.split('/')[-1][:60] for x in s[:2])}")
+    s = [x for x in st if "rtfs_net_amd" in x or "train_glue" in x or "optim" in x or "clip_grad" in x]
+    print(f"{c:5d} {t:9.1f} us  {k:16s} {' <- '.join(x.split('/')[-1][:70] for x in s[:2])}")
 print("sum", sum(r[1] for r in rows))
