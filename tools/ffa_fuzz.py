@@ -1,4 +1,4 @@
-"""Random-shape fuzz of the three fast-FIR entry points (layer-0 unfold GEMM, ConvTranspose1d forward, its input gradient) against float64 on the GPU:
+"""Random-shape fuzz of the three fast-FIR entry points (layer-0 unfold GEMM - also in the six-term split -, ConvTranspose1d forward, its input gradient) against float64 on the GPU:
 every output ROW on its own, at shapes that take the fast-FIR kernels (pair rows per sequence Lv from 21 up, two- to four-sequence tiles, ragged last tile).
     python tools/ffa_fuzz.py [n_shapes] [seed]"""
 import os, sys, random
@@ -32,6 +32,10 @@ def one(B, T2, dim, g):
     U = torch.full((S * L * 256,), float("nan"), device="cuda")
     lib.call("rtfs_dp_unfold_gemm_fwd", G, gamma, beta, W0, U, B, T2, dim, 0)
     out.append(("unfold", rows_err(U.view(S, L, 256), want), (S * ((L + 2) // 2) + 62) // 63 >= 512 and (L + 2) // 2 >= 21))
+    # the same GEMM in the six-term split (unfold_ws6_kernel from 512 flattened 64-row tiles on, L >= 32)
+    U6 = torch.full((S * L * 256,), float("nan"), device="cuda")
+    lib.call("rtfs_dp_unfold_gemm_fwd_bf16", G, gamma, beta, W0, U6, B, T2, dim, 0, 6)
+    out.append(("unfold_x6", rows_err(U6.view(S, L, 256), want), (S * L + 63) // 64 >= 512 and L >= 32))
     # ConvTranspose forward (in place on a copy of G)
     H3 = torch.randn(S, L, 64, generator=g).cuda()
     hp = torch.zeros(S, npos + 14, 64, dtype=torch.float64, device="cuda")
