@@ -648,6 +648,31 @@ def test_attn_out_entry_in_place_and_out_of_place():
     assert torch.equal(Gout, G) and torch.equal(ypre2, ypre) and torch.equal(Gin.cpu(), G0)
 
 
+@pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125), (23, 50)])
+@pytest.mark.parametrize("dim", [4, 3])
+def test_fold_gemm_bwd_entry_isolated(B, T2, dim):
+    """rtfs_fold_gemm_bwd in isolation (input gradient of LN4D-output -> unfold -> layer-0 GEMM, autograd over rnn_layers.py:146-150:
+    dxn[p][c] = sum_k sum_n dU0[p - k][n] W0[n][64 k + c]) against float64, every output row on its own as well (until round 5 this entry point was
+    only covered end to end by the gradient fixtures)."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(11 * B + T2 + dim)
+    S, npos = (B * T2, 64) if dim == 4 else (B * 64, T2)
+    L = npos - 7
+    dU = torch.randn(S, L, 256, generator=g)
+    W0 = torch.randn(256, 512, generator=g) * 0.05  # [n][64 k + c]
+    Wf = W0.view(256, 8, 64).flip(1).permute(2, 1, 0).reshape(64, 2048).contiguous()  # [c][256 k' + n], k' = 7 - k (hip_train.TrainWeights)
+    want = torch.zeros(S, npos, 64, dtype=torch.float64)
+    for k in range(8):
+        want[:, k:k + L] += dU.double() @ W0.double()[:, 64 * k:64 * k + 64]
+    want = want.view(B, T2, 64, 64) if dim == 4 else want.view(B, 64, T2, 64).permute(0, 2, 1, 3)
+    dxn = torch.full((B, T2, 64, 64), float("nan"), device="cuda")
+    lib.call("rtfs_fold_gemm_bwd", dU.cuda(), Wf.cuda(), dxn, B, T2, dim)
+    assert rel(dxn.cpu(), want) < 2e-6
+    rows = (dxn.double().cpu() - want).reshape(-1, 64).norm(dim=-1) / want.reshape(-1, 64).norm(dim=-1)
+    assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
+
+
 @pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_convt_bwd_input_entry_isolated(B, T2, dim):
