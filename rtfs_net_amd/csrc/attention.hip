@@ -160,16 +160,19 @@ __global__ __launch_bounds__(256, 2) void attn_qkv_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 template <int MAXKT, int PREC = 0>  // PREC = the NT of common.h (0 fp32, 1 bf16, 3 split-bf16); Q, K, V, P are packed in registers
 __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restrict__ Q, const float* __restrict__ Kx, const float* __restrict__ V,
-                                                           float* __restrict__ O, float* __restrict__ LSE, int T2) {
+                                                           float* __restrict__ O, float* __restrict__ LSE, int T2, int fsplit) {
     constexpr int LDS_S = MAXKT * 32 + 4;
     __shared__ __attribute__((aligned(16))) float Ss[32 * LDS_S];
+    // fsplit = 2 (small batches, round 5: 16 workgroups per utterance leave a batch-1 launch on 16 of 256 CUs, 41 us): two workgroups per query tile, each
+    // recomputes the tile's scores and softmax (a fifth of the products) and takes one half of the wave's 256 output features - the same arithmetic per
+    // output, so the same bits; gridDim.x = 2 x query tiles, the two halves next to each other on one XCD.
     // Workgroup -> (query tile, head, utterance).  The query tiles of one (head, utterance) pair all read that pair's K and V (640 KB at 2 s): in
     // launch order they would sit on different XCDs (workgroup l runs on XCD l % 8 - observed placement, a speed heuristic only) and every XCD would
     // fetch K / V for itself (round 3: 344 MB fetched per launch against 96 MB of Q / K / V).  Consecutive workgroups OF ONE XCD take the query tiles
     // of one pair instead: pair = (slot / nq) * 8 + xcd with slot = l / 8, so K / V come from HBM once per pair and from that XCD's L2 afterwards.
     int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     {
-        const int nq = gridDim.x, npair = gridDim.y * gridDim.z;
+        const int nq = gridDim.x, npair = gridDim.y * gridDim.z;  // (nq counts the halves of fsplit = 2 as tiles of their own)
         if ((npair & 7) == 0) {
             const int l = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z), slot = l >> 3;
             const int pair = (slot / nq) * 8 + (l & 7);
@@ -177,6 +180,8 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
         }
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const int pass0 = fsplit == 2 ? (qt & 1) : 0, pass1 = fsplit == 2 ? pass0 + 1 : 2;
+    if (fsplit == 2) qt >>= 1;
     const int q0 = qt * 32;
     const int NT = (T2 + 31) / 32;
     const size_t headoff = ((size_t)b * kHeads + h) * T2;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
         }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
-        if (LSE && lane == 0 && q0 + w * 8 + rr < T2) LSE[headoff + q0 + w * 8 + rr] = mx + __logf(sum);  // training: log-sum-exp of the scaled scores
+        if (LSE && lane == 0 && pass0 == 0 && q0 + w * 8 + rr < T2) LSE[headoff + q0 + w * 8 + rr] = mx + __logf(sum);  // training: log-sum-exp of the scaled scores
 #pragma unroll
         for (int j = 0; j < MAXKT / 2; ++j) {
             const int col = lane + j * 64;
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_core_kernel(const float* __restri
 
     // ---- O = P V: two passes of 4 feature tiles (128 features) per wave ----
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = pass0; pass < pass1; ++pass) {
         const int n0 = w * 256 + pass * 128;
         floatx16 acc[4];
 #pragma unroll
@@ -548,19 +553,20 @@ template <int NT>
 static int attn_core_impl(const float* Q, const float* K, const float* V, float* O, float* LSE_or_null, int B, int T2, void* stream) {
     if (B <= 0 || T2 <= 0) return RTFS_EINVAL;
     dim3 grid((T2 + 31) / 32, kHeads, B);
+    const int fsplit = (long long)grid.x * kHeads * B <= 128 ? 2 : 1;  // below half a workgroup per CU: two workgroups per query tile (see attn_core_kernel)
     if (T2 > 1024) {  // past 16.4 s of audio the [32][T2] score tile no longer fits the LDS: key-blocked two-sweep kernel
         hipLaunchKernelGGL((attn_core_long_kernel<NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
     }
     if (T2 <= 128)
-        hipLaunchKernelGGL((attn_core_kernel<4, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<4, NT>), dim3(grid.x * fsplit, grid.y, grid.z), dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2, fsplit);
     else if (T2 <= 256)
-        hipLaunchKernelGGL((attn_core_kernel<8, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<8, NT>), dim3(grid.x * fsplit, grid.y, grid.z), dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2, fsplit);
     else if (T2 <= 512)
-        hipLaunchKernelGGL((attn_core_kernel<16, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<16, NT>), dim3(grid.x * fsplit, grid.y, grid.z), dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2, fsplit);
     else
-        hipLaunchKernelGGL((attn_core_kernel<32, NT>), grid, dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2);
+        hipLaunchKernelGGL((attn_core_kernel<32, NT>), dim3(grid.x * fsplit, grid.y, grid.z), dim3(256), 0, (hipStream_t)stream, Q, K, V, O, LSE_or_null, T2, fsplit);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
