@@ -429,6 +429,10 @@ int rtfs_vp_gate_proj_bwd(const float* dyhat, const float* y, const double* y_st
 int rtfs_vp_attn_param_count(void);
 int rtfs_vp_attn_mask_size(int Tg);
 int rtfs_vp_attn_fwd(const float* g, const float* params, const float* pe, const float* masks_or_null, float* out, int B, int Tg, void* stream);
+/* the same block in eval mode for MORE than 16 pooled tokens (2 <= Tg <= 1024; utterances longer than 5.1 s - the reference has no length limit): no masks, nothing
+ * kept for an adjoint; work: [B][rtfs_vp_attn_long_work_floats(Tg)] floats of device scratch */
+int rtfs_vp_attn_long_work_floats(int Tg);
+int rtfs_vp_attn_long_fwd(const float* g, const float* params, const float* pe, float* out, float* work, int B, int Tg, void* stream);
 int rtfs_vp_attn_bwd(const float* g, const float* params, const float* pe, const float* masks_or_null, const float* dout, float* dg, float* dparams, int B,
                      int Tg, void* stream);
 

@@ -215,6 +215,121 @@ __global__ __launch_bounds__(256) void vp_attn_fwd_kernel(const float* __restric
     va_forward(L, g + (size_t)b * AH * Tg, Pm, pe, masks ? masks + (size_t)b * VaMask::size(Tg) : nullptr, out + (size_t)b * AH * Tg, Tg, red);
 }
 
+// GlobalAttention in EVAL mode for more than AMAXT pooled tokens (utterances longer than 5.1 s: Tg = 27 at 8.5 s, 188 at 120 s; the reference has no length
+// limit, attention.py:28-73 + conv_layers.py:218-259).  Same arithmetic as va_forward without the stochastic layers; the per-token intermediates live in
+// a global workspace instead of LDS (one workgroup per utterance: a workgroup's own global writes are visible to it after a barrier), nothing is
+// kept for an adjoint, and the softmax walks the keys twice (maximum; exponentials, their sum and the weighted values together) instead of holding
+// a row of scores in registers.  work: [B][704 Tg] floats = Y [Tg][64] | QKV [Tg][192] | O [Tg][64] | X1 [64][Tg] | E [128][Tg] | Rd [128][Tg] | DH [64][Tg].
+__global__ __launch_bounds__(256) void vp_attn_long_fwd_kernel(const float* __restrict__ g, const float* __restrict__ Pm, const float* __restrict__ pe,
+                                                               float* __restrict__ out, float* __restrict__ work, int Tg) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* gb = g + (size_t)b * AH * Tg;
+    float* ob = out + (size_t)b * AH * Tg;
+    float* Y = work + (size_t)b * 704 * Tg;
+    float* QKV = Y + AH * Tg;
+    float* O = QKV + 3 * AH * Tg;
+    float* X1 = O + AH * Tg;
+    float* E = X1 + AH * Tg;
+    float* Rd = E + AF * Tg;
+    float* DH = Rd + AF * Tg;
+    for (int t = w; t < Tg; t += 4) {  // LayerNorm over the channels of g^T + positional encoding
+        const float v = gb[lane * Tg + t];
+        const float mean = wave_sum(v) * (1.f / 64.f);
+        const float d = v - mean;
+        const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + kEps);
+        Y[t * AH + lane] = fmaf(d * rstd, Pm[VaOff::ln1g + lane], Pm[VaOff::ln1b + lane]) + pe[t * AH + lane];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Tg * 3 * AH; idx += 256) {  // in-projection
+        const int t = idx / (3 * AH), n = idx - t * 3 * AH;
+        QKV[idx] = va_dot_row<AH>(Pm + VaOff::inw + n * AH, Y + t * AH, 1, Pm[VaOff::inb + n]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < AHEADS * Tg; idx += 256) {  // per (head, query): softmax(q k^T / sqrt(8)) . v
+        const int h = idx / Tg, tq = idx - h * Tg;
+        float q[AHD];
+#pragma unroll
+        for (int e = 0; e < AHD; ++e) q[e] = QKV[tq * 3 * AH + h * AHD + e] * 0.35355339059327373f;
+        float mx = -1e30f;
+        for (int tk = 0; tk < Tg; ++tk) {
+            const float4 k0 = ld4(QKV + tk * 3 * AH + AH + h * AHD), k1 = ld4(QKV + tk * 3 * AH + AH + h * AHD + 4);
+            const float sc = q[0] * k0.x + q[1] * k0.y + q[2] * k0.z + q[3] * k0.w + q[4] * k1.x + q[5] * k1.y + q[6] * k1.z + q[7] * k1.w;
+            mx = fmaxf(mx, sc);
+        }
+        float den = 0.f, o[AHD];
+#pragma unroll
+        for (int e = 0; e < AHD; ++e) o[e] = 0.f;
+        for (int tk = 0; tk < Tg; ++tk) {
+            const float* row = QKV + tk * 3 * AH + h * AHD;
+            const float4 k0 = ld4(row + AH), k1 = ld4(row + AH + 4), v0 = ld4(row + 2 * AH), v1 = ld4(row + 2 * AH + 4);
+            const float sc = q[0] * k0.x + q[1] * k0.y + q[2] * k0.z + q[3] * k0.w + q[4] * k1.x + q[5] * k1.y + q[6] * k1.z + q[7] * k1.w;
+            const float p = __expf(sc - mx);
+            den += p;
+            o[0] = fmaf(p, v0.x, o[0]), o[1] = fmaf(p, v0.y, o[1]), o[2] = fmaf(p, v0.z, o[2]), o[3] = fmaf(p, v0.w, o[3]);
+            o[4] = fmaf(p, v1.x, o[4]), o[5] = fmaf(p, v1.y, o[5]), o[6] = fmaf(p, v1.z, o[6]), o[7] = fmaf(p, v1.w, o[7]);
+        }
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int e = 0; e < AHD; ++e) O[tq * AH + h * AHD + e] = o[e] * inv;
+    }
+    __syncthreads();
+    for (int t = w; t < Tg; t += 4) {  // out-projection + residual (Y), LayerNorm2, transpose back, + block residual g -> X1 [64][Tg]
+        const float v = va_dot_row<AH>(Pm + VaOff::outw + lane * AH, O + t * AH, 1, Pm[VaOff::outb + lane]) + Y[t * AH + lane];
+        const float mean = wave_sum(v) * (1.f / 64.f);
+        const float d = v - mean;
+        const float rstd = 1.0f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + kEps);
+        X1[lane * Tg + t] = fmaf(d * rstd, Pm[VaOff::ln2g + lane], Pm[VaOff::ln2b + lane]) + gb[lane * Tg + t];
+    }
+    __syncthreads();
+    float ls = 0.f, lq = 0.f;
+    for (int idx = tid; idx < AF * Tg; idx += 256) {  // FFN encoder 64 -> 128 (no bias) + gLN over (128, Tg)
+        const int n = idx / Tg, t = idx - n * Tg;
+        const float v = va_dot_row<AH>(Pm + VaOff::encw + n * AH, X1 + t, Tg, 0.f);
+        E[idx] = v;
+        ls += v, lq = fmaf(v, v, lq);
+    }
+    {
+        const float n = (float)(AF * Tg);
+        const float mean = va_block_sum(ls, red) / n;
+        const float var = fmaxf(va_block_sum(lq, red) / n - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + kEps);
+        for (int idx = tid; idx < AF * Tg; idx += 256) {  // (every thread normalises the elements it wrote)
+            const int c = idx / Tg;
+            E[idx] = fmaf((E[idx] - mean) * rstd, Pm[VaOff::encg + c], Pm[VaOff::encb + c]);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < AF * Tg; idx += 256) {  // refiner: depth-wise k = 3 ('same') + bias + ReLU
+        const int c = idx / Tg, t = idx - c * Tg;
+        float v = Pm[VaOff::refb + c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int p = t - 1 + k;
+            if (p >= 0 && p < Tg) v = fmaf(Pm[VaOff::refw + c * 3 + k], E[c * Tg + p], v);
+        }
+        Rd[idx] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    ls = 0.f, lq = 0.f;
+    for (int idx = tid; idx < AH * Tg; idx += 256) {  // decoder 128 -> 64 (no bias) + gLN over (64, Tg) + the FFN residual
+        const int c = idx / Tg, t = idx - c * Tg;
+        const float v = va_dot_row<AF>(Pm + VaOff::decw + c * AF, Rd + t, Tg, 0.f);
+        DH[idx] = v;
+        ls += v, lq = fmaf(v, v, lq);
+    }
+    {
+        const float n = (float)(AH * Tg);
+        const float mean = va_block_sum(ls, red) / n;
+        const float var = fmaxf(va_block_sum(lq, red) / n - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + kEps);
+        for (int idx = tid; idx < AH * Tg; idx += 256) {
+            const int c = idx / Tg;
+            ob[idx] = fmaf((DH[idx] - mean) * rstd, Pm[VaOff::decg + c], Pm[VaOff::decb + c]) + X1[idx];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void vp_attn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ Pm, const float* __restrict__ pe,
                                                           const float* __restrict__ masks, const float* __restrict__ dout, float* __restrict__ dg,
                                                           float* __restrict__ dP, int Tg) {
@@ -477,6 +592,15 @@ int rtfs_vp_attn_fwd(const float* g, const float* params, const float* pe, const
     if (va_set_lds(reinterpret_cast<const void*>(vp_attn_fwd_kernel), set) != RTFS_OK) return RTFS_ELAUNCH;
     hipLaunchKernelGGL(vp_attn_fwd_kernel, dim3(B), dim3(256), VaLds::floats(Tg, false) * sizeof(float), (hipStream_t)stream, g, params, pe, masks_or_null,
                        out, Tg);
+    RTFS_LAUNCH_CHECK();
+    return RTFS_OK;
+}
+
+// eval mode, 2 <= Tg <= 1024 pooled tokens (no masks, nothing kept for an adjoint): work = [B][rtfs_vp_attn_long_work_floats(Tg)] floats of scratch
+int rtfs_vp_attn_long_work_floats(int Tg) { return 704 * Tg; }
+int rtfs_vp_attn_long_fwd(const float* g, const float* params, const float* pe, float* out, float* work, int B, int Tg, void* stream) {
+    if (B <= 0 || Tg < 2 || Tg > 1024) return RTFS_EINVAL;
+    hipLaunchKernelGGL(vp_attn_long_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, g, params, pe, out, work, Tg);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

@@ -112,6 +112,8 @@ SIGNATURES = {
     "rtfs_vp_attn_param_count": [],
     "rtfs_vp_attn_mask_size": [I],
     "rtfs_vp_attn_fwd": [P, P, P, P, P, I, I, P],
+    "rtfs_vp_attn_long_work_floats": [I],
+    "rtfs_vp_attn_long_fwd": [P, P, P, P, P, I, I, P],
     "rtfs_vp_attn_bwd": [P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],

@@ -462,7 +462,7 @@ class HipForward:
                 lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
             elif use_hip and 100 < Tv <= 4096:
                 # longer than the one-kernel form's LDS (4 s): the multi-launch kernels of the training step with running-statistics slots
-                # (models/vp_train.py; GlobalAttention on HIP up to 16 pooled tokens = Tv <= 128, the PyTorch module beyond)
+                # (models/vp_train.py; GlobalAttention on HIP as well: the LDS form up to 16 pooled tokens = Tv <= 128, the workspace form beyond)
                 from .vp_train import vp_block_eval
 
                 v1 = vp_block_eval(vblock, vin, (pw._scal["refinement_module.video_net.blocks.gateway.full_layer.4.weight"],

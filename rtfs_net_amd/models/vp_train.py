@@ -539,7 +539,7 @@ def vp_block_train(trainer: VPTrainer, x: torch.Tensor, slopes=None) -> torch.Te
 @torch.no_grad()
 def vp_block_eval(vb, x, slopes=None):
     """The VP block in eval mode WITHOUT autograd on the multi-launch kernels (any length up to 4096 frames; the one-kernel inference form
-    csrc/vp.hip holds 4 s): stage A, GlobalAttention (HIP up to 16 pooled tokens, else the module), stage B; BatchNorm from the running statistics."""
+    csrc/vp.hip holds 4 s): stage A, GlobalAttention (HIP: the one-workgroup LDS form up to 16 pooled tokens, its workspace form up to 1024; other configurations: the module), stage B; BatchNorm from the running statistics."""
     tr = vb.__dict__.get("_hip_eval_trainer")  # kept on the module itself (not a parameter / buffer / child: invisible to state_dict), dies with it
     if tr is None or tr.bns[0] is not vb.projection.full_layer[3]:
         if not supported(vb):
@@ -553,6 +553,13 @@ def vp_block_eval(vb, x, slopes=None):
         g2 = torch.empty_like(g)
         packed = torch.cat([p.detach().float().reshape(-1) for p in attn_params(ga)])
         lib.call("rtfs_vp_attn_fwd", g, packed, ga.MHSA.pos_enc.pe[0, :g.shape[-1]].float().contiguous(), None, g2, g.shape[0], g.shape[-1])
+    elif attn_supported(ga) and 16 < g.shape[-1] <= 1024 and ga.MHSA.pos_enc.pe.shape[1] >= g.shape[-1]:
+        # more than 16 pooled tokens (utterances longer than 5.1 s): the workspace form of the same arithmetic (csrc/vp_attn.hip vp_attn_long_fwd_kernel)
+        B, _, Tg = g.shape
+        g2 = torch.empty_like(g)
+        packed = torch.cat([p.detach().float().reshape(-1) for p in attn_params(ga)])
+        work = torch.empty(B * lib.load().rtfs_vp_attn_long_work_floats(Tg), device=g.device)
+        lib.call("rtfs_vp_attn_long_fwd", g, packed, ga.MHSA.pos_enc.pe[0, :Tg].float().contiguous(), g2, work, B, Tg)
     else:
         g2 = ga(g)
     return tr.forward_b(st, g2)

@@ -167,6 +167,36 @@ def test_global_attention_hip_training_kernels(B, Tg, drop):
         assert e < 1e-4, (i, tuple(p.shape), e)
 
 
+@pytest.mark.parametrize("B,Tg", [(2, 17), (3, 27), (1, 188), (2, 64), (1, 500)])
+def test_global_attention_hip_eval_more_than_16_tokens(B, Tg):
+    """rtfs_vp_attn_long_fwd (csrc/vp_attn.hip vp_attn_long_fwd_kernel: GlobalAttention in eval mode with its per-token intermediates in a global
+    workspace, utterances longer than 5.1 s: 27 pooled tokens at 8.5 s, 188 at 120 s) against the module itself (attention.py:28-73,
+    conv_layers.py:218-259), and at 16 tokens against the one-workgroup LDS kernel."""
+    from rtfs_net_amd import lib
+    from rtfs_net_amd.models import vp_train as vt
+
+    vb = _block(True)
+    ga = vb.globalatt[0].eval()
+    assert vt.attn_supported(ga)
+    gen = torch.Generator().manual_seed(7 * B + Tg)
+    g = torch.randn(B, 64, Tg, generator=gen).cuda()
+    packed = torch.cat([p.detach().float().reshape(-1) for p in vt.attn_params(ga)])
+    pe = ga.MHSA.pos_enc.pe[0, :Tg].float().contiguous()
+    out = torch.full_like(g, float("nan"))
+    work = torch.empty(B * lib.load().rtfs_vp_attn_long_work_floats(Tg), device="cuda")
+    lib.call("rtfs_vp_attn_long_fwd", g, packed, pe, out, work, B, Tg)
+    with torch.no_grad():
+        ref = ga(g)
+    assert rel(out, ref) < 2e-6
+    g16 = g[:, :, :16].contiguous()
+    a, b = torch.empty_like(g16), torch.empty_like(g16)
+    lib.call("rtfs_vp_attn_fwd", g16, packed, pe[:16].contiguous(), None, a, B, 16)
+    lib.call("rtfs_vp_attn_long_fwd", g16, packed, pe[:16].contiguous(), b, work, B, 16)
+    assert rel(b, a) < 1e-6
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_vp_attn_long_fwd", g, packed, pe, out, work, B, 1025)
+
+
 @pytest.mark.parametrize("B,Tv", [(3, 50), (2, 12), (1, 100), (2, 7), (1, 230)])
 def test_caf_video_side_hip_training_kernels(B, Tv):
     """CAFVideoFn (rtfs_caf_video_fwd + rtfs_caf_video_bwd) against torch autograd over the cell's modules (layers/fusion.py:255,262-265 as the
