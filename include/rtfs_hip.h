@@ -276,7 +276,7 @@ int rtfs_spec_patches(const float* spec, float* patches, int B, int T, void* str
 
 /* ---- a9 / f3: VP block = TDANetBlock with is2d = False (separators/tdanet.py:106-133) + GlobalAttention (layers/attention.py:28-73,
  * 192-220), eval mode, one launch: x, out [B][512][Tv] (NCT, as the reference hands the lip embedding); params: rtfs_vp_param_count()
- * floats packed as VpOff in csrc/vp.hip (BatchNorm1d folded); pe: rows of the PositionalEncoding buffer [>= 16][64].  8 <= Tv <= 100. */
+ * floats packed as VpOff in csrc/vp.hip (BatchNorm1d folded); pe: rows of the PositionalEncoding buffer [>= 16][64].  3 <= Tv <= 100. */
 int rtfs_vp_param_count(void);
 int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, float* out, int B, int Tv, void* stream);
 

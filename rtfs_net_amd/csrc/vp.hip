@@ -349,9 +349,9 @@ extern "C" {
 int rtfs_vp_param_count(void) { return VpOff::total; }
 
 // x, out: [B][512][Tv] (the reference's NCT layout of the lip embedding); params: rtfs_vp_param_count() floats; pe: [>= Tg][64] rows
-// of the positional-encoding buffer.  8 <= Tv <= 100 (25 fps x 4 s).
+// of the positional-encoding buffer.  3 <= Tv <= 100 (25 fps x 4 s).
 int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, float* out, int B, int Tv, void* stream) {
-    if (B <= 0 || Tv < 8 || Tv > VMAXT) return RTFS_EINVAL;
+    if (B <= 0 || Tv < 3 || Tv > VMAXT) return RTFS_EINVAL;  // (1 and 2 frames - 40 / 80 ms of video - do not match the modules: PyTorch glue, hip_path.py)
     int T = Tv, sumT = Tv;
     for (int i = 1; i < 4; ++i) T = (T - 1) / 2 + 1, sumT += T;
     if (T > 16) return RTFS_EINVAL;
