@@ -623,6 +623,9 @@ def test_convt_entry_isolated(B, T2, dim, terms, tol):
     else:
         lib.call("rtfs_dp_convt_fwd_to", H3.cuda(), W.cuda(), bias.cuda(), Gin, Gout, B, T2, dim)
     assert torch.equal(Gout, G) and torch.equal(Gin.cpu(), G0)
+    if not terms:  # Gin == Gout: the in-place call through the out-of-place entry point
+        lib.call("rtfs_dp_convt_fwd_to", H3.cuda(), W.cuda(), bias.cuda(), Gin, Gin, B, T2, dim)
+        assert torch.equal(Gin, G)
 
 
 def test_attn_out_entry_in_place_and_out_of_place():
