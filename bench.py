@@ -513,7 +513,7 @@ def brief(t):
 #     split_bf16x6       the headline workload with --dtype bf16x6: every fp32 operand as three bf16 values, six products on the bf16 MFMA pipe - fp32-EQUIVALENT
 #                        accuracy (every stage within 2e-6 of the fp32 path, tests/test_hip_bf16.py), not the fp32 pipe: reported next to the headline, never as it
 #   in child processes (the training step holds ~60 GB of activations):
-#     training_step / training_step_split_bf16    BASELINE config 3 (`--mode train`), fp32 and bf16x3
+#     training_step / training_step_split_bf16 / training_step_split_bf16x6    BASELINE config 3 (`--mode train`), fp32, bf16x3 and the fp32-equivalent six-term split
 INFER_RIDERS = [
     ("config2", dict(layers=4, batch=16, seconds=2.0, dtype="f32", steps=10, warmup=2)),
     ("config5_bf16x3", dict(layers=12, batch=16, seconds=4.0, dtype="bf16x3", steps=6, warmup=2)),
@@ -620,6 +620,7 @@ def main():
             nt = str(max(2, min(20, args.steps)))
             res["training_step"] = brief(child(["--mode", "train", "--steps", nt, "--warmup", "3"]))
             res["training_step_split_bf16"] = brief(child(["--mode", "train", "--dtype", "bf16x3", "--steps", nt, "--warmup", "3"]))
+            res["training_step_split_bf16x6"] = brief(child(["--mode", "train", "--dtype", "bf16x6", "--steps", "10", "--warmup", "3"]))
     # N > 1, default (inference) line: BASELINE config 4 rides along as `training_step_dp` - the training step under SyncBatchNorm +
     # DistributedDataParallel on the same N GPUs, `--batch` utterances per rank (global batch N x batch), measured by a CHILD
     # `torch.distributed.run` of this script in `--mode train` once every rank of this run has released its GPU: a hang or a failure over there costs

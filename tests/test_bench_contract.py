@@ -62,6 +62,8 @@ def test_single_process_line():
     assert "loop" in res["cpu_baseline"]["sru"]  # (which SRU loop the oracle ran: the C restatement where gcc exists, else the Python one)
     tb = res["training_step_split_bf16"]
     assert tb is not None and tb["dtype"] == "bf16x3" and tb["value"] > 0 and "training step" in tb["workload"]
+    t6 = res["training_step_split_bf16x6"]
+    assert t6 is not None and t6["dtype"] == "bf16x6" and t6["value"] > 0 and "training step" in t6["workload"]
     # the other BASELINE.json configurations ride along at their OWN sizes (bench.py INFER_RIDERS)
     c2, c5, c5b, b1 = res["config2"], res["config5_bf16x3"], res["config5_bf16"], res["latency_b1"]
     assert c2 is not None and "RTFS-Net-4" in c2["workload"] and "batch 16" in c2["workload"] and c2["value"] > 0
