@@ -914,7 +914,7 @@ int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float
     const float* W = (const float*)WpT_pk;
     RTFS_TERMS_DISPATCH(terms, proj_gateway_bwd_impl<1>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream),
                         proj_gateway_bwd_impl<3>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream),
-                        proj_gateway_bwd_impl<6>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream));
+                        proj_gateway_bwd_impl<0>(dy0, W, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream));  // (terms 6: HBM-bound, the fp32 kernel - 1048 against 1140 us)
 }
 
 // dU0: [S][L][256] -> dxn in G layout [B][T2][F2][64] (plain store).  Wt: [64][2048], Wt[c][k'*256+n] = W0t[n][(7-k')*64+c]
@@ -923,7 +923,9 @@ int rtfs_fold_gemm_bwd(const float* dU0, const float* Wt, float* dxn, int B, int
 }
 int rtfs_fold_gemm_bwd_bf16(const float* dU0, const void* Wpk, float* dxn, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, fold_impl<1>(dU0, W, dxn, B, T2, dim, stream), fold_impl<3>(dU0, W, dxn, B, T2, dim, stream), fold_impl<6>(dU0, W, dxn, B, T2, dim, stream));
+    // terms 6 (operands are plain fp32 in this mode): the fp32 kernel - the six-term form of this LDS-staged kernel splits every fragment it reads in registers and
+    // measured 783-891 us against 558-585 (round 5, profiles/r05f_bf16x6_train_kernel_stats.txt); fp32-equivalent either way
+    RTFS_TERMS_DISPATCH(terms, fold_impl<1>(dU0, W, dxn, B, T2, dim, stream), fold_impl<3>(dU0, W, dxn, B, T2, dim, stream), fold_impl<0>(dU0, W, dxn, B, T2, dim, stream));
 }
 
 // dG: G layout -> dH3 [S][L][64].  Wt: [64 j][512], Wt[j][k*64+c] = Wct[j][c][k]
@@ -937,7 +939,8 @@ int rtfs_convt_bwd_input_form(const float* dG, const float* Wt, float* dH3, int 
 }
 int rtfs_convt_bwd_input_bf16(const float* dG, const void* Wpk, float* dH3, int B, int T2, int dim, int terms, void* stream) {
     const float* W = (const float*)Wpk;
-    RTFS_TERMS_DISPATCH(terms, convt_bwd_impl<1>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<3>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<6>(dG, W, dH3, B, T2, dim, stream));
+    // terms 6: the fp32 path (fast-FIR kernel at large batch: 121 us against 244 for the six-term LDS-staged form)
+    RTFS_TERMS_DISPATCH(terms, convt_bwd_impl<1>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<3>(dG, W, dH3, B, T2, dim, stream), convt_bwd_impl<0>(dG, W, dH3, B, T2, dim, stream));
 }
 
 }  // extern "C"

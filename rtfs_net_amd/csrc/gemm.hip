@@ -1685,6 +1685,12 @@ int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_nul
 int rtfs_gemm_rows_bf16(const float* X, const void* Wpk, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, int terms, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const float* W = (const float*)Wpk;
+    // terms 6 (plain fp32 operands): the narrow maps at large M are stream-bound and have a weight-stationary fp32 kernel (rows_ws64_kernel: 60 us against 115
+    // for the six-term LDS-staged form at K = 192) - fp32-equivalent either way
+    if (terms == 6 && N == 64 && bias_or_null == nullptr && M >= 65536 && (long long)M * K * 4 < (1LL << 31) && (K == 192 || K == 96 || K == 64 || (K == 256 && !accumulate)))
+        return rtfs_gemm_rows(X, W, bias_or_null, Y, M, K, N, accumulate, stream);
+    // ... and the 256 x 256 input-gradient GEMMs of the training step: fp32 has the weight-stationary ws256_kernel (1.03 ms), the six-term form here is the LDS-staged one (2.2 ms)
+    if (terms == 6 && K == 256 && N == 256 && !accumulate && M >= 65536) return rtfs_gemm_rows(X, W, bias_or_null, Y, M, K, N, accumulate, stream);
 #define RG(KK, NN, BM, WM, WN)  \
     if (K == KK && N == NN)     \
         RTFS_TERMS_DISPATCH(terms, (rows_gemm<KK, NN, BM, WM, WN, 1>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 3>(X, W, bias_or_null, Y, M, accumulate, st)), (rows_gemm<KK, NN, BM, WM, WN, 6>(X, W, bias_or_null, Y, M, accumulate, st)));
