@@ -275,7 +275,10 @@ __device__ __forceinline__ void mma_block_bn(floatx16 (&acc)[WM][WN], const floa
 //   NT = 6  fp32-equivalent: a = a_hi + a_mid + a_lo carries all 24 mantissa bits of the fp32 operand in three bfloat16 values; the six
 //           products hh, hm, mh, hl, lh, mm are accumulated in fp32, the dropped ml, lm, ll terms are <= 2^-23 |a b| - the size of ONE fp32
 //           rounding.  6 x 32 cycles per K = 16 against 8 x 64 on the fp32 pipe: 2.7x its rate at its accuracy (not bit-identical to it).
-//           Operands stay plain fp32 in HBM and LDS (three planes do not fit the 16-byte slot below) and are split in registers.
+//           Operands stay plain fp32 in HBM; the generic (LDS-staged) kernels keep fp32 tiles in LDS as well (three planes do not fit the 16-byte slot
+//           below) and split every fragment in registers - ~56 VALU instructions per ds_read_b128, which is why the mode's two hottest kernels have their
+//           own forms that split each operand ONCE into three bf16 planes (unfold_ws6_kernel, sru_layer_kernel<., 6, .>: dualpath.hip, round 5), and why
+//           some entry points route this mode to their fp32 kernel where that one is weight-stationary (gemm.hip, bwd_gemm.hip).
 // PACKED SLOT.  The fp32 kernels stage operands k-contiguously as float4 = 4 consecutive k.  The bf16 paths keep every address,
 // stride and swizzle of those layouts and store in the same 16 bytes the 4 hi halves and the 4 lo halves of the same 4 k values:
 //      slot = [hi(k0) hi(k1) | hi(k2) hi(k3) | lo(k0) lo(k1) | lo(k2) lo(k3)]        (4 dwords)
