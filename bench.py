@@ -247,7 +247,14 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
             net = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], bucket_cap_mb=25)
             ar = AllReduceTimer(dist, world)
             net.register_comm_hook(ar, timed_allreduce_hook)  # the default hook's arithmetic (grad / world, sum) with HIP events around it
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+        # optimizer: AdamW + clipping in two HIP launches (rtfs_net_amd.optim.FusedAdamW: torch.optim.AdamW's arithmetic and state_dict, the clip coefficient
+        # formed on the device); --torch-optimizer runs the PyTorch pair instead (clip_grad_norm_ + foreach AdamW: ~15 launches, host-bound ~2 ms per step)
+        if a.torch_optimizer:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
+        else:
+            from rtfs_net_amd.optim import FusedAdamW
+
+            opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.1)
 
         from rtfs_net_amd.losses import PITLossWrapper, pairwise_neg_snr
 
@@ -259,8 +266,11 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
             est = net(mix, emb)
             loss = loss_fn(est, target)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
-            opt.step()
+            if a.torch_optimizer:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+                opt.step()
+            else:
+                opt.step(max_norm=5.0)
             return est.detach()
 
         for _ in range(a.warmup):
@@ -332,6 +342,9 @@ def measure(a, rank, world, local_rank, dist, one_gpu):
                          f"RTFS-Net-{a.layers} training step (forward + backward + AdamW, neg-SNR loss), ")
                         + f"{a.seconds:g} s @16 kHz, batch {a.batch} per GPU, " + DTYPE_TEXT[a.dtype] + ", random-init weights",
             "mode": a.mode + ("+lip-encoder" if a.lip else ""),
+            **({"optimizer": ("torch.optim.AdamW (foreach) + torch.nn.utils.clip_grad_norm_(5.0)" if a.torch_optimizer else
+                              "rtfs_net_amd.optim.FusedAdamW: clip_grad_norm_(5.0) + AdamW(lr 1e-3, wd 0.1) as two HIP launches, torch.optim.AdamW's arithmetic and state")}
+               if a.mode == "train" else {}),
             "global_batch": world * a.batch, "frames_per_utt": T, "utt_per_s": world * a.batch * a.steps / elapsed,
             "parallelism": (f"utterance-sharded x{world} (contiguous shards of one global batch), no data-path collective" if a.mode == "infer" else
                             f"dp{world}: DistributedDataParallel (one gradient bucket, all-reduce over " + ("RCCL" if not one_gpu else "gloo")
@@ -543,6 +556,7 @@ def main():
     ap.add_argument("--roofline-kernel", default=None, help="entry point timed for the roofline object (default: rtfs_dp_unfold_gemm_fwd, "
                     "or rtfs_wgrad's layer-0 Toeplitz launches in --mode train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="--mode train: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW instead of rtfs_net_amd.optim.FusedAdamW")
     ap.add_argument("--no-train-line", action="store_true", help="skip the riders of the default N = 1 line (they are skipped together with the CPU baseline as well)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()

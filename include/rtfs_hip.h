@@ -436,6 +436,19 @@ int rtfs_vp_attn_long_fwd(const float* g, const float* params, const float* pe, 
 int rtfs_vp_attn_bwd(const float* g, const float* params, const float* pe, const float* masks_or_null, const float* dout, float* dg, float* dparams, int B,
                      int Tg, void* stream);
 
+/* ---- optimizer step of the training step (BASELINE config 3 / 4): torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (config yaml:117-120, train.py:135-146
+ * hand both to PyTorch / Lightning) as TWO launches over a chunk map of all parameter tensors, csrc/optim.hip; host side rtfs_net_amd/optim.py (FusedAdamW).
+ * Tables (DEVICE memory): params / grads / exp_avg / exp_avg_sq = [n_tensors] int64 device pointers to contiguous fp32 tensors, sizes = [n_tensors] int64 element
+ * counts, chunks = [n_chunks][2] int32 (tensor index, first element; 1024 elements per chunk).  rtfs_grad_sqnorm zeroes *sqnorm and adds the sum of squares of
+ * every gradient element; rtfs_adamw_clip_step scales the gradients in place by min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) (max_norm <= 0: no clipping, sqnorm
+ * not read) and applies AdamW with decoupled weight decay in torch.optim.AdamW's operation order; bias_correction1 = 1 - beta1^step, bias_correction2_sqrt =
+ * sqrt(1 - beta2^step) of this step; the hyper-parameters are doubles because torch forms 1 - beta, lr / bias_correction1 ... in double before they become fp32. */
+int rtfs_grad_sqnorm(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq, const long long* sizes,
+                     const int* chunks, int n_chunks, double* sqnorm, void* stream);
+int rtfs_adamw_clip_step(const long long* params, const long long* grads, const long long* exp_avg, const long long* exp_avg_sq, const long long* sizes,
+                         const int* chunks, int n_chunks, const double* sqnorm, double max_norm, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, double bias_correction1, double bias_correction2_sqrt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@ P = c_void_p
 I = c_int
 F = c_float
 LL = c_longlong
+D = c_double
 
 # name -> argtypes, in the order of include/rtfs_hip.h
 SIGNATURES = {
@@ -114,6 +115,8 @@ SIGNATURES = {
     "rtfs_vp_attn_fwd": [P, P, P, P, P, I, I, P],
     "rtfs_vp_attn_long_work_floats": [I],
     "rtfs_vp_attn_long_fwd": [P, P, P, P, P, I, I, P],
+    "rtfs_grad_sqnorm": [P, P, P, P, P, P, I, P, P],
+    "rtfs_adamw_clip_step": [P, P, P, P, P, P, I, P, D, D, D, D, D, D, D, D, P],
     "rtfs_vp_attn_bwd": [P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],

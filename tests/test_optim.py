@@ -1,0 +1,92 @@
+"""rtfs_net_amd.optim.FusedAdamW (csrc/optim.hip: gradient clipping + AdamW of the training step as two launches) against
+torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW - the pair the reference's trainer runs (config yaml:117-120, train.py:135-146)."""
+import copy
+
+import pytest
+import torch
+
+from util import make_model, rel
+
+
+def _close(a, b, lr=1e-3):
+    """error of an updated parameter relative to max(its norm, the size of one update): a scalar parameter that an update of size lr moves to 1e-5 carries the
+    update's rounding 100 times magnified if it is measured against its own value"""
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / max(float(b.norm()), lr * b.numel() ** 0.5))
+
+
+def test_fused_adamw_is_an_optimizer_with_adamw_state_keys():
+    from rtfs_net_amd.optim import FusedAdamW
+
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = FusedAdamW([w], lr=1e-3, weight_decay=0.1)
+    assert isinstance(opt, torch.optim.Optimizer) and opt.param_groups[0]["betas"] == (0.9, 0.999) and opt.param_groups[0]["eps"] == 1e-8
+    assert opt.step() is None  # no gradient: nothing to do (and no GPU needed)
+    with pytest.raises(ValueError):
+        FusedAdamW([w], lr=-1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_norm", [5.0, 1e-2, None])
+def test_fused_adamw_matches_torch_adamw_and_clip(max_norm):
+    """three steps on RTFS-Net-2's 403 parameter tensors with random gradients (clipping inactive at 5.0 on step 0 or not, always active at 1e-2, off):
+    parameters, both moments and the clipped gradients against the torch pair; optimizer state_dicts interchange"""
+    from rtfs_net_amd.optim import FusedAdamW
+
+    model, _, _ = make_model(2, "cuda")
+    ref = copy.deepcopy(model)
+    pa, pb = list(model.parameters()), list(ref.parameters())
+    fused = FusedAdamW(pa, lr=1e-3, weight_decay=0.1)
+    torch_opt = torch.optim.AdamW(pb, lr=1e-3, weight_decay=0.1)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for it in range(3):
+        for a, b in zip(pa, pb):
+            g = torch.randn(a.shape, device="cuda", generator=gen) * (0.3 if it else 3.0)
+            a.grad, b.grad = g.clone(), g.clone()
+        fused.step(max_norm=max_norm)
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        torch_opt.step()
+        torch.cuda.synchronize()
+        worst = max(_close(a, b) for a, b in zip(pa, pb))
+        worst_g = max(rel(a.grad, b.grad) for a, b in zip(pa, pb))
+        assert worst < 1e-6 and worst_g < 1e-6, (it, worst, worst_g)
+    for a, b in zip(pa, pb):
+        sa, sb = fused.state[a], torch_opt.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 3.0
+        assert _close(sa["exp_avg"], sb["exp_avg"], 0.1) < 1e-6 and _close(sa["exp_avg_sq"], sb["exp_avg_sq"], 1e-3) < 1e-6  # (scales of one moment update)
+    # the state interchanges with torch.optim.AdamW's (same keys): continue the torch optimizer's run in the fused one and vice versa
+    fused2 = FusedAdamW(pa, lr=1e-3, weight_decay=0.1)
+    fused2.load_state_dict(torch_opt.state_dict())
+    torch2 = torch.optim.AdamW(pb, lr=1e-3, weight_decay=0.1)
+    torch2.load_state_dict(fused.state_dict())
+    for a, b in zip(pa, pb):
+        g = torch.randn(a.shape, device="cuda", generator=gen)
+        a.grad, b.grad = g.clone(), g.clone()
+    fused2.step(max_norm=max_norm)
+    if max_norm is not None:
+        torch.nn.utils.clip_grad_norm_(pb, max_norm)
+    torch2.step()
+    assert max(_close(a, b) for a, b in zip(pa, pb)) < 1e-6
+    assert float(fused2.state[pa[0]]["step"]) == 4.0
+
+
+@pytest.mark.gpu
+def test_fused_adamw_survives_a_host_that_runs_ahead():
+    """the gradient pointer row of a step is staged in pinned memory and copied asynchronously: many steps enqueued without a synchronisation must each
+    see THEIR gradients (a reused staging row would be overwritten by the host before the device has copied it)"""
+    from rtfs_net_amd.optim import FusedAdamW
+
+    p = [torch.nn.Parameter(torch.zeros(1 << 20, device="cuda")) for _ in range(4)]
+    q = [torch.nn.Parameter(torch.zeros(1 << 20, device="cuda")) for _ in range(4)]
+    fused, ref = FusedAdamW(p, lr=1e-2, weight_decay=0.0), torch.optim.AdamW(q, lr=1e-2, weight_decay=0.0)
+    big = torch.randn(4096, 4096, device="cuda")
+    for it in range(40):
+        (big @ big).sum()  # keep the device busy so that the host gets ahead
+        for a, b in zip(p, q):
+            g = torch.full((1 << 20,), float(it % 5) - 2.0, device="cuda")
+            a.grad, b.grad = g, g.clone()
+        fused.step()
+        ref.step()
+    torch.cuda.synchronize()
+    assert max(_close(a, b, 1e-2) for a, b in zip(p, q)) < 1e-6
