@@ -121,7 +121,7 @@ def test_vp_block_matches_oracle_on_cpu():
 
 
 def test_ctypes_signatures_match_header():
-    """argument count and kind (pointer / int / float / long long) of every binding equals the C prototype"""
+    """argument count and kind (pointer / int / float / double / long long) of every binding equals the C prototype"""
     import ctypes
 
     from rtfs_net_amd import lib
@@ -130,7 +130,7 @@ def test_ctypes_signatures_match_header():
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     protos = dict(re.findall(r"^int (rtfs_\w+)\(([^;]*?)\);", header, flags=re.M | re.S))
     assert set(protos) == set(lib.SIGNATURES)
-    kind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_float: "F", ctypes.c_longlong: "L"}
+    kind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_float: "F", ctypes.c_longlong: "L", ctypes.c_double: "D"}
     for name, args in protos.items():
         want = []
         for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
@@ -142,6 +142,8 @@ def test_ctypes_signatures_match_header():
                 want.append("L")
             elif a.startswith("float"):
                 want.append("F")
+            elif a.startswith("double"):
+                want.append("D")
             elif a.startswith("int"):
                 want.append("I")
             else:
