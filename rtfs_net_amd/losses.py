@@ -58,6 +58,9 @@ class PairwiseNegSDR(nn.Module):
         return _PairwiseNegSDRFn.apply(ests, targets, _KINDS[self.sdr_type], self.zero_mean, self.take_log)
 
 
+_PERM_CACHE = {}
+
+
 class PITLossWrapper(nn.Module):
     """pit_from="pw_mtx" (the only mode train.py / the metrics use: train.py:98-101, metrics/allwrapper.py:32-33)."""
 
@@ -81,8 +84,15 @@ class PITLossWrapper(nn.Module):
         n = pair_wise_losses.shape[-1]
         pwl = pair_wise_losses.transpose(-1, -2)
         if n <= 3:  # pit_wrapper.py:82-107
-            perms = torch.tensor(list(permutations(range(n))), dtype=torch.long, device=pwl.device)
-            one_hot = pwl.new_zeros((*perms.size(), n)).scatter_(2, perms.unsqueeze(2), 1)
+            # the permutation table and its one-hot form are constants of (n, device, dtype): built once.  Built per call (as the reference does), the
+            # host-to-device copy of the table is a blocking transfer in the middle of the training step - the host then waits for the whole forward and the
+            # device idles ~0.9 ms while the loss and the first backward launches are enqueued (round 5, tools/train_gaps.py)
+            key = (n, pwl.device, pwl.dtype)
+            cached = _PERM_CACHE.get(key)
+            if cached is None:
+                perms = torch.tensor(list(permutations(range(n))), dtype=torch.long, device=pwl.device)
+                cached = _PERM_CACHE[key] = (perms, pwl.new_zeros((*perms.size(), n)).scatter_(2, perms.unsqueeze(2), 1))
+            perms, one_hot = cached
             loss_set = torch.einsum("bij,pij->bp", pwl, one_hot) / n
             min_loss, idx = torch.min(loss_set, dim=1)
             return min_loss, perms[idx]
