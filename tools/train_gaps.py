@@ -1,7 +1,7 @@
 """GPU idle time inside the training step: `rocprofv3 --kernel-trace --output-format csv` of `bench.py --mode train`, then the union of all kernel
 intervals of the LAST step (both streams) - busy time, idle time, and the largest gaps with the kernels on either side.
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tg -o t -- python /root/repo/bench.py --mode train --steps 4 --warmup 2 --no-cpu-baseline
-    python tools/train_gaps.py /tmp/tg"""
+    python tools/train_gaps.py /tmp/tg [marker kernel, default adamw_clip_kernel; the inference forward: istft_ola_kernel]"""
 import csv, glob, sys
 
 path = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -10,7 +10,8 @@ for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70]))
 rows.sort()
 # steps are delimited by the optimizer kernel (adamw_clip_kernel) - take the interval between the last two
-marks = [i for i, r in enumerate(rows) if "adamw_clip_kernel" in r[2] or "multi_tensor_apply" in r[2] and False]
+marker = sys.argv[2] if len(sys.argv) > 2 else "adamw_clip_kernel"  # a kernel that runs once per step (inference: istft_ola_kernel)
+marks = [i for i, r in enumerate(rows) if marker in r[2]]
 if len(marks) < 2:
     sys.exit("no step markers")
 a, b = marks[-2] + 1, marks[-1] + 1
