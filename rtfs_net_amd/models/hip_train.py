@@ -412,7 +412,9 @@ class HipTrainer:
                 with torch.no_grad():
                     mom = bn.momentum if bn.momentum is not None else 0.1
                     bn.running_mean.mul_(1 - mom).add_(mom * mean_u)
-                    bn.running_var.mul_(1 - mom).add_(mom * var_u * out["n"] / max(out["n"] - 1, 1))
+                    nn_ = out["n"]
+                    unbias = nn_ / torch.clamp(nn_ - 1, min=1) if isinstance(nn_, torch.Tensor) else nn_ / max(nn_ - 1, 1)
+                    bn.running_var.mul_(1 - mom).add_((mom * var_u * unbias).to(bn.running_var.dtype))
                     bn.num_batches_tracked += 1
             else:
                 mean_u, var_u = bn.running_mean.float(), bn.running_var.float()
@@ -723,9 +725,9 @@ def caf_bn_batch_stats(sums, n_local, sync):
     in fp32; with sync (nn.SyncBatchNorm, train.py:145 sync_batchnorm=True) the statistics are those of the union of all ranks."""
     local, n = sums, float(n_local)
     if sync:
-        buf = torch.cat([sums.reshape(-1), torch.tensor([n], dtype=torch.float64, device=sums.device)])
+        buf = torch.cat([sums.reshape(-1), sums.new_full((1,), n)])  # (new_full: a fill launch, not a blocking host-to-device copy of a Python list)
         torch.distributed.all_reduce(buf)
-        sums, n = buf[:-1].view(2, -1), float(buf[-1].item())
+        sums, n = buf[:-1].view(2, -1), buf[-1]  # (n stays a 0-d device tensor: .item() here is a host-device synchronisation in the middle of every DDP step)
     mean = sums[0] / n
     var = (sums[1] / n - mean * mean).clamp_min(0)
     lcov = local[1] - mean * local[0]  # sum_local (x - mean) x, differenced in fp64
