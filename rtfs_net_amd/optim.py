@@ -106,4 +106,9 @@ class FusedAdamW(torch.optim.Optimizer):
             lib.call("rtfs_adamw_clip_step", d[0], d[1], d[2], d[3], d[4], plan["chunks"], plan["n_chunks"], sq if clip else plan["sqnorm"],
                      float(max_norm) if clip else 0.0, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                      1.0 - b1 ** k, math.sqrt(1.0 - b2 ** k))
+            # the kernel wrote the parameters, moments and gradients through raw pointers: tell autograd (and everything keyed on version counters -
+            # the kernel-layout weight copies of rtfs_net_amd.models are rebuilt when a parameter's counter moves) that these tensors changed
+            torch.autograd.graph.increment_version(ps)
+            torch.autograd.graph.increment_version([p.grad for p in ps])
+            torch.autograd.graph.increment_version([self.state[p]["exp_avg"] for p in ps] + [self.state[p]["exp_avg_sq"] for p in ps])
         return loss

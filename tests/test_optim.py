@@ -90,3 +90,45 @@ def test_fused_adamw_survives_a_host_that_runs_ahead():
         ref.step()
     torch.cuda.synchronize()
     assert max(_close(a, b, 1e-2) for a, b in zip(p, q)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_fused_adamw_step_reaches_the_hip_forward():
+    """the HIP path keeps kernel-layout copies of the weights keyed on the parameters' version counters; FusedAdamW writes the parameters through raw
+    pointers and must move those counters - two training steps with it give the outputs of two steps with torch.optim.AdamW + clip_grad_norm_"""
+    from rtfs_net_amd.optim import FusedAdamW
+    from util import synth
+
+    outs = []
+    for fused in (True, False):
+        model, _, _ = make_model(2, "cuda")
+        model.train()
+        for mod in model.modules():  # no stochastic layers: the two runs must see the same forward
+            if isinstance(getattr(mod, "p", None), float):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        mix, _, emb = synth.synth_inputs(2, 8000, 12)
+        mix, emb = mix.cuda(), emb.cuda()
+        opt = FusedAdamW(model.parameters(), lr=1e-2, weight_decay=0.1) if fused else torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.1)
+        v0 = next(model.parameters())._version
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            model(mix, emb).square().mean().backward()
+            if fused:
+                opt.step(max_norm=5.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+                opt.step()
+        assert next(model.parameters())._version > v0
+        with torch.no_grad():  # a third forward, still in train mode: the biases in front of BatchNorm layers have analytically zero gradients, Adam turns their
+            outs.append(model(mix, emb).clone())  # rounding noise into +-lr updates that differ run to run and only show through RUNNING statistics (eval mode)
+    first = make_model(2, "cuda")[0].train()
+    for mod in first.modules():
+        if isinstance(getattr(mod, "p", None), float):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    with torch.no_grad():
+        assert rel(outs[0], first(mix, emb)) > 1e-3  # the two steps did move the output
+    assert rel(outs[0], outs[1]) < 2e-4  # (observed 3e-5 at lr = 1e-2: the noise-driven +-lr updates of the zero-gradient parameters are not exactly invisible in fp32)
