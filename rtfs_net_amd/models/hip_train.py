@@ -71,6 +71,111 @@ class TrainWeights(PreparedWeights):
                     a[k] = pack_bf16(a[k])
 
 
+class _IndexModel:
+    """stand-in for the model while a gather plan is built: everything is the model's, except that state_dict() holds, for every floating-point
+    tensor, the POSITIONS of its elements in one flat buffer (as float32 numbers, exact below 2^24)"""
+
+    def __init__(self, model, sd_idx):
+        object.__setattr__(self, "_m", model)
+        object.__setattr__(self, "_sd", sd_idx)
+
+    def state_dict(self):
+        return self._sd
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+
+class GatherTrainWeights:
+    """TrainWeights whose re-layout is ONE gather.  Every kernel-layout copy TrainWeights makes in the fp32 modes is a permutation / slice / concatenation of
+    parameter elements (plus zero padding), but as ~150 separate torch launches issued right after the step's one device-to-host transfer, where the host cannot
+    be ahead of the device: ~3 ms per training step, most of it idle device (round 5, tools/train_gaps.py).  Here the construction code of TrainWeights runs
+    ONCE on index-valued stand-ins (_IndexModel): what comes out is, for every element of every derived tensor, the position of its source element in a flat
+    buffer of all floating-point state tensors.  Per step: one multi-tensor copy of the state into the flat buffer, one index_select into a persistent buffer
+    that the (persistent) nested dicts are views of, and the scalar slots (PReLU slopes, SRU scale_x: kernel arguments passed by value) from one transfer."""
+
+    def __init__(self, model, prec):
+        dev = next(model.parameters()).device
+        sd = model.state_dict()
+        names = [k for k, v in sd.items() if v.is_floating_point()]
+        self.srcs = [sd[k].detach() for k in names]
+        sizes = [t.numel() for t in self.srcs]
+        total = 1 + sum(sizes)  # element 0 stays zero: the source of every padding element
+        if total >= 1 << 24:
+            raise ValueError("GatherTrainWeights: more than 2^24 state elements (float32 index arithmetic)")
+        self.flat = torch.zeros(total, device=dev)
+        sd_idx, self.flat_views, off = dict(sd), [], 1
+        for k, t, n in zip(names, self.srcs, sizes):
+            self.flat_views.append(self.flat[off:off + n].view(t.shape))
+            sd_idx[k] = (torch.arange(n, device=dev, dtype=torch.float32) + off).view(t.shape)
+            off += n
+        tw = TrainWeights(_IndexModel(model, sd_idx), prec)
+        self.caf_prefix, self.prec = tw.caf_prefix, prec
+        self.w, self.blocks, self._scal = tw.w, tw.blocks, tw._scal
+        for tag in ("key", "value"):  # BatchNorm folded with RUNNING statistics (eval under autograd): arithmetic, not a gather - see refresh()
+            self.w.pop(f"caf_{tag}_s", None), self.w.pop(f"caf_{tag}_b", None)
+        leaves, self.scalars = [], []
+
+        def walk(c):
+            items = c.items() if isinstance(c, dict) else enumerate(c)
+            for k, v in list(items):
+                if isinstance(v, tuple):
+                    v = c[k] = list(v)
+                if isinstance(v, torch.Tensor):
+                    leaves.append((c, k, v))
+                elif isinstance(v, float):
+                    self.scalars.append((c, k, int(round(v))))
+                elif isinstance(v, (dict, list)):
+                    walk(v)
+
+        walk(self.w), walk(self.blocks), walk(self._scal)
+        self.idx = torch.cat([t.reshape(-1) for _, _, t in leaves]).round().long()
+        assert int(self.idx.min()) >= 0 and int(self.idx.max()) < total
+        self.derived = torch.empty(self.idx.numel(), device=dev)
+        o = 0
+        for c, k, t in leaves:
+            c[k] = self.derived[o:o + t.numel()].view(t.shape)
+            o += t.numel()
+        self.sidx = torch.tensor([i for _, _, i in self.scalars], device=dev, dtype=torch.long)
+        self.ptrs = tuple(t.data_ptr() for t in self.srcs)
+        self.version, self._pending = None, None
+        self.refresh(model)
+
+    def same_storage(self, model):
+        """the plan reads the state through the tensors it was built from: a model moved / re-allocated since needs a new plan"""
+        sd = model.state_dict()
+        live = tuple(v.data_ptr() for v in sd.values() if v.is_floating_point())
+        return live == self.ptrs
+
+    @torch.no_grad()
+    def refresh(self, model, fp=None, defer_scalars=False):
+        """defer_scalars: the scalar slots keep their OLD values until finish_scalars() - the caller launches what needs no scalar first (STFT, encoder,
+        bottleneck: 1.3 ms of device work) and waits for the transfer behind those launches instead of in front of them"""
+        torch._foreach_copy_(self.flat_views, self.srcs)
+        torch.index_select(self.flat, 0, self.idx, out=self.derived)
+        host = torch.empty(self.sidx.numel(), dtype=torch.float32, pin_memory=True)
+        host.copy_(self.flat[self.sidx], non_blocking=True)  # the step's one device-to-host transfer
+        self._pending = (host, torch.cuda.current_stream(self.flat.device).record_event())
+        if not defer_scalars:
+            self.finish_scalars()
+        if not model.training:  # eval under autograd: the CAF embeddings' BatchNorm folded with its running statistics (PreparedWeights.__init__)
+            sd = model.state_dict()
+            for tag in ("key", "value"):
+                q = f"{self.caf_prefix}{tag}_embed.full_layer."
+                scale = sd[q + "3.weight"].float() / torch.sqrt(sd[q + "3.running_var"].float() + 1e-5)
+                self.w[f"caf_{tag}_s"] = _f32(sd[q + "2.weight"].reshape(C).float() * scale)
+                self.w[f"caf_{tag}_b"] = _f32(sd[q + "3.bias"].float() - sd[q + "3.running_mean"].float() * scale)
+        self.version = fp if fp is not None else PreparedWeights.fingerprint(model, training=model.training)
+
+    def finish_scalars(self):
+        if self._pending is not None:
+            host, ev = self._pending
+            ev.synchronize()
+            for (c, k, _), v in zip(self.scalars, host.tolist()):
+                c[k] = v
+            self._pending = None
+
+
 class Ctx:
     """bag of saved tensors"""
 
@@ -144,10 +249,19 @@ class HipTrainer:
         self._prep = None
         self.prec = 0  # AVNet.set_compute_dtype: 0 fp32, 1 bf16, 3 split-bf16 products in every MFMA kernel of the step
 
-    def weights(self) -> TrainWeights:
+    def weights(self, defer_scalars=False):
+        """defer_scalars (forward_a only): the caller calls `.finish_scalars()` on the result before it reads a scalar slot (PReLU slopes, scale_x, `_scal`)"""
         fp = PreparedWeights.fingerprint(self.model, training=self.model.training)  # eval under autograd: running statistics are inputs too
-        if self._prep is None or self._prep.version != fp or self._prep.prec != self.prec:
-            self._prep = TrainWeights(self.model, self.prec)
+        if self._prep is not None and self._prep.version == fp and self._prep.prec == self.prec:
+            if isinstance(self._prep, GatherTrainWeights) and not defer_scalars:
+                self._prep.finish_scalars()
+            return self._prep
+        if self.prec in PACKED_WEIGHT_MODES or not self.model._hip.fuse.get("wgather", True):
+            self._prep = TrainWeights(self.model, self.prec)  # bf16 / split-bf16: the host-packed copies are arithmetic, not a gather
+        elif isinstance(self._prep, GatherTrainWeights) and self._prep.prec == self.prec and self._prep.same_storage(self.model):
+            self._prep.refresh(self.model, fp, defer_scalars)  # same tensors, new values (an optimizer step): one copy + one gather
+        else:
+            self._prep = GatherTrainWeights(self.model, self.prec)
         return self._prep
 
     def _call(self, name, *args):
@@ -317,8 +431,6 @@ class HipTrainer:
     def forward_a(self, wav):
         """STFT, encoder conv, bottleneck, RTFS block 0 (everything before the CAF cell) -> ctx with x0, a0, a_emb."""
         m = self.model
-        pw = self.weights()
-        w = pw.w
         wav = wav.to(torch.float32).contiguous()
         B, L = wav.shape
         T = 1 + L // 128
@@ -327,6 +439,8 @@ class HipTrainer:
             raise ValueError("input too short for the HIP path: need at least 16 STFT frames (L >= 1920 samples)")
         if T * F_BINS * C * 4 > 2 ** 30:  # (the inference path's guard, hip_path.HipForward: 32-bit offsets inside an utterance, tested envelope)
             raise ValueError(f"training segment too long for the HIP path: {L} samples (about 65 s at most)")
+        pw = self.weights(defer_scalars=True)  # (scalar slots are read from block 0 on: finish_scalars() below, behind the first three launches)
+        w = pw.w
         TF = T * F_BINS
         dev = wav.device
         R = m.refinement_module.audio_net.repeats
@@ -341,6 +455,8 @@ class HipTrainer:
         self._call("rtfs_enc_conv_fwd", c.spec, w["enc"], c.a_emb, stats[0], B, T)
         c.a0 = torch.empty_like(c.a_emb)
         self._call("rtfs_bottleneck_fwd", c.a_emb, stats[0], w["bn_g"], w["bn_b"], w["bn_w"], w["bn_bias"], c.a0, B, TF)
+        if isinstance(pw, GatherTrainWeights):
+            pw.finish_scalars()  # the device has 1.3 ms of work queued: the host waits for the scalars without starving it
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
         c.blk = []
