@@ -109,7 +109,7 @@ class GatherTrainWeights:
             self.flat_views.append(self.flat[off:off + n].view(t.shape))
             sd_idx[k] = (torch.arange(n, device=dev, dtype=torch.float32) + off).view(t.shape)
             off += n
-        tw = TrainWeights(_IndexModel(model, sd_idx), prec)
+        tw = TrainWeights(_IndexModel(model, sd_idx), 0)  # (the fp32 structure; the bf16 / split-bf16 modes pack a contiguous region of it below)
         self.caf_prefix, self.prec = tw.caf_prefix, prec
         self.w, self.blocks, self._scal = tw.w, tw.blocks, tw._scal
         for tag in ("key", "value"):  # BatchNorm folded with RUNNING statistics (eval under autograd): arithmetic, not a gather - see refresh()
@@ -129,12 +129,35 @@ class GatherTrainWeights:
                     walk(v)
 
         walk(self.w), walk(self.blocks), walk(self._scal)
+        # bf16 / split-bf16 step: the weights that are ONLY MFMA operands are handed over host-packed (hip_path.pack_bf16: every 4 consecutive k -> 4 hi + 4 lo
+        # bfloat16).  Their fp32 layouts are gathered into ONE contiguous region first, so the packing of all of them is one pass over that region.
+        packed_ids = set()
+        if prec in PACKED_WEIGHT_MODES:
+            def mark(c, keys):
+                for k in keys:
+                    packed_ids.add((id(c), k))
+            mark(self.w, ("bn_w", "mask_w", "dec_w", "bn_wT", "mask_wT", "dec_wT"))
+            for b in self.blocks:
+                mark(b, ("pw", "rw", "pwT", "rwT"))
+                for j in (0, 1):
+                    mark(b[f"dp{j}"], ("w0", "ct_w", "fold_w", "ctbi_w"))
+                    for lw in b[f"dp{j}"]["layers"][1:]:
+                        mark(lw, ("wT",))
+                mark(b["attn"], ("w", "ow", "wT", "owT"))
+            leaves.sort(key=lambda l: (id(l[0]), l[1]) not in packed_ids)  # (stable: packed leaves first)
         self.idx = torch.cat([t.reshape(-1) for _, _, t in leaves]).round().long()
         assert int(self.idx.min()) >= 0 and int(self.idx.max()) < total
         self.derived = torch.empty(self.idx.numel(), device=dev)
+        self.n_packed = sum(t.numel() for c, k, t in leaves if (id(c), k) in packed_ids)
+        assert self.n_packed % 4 == 0
+        self.packed = torch.empty(self.n_packed // 4, 8, dtype=torch.bfloat16, device=dev) if self.n_packed else None
         o = 0
         for c, k, t in leaves:
-            c[k] = self.derived[o:o + t.numel()].view(t.shape)
+            if (id(c), k) in packed_ids:
+                assert t.ndim == 2 and t.shape[1] % 4 == 0 and o % 4 == 0
+                c[k] = self.packed[o // 4:(o + t.numel()) // 4].view(t.shape[0], t.shape[1] // 4, 8)
+            else:
+                c[k] = self.derived[o:o + t.numel()].view(t.shape)
             o += t.numel()
         self.sidx = torch.tensor([i for _, _, i in self.scalars], device=dev, dtype=torch.long)
         self.ptrs = tuple(t.data_ptr() for t in self.srcs)
@@ -153,6 +176,11 @@ class GatherTrainWeights:
         bottleneck: 1.3 ms of device work) and waits for the transfer behind those launches instead of in front of them"""
         torch._foreach_copy_(self.flat_views, self.srcs)
         torch.index_select(self.flat, 0, self.idx, out=self.derived)
+        if self.packed is not None:  # pack_bf16 over the whole packed region at once
+            r = self.derived[:self.n_packed]
+            hi = r.bfloat16()
+            lo = (r - hi.float()).bfloat16()
+            torch.cat([hi.view(-1, 4), lo.view(-1, 4)], -1, out=self.packed)
         host = torch.empty(self.sidx.numel(), dtype=torch.float32, pin_memory=True)
         host.copy_(self.flat[self.sidx], non_blocking=True)  # the step's one device-to-host transfer
         self._pending = (host, torch.cuda.current_stream(self.flat.device).record_event())
@@ -256,8 +284,8 @@ class HipTrainer:
             if isinstance(self._prep, GatherTrainWeights) and not defer_scalars:
                 self._prep.finish_scalars()
             return self._prep
-        if self.prec in PACKED_WEIGHT_MODES or not self.model._hip.fuse.get("wgather", True):
-            self._prep = TrainWeights(self.model, self.prec)  # bf16 / split-bf16: the host-packed copies are arithmetic, not a gather
+        if not self.model._hip.fuse.get("wgather", True):
+            self._prep = TrainWeights(self.model, self.prec)
         elif isinstance(self._prep, GatherTrainWeights) and self._prep.prec == self.prec and self._prep.same_storage(self.model):
             self._prep.refresh(self.model, fp, defer_scalars)  # same tensors, new values (an optimizer step): one copy + one gather
         else:

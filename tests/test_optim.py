@@ -151,6 +151,34 @@ def _same_tree(a, b, path=""):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", [3, 1])
+def test_gather_train_weights_packed_modes(prec):
+    """the same in the bf16 / split-bf16 modes: the host-packed MFMA weights (hip_path.pack_bf16) come out of ONE packing pass over a contiguous region of
+    the gathered fp32 layouts - bit for bit what TrainWeights packs tensor by tensor, before and after the parameters move"""
+    from rtfs_net_amd.models.hip_train import GatherTrainWeights, TrainWeights
+
+    model, _, _ = make_model(2, "cuda")
+    model.train()
+
+    def rebuilt():
+        t = TrainWeights(model, prec)
+        for k in ("caf_key_s", "caf_key_b", "caf_value_s", "caf_value_b"):
+            t.w.pop(k)
+        return t
+
+    gw = GatherTrainWeights(model, prec)
+    for _ in range(2):
+        tw = rebuilt()
+        assert gw.blocks[0]["pw"].dtype == torch.bfloat16 and gw.blocks[0]["dp0"]["layers"][1]["w"].dtype == torch.float32
+        for a, b in ((gw.w, tw.w), (gw.blocks, tw.blocks), (gw._scal, tw._scal)):
+            _same_tree(a, b)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.01)
+        gw.refresh(model)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("training", [True, False])
 def test_gather_train_weights_equal_the_rebuilt_ones(training):
     """GatherTrainWeights (the kernel-layout weight copies of the training step as one multi-tensor copy + one gather, plan built by running TrainWeights'
