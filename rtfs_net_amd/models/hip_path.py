@@ -168,12 +168,20 @@ class PreparedWeights:
         buffers only - batch statistics replace the running ones, which the step itself updates in place (keying on them
         forced a rebuild, and its device->host sync, between every forward and backward).
         NOT seen: writes through `.data` / `torch.Tensor.set_` (no version bump): call `model.invalidate_hip_cache()` after them."""
-        tensors = list(model.parameters())
-        if training:
-            tensors += [b for n, b in model.named_buffers() if n.endswith("scale_x")]
-        else:
-            tensors += list(model.buffers())
-        return tuple((p.data_ptr(), p._version) for p in tensors)
+        # (a plain walk over the module tree: model.parameters() / named_buffers() build every dotted name and a de-duplication set on the way -
+        # 1.2 ms of host time per forward for RTFS-Net's 365 state tensors, ~4x this walk; shared modules are simply seen twice)
+        out = []
+        stack = [model]
+        while stack:
+            mod = stack.pop()
+            for p in mod._parameters.values():
+                if p is not None:
+                    out.append((p.data_ptr(), p._version))
+            for n, b in mod._buffers.items():
+                if b is not None and (not training or n == "scale_x"):
+                    out.append((b.data_ptr(), b._version))
+            stack.extend(m for m in mod._modules.values() if m is not None)
+        return tuple(out)
 
     @staticmethod
     def _dw(sd, prefix):
