@@ -449,6 +449,18 @@ int rtfs_adamw_clip_step(const long long* params, const long long* grads, const 
                          const int* chunks, int n_chunks, const double* sqnorm, double max_norm, double lr, double beta1, double beta2, double eps,
                          double weight_decay, double bias_correction1, double bias_correction2_sqrt, void* stream);
 
+/* ---- BatchNorm2d (batch statistics) of the CAF cell's key / value embeddings in the training step (fusion.py:249-253), csrc/optim.hip: the per-channel
+ * arithmetic between rtfs_chan_stats and the cell (forward: folded scale / shift, running-statistics update) and between rtfs_caf_bwd_reduce and
+ * rtfs_caf_bwd_apply (adjoint: coefficients c1, c2, c3 + the three parameter gradients per tag), one launch each.  sums: [2][C] fp64; n: one double ON THE
+ * DEVICE (positions behind sums_glob); *_glob: sums over all ranks under SyncBatchNorm, the local pointer otherwise.  R: [4][C] = (sum dy, sum dy x) of key, of value. */
+int rtfs_caf_bn_prepare(const double* sums_glob, const double* sums_loc, const double* n, const float* k_dw, const float* k_g, const float* k_be,
+                        float* k_run_mean, float* k_run_var, long long* k_batches, float* k_inv, float* k_mean_u, float* k_s, float* k_b, const float* v_dw,
+                        const float* v_g, const float* v_be, float* v_run_mean, float* v_run_var, long long* v_batches, float* v_inv, float* v_mean_u, float* v_s,
+                        float* v_b, float momentum, float eps, float* mean_x, float* var_x, float* lsum, float* lcov, void* stream);
+int rtfs_caf_bn_adjoint(const float* R_loc, const float* R_glob, const double* n, const float* mean_x, const float* lsum, const float* lcov, const float* k_dw,
+                        const float* k_g, const float* k_inv, float* k_d_dw, float* k_d_g, float* k_d_be, const float* v_dw, const float* v_g,
+                        const float* v_inv, float* v_d_dw, float* v_d_g, float* v_d_be, float* coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,8 @@ SIGNATURES = {
     "rtfs_vp_attn_long_fwd": [P, P, P, P, P, I, I, P],
     "rtfs_grad_sqnorm": [P, P, P, P, P, P, I, P, P],
     "rtfs_adamw_clip_step": [P, P, P, P, P, P, I, P, D, D, D, D, D, D, D, D, P],
+    "rtfs_caf_bn_prepare": [P] * 23 + [F, F, P, P, P, P, P],
+    "rtfs_caf_bn_adjoint": [P] * 19 + [P],
     "rtfs_vp_attn_bwd": [P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],

@@ -540,6 +540,29 @@ class HipTrainer:
         m = self.model
         cell = m.refinement_module.crossmodal_fusion.get_fusion_block(0).audio_lstm
         out = {"training": training}
+        bk, bv = cell.key_embed.full_layer[3], cell.value_embed.full_layer[3]
+        if (training and m._hip.fuse.get("cafbn", True) and bk.momentum == bv.momentum and bk.eps == bv.eps and bk.running_mean is not None
+                and bk.running_mean.dtype == torch.float32):
+            # one launch for the per-channel arithmetic (csrc/optim.hip caf_bn_prepare_kernel; ~47 tiny torch launches on the critical path before)
+            sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
+            self._call("rtfs_chan_stats", x, sums[0], sums[1], rows)
+            out["sync"] = (torch.distributed.is_available() and torch.distributed.is_initialized() and isinstance(bk, torch.nn.SyncBatchNorm))
+            if out["sync"]:  # train.py:145 sync_batchnorm=True: statistics of the union of all ranks
+                buf = torch.cat([sums.reshape(-1), sums.new_full((1,), float(rows))])
+                torch.distributed.all_reduce(buf)
+                glob, nptr = buf[:2 * C], buf[2 * C:]
+            else:
+                glob, nptr = sums, sums.new_full((1,), float(rows))
+            o = torch.empty(12, C, device=x.device)
+            lib.call("rtfs_caf_bn_prepare", glob, sums, nptr,
+                     w["caf_key_dw"], w["caf_key_g"], w["caf_key_be"], bk.running_mean, bk.running_var, bk.num_batches_tracked, o[0], o[1], o[2], o[3],
+                     w["caf_value_dw"], w["caf_value_g"], w["caf_value_be"], bv.running_mean, bv.running_var, bv.num_batches_tracked, o[4], o[5], o[6], o[7],
+                     float(bk.momentum if bk.momentum is not None else 0.1), float(bk.eps), o[8], o[9], o[10], o[11])
+            # (written through raw pointers: the inference path keys its folded CAF weights on these buffers' version counters)
+            torch.autograd.graph.increment_version([bk.running_mean, bk.running_var, bk.num_batches_tracked, bv.running_mean, bv.running_var, bv.num_batches_tracked])
+            out.update({"key_inv": o[0], "key_mean_u": o[1], "ks": o[2], "kb": o[3], "value_inv": o[4], "value_mean_u": o[5], "vs": o[6], "vb": o[7],
+                        "mean_x": o[8], "var_x": o[9], "lsum": o[10], "lsq": o[11], "n": nptr, "fused": True})
+            return out
         if training:
             sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
             self._call("rtfs_chan_stats", x, sums[0], sums[1], rows)
@@ -846,6 +869,17 @@ class HipTrainer:
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
         """BatchNorm adjoint of the CAF key/value embeddings -> per-channel coefficients for rtfs_caf_bwd_apply + parameter grads."""
         dev = Rr.device
+        if cf.get("fused"):  # csrc/optim.hip caf_bn_adjoint_kernel: the arithmetic below (caf_bn_adjoint) as one launch
+            Rg = Rr
+            if cf.get("sync", False):
+                Rg = Rr.clone()
+                torch.distributed.all_reduce(Rg)
+            coef, gd = torch.empty(6, C, device=dev), torch.empty(6, C, device=dev)
+            lib.call("rtfs_caf_bn_adjoint", Rr, Rg, cf["n"], cf["mean_x"], cf["lsum"], cf["lsq"], w["caf_key_dw"], w["caf_key_g"], cf["key_inv"], gd[0], gd[1], gd[2],
+                     w["caf_value_dw"], w["caf_value_g"], cf["value_inv"], gd[3], gd[4], gd[5], coef)
+            for j, tag in enumerate(("key", "value")):
+                gr[f"caf_{tag}_dw"], gr[f"caf_{tag}_g"], gr[f"caf_{tag}_be"] = gd[3 * j], gd[3 * j + 1], gd[3 * j + 2]
+            return coef
         coef = torch.zeros(6, C, device=dev)
         for j, tag in enumerate(("key", "value")):
             dw, gm = w[f"caf_{tag}_dw"], w[f"caf_{tag}_g"]

@@ -217,3 +217,39 @@ def test_gather_train_weights_equal_the_rebuilt_ones(training):
     model.cpu()
     model.cuda()
     assert not gw.same_storage(model)  # re-allocated parameters: HipTrainer.weights() builds a new plan
+
+
+@pytest.mark.gpu
+def test_caf_batchnorm_kernels_match_the_torch_arithmetic():
+    """rtfs_caf_bn_prepare / rtfs_caf_bn_adjoint (csrc/optim.hip: the per-channel BatchNorm2d arithmetic of the CAF cell's key / value embeddings in the training
+    step, fusion.py:249-253, as one launch each) against the torch-op form they replace (model._hip.fuse["cafbn"] = False): the waveform, every gradient of the
+    cell's embeddings, the running statistics and num_batches_tracked after one step"""
+    from util import synth
+
+    res = []
+    for fused in (True, False):
+        model, _, _ = make_model(2, "cuda")
+        model.train()
+        for mod in model.modules():
+            if isinstance(getattr(mod, "p", None), float):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        model._hip.fuse["cafbn"] = fused
+        mix, _, emb = synth.synth_inputs(3, 8000, 12)
+        out = model(mix.cuda(), emb.cuda())
+        out.square().mean().backward()
+        cell = model.refinement_module.crossmodal_fusion.get_fusion_block(0).audio_lstm
+        named = dict(cell.named_parameters())
+        grads = {n: p.grad.clone() for n, p in named.items() if n.startswith(("key_embed", "value_embed"))}
+        stats = {n: b.clone() for n, b in cell.named_buffers() if n.startswith(("key_embed", "value_embed"))}
+        res.append((out.detach().clone(), grads, stats))
+    (oa, ga, sa), (ob, gb, sb) = res
+    assert rel(oa, ob) < 1e-6 and len(ga) == 6 and len(sa) == 6
+    for n in ga:
+        assert rel(ga[n], gb[n]) < 1e-4, (n, rel(ga[n], gb[n]))  # (d(dw) is a difference of three sums of ~1e5 terms each: 2e-5 between two fp32 evaluation orders)
+    for n in sa:
+        if n.endswith("num_batches_tracked"):
+            assert int(sa[n]) == int(sb[n]) == 1
+        else:
+            assert rel(sa[n], sb[n]) < 1e-6, n
