@@ -4,6 +4,7 @@
 //   rtfs_sru_scan_train_fwd   forward recurrence that also stores the cell state C[s][l][64] (needed by the adjoint)
 //   rtfs_sru_scan_bwd         reverse-time adjoint: dH -> dU (same layout as U), dX (skip input, layers 1-3),
 //                             weight_c / bias gradients accumulated with one atomic per lane per sequence
+//   rtfs_sru_layer_bwd        layers 1-3: the recurrence adjoint with the weight and input gradients of the projection in the same launch (dU stays in LDS)
 //   rtfs_ln4d_c_bwd           adjoint of LayerNormalization4D over the 64 channels of each position (normalizations.py:33-37)
 //   rtfs_seq_gather           G layout -> sequence-major [S][npos][64] copy, raw or LN4D-normalised (operands of rtfs_wgrad)
 #include "common.h"
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void sru_scan_train_kernel(const float* __rest
 template <int KM>
 __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restrict__ U, const float* __restrict__ X, const float* __restrict__ Cst,
                                                            const float* __restrict__ wc, const float* __restrict__ bias, float scale_x,
-                                                           const float* __restrict__ dH, float* __restrict__ dU, float* __restrict__ dX,
-                                                           float* __restrict__ scr, int S, int L) {
+                                                           const float* __restrict__ dH, const float* __restrict__ dH2, float* __restrict__ dU,
+                                                           float* __restrict__ dX, float* __restrict__ scr, int S, int L) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= S) return;
     const int lane = threadIdx.x & 63;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restri
             cpv[j] = Cst[o64 + (size_t)lp * 64];
             cv[j] = Cst[o64 + (size_t)l * 64];
             ghv[j] = dH[o64 + (size_t)l * 64];
+            if (dH2) ghv[j] += dH2[o64 + (size_t)l * 64];  // the gradient arrives as the two per-direction parts of rtfs_sru_layer_bwd
             if (KM == 4) {
                 const float4 v = ld4(u + (size_t)l * 256);
                 u0v[j] = v.x, u1v[j] = v.y, u2v[j] = v.z, xpv[j] = v.w;
@@ -152,6 +154,245 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restri
     atomicAdd(mine + 64 + lane, awr);
     atomicAdd(mine + 128 + lane, abf);
     atomicAdd(mine + 192 + lane, abr);
+}
+
+// ---- adjoint of one SRU layer 1-3 in ONE launch: recurrence adjoint + weight gradient + input gradient ----
+// The three-launch form (sru_scan_bwd_kernel<3>, wgrad_kernel, rows_ws64_kernel) writes dU [S L][192] once and reads it twice: 642 + 233 + 233 MB
+// per layer at 32 utterances.  Here dU lives 8 steps at a time in LDS.  A wave owns ONE DIRECTION OF TWO SEQUENCES (lane = 32 * which sequence +
+// hidden unit), runs 8 steps of the adjoint recurrence of both, parks dU (transposed: [sequence][step][gate * 32 + unit]) and the highway term in its
+// LDS slab, then on the fp32 MFMA (16 x 16 x 4):
+//   dW[n][k]      += sum_(seq, step) dU[seq, step][n] X[seq, t(step)][k]    24 tiles (this direction's 96 rows n), K = 16 (sequence, step) pairs
+//   dXd[seq, t][k] = sum_n dU[seq, t][n] W[n][k] (+ highway on the direction's own 32 columns k)        4 tiles of 16 (sequence, step) rows, K = 96
+// The two directions reach a time t in different iterations, so each writes its own buffer (dX0: forward direction, dX1: backward direction) and the
+// consumer adds them - the next layer down takes the pair as dH, dH2.  (A one-buffer form - one wave per sequence, the later direction adding to the
+// earlier one's rows behind a fence - measured 250 us per layer: one wave per SIMD, every load and LDS round trip bare.)  Two waves per SIMD here: one's
+// recurrence and memory waits run under the other's MFMAs.  dW stays in 96 accumulator registers over all pairs of the wave, is summed over the four
+// waves of a direction in LDS and leaves through the spread scratch [dW 12288 | dwc 128 | dbias 128].
+// HBM per layer: U, X, C, dH (x 2) in, dX0 + dX1 out = 523 MB (three launches: 1108 MB); 11.2 GFLOP.
+constexpr int kLbTS = 97;                         // floats per step row of a sequence's dU slab
+constexpr int kLbTD = 8 * kLbTS + 24;             // floats per sequence (32 mod 64: the two sequences' scan writes fall 32 banks apart)
+constexpr int kLbPS = 36;                         // floats per row of the highway slab [16 (sequence, step)][32]
+constexpr int kLbWave = 2 * kLbTD + 16 * kLbPS;   // 2176 floats per wave
+constexpr int kLbOS = 68;                         // floats per row of the output tile staged in the dU slab [16][64]
+static_assert(16 * kLbOS <= 2 * kLbTD, "the output tile is staged in the dU slab");
+#ifndef LB_ABL
+#define LB_ABL 0  // timing-only builds (tools/ffa_ablate.sh lb <mask>): 1 no dW MFMAs, 2 no dX MFMAs, 4 no recurrence arithmetic, 8 no dX stores, 16 no operand loads
+#endif
+
+// dU column (gate * 32 + unit) of k-slice g of MFMA q of the dX tiles: the 16 rows x 4 slices of one A read fall on 64 different banks
+__device__ __forceinline__ int lb_col(int q, int g) { return 32 * (q >> 3) + (q & 7) + 8 * g; }
+
+__global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restrict__ U, const float* __restrict__ X, const float* __restrict__ Cst,
+                                                            const float* __restrict__ W, const float* __restrict__ wc, const float* __restrict__ bias,
+                                                            float scale_x, const float* __restrict__ dH, const float* __restrict__ dH2,
+                                                            float* __restrict__ dX0, float* __restrict__ dX1, float* __restrict__ scr, int S, int L) {
+    __shared__ float WsB[2 * 24 * 4 * 64];  // the B operands of the dX tiles in issue order: [direction][q][column tile][lane]
+    __shared__ float Tw[8][kLbWave];
+    for (int e = threadIdx.x; e < 2 * 24 * 4 * 64; e += 512) {
+        const int ln = e & 63, ct = (e >> 6) & 3, q = (e >> 8) % 24, d = e / (24 * 256);
+        const int col = lb_col(q, ln >> 4), n = (col >> 5) * 64 + d * 32 + (col & 31);
+        WsB[e] = W[n * 64 + 16 * ct + (ln & 15)];
+    }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int d = wv & 1;  // the wave's direction: iteration i of the adjoint visits position t = d ? i : L - 1 - i
+    const int lane = threadIdx.x & 63, g = lane >> 4, j16 = lane & 15, hs = lane >> 5, un = lane & 31;
+    const float wf = wc[d * 32 + un], wr = wc[64 + d * 32 + un], bf = bias[d * 32 + un], br = bias[64 + d * 32 + un];
+    float* Ts = Tw[wv];
+    float* Ps = Ts + 2 * kLbTD;
+    float* tw = Ts + hs * kLbTD + un;  // this lane's column of its sequence's slab
+    float* dXd = d ? dX1 : dX0;
+    floatx4 accW[6][4];
+#pragma unroll
+    for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) accW[rt][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float awf = 0.f, awr = 0.f, abf = 0.f, abr = 0.f;
+    const int npair = (S + 1) >> 1, pstep = gridDim.x * 4;
+    int p = blockIdx.x * 4 + (wv >> 1);
+    if (p < npair) {
+        // scan operands of 8 adjoint iterations i0 .. i0 + 7 of the pair pn (clamped, unconditional)
+        float pu0[8], pu1[8], pu2[8], pc[8], pgh[8], pg2[8], pxp[8], pcn;
+        auto load = [&](int pn, int i0) {
+            const unsigned sq = min(2 * pn + hs, S - 1), b64 = sq * (unsigned)L * 64u + d * 32 + un, b192 = sq * (unsigned)L * 192u + d * 32 + un;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = min(i0 + j, L - 1);
+                const unsigned t = d ? i : L - 1 - i, o = b64 + t * 64u, o3 = b192 + t * 192u;
+                pc[j] = Cst[o];
+                pgh[j] = dH[o];
+                pg2[j] = dH2 ? dH2[o] : 0.f;
+                pxp[j] = X[o];
+                pu0[j] = U[o3], pu1[j] = U[o3 + 64], pu2[j] = U[o3 + 128];
+            }
+            const int i = min(i0 + 8, L - 1);
+            pcn = Cst[b64 + (d ? i : L - 1 - i) * 64u];
+        };
+        if (!(LB_ABL & 16)) load(p, 0);
+        float dc = 0.f;
+#pragma unroll 1
+        for (int i0 = 0;;) {
+            const bool live = 2 * p + hs < S;  // the second sequence of the last pair of an odd S is a clamped copy: nothing of it is kept
+            // rows of X of this chunk as B operands of the dW tiles: k = 4 q + g = 8 (which sequence) + step
+            float xa[4][4];
+            {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned sq = min(2 * p + (q >> 1), S - 1);
+                    const int i = min(i0 + 4 * (q & 1) + g, L - 1);
+                    const unsigned o = (sq * (unsigned)L + (d ? i : L - 1 - i)) * 64u + j16;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) xa[q][ct] = X[o + 16 * ct];
+                }
+            }
+            if (i0 == 0) dc = 0.f;
+            // ---- 8 steps of the adjoint recurrence (sru_scan_bwd_kernel's arithmetic); no branch per step: a step past the end of the sequence (clamped
+            // operands, only behind the last real step) runs with gh = 0 and dct = 0, all its outputs are zero ----
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j;
+                float du0 = 0.f, du1 = 0.f, du2 = 0.f, dxp = 0.f;
+                if (!(LB_ABL & 4)) {
+                    const bool ok = live && i < L;
+                    const float cprev = i < L - 1 ? (j < 7 ? pc[j + 1] : pcn) : 0.f;
+                    const float c = pc[j], gh = ok ? pgh[j] + pg2[j] : 0.f, u0 = pu0[j], u1 = pu1[j], u2 = pu2[j], xp = pxp[j] * scale_x;
+                    const float f = sigmoidf_fast(u1 + bf + wf * cprev);
+                    const float r = sigmoidf_fast(u2 + br + wr * cprev);
+                    dxp = gh * (1.f - r);
+                    const float dr = gh * (c - xp);
+                    du2 = dr * r * (1.f - r);
+                    const float dct = ok ? gh * r + dc : 0.f;
+                    du0 = dct * (1.f - f);
+                    const float df = dct * (cprev - u0);
+                    du1 = df * f * (1.f - f);
+                    dc = dct * f + du1 * wf + du2 * wr;
+                    awf = fmaf(du1, cprev, awf);
+                    awr = fmaf(du2, cprev, awr);
+                    abf += du1;
+                    abr += du2;
+                }
+                tw[j * kLbTS] = du0, tw[j * kLbTS + 32] = du1, tw[j * kLbTS + 64] = du2;
+                Ps[(8 * hs + j) * kLbPS + un] = dxp * scale_x;
+            }
+            // ---- operands of the next chunk (of this pair, or the first of the wave's next pair): in flight under the MFMAs ----
+            const bool last = i0 + 8 >= L;
+            const int pn = last ? p + pstep : p, in = last ? 0 : i0 + 8;
+            if (!(LB_ABL & 16)) load(pn < npair ? pn : p, in);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- dW: 4 groups (4 (sequence, step) pairs) of 24 MFMAs; the six A operands of a group are read from LDS one group ahead ----
+            {
+                float aw[2][6];
+                const float* tr = Ts + g * kLbTS + j16;
+#pragma unroll
+                for (int rt = 0; rt < 6; ++rt) aw[0][rt] = tr[16 * rt];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q + 1 < 4) {
+#pragma unroll
+                        for (int rt = 0; rt < 6; ++rt) aw[(q + 1) & 1][rt] = tr[((q + 1) >> 1) * kLbTD + 4 * ((q + 1) & 1) * kLbTS + 16 * rt];
+                    }
+                    if (!(LB_ABL & 1)) {
+#pragma unroll
+                        for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) accW[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[q & 1][rt], xa[q][ct], accW[rt][ct], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- dX: 12 groups of two k-steps (2 A + 8 B operands, 8 MFMAs), operands read one group ahead ----
+            {
+                floatx4 ax[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) ax[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+                float oa[2][2], ob[2][2][4];
+                const float* ta = Ts + (j16 >> 3) * kLbTD + (j16 & 7) * kLbTS + 8 * g;
+                const float* wb = WsB + d * 24 * 256 + lane;
+                auto fetch = [&](int gx, int slot) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = 2 * gx + h;
+                        oa[slot][h] = ta[32 * (q >> 3) + (q & 7)];
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) ob[slot][h][ct] = wb[(q * 4 + ct) * 64];
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int gx = 0; gx < 12; ++gx) {
+                    if (gx + 1 < 12) fetch(gx + 1, (gx + 1) & 1);
+                    if (LB_ABL & 2) continue;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) ax[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[gx & 1][h], ob[gx & 1][h][ct], ax[ct], 0, 0, 0);
+                }
+                // the tile (rows 4 g + r = sequence g >> 1 of the pair, iteration i0 + 4 (g & 1) + r; + highway on the direction's own columns) goes
+                // through the dU slab, which the MFMAs above have finished reading, and leaves as whole 256-byte rows: 4 x 16-byte stores per lane
+                // instead of 16 x 4-byte stores on 64-byte pieces
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float v = ax[ct][r];
+                        if ((ct >> 1) == d) v += Ps[(4 * g + r) * kLbPS + 16 * (ct & 1) + j16];
+                        Ts[(4 * g + r) * kLbOS + 16 * ct + j16] = v;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = 4 * k + g;  // (sequence row >> 3, step row & 7)
+                    const unsigned sq = 2 * p + (row >> 3);
+                    const int i = i0 + (row & 7);
+                    const bool ok = sq < (unsigned)S && i < L && !(LB_ABL & 8);
+                    const float4 v = ld4(Ts + row * kLbOS + 4 * j16);
+                    if (ok) st4(dXd + ((size_t)sq * L + (d ? i : L - 1 - i)) * 64 + 4 * j16, v);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (last) {
+                p += pstep;
+                i0 = 0;
+                if (p >= npair) break;
+            } else {
+                i0 += 8;
+            }
+        }
+    }
+    // dW of the four waves of a direction is summed in LDS (the slabs are free now; [direction][register][lane], one wave after the other) before it goes
+    // to this workgroup's scratch copy: a quarter of the global atomics
+    float* mine = spread_copy(scr, blockIdx.x);  // [dW 192 x 64 | dwc 128 | dbias 128]
+    float* red = &Tw[0][0] + d * 96 * 64 + lane;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        __syncthreads();
+        if ((wv >> 1) == k) {
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* q = red + ((rt * 4 + ct) * 4 + r) * 64;
+                        *q = k ? *q + accW[rt][ct][r] : accW[rt][ct][r];
+                    }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * 96 * 64; e += 512) {
+        const int ln = e & 63, reg = (e >> 6) % 96, dd = e / (96 * 64);
+        const int r = reg & 3, ct = (reg >> 2) & 3, rt = reg >> 4;
+        const int col = 16 * rt + 4 * (ln >> 4) + r, n = (col >> 5) * 64 + dd * 32 + (col & 31);
+        atomicAdd(mine + n * 64 + 16 * ct + (ln & 15), (&Tw[0][0])[e]);
+    }
+    atomicAdd(mine + 12288 + d * 32 + un, awf);
+    atomicAdd(mine + 12288 + 64 + d * 32 + un, awr);
+    atomicAdd(mine + 12288 + 128 + d * 32 + un, abf);
+    atomicAdd(mine + 12288 + 192 + d * 32 + un, abr);
 }
 
 // LN4D over channels, adjoint.  dxn, G, dG in G layout [rows][64]; dG += dx; dgamma/dbeta += per-channel sums.
@@ -271,20 +512,41 @@ int rtfs_sru_scan_train_fwd(const float* U, const float* X, const float* wc, con
 }
 
 // dwc, dbias: [2][64] accumulated into.  km = 3 also writes dX [S][L][64] (gradient w.r.t. the skip input, already * scale_x).
-int rtfs_sru_scan_bwd(const float* U, const float* X, const float* C, const float* wc, const float* bias, float scale_x, const float* dH, float* dU,
-                      float* dX, float* dwc, float* dbias, int S, int L, int km, void* stream) {
+// dH2 (nullable): a second part of the incoming gradient, added to dH on load.
+int rtfs_sru_scan_bwd2(const float* U, const float* X, const float* C, const float* wc, const float* bias, float scale_x, const float* dH,
+                       const float* dH2, float* dU, float* dX, float* dwc, float* dbias, int S, int L, int km, void* stream) {
     if (S <= 0 || L <= 0) return RTFS_EINVAL;
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
     dim3 grid((S + 3) / 4);
     if (km == 4)
-        hipLaunchKernelGGL((sru_scan_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, scr, S, L);
+        hipLaunchKernelGGL((sru_scan_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dH2, dU, dX, scr, S, L);
     else if (km == 3)
-        hipLaunchKernelGGL((sru_scan_bwd_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dU, dX, scr, S, L);
+        hipLaunchKernelGGL((sru_scan_bwd_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, U, X, C, wc, bias, scale_x, dH, dH2, dU, dX, scr, S, L);
     else
         return RTFS_EINVAL;
     RTFS_LAUNCH_CHECK();
     return spread_finish(scr, SpreadOut{{dwc, dbias}, {128, 128}}, (hipStream_t)stream);
+}
+
+int rtfs_sru_scan_bwd(const float* U, const float* X, const float* C, const float* wc, const float* bias, float scale_x, const float* dH, float* dU,
+                      float* dX, float* dwc, float* dbias, int S, int L, int km, void* stream) {
+    return rtfs_sru_scan_bwd2(U, X, C, wc, bias, scale_x, dH, nullptr, dU, dX, dwc, dbias, S, L, km, stream);
+}
+
+// The adjoint of one fused SRU layer (rtfs_sru_layer_fwd in training mode) in one launch: W [192][64] as the forward takes it.  The incoming gradient
+// is dH (+ dH2 when not null); the gradient w.r.t. the layer input (recurrence skip term + dU . W) leaves as TWO parts, dX0 + dX1 [S][L][64] each (the
+// forward and the backward direction's share; both fully written) - hand them to the next layer down as dH, dH2.  dW [192][64], dwc, dbias [2][64]
+// are accumulated into.
+int rtfs_sru_layer_bwd(const float* U, const float* X, const float* C, const float* W, const float* wc, const float* bias, float scale_x, const float* dH,
+                       const float* dH2, float* dX0, float* dX1, float* dW, float* dwc, float* dbias, int S, int L, void* stream) {
+    if (S <= 0 || L <= 0 || (long long)S * L * 768 >= (1ll << 32)) return RTFS_EINVAL;  // 32-bit byte offsets into U
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int npair = (S + 1) / 2, nwg = min((npair + 3) / 4, 256);
+    hipLaunchKernelGGL(sru_layer_bwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, U, X, C, W, wc, bias, scale_x, dH, dH2, dX0, dX1, scr, S, L);
+    RTFS_LAUNCH_CHECK();
+    return spread_finish(scr, SpreadOut{{dW, dwc, dbias}, {12288, 128, 128}}, (hipStream_t)stream);
 }
 
 int rtfs_ln4d_c_bwd(const float* dxn, const float* G, const float* gamma, float* dG, float* dgamma, float* dbeta, long long rows, void* stream) {

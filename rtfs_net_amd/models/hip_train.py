@@ -644,19 +644,30 @@ class HipTrainer:
         self._wg("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
         self._call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
-        # SRU layers 3..1
+        # SRU layers 3..1.  fp32 (and the six-term mode, whose backward GEMMs are the fp32 kernels): one launch per layer - recurrence adjoint, weight
+        # gradient and input gradient with dU held in LDS (rtfs_sru_layer_bwd); the input gradient arrives as two parts (one per scan direction) that
+        # the next layer down adds on load.  Otherwise the three launches (dU through HBM).
+        one_launch = self.model._hip.fuse["srubwd"] and self.prec in (0, 6) and S * L < 5_500_000
+        dh2 = None
         for l in (3, 2, 1):
             lw = d["layers"][l]
+            if one_launch:
+                dxa, dxb = torch.empty(S * L * 64, device=dev), torch.empty(S * L * 64, device=dev)
+                lib.call("rtfs_sru_layer_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["w"], lw["wc"], lw["bias"], lw["scale_x"], dh, dh2, dxa, dxb,
+                         g(f"l{l}.w", 192 * 64), g(f"l{l}.wc", 128), g(f"l{l}.bias", 128), S, L)
+                dh, dh2 = dxa, dxb
+                continue
             dU = torch.empty(S * L * 192, device=dev)
             dx = torch.empty(S * L * 64, device=dev)
-            self._call("rtfs_sru_scan_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dU, dx, g(f"l{l}.wc", 128), g(f"l{l}.bias", 128),
-                     S, L, 3)
+            self._call("rtfs_sru_scan_bwd2", sv.U[l], sv.h[l - 1], sv.c[l], lw["wc"], lw["bias"], lw["scale_x"], dh, dh2, dU, dx, g(f"l{l}.wc", 128),
+                       g(f"l{l}.bias", 128), S, L, 3)
             self._wg("rtfs_wgrad", dU, 192, sv.h[l - 1], 64, g(f"l{l}.w", 192 * 64), 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
             self._call("rtfs_gemm_rows", dU, lw["wT"], None, dx, S * L, 192, 64, 1)  # dx += dU . W
-            dh = dx
+            dh, dh2 = dx, None
         l0 = d["layers"][0]
         dU0 = torch.empty(S * L * 256, device=dev)
-        self._call("rtfs_sru_scan_bwd", sv.U[0], None, sv.c[0], l0["wc"], l0["bias"], l0["scale_x"], dh, dU0, None, g("l0.wc", 128), g("l0.bias", 128), S, L, 4)
+        self._call("rtfs_sru_scan_bwd2", sv.U[0], None, sv.c[0], l0["wc"], l0["bias"], l0["scale_x"], dh, dh2, dU0, None, g("l0.wc", 128), g("l0.bias", 128),
+                   S, L, 4)
         # layer-0 GEMM: weight gradient over the Toeplitz windows, input gradient by folding
         xn_seq = torch.empty(S * npos * 64, device=dev)
         self._call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)

@@ -676,6 +676,52 @@ def test_fold_gemm_bwd_entry_isolated(B, T2, dim):
     assert float(rows.max()) < 5e-6, (float(rows.max()), int(rows.argmax()))
 
 
+@pytest.mark.parametrize("S,L", [(1, 1), (3, 7), (5, 8), (6, 9), (9, 33), (130, 57), (71, 118), (2100, 57), (4200, 20)])
+def test_sru_layer_bwd_entry_matches_three_launches(S, L):
+    """rtfs_sru_layer_bwd (recurrence adjoint + weight gradient + input gradient of an SRU layer 1-3 in one launch, dU held in LDS; autograd over
+    sru.SRU's layer, rnn_layers.py:100-105) against the three launches it replaces - rtfs_sru_scan_bwd(km = 3), rtfs_wgrad, rtfs_gemm_rows - which the
+    gradient fixtures pin to the float64 oracle: same dX (= dX0 + dX1, the two directions' parts), dW, dwc, dbias up to the order of the fp32 sums.
+    Lengths on both sides of the 8-step chunk, odd and even sequence counts (a wave owns a pair), more pairs than one pass of the persistent grid;
+    the incoming gradient in one part and split in two (dH + dH2, as the layer below a fused layer receives it)."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(97 * S + L)
+    X = torch.randn(S, L, 64, generator=g).cuda()
+    W = (torch.randn(192, 64, generator=g) * 0.15).cuda()
+    wc = (torch.randn(128, generator=g) * 0.5).cuda()
+    bias = (torch.randn(128, generator=g) * 0.5).cuda()
+    dH = torch.randn(S, L, 64, generator=g).cuda()
+    scale = 1.7
+    H, C, U = torch.empty_like(X), torch.empty_like(X), torch.empty(S, L, 192, device="cuda")
+    lib.call("rtfs_sru_layer_fwd", X, W, wc, bias, scale, H, C, U, S, L)
+    # the three launches
+    dU, dX0 = torch.empty_like(U), torch.empty_like(X)
+    dwc0, db0, dW0 = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda"), torch.zeros(192 * 64, device="cuda")
+    lib.call("rtfs_sru_scan_bwd", U, X, C, wc, bias, scale, dH, dU, dX0, dwc0, db0, S, L, 3)
+    lib.call("rtfs_wgrad", dU, 192, X, 64, dW0, 64, None, S * L, 0, 0, 0, 1, 192, 64, 0, None, None, 0.0, None, 0)
+    lib.call("rtfs_gemm_rows", dU, W.t().contiguous(), None, dX0, S * L, 192, 64, 1)
+    part = torch.randn(S, L, 64, generator=g).cuda()
+    for dHa, dHb in ((dH, None), (part, dH - part)):
+        # one launch; the accumulated outputs start from a known non-zero value
+        dXa, dXb = torch.full_like(X, float("nan")), torch.full_like(X, float("nan"))
+        dwc1, db1, dW1 = torch.ones(128, device="cuda"), torch.ones(128, device="cuda"), torch.ones(192 * 64, device="cuda")
+        lib.call("rtfs_sru_layer_bwd", U, X, C, W, wc, bias, scale, dHa, dHb, dXa, dXb, dW1, dwc1, db1, S, L)
+        torch.cuda.synchronize()
+        assert torch.isfinite(dXa).all() and torch.isfinite(dXb).all()
+        dX1 = dXa + dXb
+        tol = 2e-6 if dHb is None else 2e-5  # (dH - part) + part is dH only to an ulp of the larger operand
+        assert rel(dX1, dX0) < tol, rel(dX1, dX0)
+        rows = (dX1.double() - dX0.double()).norm(dim=-1) / dX0.double().norm(dim=-1).clamp_min(1e-3)
+        assert float(rows.max()) < 10 * tol, (float(rows.max()), int(rows.argmax()))
+        assert rel(dW1 - 1, dW0) < 10 * tol and rel(dwc1 - 1, dwc0) < 10 * tol and rel(db1 - 1, db0) < 10 * tol, (
+            rel(dW1 - 1, dW0), rel(dwc1 - 1, dwc0), rel(db1 - 1, db0))
+    # rtfs_sru_scan_bwd2 (the layer below a fused layer: gradient in two parts) = rtfs_sru_scan_bwd on the sum
+    dU2, dX2 = torch.empty_like(U), torch.empty_like(X)
+    dwc2, db2 = torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    lib.call("rtfs_sru_scan_bwd2", U, X, C, wc, bias, scale, part, dH - part, dU2, dX2, dwc2, db2, S, L, 3)
+    assert rel(dU2, dU) < 2e-5 and rel(dwc2, dwc0) < 2e-4
+
+
 @pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_convt_bwd_input_entry_isolated(B, T2, dim):
