@@ -251,9 +251,10 @@ int rtfs_sru_scan_bwd2(const float* U, const float* X, const float* C, const flo
 /* the adjoint of rtfs_sru_layer_fwd (layers 1-3, training mode) in one launch - rtfs_sru_scan_bwd(km = 3) + rtfs_wgrad + rtfs_gemm_rows with dU held in
  * LDS (reference: autograd over sru.SRU's layer, rnn_layers.py:100-105): W [192][64] as the forward takes it; incoming gradient dH (+ dH2 when not
  * null); the input gradient leaves as two fully written parts dX0 + dX1 [S][L][64] (one per scan direction; the next layer down takes them as dH,
- * dH2); dW [192][64], dwc, dbias [2][64] accumulated into.  S * L < 5.59 M positions. */
+ * dH2); dW [192][64], dwc, dbias [2][64] accumulated into; work: rtfs_sru_layer_bwd_work_floats(S) floats of device scratch.  S * L < 2.79 M positions. */
+int rtfs_sru_layer_bwd_work_floats(int S);
 int rtfs_sru_layer_bwd(const float* U, const float* X, const float* C, const float* W, const float* wc, const float* bias, float scale_x, const float* dH,
-                       const float* dH2_or_null, float* dX0, float* dX1, float* dW, float* dwc, float* dbias, int S, int L, void* stream);
+                       const float* dH2_or_null, float* dX0, float* dX1, float* work, float* dW, float* dwc, float* dbias, int S, int L, void* stream);
 int rtfs_ln4d_c_bwd(const float* dxn, const float* G, const float* gamma, float* dG, float* dgamma, float* dbeta, long long rows, void* stream);
 int rtfs_seq_gather(const float* G, const float* gamma, const float* beta, int ln, float* out, int B, int T2, int dim, void* stream);
 /* attention adjoints */

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void sru_scan_bwd_kernel(const float* __restri
 // consumer adds them - the next layer down takes the pair as dH, dH2.  (A one-buffer form - one wave per sequence, the later direction adding to the
 // earlier one's rows behind a fence - measured 250 us per layer: one wave per SIMD, every load and LDS round trip bare.)  Two waves per SIMD here: one's
 // recurrence and memory waits run under the other's MFMAs.  dW stays in 96 accumulator registers over all pairs of the wave, is summed over the four
-// waves of a direction in LDS and leaves through the spread scratch [dW 12288 | dwc 128 | dbias 128].
+// waves of a direction in LDS and leaves as the workgroup's partial in `work` (sru_layer_bwd_reduce_kernel adds the partials); dwc, dbias: spread scratch.
 // HBM per layer: U, X, C, dH (x 2) in, dX0 + dX1 out = 523 MB (three launches: 1108 MB); 11.2 GFLOP.
 constexpr int kLbTS = 97;                         // floats per step row of a sequence's dU slab
 constexpr int kLbTD = 8 * kLbTS + 24;             // floats per sequence (32 mod 64: the two sequences' scan writes fall 32 banks apart)
@@ -185,7 +185,19 @@ __device__ __forceinline__ int lb_col(int q, int g) { return 32 * (q >> 3) + (q 
 __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restrict__ U, const float* __restrict__ X, const float* __restrict__ Cst,
                                                             const float* __restrict__ W, const float* __restrict__ wc, const float* __restrict__ bias,
                                                             float scale_x, const float* __restrict__ dH, const float* __restrict__ dH2,
-                                                            float* __restrict__ dX0, float* __restrict__ dX1, float* __restrict__ scr, int S, int L) {
+                                                            float* __restrict__ dX0, float* __restrict__ dX1, float* __restrict__ work,
+                                                            float* __restrict__ scr, int S, int L) {
+#ifdef LB_TIMING  // timing-only build (tools/ffa_ablate.sh lb with ABL_FLAGS=-DLB_TIMING, tools/sru_bwd_bench.py): s_memtime ticks per phase, per wave, into dX0
+    unsigned long long lb_tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lb_last = __builtin_amdgcn_s_memtime();
+#define LB_TICK(k)                                                      \
+    {                                                                   \
+        const unsigned long long lb_now = __builtin_amdgcn_s_memtime(); \
+        lb_tm[k] += lb_now - lb_last;                                   \
+        lb_last = lb_now;                                               \
+    }
+#else
+#define LB_TICK(k)
+#endif
     __shared__ float WsB[2 * 24 * 4 * 64];  // the B operands of the dX tiles in issue order: [direction][q][column tile][lane]
     __shared__ float Tw[8][kLbWave];
     for (int e = threadIdx.x; e < 2 * 24 * 4 * 64; e += 512) {
@@ -213,36 +225,46 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
     if (p < npair) {
         // scan operands of 8 adjoint iterations i0 .. i0 + 7 of the pair pn (clamped, unconditional)
         float pu0[8], pu1[8], pu2[8], pc[8], pgh[8], pg2[8], pxp[8], pcn;
+        // operands come through buffer loads: descriptor (scalar) + per-lane byte offset of the sequence and column (one register for the whole pair) +
+        // scalar byte offset of the row of iteration i - no vector address arithmetic per load (the wave issues 57 - 73 loads per chunk)
+        const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)((long long)S * L * 768), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)((long long)S * L * 256), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Cst), 0, (int)((long long)S * L * 256), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dH), 0, (int)((long long)S * L * 256), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rG2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dH2 ? dH2 : dH), 0, (int)((long long)S * L * 256), 0x00020000);
+        auto bld = [](const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+        };
         auto load = [&](int pn, int i0) {
-            const unsigned sq = min(2 * pn + hs, S - 1), b64 = sq * (unsigned)L * 64u + d * 32 + un, b192 = sq * (unsigned)L * 192u + d * 32 + un;
+            const unsigned sq = min(2 * pn + hs, S - 1), v64 = (sq * (unsigned)L * 64u + d * 32 + un) * 4u, v192 = (sq * (unsigned)L * 192u + d * 32 + un) * 4u;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int i = min(i0 + j, L - 1);
-                const unsigned t = d ? i : L - 1 - i, o = b64 + t * 64u, o3 = b192 + t * 192u;
-                pc[j] = Cst[o];
-                pgh[j] = dH[o];
-                pg2[j] = dH2 ? dH2[o] : 0.f;
-                pxp[j] = X[o];
-                pu0[j] = U[o3], pu1[j] = U[o3 + 64], pu2[j] = U[o3 + 128];
+                const int i = min(i0 + j, L - 1), t = d ? i : L - 1 - i;  // uniform
+                pc[j] = bld(rC, v64, t * 256);
+                pgh[j] = bld(rG, v64, t * 256);
+                pg2[j] = dH2 ? bld(rG2, v64, t * 256) : 0.f;
+                pxp[j] = bld(rX, v64, t * 256);
+                pu0[j] = bld(rU, v192, t * 768), pu1[j] = bld(rU, v192 + 256, t * 768), pu2[j] = bld(rU, v192 + 512, t * 768);
             }
             const int i = min(i0 + 8, L - 1);
-            pcn = Cst[b64 + (d ? i : L - 1 - i) * 64u];
+            pcn = bld(rC, v64, (d ? i : L - 1 - i) * 256);
         };
         if (!(LB_ABL & 16)) load(p, 0);
         float dc = 0.f;
 #pragma unroll 1
         for (int i0 = 0;;) {
+            LB_TICK(0);
             const bool live = 2 * p + hs < S;  // the second sequence of the last pair of an odd S is a clamped copy: nothing of it is kept
             // rows of X of this chunk as B operands of the dW tiles: k = 4 q + g = 8 (which sequence) + step
             float xa[4][4];
             {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned sq = min(2 * p + (q >> 1), S - 1);
+                    const int sq = min(2 * p + (q >> 1), S - 1);  // uniform
                     const int i = min(i0 + 4 * (q & 1) + g, L - 1);
-                    const unsigned o = (sq * (unsigned)L + (d ? i : L - 1 - i)) * 64u + j16;
+                    const unsigned vo = ((d ? i : L - 1 - i) * 64u + j16) * 4u;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) xa[q][ct] = X[o + 16 * ct];
+                    for (int ct = 0; ct < 4; ++ct) xa[q][ct] = bld(rX, vo + 64 * ct, sq * L * 256);
                 }
             }
             if (i0 == 0) dc = 0.f;
@@ -274,12 +296,14 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
                 tw[j * kLbTS] = du0, tw[j * kLbTS + 32] = du1, tw[j * kLbTS + 64] = du2;
                 Ps[(8 * hs + j) * kLbPS + un] = dxp * scale_x;
             }
+            LB_TICK(1);
             // ---- operands of the next chunk (of this pair, or the first of the wave's next pair): in flight under the MFMAs ----
             const bool last = i0 + 8 >= L;
             const int pn = last ? p + pstep : p, in = last ? 0 : i0 + 8;
             if (!(LB_ABL & 16)) load(pn < npair ? pn : p, in);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            LB_TICK(2);
             // ---- dW: 4 groups (4 (sequence, step) pairs) of 24 MFMAs; the six A operands of a group are read from LDS one group ahead ----
             {
                 float aw[2][6];
@@ -300,6 +324,7 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
                     }
                 }
             }
+            LB_TICK(3);
             // ---- dX: 12 groups of two k-steps (2 A + 8 B operands, 8 MFMAs), operands read one group ahead ----
             {
                 floatx4 ax[4];
@@ -327,6 +352,7 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
 #pragma unroll
                         for (int ct = 0; ct < 4; ++ct) ax[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[gx & 1][h], ob[gx & 1][h][ct], ax[ct], 0, 0, 0);
                 }
+                LB_TICK(4);
                 // the tile (rows 4 g + r = sequence g >> 1 of the pair, iteration i0 + 4 (g & 1) + r; + highway on the direction's own columns) goes
                 // through the dU slab, which the MFMAs above have finished reading, and leaves as whole 256-byte rows: 4 x 16-byte stores per lane
                 // instead of 16 x 4-byte stores on 64-byte pieces
@@ -354,6 +380,7 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            LB_TICK(5);
             if (last) {
                 p += pstep;
                 i0 = 0;
@@ -363,9 +390,11 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
             }
         }
     }
-    // dW of the four waves of a direction is summed in LDS (the slabs are free now; [direction][register][lane], one wave after the other) before it goes
-    // to this workgroup's scratch copy: a quarter of the global atomics
-    float* mine = spread_copy(scr, blockIdx.x);  // [dW 192 x 64 | dwc 128 | dbias 128]
+    LB_TICK(6);
+    // dW of the four waves of a direction is summed in LDS (the slabs are free now; [direction][register][lane], one wave after the other) and leaves as
+    // this workgroup's partial in `work` [workgroup][direction][register][lane] - plain stores; sru_layer_bwd_reduce_kernel adds the partials into dW.
+    // (Through atomics into the spread scratch - 24 per thread - this tail was 54 k of the wave's 387 k cycles.)
+    float* mine = spread_copy(scr, blockIdx.x);  // [dwc 128 | dbias 128]
     float* red = &Tw[0][0] + d * 96 * 64 + lane;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
@@ -383,16 +412,31 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * 96 * 64; e += 512) {
-        const int ln = e & 63, reg = (e >> 6) % 96, dd = e / (96 * 64);
-        const int r = reg & 3, ct = (reg >> 2) & 3, rt = reg >> 4;
-        const int col = 16 * rt + 4 * (ln >> 4) + r, n = (col >> 5) * 64 + dd * 32 + (col & 31);
-        atomicAdd(mine + n * 64 + 16 * ct + (ln & 15), (&Tw[0][0])[e]);
+    for (int e = threadIdx.x * 4; e < 2 * 96 * 64; e += 2048) st4(work + (size_t)blockIdx.x * 12288 + e, ld4(&Tw[0][0] + e));
+#ifdef LB_TIMING
+    lb_tm[7] += __builtin_amdgcn_s_memtime() - lb_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(dX0) + (blockIdx.x * 8 + wv) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = lb_tm[k];
     }
-    atomicAdd(mine + 12288 + d * 32 + un, awf);
-    atomicAdd(mine + 12288 + 64 + d * 32 + un, awr);
-    atomicAdd(mine + 12288 + 128 + d * 32 + un, abf);
-    atomicAdd(mine + 12288 + 192 + d * 32 + un, abr);
+#endif
+    atomicAdd(mine + d * 32 + un, awf);
+    atomicAdd(mine + 64 + d * 32 + un, awr);
+    atomicAdd(mine + 128 + d * 32 + un, abf);
+    atomicAdd(mine + 192 + d * 32 + un, abr);
+}
+
+// dW[n][k] += sum over the workgroups' partials (work [nwg][direction][register (row tile, column tile, r)][lane]); grid (48, 8): blockIdx.y takes every
+// eighth partial, eight atomics per element
+__global__ __launch_bounds__(256) void sru_layer_bwd_reduce_kernel(const float* __restrict__ work, float* __restrict__ dW, int nwg) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float t = 0.f;
+    for (int w = blockIdx.y; w < nwg; w += 8) t += work[(size_t)w * 12288 + e];
+    const int ln = e & 63, reg = (e >> 6) % 96, dd = e / (96 * 64);
+    const int r = reg & 3, ct = (reg >> 2) & 3, rt = reg >> 4;
+    const int col = 16 * rt + 4 * (ln >> 4) + r, n = (col >> 5) * 64 + dd * 32 + (col & 31);
+    atomicAdd(dW + n * 64 + 16 * ct + (ln & 15), t);
 }
 
 // LN4D over channels, adjoint.  dxn, G, dG in G layout [rows][64]; dG += dx; dgamma/dbeta += per-channel sums.
@@ -537,16 +581,23 @@ int rtfs_sru_scan_bwd(const float* U, const float* X, const float* C, const floa
 // The adjoint of one fused SRU layer (rtfs_sru_layer_fwd in training mode) in one launch: W [192][64] as the forward takes it.  The incoming gradient
 // is dH (+ dH2 when not null); the gradient w.r.t. the layer input (recurrence skip term + dU . W) leaves as TWO parts, dX0 + dX1 [S][L][64] each (the
 // forward and the backward direction's share; both fully written) - hand them to the next layer down as dH, dH2.  dW [192][64], dwc, dbias [2][64]
-// are accumulated into.
+// are accumulated into.  work: rtfs_sru_layer_bwd_work_floats(S) floats of device scratch (the workgroups' partial dW).
+static int sru_layer_bwd_nwg(int S) { return min(((S + 1) / 2 + 3) / 4, 256); }
+
+int rtfs_sru_layer_bwd_work_floats(int S) { return S > 0 ? sru_layer_bwd_nwg(S) * 12288 : 0; }
+
 int rtfs_sru_layer_bwd(const float* U, const float* X, const float* C, const float* W, const float* wc, const float* bias, float scale_x, const float* dH,
-                       const float* dH2, float* dX0, float* dX1, float* dW, float* dwc, float* dbias, int S, int L, void* stream) {
-    if (S <= 0 || L <= 0 || (long long)S * L * 768 >= (1ll << 32)) return RTFS_EINVAL;  // 32-bit byte offsets into U
+                       const float* dH2, float* dX0, float* dX1, float* work, float* dW, float* dwc, float* dbias, int S, int L, void* stream) {
+    if (S <= 0 || L <= 0 || (long long)S * L * 768 >= (1ll << 31)) return RTFS_EINVAL;  // buffer descriptors: byte sizes in an int
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
-    const int npair = (S + 1) / 2, nwg = min((npair + 3) / 4, 256);
-    hipLaunchKernelGGL(sru_layer_bwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, U, X, C, W, wc, bias, scale_x, dH, dH2, dX0, dX1, scr, S, L);
+    const int nwg = sru_layer_bwd_nwg(S);
+    hipLaunchKernelGGL(sru_layer_bwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, U, X, C, W, wc, bias, scale_x, dH, dH2, dX0, dX1, work, scr, S,
+                       L);
     RTFS_LAUNCH_CHECK();
-    return spread_finish(scr, SpreadOut{{dW, dwc, dbias}, {12288, 128, 128}}, (hipStream_t)stream);
+    hipLaunchKernelGGL(sru_layer_bwd_reduce_kernel, dim3(48, 8), dim3(256), 0, (hipStream_t)stream, work, dW, nwg);
+    RTFS_LAUNCH_CHECK();
+    return spread_finish(scr, SpreadOut{{dwc, dbias}, {128, 128}}, (hipStream_t)stream);
 }
 
 int rtfs_ln4d_c_bwd(const float* dxn, const float* G, const float* gamma, float* dG, float* dgamma, float* dbeta, long long rows, void* stream) {

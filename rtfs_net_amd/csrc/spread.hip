@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void spread_finish_kernel(float* __restrict__ 
 // All pending regions of a deferred section in one launch.  Two regions may name the same destination (the R RTFS blocks share their weights, and a
 // block's adjoint adds into one gradient buffer per parameter): the sums are ADDED with fp32 atomics.
 constexpr int kMaxPend = 24;
-constexpr int kMaxRegion = 12544;  // largest region any producer asks for (SRU layer adjoint: 192 x 64 + 128 + 128)
+constexpr int kMaxRegion = 12352;  // largest region any producer asks for (attention QKV norm adjoint: 4 x 1024 + 2 x 4096 + 12, 32-float aligned)
 struct FlushArgs {
     int n;
     int off[kMaxPend], total[kMaxPend];

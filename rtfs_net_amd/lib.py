@@ -86,7 +86,8 @@ SIGNATURES = {
     "rtfs_sru_scan_train_fwd": [P, P, P, P, F, P, P, I, I, I, P],
     "rtfs_sru_scan_bwd": [P, P, P, P, P, F, P, P, P, P, P, I, I, I, P],
     "rtfs_sru_scan_bwd2": [P, P, P, P, P, F, P, P, P, P, P, P, I, I, I, P],
-    "rtfs_sru_layer_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, P, P, I, I, P],
+    "rtfs_sru_layer_bwd_work_floats": [I],
+    "rtfs_sru_layer_bwd": [P, P, P, P, P, P, F, P, P, P, P, P, P, P, P, I, I, P],
     "rtfs_ln4d_c_bwd": [P, P, P, P, P, P, LL, P],
     "rtfs_seq_gather": [P, P, P, I, P, I, I, I, P],
     "rtfs_attn_out_norm_bwd": [P, P, F, P, P, P, P, P, I, P],

@@ -647,13 +647,14 @@ class HipTrainer:
         # SRU layers 3..1.  fp32 (and the six-term mode, whose backward GEMMs are the fp32 kernels): one launch per layer - recurrence adjoint, weight
         # gradient and input gradient with dU held in LDS (rtfs_sru_layer_bwd); the input gradient arrives as two parts (one per scan direction) that
         # the next layer down adds on load.  Otherwise the three launches (dU through HBM).
-        one_launch = self.model._hip.fuse["srubwd"] and self.prec in (0, 6) and S * L < 5_500_000
+        one_launch = self.model._hip.fuse["srubwd"] and self.prec in (0, 6) and S * L < 2_790_000
         dh2 = None
         for l in (3, 2, 1):
             lw = d["layers"][l]
             if one_launch:
                 dxa, dxb = torch.empty(S * L * 64, device=dev), torch.empty(S * L * 64, device=dev)
-                lib.call("rtfs_sru_layer_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["w"], lw["wc"], lw["bias"], lw["scale_x"], dh, dh2, dxa, dxb,
+                work = torch.empty(lib.load().rtfs_sru_layer_bwd_work_floats(S), device=dev)
+                lib.call("rtfs_sru_layer_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["w"], lw["wc"], lw["bias"], lw["scale_x"], dh, dh2, dxa, dxb, work,
                          g(f"l{l}.w", 192 * 64), g(f"l{l}.wc", 128), g(f"l{l}.bias", 128), S, L)
                 dh, dh2 = dxa, dxb
                 continue

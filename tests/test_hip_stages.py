@@ -705,7 +705,8 @@ def test_sru_layer_bwd_entry_matches_three_launches(S, L):
         # one launch; the accumulated outputs start from a known non-zero value
         dXa, dXb = torch.full_like(X, float("nan")), torch.full_like(X, float("nan"))
         dwc1, db1, dW1 = torch.ones(128, device="cuda"), torch.ones(128, device="cuda"), torch.ones(192 * 64, device="cuda")
-        lib.call("rtfs_sru_layer_bwd", U, X, C, W, wc, bias, scale, dHa, dHb, dXa, dXb, dW1, dwc1, db1, S, L)
+        work = torch.full((lib.load().rtfs_sru_layer_bwd_work_floats(S),), float("nan"), device="cuda")
+        lib.call("rtfs_sru_layer_bwd", U, X, C, W, wc, bias, scale, dHa, dHb, dXa, dXb, work, dW1, dwc1, db1, S, L)
         torch.cuda.synchronize()
         assert torch.isfinite(dXa).all() and torch.isfinite(dXb).all()
         dX1 = dXa + dXb
