@@ -427,16 +427,18 @@ __global__ __launch_bounds__(512) void sru_layer_bwd_kernel(const float* __restr
     atomicAdd(mine + 192 + d * 32 + un, abr);
 }
 
-// dW[n][k] += sum over the workgroups' partials (work [nwg][direction][register (row tile, column tile, r)][lane]); grid (48, 8): blockIdx.y takes every
-// eighth partial, eight atomics per element
+// dW[n][k] += sum over the workgroups' partials (work [nwg][direction][register (row tile, column tile, r)][lane]); grid (12, 32), a thread owns four
+// consecutive elements: blockIdx.y takes every 32nd partial (8 independent 16-byte loads), 32 atomics per element
 __global__ __launch_bounds__(256) void sru_layer_bwd_reduce_kernel(const float* __restrict__ work, float* __restrict__ dW, int nwg) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    float t = 0.f;
-    for (int w = blockIdx.y; w < nwg; w += 8) t += work[(size_t)w * 12288 + e];
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    float4 t = f4(0, 0, 0, 0);
+#pragma unroll 8
+    for (int w = blockIdx.y; w < nwg; w += 32) t = t + ld4(work + (size_t)w * 12288 + e);
     const int ln = e & 63, reg = (e >> 6) % 96, dd = e / (96 * 64);
     const int r = reg & 3, ct = (reg >> 2) & 3, rt = reg >> 4;
     const int col = 16 * rt + 4 * (ln >> 4) + r, n = (col >> 5) * 64 + dd * 32 + (col & 31);
-    atomicAdd(dW + n * 64 + 16 * ct + (ln & 15), t);
+    float* o = dW + n * 64 + 16 * ct + (ln & 15);
+    atomicAdd(o, t.x), atomicAdd(o + 1, t.y), atomicAdd(o + 2, t.z), atomicAdd(o + 3, t.w);
 }
 
 // LN4D over channels, adjoint.  dxn, G, dG in G layout [rows][64]; dG += dx; dgamma/dbeta += per-channel sums.
@@ -595,7 +597,7 @@ int rtfs_sru_layer_bwd(const float* U, const float* X, const float* C, const flo
     hipLaunchKernelGGL(sru_layer_bwd_kernel, dim3(nwg), dim3(512), 0, (hipStream_t)stream, U, X, C, W, wc, bias, scale_x, dH, dH2, dX0, dX1, work, scr, S,
                        L);
     RTFS_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sru_layer_bwd_reduce_kernel, dim3(48, 8), dim3(256), 0, (hipStream_t)stream, work, dW, nwg);
+    hipLaunchKernelGGL(sru_layer_bwd_reduce_kernel, dim3(12, 32), dim3(256), 0, (hipStream_t)stream, work, dW, nwg);
     RTFS_LAUNCH_CHECK();
     return spread_finish(scr, SpreadOut{{dwc, dbias}, {128, 128}}, (hipStream_t)stream);
 }
