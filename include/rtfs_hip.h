@@ -82,6 +82,10 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
  * Same result as rtfs_gemm_rows_fwd(64 -> 192) followed by rtfs_sru_scan_fwd(km = 3). */
 int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                        float* Uout_or_null, int S, int L, void* stream);
+/* the same with the kernel form named (inference only; all forms give the same bits): 0 = the library's choice by S, 1 = one wave per sequence,
+ * 2 = one wave per (sequence, direction), 3 = one workgroup per (sequence, direction), its waves splitting the gates (the smallest batches) */
+int rtfs_sru_layer_fwd_form(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
+                            float* Uout_or_null, int S, int L, int form, void* stream);
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream);
 /* generic row GEMM Y (= or +=) X . Wt^T (+bias): also every input-gradient GEMM of the backward pass (Wt = transposed weight) */
 int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream);

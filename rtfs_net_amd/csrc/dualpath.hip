@@ -2095,6 +2095,104 @@ __global__ __launch_bounds__(256, 2) void sru_layer_dir_kernel(const float* __re
     }
 }
 
+// Smallest batches (a few hundred sequences): ONE WORKGROUP PER (sequence, direction).  sru_layer_dir_kernel's wave walks 96 MFMAs + 32 recurrence steps
+// per chunk in line (batch 1: 250 / 128 waves on 1024 SIMDs, 19 us per launch, 36 launches = a quarter of the forward).  Here waves 0-2 each compute ONE
+// gate's 32-step x 32-unit tile of U per chunk (32 MFMAs; the gate's 32 weight rows live in 32 registers - no weight staging in LDS) and hand it over
+// through LDS; wave 3 runs the recurrence of the PREVIOUS chunk meanwhile (two U / x' buffers, one barrier per chunk).  Same products in the same order
+// per accumulator, same recurrence arithmetic: bit-identical to sru_layer_kernel / sru_layer_dir_kernel.
+constexpr int kSruSplitBelow = 257;  // sequences (up to 512 workgroups); above: sru_layer_dir_kernel.  tools/sru_bench.py f32 <B> <form>, form 2 -> 3:
+// 125 x 57: 16.0 -> 11.6 us, 64 x 118: 26.3 -> 15.9, 250 x 57: 16.6 -> 15.0, 128 x 118: 26.8 -> 16.6, 256 x 118: 27.8 -> 22.3; 500 x 57: 18.0 -> 21.7 (not taken)
+
+__global__ __launch_bounds__(256) void sru_layer_split_kernel(const float* __restrict__ Hprev, const float* __restrict__ Wt, const float* __restrict__ wc,
+                                                              const float* __restrict__ bias, float scale_x, float* __restrict__ Hout, int S, int L) {
+    constexpr int LDU = 104, LDX = 36;  // U rows [3 gates][32] + 8: the two lane halves' rows (4 apart) fall 32 banks apart
+    __shared__ __attribute__((aligned(16))) float Us[2][32 * LDU];
+    __shared__ __attribute__((aligned(16))) float Xs[2][32 * LDX];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.x >> 1, d = blockIdx.x & 1;
+    const int lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
+    const float* hp = Hprev + (size_t)s * L * 64;
+    const int nch = (L + 31) >> 5;
+    if (wv < 3) {
+        float4 b[8];
+        {
+            const float* wr = Wt + (size_t)(wv * 64 + d * 32 + i) * 64 + 32 * kh;
+            const float sc = wv >= 1 ? kNegLog2e : 1.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = ld4(wr + 4 * q) * sc;
+        }
+        float4 a[8];
+        auto load_a = [&](int sl0) {
+            const int t = d ? max(L - 1 - (sl0 + i), 0) : min(sl0 + i, L - 1);  // rows past the end are clamped; their steps are never scanned
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = ld4(hp + (size_t)t * 64 + 32 * kh + 4 * q);
+        };
+        load_a(0);
+#pragma unroll 1
+        for (int ch = 0; ch <= nch; ++ch) {
+            if (ch < nch) {
+                float* us = Us[ch & 1];
+                if (wv == 0 && kh == d) {  // x' tile: this direction's half of the A rows
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) st4(&Xs[ch & 1][i * LDX + 4 * q], a[q]);
+                }
+                floatx16 acc;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q == 0) {
+                        floatx16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, z, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b[q].x, acc, 0, 0, 0);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b[q].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b[q].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b[q].w, acc, 0, 0, 0);
+                }
+                if (ch + 1 < nch) load_a(32 * (ch + 1));
+                // acc[r] of lane (i, kh): local step (r & 3) + 8 (r >> 2) + 4 kh, unit i of gate wv
+#pragma unroll
+                for (int r = 0; r < 16; ++r) us[((r & 3) + 8 * (r >> 2) + 4 * kh) * LDU + wv * 32 + i] = acc[r];
+            }
+            __syncthreads();
+        }
+    } else {
+        const float wf = wc[d * 32 + i] * kNegLog2e, wr = wc[64 + d * 32 + i] * kNegLog2e;
+        const float bf = bias[d * 32 + i] * kNegLog2e, br = bias[64 + d * 32 + i] * kNegLog2e;
+        float* hob = Hout + (size_t)s * L * 64;
+        const int dstr = d ? -256 : 256, off0 = (d ? (L - 1) * 256 : 0) + (d * 32 + i) * 4;  // byte offset of this column in the row of scan position 0
+        float c = 0.f;
+#pragma unroll 1
+        for (int ch = 0; ch <= nch; ++ch) {
+            if (ch >= 1 && kh == 0) {
+                const int sl0 = 32 * (ch - 1);
+                const float* us = Us[(ch - 1) & 1] + i;
+                const float* xs = Xs[(ch - 1) & 1] + i;
+                auto step = [&](int k) {
+                    const float u0 = us[k * LDU], u1 = us[k * LDU + 32], u2 = us[k * LDU + 64];
+                    const unsigned off = (unsigned)(off0 + (sl0 + k) * dstr);
+                    const float x = xs[k * LDX] * scale_x;
+                    const float f = sigmoid_from_exp2arg(fmaf(wf, c, u1) + bf);
+                    const float rg = sigmoid_from_exp2arg(fmaf(wr, c, u2) + br);
+                    c = u0 + (c - u0) * f;
+                    st1_off(hob, off, x + (c - x) * rg);
+                };
+                if (sl0 + 32 <= L) {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) step(k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k)
+                        if (sl0 + k < L) step(k);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -2286,12 +2384,18 @@ int rtfs_sru_scan_fwd(const float* U, const float* X, const float* wc, const flo
 // SRU layers 1-3 with the input projection fused: Hprev, Hout [S][L][64]; Wt [192][64], row = m*64 + dir*32 + j (k contiguous);
 // Training (both or neither): Cout cell states [S][L][64], Uout pre-activations [S][L][3][64] as rtfs_sru_scan_bwd reads them.
 // Replaces rtfs_gemm_rows_fwd(64 -> 192) + rtfs_sru_scan_fwd / rtfs_sru_scan_train_fwd (km = 3).
-int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
-                       float* Uout_or_null, int S, int L, void* stream) {
-    if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr)) return RTFS_EINVAL;
+// form (inference only): 0 = the library's choice by S; 1 = one wave per sequence (sru_layer_kernel), 2 = one wave per (sequence, direction), 3 = one
+// workgroup per (sequence, direction) with the gates split over its waves - all three give the same bits
+int rtfs_sru_layer_fwd_form(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
+                            float* Uout_or_null, int S, int L, int form, void* stream) {
+    if (S <= 0 || L <= 0 || Hprev == Hout || (Cout_or_null == nullptr) != (Uout_or_null == nullptr) || form < 0 || form > 3 || (Cout_or_null && form > 1))
+        return RTFS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define SRU_L(SAVE, NWV) hipLaunchKernelGGL((sru_layer_kernel<SAVE, 0, NWV>), dim3((S + NWV - 1) / NWV), dim3(NWV * 64), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L)
-    if (!Cout_or_null && S < 2048) {  // below 2048 sequences: one wave per (sequence, direction) (same-box A/B: batch 8 7.45 -> 7.23 ms, batch 16 equal; 4096: batch 32 slower)
+    if (form == 0 && !Cout_or_null) form = S < kSruSplitBelow ? 3 : (S < 2048 ? 2 : 1);
+    if (form == 3) {
+        hipLaunchKernelGGL(sru_layer_split_kernel, dim3(2 * S), dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, S, L);
+    } else if (form == 2) {  // below 2048 sequences: one wave per (sequence, direction) (same-box A/B: batch 8 7.45 -> 7.23 ms, batch 16 equal; 4096: batch 32 slower)
         hipLaunchKernelGGL(sru_layer_dir_kernel, dim3((2 * S + 3) / 4), dim3(256), 0, st, Hprev, Wt, wc, bias, scale_x, Hout, S, L);
     } else if (S >= 2048) {
         if (Cout_or_null) SRU_L(true, 8); else SRU_L(false, 8);
@@ -2301,6 +2405,11 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, con
 #undef SRU_L
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
+}
+
+int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* wc, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
+                       float* Uout_or_null, int S, int L, void* stream) {
+    return rtfs_sru_layer_fwd_form(Hprev, Wt, wc, bias, scale_x, Hout, Cout_or_null, Uout_or_null, S, L, 0, stream);
 }
 
 // bf16 / split-bf16 variant of rtfs_sru_layer_fwd: Wt is the PLAIN fp32 weight (packed in the kernel after the gate scaling)

@@ -34,6 +34,7 @@ SIGNATURES = {
     "rtfs_dp_unfold_gemm_fwd": [P, P, P, P, P, I, I, I, I, P],
     "rtfs_sru_scan_fwd": [P, P, P, P, F, P, I, I, I, P],
     "rtfs_sru_layer_fwd": [P, P, P, P, F, P, P, P, I, I, P],
+    "rtfs_sru_layer_fwd_form": [P, P, P, P, F, P, P, P, I, I, I, P],
     "rtfs_vp_param_count": [],
     "rtfs_vp_block_fwd": [P, P, P, P, I, I, P],
     "rtfs_neg_sdr_sums": [P, P, P, I, I, I, P],

@@ -191,8 +191,9 @@ def test_istft_roundtrip():
 @pytest.mark.parametrize("S,L", [(5, 57), (3, 118), (2, 9), (4, 32), (1, 33), (7, 1), (600, 40), (2100, 9)])
 def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
     """rtfs_sru_layer_fwd (projection on MFMA inside the recurrence) == rtfs_gemm_rows_fwd(64->192) + rtfs_sru_scan_fwd, ragged lengths
-    (chunk boundaries at 32, single-step sequences), with and without the training saves (cell states, pre-activations).  The three kernel forms -
-    one wave per (sequence, direction) below 512 sequences (inference), 4-wave workgroups below 2048, 8-wave workgroups above - give the same bits."""
+    (chunk boundaries at 32, single-step sequences), with and without the training saves (cell states, pre-activations).  The kernel forms - one
+    workgroup per (sequence, direction) up to 256 sequences, one wave per (sequence, direction) below 2048 (inference), 4-wave workgroups below 2048,
+    8-wave workgroups above (training / large batches) - give the same bits, each also named explicitly through rtfs_sru_layer_fwd_form."""
     from rtfs_net_amd import lib
 
     g = torch.Generator().manual_seed(S * 131 + L)
@@ -208,6 +209,10 @@ def test_sru_layer_fused_matches_gemm_plus_scan(S, L):
     lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, U2, S, L)
     assert float((out - ref).abs().max()) < 2e-5 and float((out2 - ref).abs().max()) < 2e-5
     assert torch.equal(out, out2)  # (the inference form of this S and the training form: same products in the same order, same recurrence)
+    for form in (1, 2, 3):  # one wave per sequence / per (sequence, direction) / one workgroup per (sequence, direction) with the gates split over its waves
+        outf = torch.full_like(h, float("nan"))
+        lib.call("rtfs_sru_layer_fwd_form", h, W, wc, bias, 0.7, outf, None, None, S, L, form)
+        assert torch.equal(outf, out), form
     assert float((U2 - U).abs().max()) < 2e-5
     with pytest.raises(RuntimeError):  # saves come as a pair
         lib.call("rtfs_sru_layer_fwd", h, W, wc, bias, 0.7, out2, cst, None, S, L)
