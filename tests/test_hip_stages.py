@@ -728,6 +728,49 @@ def test_sru_layer_bwd_entry_matches_three_launches(S, L):
     assert rel(dU2, dU) < 2e-5 and rel(dwc2, dwc0) < 2e-4
 
 
+@pytest.mark.parametrize("S,L", [(3, 7), (6, 9), (9, 33), (40, 57)])
+def test_sru_layer_bwd_entry_against_float64_autograd(S, L):
+    """rtfs_sru_layer_bwd on its own against float64 autograd over a plain restatement of the bidirectional SRU layer (sru.SRU with highway skip and
+    weight_c, as oracle/sru_ref.py states it: U = X W^T; per direction f = sigmoid(u1 + b_f + w_f c), r = sigmoid(u2 + b_r + w_r c),
+    c' = u0 + (c - u0) f, h = x' + (c' - x') r, x' = scale_x x; rnn_layers.py:100-105): dX (= dX0 + dX1), dW, dwc, dbias."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(53 * S + L)
+    X = torch.randn(S, L, 64, generator=g)
+    W = torch.randn(192, 64, generator=g) * 0.15
+    wc, bias = torch.randn(128, generator=g) * 0.5, torch.randn(128, generator=g) * 0.5
+    dH = torch.randn(S, L, 64, generator=g)
+    scale = 1.7
+    Xd, Wd, wcd, bd = (t.double().cuda().requires_grad_(True) for t in (X, W, wc, bias))
+    U = (Xd @ Wd.t()).view(S, L, 3, 2, 32)  # column = gate * 64 + direction * 32 + unit
+    xp = (Xd * scale).view(S, L, 2, 32)
+    hs = []
+    for d in (0, 1):
+        c = torch.zeros(S, 32, dtype=torch.float64, device="cuda")
+        out = [None] * L
+        for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
+            u0, u1, u2 = U[:, t, 0, d], U[:, t, 1, d], U[:, t, 2, d]
+            f = torch.sigmoid(u1 + bd[d * 32:d * 32 + 32] + wcd[d * 32:d * 32 + 32] * c)
+            r = torch.sigmoid(u2 + bd[64 + d * 32:96 + d * 32] + wcd[64 + d * 32:96 + d * 32] * c)
+            c = u0 + (c - u0) * f
+            out[t] = xp[:, t, d] + (c - xp[:, t, d]) * r
+        hs.append(torch.stack(out, dim=1))
+    Hd = torch.cat(hs, dim=-1)  # [S][L][64], column = direction * 32 + unit
+    (Hd * dH.double().cuda()).sum().backward()
+    # the HIP path: forward (saves), then the one-launch adjoint
+    Xc, Wc, wcc, bc, dHc = X.cuda(), W.cuda(), wc.cuda(), bias.cuda(), dH.cuda()
+    H, C, Uc = torch.empty_like(Xc), torch.empty_like(Xc), torch.empty(S, L, 192, device="cuda")
+    lib.call("rtfs_sru_layer_fwd", Xc, Wc, wcc, bc, scale, H, C, Uc, S, L)
+    assert rel(H, Hd.detach()) < 2e-6
+    dXa, dXb = torch.empty_like(Xc), torch.empty_like(Xc)
+    dW, dwc, db = torch.zeros(192 * 64, device="cuda"), torch.zeros(128, device="cuda"), torch.zeros(128, device="cuda")
+    work = torch.empty(lib.load().rtfs_sru_layer_bwd_work_floats(S), device="cuda")
+    lib.call("rtfs_sru_layer_bwd", Uc, Xc, C, Wc, wcc, bc, scale, dHc, None, dXa, dXb, work, dW, dwc, db, S, L)
+    assert rel(dXa + dXb, Xd.grad) < 5e-6, rel(dXa + dXb, Xd.grad)
+    assert rel(dW.view(192, 64), Wd.grad) < 5e-6 and rel(dwc, wcd.grad) < 5e-6 and rel(db[:128], bd.grad) < 5e-6, (
+        rel(dW.view(192, 64), Wd.grad), rel(dwc, wcd.grad), rel(db, bd.grad))
+
+
 @pytest.mark.parametrize("B,T2", [(19, 125), (10, 250), (3, 125)])
 @pytest.mark.parametrize("dim", [4, 3])
 def test_convt_bwd_input_entry_isolated(B, T2, dim):
