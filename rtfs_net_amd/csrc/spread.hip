@@ -89,7 +89,10 @@ DevState* dev_state() {
         float* p = nullptr;
         const size_t bytes = (size_t)kSpread * kSpreadCap * sizeof(float);
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, bytes) != hipSuccess) return nullptr;
+        // the fill runs on the NULL stream and returns before it has run; the first producer may be on a non-blocking stream (the training step's
+        // weight-gradient side stream, torch.cuda.Stream) that the null stream does not order: without the wait its first partial sums can land before
+        // the fill and be zeroed (seen once in ~25 runs of the GPU suite: one parameter gradient of the first training step of the process missing)
+        if (hipMemset(p, 0, bytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
         d.scr = p;
     }
     return &d;

@@ -631,6 +631,15 @@ class HipTrainer:
         if dIn is not None:
             self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
 
+    def _sru_bwd_work(self, S, dev):
+        """the workgroups' partial-dW scratch of rtfs_sru_layer_bwd: one buffer per device, reused by every layer of every step (main stream only)"""
+        n = lib.load().rtfs_sru_layer_bwd_work_floats(S)
+        cache = self.__dict__.setdefault("_sru_work", {})
+        buf = cache.get(dev)
+        if buf is None or buf.numel() < n:
+            buf = cache[dev] = torch.empty(n, device=dev)
+        return buf
+
     def _dual_path_bwd(self, dG, d, sv, B, T2, dim, gr, key):
         """dG: gradient w.r.t. the stage output (G layout), updated IN PLACE to the gradient w.r.t. the stage input."""
         S, npos = (B * T2, F2) if dim == 4 else (B * F2, T2)
@@ -653,7 +662,7 @@ class HipTrainer:
             lw = d["layers"][l]
             if one_launch:
                 dxa, dxb = torch.empty(S * L * 64, device=dev), torch.empty(S * L * 64, device=dev)
-                work = torch.empty(lib.load().rtfs_sru_layer_bwd_work_floats(S), device=dev)
+                work = self._sru_bwd_work(S, dev)
                 lib.call("rtfs_sru_layer_bwd", sv.U[l], sv.h[l - 1], sv.c[l], lw["w"], lw["wc"], lw["bias"], lw["scale_x"], dh, dh2, dxa, dxb, work,
                          g(f"l{l}.w", 192 * 64), g(f"l{l}.wc", 128), g(f"l{l}.bias", 128), S, L)
                 dh, dh2 = dxa, dxb
