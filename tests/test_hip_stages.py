@@ -1141,6 +1141,51 @@ def test_training_step_fusion_switches_leave_the_gradients_alone(switch):
         assert float((g - grads[False][n]).norm()) <= 2e-5 * float(g.norm()) + 1e-6 * scale, n
 
 
+def test_spread_scratch_first_use_on_a_side_stream_is_ordered_after_its_zero_fill():
+    """A lane's scratch is allocated and zero-filled on its first use.  The fill runs on the NULL stream; a torch side stream is non-blocking, so
+    nothing orders it against the lane's first producer unless the library waits for the fill.  In a fresh process: the null stream is kept busy, then
+    a deferred section on lane 1 runs one reducer (rtfs_ln4d_c_bwd: dgamma, dbeta through the scratch) on a side stream and is flushed only after the
+    null stream has drained - a fill that was still queued behind the busy null stream would wipe the pending partial sums (round 5: one parameter
+    gradient of a process's first training step missing, once in ~25 runs of this suite)."""
+    import subprocess
+    import sys
+
+    code = r"""
+import sys
+import torch
+sys.path.insert(0, ".")
+from rtfs_net_amd import lib
+g = torch.Generator().manual_seed(3)
+rows = 4096
+dxn, G = torch.randn(rows, 64, generator=g).cuda(), torch.randn(rows, 64, generator=g).cuda()
+gamma = (torch.rand(64, generator=g) + 0.5).cuda()
+dG, dgam, dbet = torch.zeros(rows, 64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+x = torch.randn(8192, 8192, device="cuda")
+side = torch.cuda.Stream()
+torch.cuda.synchronize()
+for _ in range(40):
+    y = x @ x  # ~100 ms of work on the null stream
+lib.spread_lane(1)
+with torch.cuda.stream(side):
+    lib.spread_defer(True, "cuda:0")
+    lib.call("rtfs_ln4d_c_bwd", dxn, G, gamma, dG, dgam, dbet, rows)
+    side.synchronize()
+    torch.cuda.default_stream().synchronize()  # (a fill still queued on the null stream has run by now)
+    lib.spread_defer(False, "cuda:0")
+lib.spread_lane(0)
+torch.cuda.synchronize()
+Gd = G.double()
+xh = (Gd - Gd.mean(-1, keepdim=True)) / torch.sqrt(Gd.var(-1, unbiased=False, keepdim=True) + 1e-5)
+want_b, want_g = dxn.double().sum(0), (dxn.double() * xh).sum(0)
+eb = float((dbet.double() - want_b).norm() / want_b.norm())
+eg = float((dgam.double() - want_g).norm() / want_g.norm())
+print("ERR", eb, eg)
+assert eb < 1e-5 and eg < 1e-4, (eb, eg)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_spread_lanes_keep_concurrent_reducers_apart():
     """rtfs_spread_lane (csrc/spread.hip): reducers issued on a second stream with lane 1 run concurrently with lane 0's on the main stream - each lane has
     its own scratch, cursor and deferred section.  Forty producers per stream, interleaved, immediate and deferred mode, against a serial run; without the
