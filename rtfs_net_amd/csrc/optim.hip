@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(OptTables t, const doub
     float coef = 1.f;
     if (max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
         const float total = (float)sqrt(*sqnorm);
-        coef = fminf(max_norm / (total + 1e-6f), 1.f);
+        // a NaN norm goes through to every gradient and parameter as torch.clamp does (fminf alone would return 1 and hide a diverged step from NaN-skip logic)
+        coef = (total == total) ? fminf(max_norm / (total + 1e-6f), 1.f) : total;
     }
 #pragma unroll
     for (int k = 0; k < kOptChunk / 256; ++k) {

@@ -90,8 +90,12 @@ class PITLossWrapper(nn.Module):
             key = (n, pwl.device, pwl.dtype)
             cached = _PERM_CACHE.get(key)
             if cached is None:
-                perms = torch.tensor(list(permutations(range(n))), dtype=torch.long, device=pwl.device)
-                cached = _PERM_CACHE[key] = (perms, pwl.new_zeros((*perms.size(), n)).scatter_(2, perms.unsqueeze(2), 1))
+                # built outside inference mode: a table first made under torch.inference_mode() (Lightning's sanity-check validation) would be an
+                # inference tensor, which the first training step's einsum could not save for backward
+                with torch.inference_mode(False), torch.no_grad():
+                    perms = torch.tensor(list(permutations(range(n))), dtype=torch.long, device=pwl.device)
+                    one_hot = torch.zeros((*perms.size(), n), dtype=pwl.dtype, device=pwl.device).scatter_(2, perms.unsqueeze(2), 1)
+                cached = _PERM_CACHE[key] = (perms, one_hot)
             perms, one_hot = cached
             loss_set = torch.einsum("bij,pij->bp", pwl, one_hot) / n
             min_loss, idx = torch.min(loss_set, dim=1)

@@ -160,15 +160,29 @@ class GatherTrainWeights:
                 c[k] = self.derived[o:o + t.numel()].view(t.shape)
             o += t.numel()
         self.sidx = torch.tensor([i for _, _, i in self.scalars], device=dev, dtype=torch.long)
-        self.ptrs = tuple(t.data_ptr() for t in self.srcs)
+        self.ptrs = self._storage(model)
+        # eval under autograd folds the CAF embeddings' BatchNorm with its running statistics: the six state tensors per embedding, looked up once (a
+        # re-allocated one fails same_storage() and the plan is rebuilt)
+        self._caf_bn = {tag: [sd[f"{self.caf_prefix}{tag}_embed.full_layer.{k}"] for k in ("2.weight", "3.weight", "3.bias", "3.running_mean", "3.running_var")]
+                        for tag in ("key", "value")}
         self.version, self._pending = None, None
         self.refresh(model)
 
+    @staticmethod
+    def _storage(model):
+        """addresses of every floating-point parameter and buffer, by the module-tree walk of PreparedWeights.fingerprint (model.state_dict() builds 365
+        dotted names and an OrderedDict per call: most of the host time the fingerprint walk saved)"""
+        out, stack = [], [model]
+        while stack:
+            mod = stack.pop()
+            out.extend(p.data_ptr() for p in mod._parameters.values() if p is not None and p.is_floating_point())
+            out.extend(b.data_ptr() for b in mod._buffers.values() if b is not None and b.is_floating_point())
+            stack.extend(m for m in mod._modules.values() if m is not None)
+        return tuple(out)
+
     def same_storage(self, model):
         """the plan reads the state through the tensors it was built from: a model moved / re-allocated since needs a new plan"""
-        sd = model.state_dict()
-        live = tuple(v.data_ptr() for v in sd.values() if v.is_floating_point())
-        return live == self.ptrs
+        return self._storage(model) == self.ptrs
 
     @torch.no_grad()
     def refresh(self, model, fp=None, defer_scalars=False):
@@ -187,12 +201,11 @@ class GatherTrainWeights:
         if not defer_scalars:
             self.finish_scalars()
         if not model.training:  # eval under autograd: the CAF embeddings' BatchNorm folded with its running statistics (PreparedWeights.__init__)
-            sd = model.state_dict()
             for tag in ("key", "value"):
-                q = f"{self.caf_prefix}{tag}_embed.full_layer."
-                scale = sd[q + "3.weight"].float() / torch.sqrt(sd[q + "3.running_var"].float() + 1e-5)
-                self.w[f"caf_{tag}_s"] = _f32(sd[q + "2.weight"].reshape(C).float() * scale)
-                self.w[f"caf_{tag}_b"] = _f32(sd[q + "3.bias"].float() - sd[q + "3.running_mean"].float() * scale)
+                dw, gamma, beta, mean, var = self._caf_bn[tag]
+                scale = gamma.float() / torch.sqrt(var.float() + 1e-5)
+                self.w[f"caf_{tag}_s"] = _f32(dw.reshape(C).float() * scale)
+                self.w[f"caf_{tag}_b"] = _f32(beta.float() - mean.float() * scale)
         self.version = fp if fp is not None else PreparedWeights.fingerprint(model, training=model.training)
 
     def finish_scalars(self):
@@ -474,6 +487,7 @@ class HipTrainer:
         R = m.refinement_module.audio_net.repeats
         c = Ctx()
         c.pw = pw  # the SAME prepared weights serve forward_b and both backward stages of this step (parameters do not change inside a step)
+        c.pw_version = pw.version  # ... and _same_weights() holds the later stages to it: GatherTrainWeights refreshes its buffers IN PLACE
         c.B, c.L, c.T, c.T2, c.R = B, L, T, T2, R
         c.stats = torch.zeros(1 + 12 * R, B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
         stats = c.stats
@@ -496,6 +510,7 @@ class HipTrainer:
     def forward_b(self, c, att, rsz):
         """CAF cell, RTFS blocks 1..R-1, S3 mask, decoder, iSTFT -> out [B,1,L]."""
         m = self.model
+        self._same_weights(c, "second forward stage")
         pw = c.pw
         w = pw.w
         B, L, T, T2, R = c.B, c.L, c.T, c.T2, c.R
@@ -807,6 +822,15 @@ class HipTrainer:
     def stage(self, dev):
         return _Stage(self, dev)
 
+    @staticmethod
+    def _same_weights(c, stage):
+        """GatherTrainWeights.refresh() overwrites the persistent kernel-layout buffers that c.pw aliases: forward(A) -> parameter change + another forward
+        (an optimizer step on earlier gradients, an EMA swap) -> backward(A) would run A's adjoint on the NEW weights, silently.  Refuse instead."""
+        if c.pw.version != c.pw_version:
+            raise RuntimeError(f"rtfs_net_amd: the parameters changed and a newer forward re-laid out the kernel weights between this step's forward and its "
+                               f"{stage}; run each step's backward before the next forward after a parameter update (or set RTFS_NO_WEIGHT_GATHER=1: "
+                               "per-step weight snapshots)")
+
     def backward_b(self, c, dout):
         with self.stage(dout.device):
             return self._backward_b(c, dout)
@@ -818,6 +842,7 @@ class HipTrainer:
     def _backward_b(self, c, dout):
         """adjoint of forward_b: dout [B,1,L] -> (d x0, d a0 or None, d a_emb, datt, drsz); parameter gradients go to c.gr."""
         m = self.model
+        self._same_weights(c, "backward")
         pw = c.pw
         w = pw.w
         B, L, T, T2, R, Tv = c.B, c.L, c.T, c.T2, c.R, c.Tv
@@ -865,6 +890,7 @@ class HipTrainer:
     def _backward_a(self, c, dx0, da0, da_emb):
         """adjoint of forward_a.  dx0: gradient of block 0's output (overwritten); da0: running d(a0) sum of the later blocks (updated in
         place) or None; da_emb: gradient that reached a_emb through the S3 mask (updated in place).  -> grads dict in kernel layout."""
+        self._same_weights(c, "backward (audio stage A)")
         pw = c.pw
         w = pw.w
         B, T, T2, R = c.B, c.T, c.T2, c.R

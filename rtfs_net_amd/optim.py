@@ -29,9 +29,12 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # ---- per-group launch plan: static tables (parameters, state, sizes, chunk map) + a pinned row for the gradient pointers of the step ----
     def _plan(self, gi, ps):
-        key = tuple(id(p) for p in ps)
+        # the tables hold raw device addresses: a plan is valid for exactly these parameter objects AT these addresses (p.data = ..., module.to() and
+        # re-sharding keep the Parameter object and move its storage) with these moment tensors
+        key = tuple((id(p), p.data_ptr(), p.numel()) for p in ps)
         plan = self._plans.get(gi)
-        if plan is not None and plan["key"] == key and all(self.state[p]["exp_avg"].data_ptr() == a for p, a in zip(ps, plan["m_ptrs"])):
+        if plan is not None and plan["key"] == key and all(self.state[p]["exp_avg"].data_ptr() == a and self.state[p]["exp_avg_sq"].data_ptr() == b
+                                                           for p, a, b in zip(ps, plan["m_ptrs"], plan["v_ptrs"])):
             return plan
         dev = ps[0].device
         for p in ps:
@@ -52,7 +55,7 @@ class FusedAdamW(torch.optim.Optimizer):
         host[4] = torch.tensor(sizes, dtype=torch.int64)
         plan = {"key": key, "dev": host.to(dev), "n_chunks": len(chunks), "n": len(ps),
                 "chunks": torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev), "sqnorm": torch.zeros(1, dtype=torch.float64, device=dev),
-                "m_ptrs": [self.state[p]["exp_avg"].data_ptr() for p in ps]}
+                "m_ptrs": [self.state[p]["exp_avg"].data_ptr() for p in ps], "v_ptrs": [self.state[p]["exp_avg_sq"].data_ptr() for p in ps]}
         self._plans[gi] = plan
         return plan
 
@@ -68,21 +71,17 @@ class FusedAdamW(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             if group.get("amsgrad") or group.get("maximize"):
                 raise NotImplementedError("FusedAdamW: amsgrad / maximize are not implemented")
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
+            with_grad = [p for p in group["params"] if p.grad is not None]
+            if not with_grad:
                 continue
-            plan = self._plan(gi, ps)
-            # the gradient tensors are new objects every step: their pointers go up in a FRESH pinned row (the caching host allocator keeps a block until
-            # the copy that reads it has run - the host may be several steps ahead of the device, a reused staging row would be overwritten under it)
-            row = torch.empty(plan["n"], dtype=torch.int64, pin_memory=True)
-            g_np = row.numpy()
-            for i, p in enumerate(ps):
-                g = p.grad
-                if g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
-                    raise ValueError("FusedAdamW needs dense contiguous fp32 gradients on the parameters' device")
-                g_np[i] = g.data_ptr()
-            plan["dev"][1].copy_(row, non_blocking=True)
-            work.append((group, ps, plan))
+            # one launch applies ONE pair of bias corrections: parameters whose step counts differ (a parameter that first received a gradient later, one
+            # skipped under DDP's find_unused_parameters, interchanged optimizer states) go in separate launches, as torch.optim.AdamW corrects per parameter
+            by_step = {}
+            for p in with_grad:
+                st = self.state[p]
+                by_step.setdefault(float(st["step"]) if len(st) else 0.0, []).append(p)
+            for si, (_, ps) in enumerate(sorted(by_step.items())):
+                work.append(self._stage(group, (gi, si, len(by_step)), ps))
         if not work:
             return loss
         clip = max_norm is not None
@@ -92,7 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 d = plan["dev"]
                 lib.call("rtfs_grad_sqnorm", d[0], d[1], d[2], d[3], d[4], plan["chunks"], plan["n_chunks"], plan["sqnorm"])
                 sq = plan["sqnorm"]
-            else:  # several groups: one norm over all of them (the kernel zeroes its output, so the partial sums are added here on the device)
+            else:  # several launches: one norm over all of them (the kernel zeroes its output, so the partial sums are added here on the device)
                 sq = None
                 for group, ps, plan in work:
                     d = plan["dev"]
@@ -112,3 +111,18 @@ class FusedAdamW(torch.optim.Optimizer):
             torch.autograd.graph.increment_version([p.grad for p in ps])
             torch.autograd.graph.increment_version([self.state[p]["exp_avg"] for p in ps] + [self.state[p]["exp_avg_sq"] for p in ps])
         return loss
+
+    def _stage(self, group, slot, ps):
+        """plan + this step's gradient-pointer row of one launch (the parameters of `group` that share a step count)"""
+        plan = self._plan(slot, ps)
+        # the gradient tensors are new objects every step: their pointers go up in a FRESH pinned row (the caching host allocator keeps a block until
+        # the copy that reads it has run - the host may be several steps ahead of the device, a reused staging row would be overwritten under it)
+        row = torch.empty(plan["n"], dtype=torch.int64, pin_memory=True)
+        g_np = row.numpy()
+        for i, p in enumerate(ps):
+            g = p.grad
+            if g.is_sparse or g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+                raise ValueError("FusedAdamW needs dense contiguous fp32 gradients on the parameters' device")
+            g_np[i] = g.data_ptr()
+        plan["dev"][1].copy_(row, non_blocking=True)
+        return group, ps, plan

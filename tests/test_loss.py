@@ -71,6 +71,22 @@ def test_pit_search_host_logic_matches_oracle(n):
     assert torch.equal(perm.cpu(), ref_perm)
 
 
+def test_pit_table_first_built_under_inference_mode_serves_a_training_step():
+    """Lightning's sanity-check validation runs under torch.inference_mode() before the first training step; a permutation table cached there as an
+    inference tensor cannot be saved for backward by the training step's einsum.  The cache is built outside inference mode."""
+    from rtfs_net_amd import losses
+
+    losses._PERM_CACHE.clear()
+    pw = torch.randn(3, 2, 2, generator=torch.Generator().manual_seed(0))
+    with torch.inference_mode():
+        losses.PITLossWrapper.find_best_perm(pw.clone())
+    assert not any(t.is_inference() for pair in losses._PERM_CACHE.values() for t in pair)
+    leaf = pw.clone().requires_grad_(True)
+    min_loss, _ = losses.PITLossWrapper.find_best_perm(leaf)
+    min_loss.mean().backward()
+    assert leaf.grad is not None and float(leaf.grad.abs().sum()) > 0
+
+
 def test_loss_head_refuses_cpu_tensors():
     from rtfs_net_amd.losses import pairwise_neg_snr
 

@@ -253,3 +253,54 @@ def test_caf_batchnorm_kernels_match_the_torch_arithmetic():
             assert int(sa[n]) == int(sb[n]) == 1
         else:
             assert rel(sa[n], sb[n]) < 1e-6, n
+
+
+@pytest.mark.gpu
+def test_backward_after_a_newer_forward_relaid_the_weights_is_refused():
+    """GatherTrainWeights refreshes its kernel-layout buffers in place.  forward(A) -> parameter update -> forward(B) -> backward(A) would run A's
+    adjoint on B's weights; the step refuses loudly.  Without a parameter change in between (gradient accumulation) both orders are fine."""
+    from util import synth
+
+    model, _, _ = make_model(2, "cuda")
+    mix, _, emb = synth.synth_inputs(1, 8000, 12)
+    mix, emb = mix.cuda(), emb.cuda()
+    a = model(mix, emb).square().mean()
+    b = model(mix, emb).square().mean()  # same parameters: nothing is re-laid out
+    b.backward(), a.backward()
+    a = model(mix, emb).square().mean()
+    with torch.no_grad():
+        next(model.parameters()).mul_(1.0)  # (moves the version counter)
+    model(mix, emb)
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        a.backward()
+
+
+@pytest.mark.gpu
+def test_fused_adamw_mixed_step_counts_nan_norm_and_moved_storage():
+    """parameters whose step counts differ get their own bias corrections (torch.optim.AdamW corrects per parameter); a NaN total norm reaches
+    every gradient as torch's clip does; a parameter whose storage moved under the same Parameter object is followed."""
+    from rtfs_net_amd.optim import FusedAdamW
+
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    pa = [torch.nn.Parameter(torch.randn(n, device="cuda", generator=gen)) for n in (7, 1500, 64)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    fused, ref = FusedAdamW(pa, lr=1e-2, weight_decay=0.1), torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.1)
+    for it in range(4):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 1 and it < 2:  # parameter 1 receives its first gradient two steps late
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(a.shape, device="cuda", generator=gen)
+            a.grad, b.grad = g.clone(), g.clone()
+        if it == 3:  # the storage of parameter 2 moves (what module.to() / p.data = ... do)
+            pa[2].data = pa[2].data.clone()
+        fused.step(max_norm=1.0)
+        torch.nn.utils.clip_grad_norm_([p for p in pb if p.grad is not None], 1.0)
+        ref.step()
+        assert max(_close(a, b, 1e-2) for a, b in zip(pa, pb)) < 1e-6, it
+    assert [float(fused.state[p]["step"]) for p in pa] == [4.0, 2.0, 4.0]
+    for a in pa:
+        a.grad = torch.ones_like(a)
+    pa[0].grad[0] = float("nan")
+    fused.step(max_norm=1.0)
+    assert all(bool(torch.isnan(a.grad).all()) and bool(torch.isnan(a).all()) for a in pa)
