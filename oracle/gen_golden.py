@@ -4,8 +4,10 @@ Run once in the authoring container (the reference's Python never travels to the
 
     python -m oracle.gen_golden
 
-It imports `src.models.AVNet` from /root/reference (read-only) with the import stubs of
-oracle/stubs (sru -> oracle/sru_ref.py, timm DropPath, thop, pytorch_lightning), loads the
+It imports `src.models.AVNet` from /root/reference (read-only); third-party packages the
+reference needs come from the environment when it has them and from the import stubs of
+oracle/stubs otherwise (sru -> oracle/sru_ref.py, timm DropPath, thop, pytorch_lightning:
+oracle/ref_import.py; every fixture records which SRU ran under `sru_source`), loads the
 deterministic weights of oracle/synth.py, pushes the synthetic inputs through it in eval mode and
 stores inputs/outputs -- data only, no reference source:
 
@@ -36,12 +38,18 @@ OUT = os.path.join(ROOT, "tests", "golden")
 
 
 def _import_reference():
-    for p in (REF, os.path.join(ROOT, "oracle", "stubs"), ROOT):
-        if p not in sys.path:
-            sys.path.insert(0, p)
-    from src.models import AVNet  # the reference (src/models/__init__.py:8)
+    """the reference's AVNet; a real `sru` package in the environment wins over the stub (oracle/ref_import.py)"""
+    from oracle.ref_import import import_reference, sru_source
 
+    AVNet = import_reference()
+    print("SRU arithmetic of this run:", sru_source())
     return AVNet
+
+
+def _sru_source():
+    from oracle.ref_import import sru_source
+
+    return np.array(sru_source())
 
 
 def rel(a, b):
@@ -129,7 +137,7 @@ def main():
     model, sd, mix, s1, emb, out, taps = run_reference(AVNet, synth.TINY_AUDIONET, B=2, L=1024, Tv=13)
     np.savez_compressed(os.path.join(OUT, "tiny_state.npz"), **{k: v.numpy() for k, v in sd.items()})
     np.savez_compressed(
-        os.path.join(OUT, "tiny.npz"), mix=mix.numpy(), s1=s1.numpy(), emb=emb.numpy(), out=out.numpy(),
+        os.path.join(OUT, "tiny.npz"), mix=mix.numpy(), s1=s1.numpy(), emb=emb.numpy(), out=out.numpy(), sru_source=_sru_source(),
         **{f"tap.{k}": v.numpy() for k, v in taps.items()},
     )
 
@@ -144,7 +152,7 @@ def main():
             with open(os.path.join(OUT, "state_keys.json"), "w") as f:
                 json.dump(keys, f, indent=0)
         np.savez_compressed(
-            os.path.join(OUT, f"{name}.npz"), out=out.numpy().astype(np.float32), mix_head=mix[:, :256].numpy(),
+            os.path.join(OUT, f"{name}.npz"), out=out.numpy().astype(np.float32), mix_head=mix[:, :256].numpy(), sru_source=_sru_source(),
             **{f"tap.{k}": strided(v) for k, v in taps.items()},
             **{f"norm.{k}": np.float64(v.double().norm()) for k, v in taps.items()},
         )

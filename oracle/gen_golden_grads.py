@@ -114,6 +114,9 @@ def full_model_case(AVNet, kind, training, B, L, R, Tv):
         arrays.update({f"stat.{k}": v.numpy().astype(np.float64) for k, v in stats.items()})
     if kind in ("smooth", "nonshared"):
         arrays.update({f"sd.{k}": v.numpy() for k, v in sd.items() if not torch.equal(v, sd0[k])})
+    from oracle.gen_golden import _sru_source
+
+    arrays["sru_source"] = _sru_source()
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
 
 

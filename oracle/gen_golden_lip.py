@@ -24,9 +24,11 @@ def rel(a, b):
 
 
 def main():
-    for p in (REF, os.path.join(ROOT, "oracle", "stubs"), ROOT):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.ref_import import prepare_path
+
+    prepare_path()  # /root/reference first, the import stubs last: packages the environment has are used as they are
     from src.models.videomodels import FRCNNVideoModel  # the reference
 
     from oracle import synth

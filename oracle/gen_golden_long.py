@@ -26,6 +26,8 @@ import time
 import numpy as np
 import torch
 
+from oracle.gen_golden import _sru_source
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tests", "golden")
 STRIDE = 8
@@ -68,7 +70,7 @@ def long_case(AVNet, name, R, L, Tv, check_oracle=True):
     if check_oracle and e > 2e-5:
         raise SystemExit("oracle disagrees with the reference; fixture NOT written")
     np.savez_compressed(os.path.join(OUT, name + ".npz"), out_strided=out[0, 0, ::STRIDE].numpy().copy(), stride=np.int64(STRIDE),
-                        norm=np.float64(out.double().norm()), mix_head=mix[:, :256].numpy())
+                        norm=np.float64(out.double().norm()), mix_head=mix[:, :256].numpy(), sru_source=_sru_source())
 
 
 def scale_x_case(AVNet):
@@ -96,7 +98,8 @@ def scale_x_case(AVNet):
     print(f"  scale_x: oracle-vs-reference {e:.2e}, scale_x = 1 moves the waveform by {_rel(out1, out):.2e}", flush=True)
     if e > 2e-5:
         raise SystemExit("oracle disagrees with the reference; fixture NOT written")
-    np.savez_compressed(os.path.join(OUT, "scale_x.npz"), out=out.numpy(), grad=grad.numpy().astype(np.float32), mix_head=mix[:, :256].numpy())
+    np.savez_compressed(os.path.join(OUT, "scale_x.npz"), out=out.numpy(), grad=grad.numpy().astype(np.float32), mix_head=mix[:, :256].numpy(),
+                        sru_source=_sru_source())
 
 
 def main():

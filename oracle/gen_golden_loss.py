@@ -16,9 +16,11 @@ REF = "/root/reference"
 
 
 def main():
-    for p in (REF, os.path.join(ROOT, "oracle", "stubs"), ROOT):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.ref_import import prepare_path
+
+    prepare_path()  # /root/reference first, the import stubs last: packages the environment has are used as they are
     from src.losses.matrix import PairwiseNegSDR  # the reference
     from src.losses.pit_wrapper import PITLossWrapper
 

@@ -20,8 +20,10 @@ def synthetic_manifests(d, n=7):
 
 
 def main():
-    for p in ("/root/reference", os.path.join(ROOT, "oracle", "stubs")):
-        sys.path.insert(0, p)
+    sys.path.insert(0, ROOT)
+    from oracle.ref_import import prepare_path
+
+    prepare_path()
     import importlib.util
     import types
 

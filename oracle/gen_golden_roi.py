@@ -18,8 +18,10 @@ CASES = {"val96": ("val", 5, 96, 96, 11), "val_odd": ("val", 3, 101, 93, 12), "v
 
 
 def main():
-    sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
     sys.path.insert(0, ROOT)
+    from oracle.ref_import import prepare_path
+
+    prepare_path()
     spec = importlib.util.spec_from_file_location("ref_transform", "/root/reference/src/datas/transform.py")
     ref = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref)  # the reference module, loaded by path (its package __init__ needs soundfile / lightning)

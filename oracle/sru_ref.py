@@ -15,6 +15,11 @@ Pin: setup/requirements.yaml:33 (git+https://github.com/taolei87/sru.git, HEAD),
 
     *** PARITY UNPINNED for the SRU arithmetic ***
 
+How to pin it, on any box with the package (`pip install sru==2.6.0`) - nothing has to be edited:
+    python -m pytest tests/test_sru_ref.py::test_restatement_matches_the_package     (this file against the package: forward + float64 autograd)
+    python -m oracle.regenerate_all                                                   (the generators import the installed package before the stub,
+                                                                                      oracle/ref_import.py; fixtures then say sru_source = "package sru 2.6.0")
+
 What follows restates the published algorithm of sru 2.6.0 (`SRUCell.forward` +
 `elementwise_recurrence_naive`, "Simple Recurrent Units for Highly Parallelizable Recurrence",
 Lei et al. 2018) with the constructor defaults the reference relies on:
