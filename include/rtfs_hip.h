@@ -475,6 +475,21 @@ int rtfs_caf_bn_adjoint(const float* R_loc, const float* R_glob, const double* n
                         const float* k_g, const float* k_inv, float* k_d_dw, float* k_d_g, float* k_d_be, const float* v_dw, const float* v_g,
                         const float* v_inv, float* v_d_dw, float* v_d_g, float* v_d_be, float* coef, void* stream);
 
+/* ---- module-boundary views (csrc/views.hip): the reference's stage modules called one at a time, forward hooks ------------------------------
+ * The reference runs `self.encoder(x)`, `self.audio_bottleneck(...)`, `self.refinement_module(a, v)`, `self.mask_generator(...)`,
+ * `self.decoder(...)` as ordinary modules (src/models/tdavnet.py:86-97; base_av_model.py:61-118 calls them one by one) and lets hooks see every
+ * sub-module's output.  The fused forward never materialises what the next kernel can form on load; these entry points materialise those views.
+ *   rtfs_gln_stats     stats[b] += (sum, sum of squares) of x[b] (per_utt floats per utterance, multiple of 4); the caller zeroes the slot
+ *   rtfs_norm_act_fwd  y = act(GroupNorm(1,C)(x)) (normalizations.py:8-17 + activations.py): act 0 none, 1 PReLU(slope), 2 ReLU, 3 sigmoid; x [B][rows][C]
+ *   rtfs_gateway_fwd   y = prelu(x * w + b, slope), the gateway's output (tdanet.py:34-41,108); x [rows][256]
+ *   rtfs_cl_to_nchw / rtfs_nchw_to_cl   [B][P][C] <-> [B][C][P] (P = T*F pixels) */
+int rtfs_gln_stats(const float* x, double* stats, int B, long long per_utt, void* stream);
+int rtfs_norm_act_fwd(const float* x, const double* stats, const float* gamma, const float* beta, int act, float slope, float* y, int B, long long rows,
+                      int C, void* stream);
+int rtfs_gateway_fwd(const float* x, const float* w, const float* bias, float slope, float* y, long long rows, void* stream);
+int rtfs_cl_to_nchw(const float* src, float* dst, int B, int P, int C, void* stream);
+int rtfs_nchw_to_cl(const float* src, float* dst, int B, int P, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,11 @@ SIGNATURES = {
     "rtfs_adamw_clip_step": [P, P, P, P, P, P, I, P, D, D, D, D, D, D, D, D, P],
     "rtfs_caf_bn_prepare": [P] * 23 + [F, F, P, P, P, P, P],
     "rtfs_caf_bn_adjoint": [P] * 19 + [P],
+    "rtfs_gln_stats": [P, P, I, LL, P],
+    "rtfs_norm_act_fwd": [P, P, P, P, I, F, P, I, LL, I, P],
+    "rtfs_gateway_fwd": [P, P, P, F, P, LL, P],
+    "rtfs_cl_to_nchw": [P, P, I, I, I, P],
+    "rtfs_nchw_to_cl": [P, P, I, I, I, P],
     "rtfs_vp_attn_bwd": [P, P, P, P, P, P, P, I, I, P],
     # ---- bf16 / split-bf16 MFMA variants of the inference path (extra int `terms` before the stream) ----
     "rtfs_bottleneck_fwd_bf16": [P, P, P, P, P, P, P, I, I, I, P],

@@ -22,6 +22,14 @@ from .hip_path import HipForward
 __version__ = "0.1.0"
 
 
+def _views(stage_module):
+    """the StageViews of the AVNet that owns this stage module (set by AVNet.__init__)"""
+    views = stage_module.__dict__.get("_stage_views")
+    if views is None:
+        raise RuntimeError(f"{type(stage_module).__name__} runs on the HIP kernels of the AVNet that owns it; it cannot be called on its own")
+    return views
+
+
 class STFTEncoder(nn.Module):
     def __init__(self, win, hop_length, out_chan, kernel_size, stride=1, act_type=None, norm_type=None, bias=False, **kw):
         super().__init__()
@@ -36,7 +44,9 @@ class STFTEncoder(nn.Module):
     def get_config(self):
         return dict(win=self.win, hop_length=self.hop_length, out_chan=self.out_chan, kernel_size=self.kernel_size)
 
-    forward = M._holder_forward
+    def forward(self, x):
+        """[B, L] | [L] | [B, 1, L] -> [B, 256, T, F] (encoder.py:161-175) on the HIP kernels (models/stage_views.py)"""
+        return _views(self).encoder(x)
 
 
 class STFTDecoder(nn.Module):
@@ -50,7 +60,9 @@ class STFTDecoder(nn.Module):
     def get_config(self):
         return dict(win=self.win, hop_length=self.hop_length, in_chan=self.in_chan, n_src=self.n_src, kernel_size=self.kernel_size)
 
-    forward = M._holder_forward
+    def forward(self, x, input_shape):
+        """[B, n_src, 256, T, F], shape of the mixture -> [B, n_src, L] (decoder.py:110-132)"""
+        return _views(self).decoder(x, input_shape)
 
 
 class MaskGenerator(nn.Module):
@@ -62,7 +74,16 @@ class MaskGenerator(nn.Module):
     def get_config(self):
         return dict(n_src=self.n_src, in_chan=self.in_chan, bottleneck_chan=self.bottleneck_chan, mask_act=self.mask_act, RI_split=self.RI_split)
 
-    forward = M._holder_forward
+    def forward(self, refined_features, audio_mixture_embedding):
+        """-> [B, n_src, 256, T, F] (mask_generator.py:89-99 with __apply_masks :67-87)"""
+        return _views(self).mask(refined_features, audio_mixture_embedding)
+
+
+class AudioBottleneck(M.ConvNormAct):
+    """`audio_bottleneck` (tdavnet.py:59): the ConvNormAct parameter tree, its forward on the HIP kernels"""
+
+    def forward(self, x):
+        return _views(self).bottleneck(x)
 
 
 class RefinementModule(nn.Module):
@@ -84,7 +105,9 @@ class RefinementModule(nn.Module):
         return dict(audio_params=self.audio_params, video_params=self.video_params, fusion_params=self.fusion_params,
                     audio_bn_chan=self.audio_bn_chan, video_bn_chan=self.video_bn_chan)
 
-    forward = M._holder_forward
+    def forward(self, audio, video):
+        """[B, 256, T, F], [B, 512, Tv] -> refined [B, 256, T, F] (refinement_module.py:45-62)"""
+        return _views(self).refinement(audio, video)
 
 
 class AVNet(nn.Module):
@@ -109,7 +132,7 @@ class AVNet(nn.Module):
         self.video_bn_chan = self.video_bn_params.get("out_chan", self.pretrained_vout_chan)
 
         bn = {k: v for k, v in self.audio_bn_params.items() if k in ("pre_norm_type", "pre_act_type", "norm_type", "act_type", "out_chan", "kernel_size", "is2d")}
-        self.audio_bottleneck = M.ConvNormAct(in_chan=self.enc_out_chan, **{"is2d": False, **bn})
+        self.audio_bottleneck = AudioBottleneck(in_chan=self.enc_out_chan, **{"is2d": False, **bn})
         self.video_bottleneck = M.ConvNormAct(self.pretrained_vout_chan, self.video_bn_chan, self.video_bn_params.get("kernel_size", -1),
                                               is2d=self.video_bn_params.get("is2d", False))
         self.refinement_module = RefinementModule(self.audio_params, self.video_params, self.audio_bn_chan, self.video_bn_chan, self.fusion_params)
@@ -118,6 +141,11 @@ class AVNet(nn.Module):
         self.decoder = STFTDecoder(**{k: v for k, v in enc_dec_params.items() if k not in ("in_chan", "n_src")},
                                    in_chan=self.enc_out_chan * n_src, n_src=n_src)
         self._hip = HipForward(self)
+        from .stage_views import StageViews
+
+        views = StageViews(self._hip)
+        for stage in (self.encoder, self.audio_bottleneck, self.refinement_module, self.mask_generator, self.decoder):
+            stage.__dict__["_stage_views"] = views  # (plain attribute: not a sub-module, not in the state dict; deepcopy follows it to the copy's own HipForward)
         self._warned_eval_grad = False
         # any state-dict load (load_state_dict, from_pretrain, load_state_dict_in, Lightning checkpoints) drops the kernel-layout copies
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_hip_cache())
@@ -194,7 +222,15 @@ class AVNet(nn.Module):
             raise ValueError("RTFS-Net needs the lip embedding tensor [B, 512, Tv]")
         if not x.is_cuda:
             raise RuntimeError("AVNet.forward runs on an MI355X HIP device only: move the model and inputs to 'cuda' (no CPU fallback)")
+        from .stage_views import any_served_hooks
+
+        hooks = any_served_hooks(self)
         with torch.cuda.device(x.device):  # launches, side streams and scratch follow the tensors' device, not the process default
+            if hooks and (self.training or (torch.is_grad_enabled() and (mouth_embedding.requires_grad or any(p.requires_grad for p in self.parameters())))):
+                raise NotImplementedError("rtfs_net_amd: forward hooks are served on the inference path (model.eval() under torch.no_grad()); the training step is "
+                                          "one autograd chain over HIP kernels - remove the hooks or capture the stages in an evaluation pass")
+            if hooks:
+                return self._forward_by_modules(audio_mixture, x, mouth_embedding)
             if torch.is_grad_enabled() and (mouth_embedding.requires_grad or any(p.requires_grad for p in self.parameters())):
                 if not self.training and not self._warned_eval_grad:
                     self._warned_eval_grad = True
@@ -209,6 +245,19 @@ class AVNet(nn.Module):
                     out = self._forward_autograd(x, mouth_embedding)
                 return out.detach()
             return self._hip(x, mouth_embedding)
+
+    def _forward_by_modules(self, audio_mixture, x, mouth_embedding):
+        """tdavnet.py:86-97 stage by stage through the modules' `__call__` (torch fires their hooks; models/stage_views.py fires the hooks of the modules inside
+        the refinement module).  Same kernels as the fused route plus the NCHW views at the five module boundaries: a debugging / profiling route."""
+        from .stage_views import refuse_unserved_hooks
+
+        refuse_unserved_hooks(self)
+        audio_mixture_embedding = self.encoder(x)
+        audio = self.audio_bottleneck(audio_mixture_embedding)
+        video = self.video_bottleneck(mouth_embedding.to(torch.float32))
+        refined_features = self.refinement_module(audio, video)
+        separated_audio_embeddings = self.mask_generator(refined_features, audio_mixture_embedding)
+        return self.decoder(separated_audio_embeddings, x.shape)
 
     # names of the parameters whose gradients come from the HIP backward chain (everything but the video-side glue)
     def _hip_param_names(self):

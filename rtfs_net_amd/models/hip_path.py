@@ -268,6 +268,7 @@ class HipForward:
                      "mixgln": not off("RTFS_NO_MIXGLN_FUSION"), "d0tail": not off("RTFS_NO_D0TAIL_FUSION"),
                      "wgside": not off("RTFS_NO_WGRAD_SIDE"), "wgather": not off("RTFS_NO_WEIGHT_GATHER"), "cafbn": not off("RTFS_NO_CAF_BN_FUSION"),
                      "decmask": not off("RTFS_NO_DECMASK_FUSION"), "srubwd": not off("RTFS_NO_SRU_BWD_FUSION")}  # (mixgln, d0tail, wgside, srubwd: training step only, models/hip_train.py)
+        self.vp_ran_as_modules = False
         self.vp_glue = off("RTFS_VP_GLUE")  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
         self.vp_side_stream = not off("RTFS_VP_NO_SIDE")
 
@@ -394,6 +395,8 @@ class HipForward:
         else:
             lib.call("rtfs_dwconv_fwd", F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [cl], [st[9]], B, T, F_BINS)
             lib.call("rtfs_dwconv_fwd", F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [cg, cgate], [st[10], st[11]], B, T2, F2)
+        if tap is not None:
+            tap["cl"], tap["cg"], tap["cgate"] = cl, cg, cgate  # (pre-norm outputs of concat_layers[0]'s three convolutions: the hook views mix them)
         if caf is not None:
             ks, kb, vs, vb, att, rsz, Tv, add_input = caf()  # (waits for the video branch's side stream, launches the cell's video side)
             nxt = next_proj if add_input else None
@@ -410,6 +413,89 @@ class HipForward:
         self._mm("rtfs_resid_fwd", cl, st[9], cl_[2], cl_[3], D0, st[1], d0g, d0be, cg, st[10], cg_[2], cg_[3], cgate, st[11], cgate_[2],
                  cgate_[3], self._wk(bw, "rw"), bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, B, T, T2)
         return False
+
+    def _refine(self, pw, a0, emb, stats, B, T, T2, taps, bottleneck=True):
+        """RefinementModule.forward (refinement_module.py:45-62) on channels-last buffers: RTFS block 0 on a0 with the VP block underneath it on a side
+        stream, the CAF cell, blocks 1..R-1 on `previous + a0`.  -> (refined, a spare [B][TF][256] buffer)."""
+        m, w = self.model, pw.w
+        dev = a0.device
+        TF = T * F_BINS
+        R = m.refinement_module.audio_net.repeats
+        # a9: VP block (PyTorch-ROCm glue) -- independent of the audio branch until the CAF cell, so its ~100 tiny
+        # launches run on a side stream underneath the encoder / bottleneck / first RTFS block
+        if self._vp_stream is None or self._vp_stream.device != dev:
+            self._vp_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        self._vp_stream.wait_stream(cur)
+        Tv = emb.shape[-1]
+        att = torch.empty(B * Tv * C, device=dev)  # (allocated on the main stream: its allocator owns them, the side stream only fills them)
+        rsz = torch.empty_like(att)
+        with torch.cuda.stream(self._vp_stream):
+            # (bottleneck=False: `emb` is already video_bottleneck's output - the stage modules called one by one, models/stage_views.py)
+            vin = (m.video_bottleneck(emb.to(torch.float32)) if bottleneck else emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
+            vblock = m.refinement_module.video_net.get_block(0)
+            use_hip = w["vp"] is not None and not self.vp_glue
+            if use_hip and 3 <= Tv <= 100:  # (round 5: the kernel matches the modules from 3 frames on; it was only tested from 8)
+                v1 = torch.empty_like(vin)
+                lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
+            elif use_hip and 100 < Tv <= 4096:
+                # longer than the one-kernel form's LDS (4 s): the multi-launch kernels of the training step with running-statistics slots
+                # (models/vp_train.py; GlobalAttention on HIP as well: the LDS form up to 16 pooled tokens = Tv <= 128, the workspace form beyond)
+                from .vp_train import vp_block_eval
+
+                v1 = vp_block_eval(vblock, vin, (pw._scal["refinement_module.video_net.blocks.gateway.full_layer.4.weight"],
+                                                 pw._scal["refinement_module.video_net.blocks.projection.full_layer.4.weight"]))
+            else:  # other video_params / one or two frames: PyTorch-ROCm glue (models/modules.py)
+                v1 = vblock(vin).contiguous()
+            self.vp_ran_as_modules = not (use_hip and 3 <= Tv <= 4096)  # (forward hooks: torch fires the modules' own, models/stage_views.py the kernels')
+            # the CAF cell's video side (one workgroup per utterance, 64 us) rides on the side stream as well
+            lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
+                     w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
+
+        blocks = pw.blocks
+        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
+        x = torch.empty_like(a0)
+        last = R == 1
+        fuse = len(blocks) == 1 and self.fuse["proj"]  # shared block weights: block i+1's projection = block i's
+
+        def caf_video():  # join the side stream: att / rsz (and v1 for the taps) are ready past this point
+            cur.wait_stream(self._vp_stream)
+            v1.record_stream(cur)
+
+        y0_next = None
+        # stage taps want the block output itself; Tv > T cannot happen on the product path (25 video frames / s vs 125 STFT frames / s)
+        if taps is None and Tv <= T and self.fuse["caf"]:
+            # block 0 + CAF cell (+ block 1's projection) in one residual kernel: the block output never reaches HBM (a10 / fusion.py:259-272)
+            def caf_args():
+                caf_video()
+                return w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, Tv, not last
+
+            s = x
+            nxt = (torch.empty(B * TF * H, device=dev), stats[13]) if (fuse and not last) else None
+            if self._block(a0, s, None, bw(0), stats[1:13], B, T, T2, next_proj=nxt, caf=caf_args):
+                y0_next = nxt[0]
+            x = torch.empty_like(a0)
+        else:
+            self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
+            caf_video()
+            s = torch.empty_like(a0)
+            lib.call("rtfs_caf_fuse_fwd", x, w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, None if last else a0, s, B, T, Tv)
+            if taps is not None:
+                taps["block0"], taps["vp"] = x.clone(), v1
+                taps["caf_plus_a0" if not last else "caf"] = s.clone()
+        for i in range(1, R):
+            last = i == R - 1
+            y0_cur, nxt = y0_next, None
+            if fuse and not last:
+                nxt = (torch.empty(B * TF * H, device=dev), stats[1 + 12 * (i + 1)])
+            tap_i = _TapView(taps, i) if (taps is not None and self.tap_all_blocks) else None
+            fused = self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, tap=tap_i, y0=y0_cur, next_proj=nxt)
+            y0_next = nxt[0] if fused else None
+            if tap_i is not None:
+                tap_i["block"] = x.clone()
+            s, x = x, s
+        return s, x
 
     @torch.no_grad()
     def __call__(self, wav: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
@@ -452,78 +538,7 @@ class HipForward:
         if taps is not None:
             taps["spec"], taps["a_emb"], taps["a0"] = spec, a_emb, a0
 
-        # a9: VP block (PyTorch-ROCm glue) -- independent of the audio branch until the CAF cell, so its ~100 tiny
-        # launches run on a side stream underneath the encoder / bottleneck / first RTFS block
-        if self._vp_stream is None or self._vp_stream.device != dev:
-            self._vp_stream = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream()
-        self._vp_stream.wait_stream(cur)
-        Tv = emb.shape[-1]
-        att = torch.empty(B * Tv * C, device=dev)  # (allocated on the main stream: its allocator owns them, the side stream only fills them)
-        rsz = torch.empty_like(att)
-        with torch.cuda.stream(self._vp_stream):
-            vin = m.video_bottleneck(emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
-            vblock = m.refinement_module.video_net.get_block(0)
-            use_hip = w["vp"] is not None and not self.vp_glue
-            if use_hip and 3 <= Tv <= 100:  # (round 5: the kernel matches the modules from 3 frames on; it was only tested from 8)
-                v1 = torch.empty_like(vin)
-                lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
-            elif use_hip and 100 < Tv <= 4096:
-                # longer than the one-kernel form's LDS (4 s): the multi-launch kernels of the training step with running-statistics slots
-                # (models/vp_train.py; GlobalAttention on HIP as well: the LDS form up to 16 pooled tokens = Tv <= 128, the workspace form beyond)
-                from .vp_train import vp_block_eval
-
-                v1 = vp_block_eval(vblock, vin, (pw._scal["refinement_module.video_net.blocks.gateway.full_layer.4.weight"],
-                                                 pw._scal["refinement_module.video_net.blocks.projection.full_layer.4.weight"]))
-            else:  # other video_params / one or two frames: PyTorch-ROCm glue (models/modules.py)
-                v1 = vblock(vin).contiguous()
-            # the CAF cell's video side (one workgroup per utterance, 64 us) rides on the side stream as well
-            lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
-                     w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)
-
-        blocks = pw.blocks
-        bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
-        # block 0 on a0, then CAF (writes caf + a0 = next block input), then blocks 1..R-1
-        x = torch.empty_like(a_emb)
-        last = R == 1
-        fuse = len(blocks) == 1 and self.fuse["proj"]  # shared block weights: block i+1's projection = block i's
-
-        def caf_video():  # join the side stream: att / rsz (and v1 for the taps) are ready past this point
-            cur.wait_stream(self._vp_stream)
-            v1.record_stream(cur)
-
-        y0_next = None
-        # stage taps want the block output itself; Tv > T cannot happen on the product path (25 video frames / s vs 125 STFT frames / s)
-        if taps is None and Tv <= T and self.fuse["caf"]:
-            # block 0 + CAF cell (+ block 1's projection) in one residual kernel: the block output never reaches HBM (a10 / fusion.py:259-272)
-            def caf_args():
-                caf_video()
-                return w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, Tv, not last
-
-            s = x
-            nxt = (torch.empty(B * TF * H, device=dev), stats[13]) if (fuse and not last) else None
-            if self._block(a0, s, None, bw(0), stats[1:13], B, T, T2, next_proj=nxt, caf=caf_args):
-                y0_next = nxt[0]
-            x = torch.empty_like(a_emb)
-        else:
-            self._block(a0, x, None, bw(0), stats[1:13], B, T, T2, tap=taps)
-            caf_video()
-            s = torch.empty_like(a_emb)
-            lib.call("rtfs_caf_fuse_fwd", x, w["caf_key_s"], w["caf_key_b"], w["caf_value_s"], w["caf_value_b"], att, rsz, None if last else a0, s, B, T, Tv)
-            if taps is not None:
-                taps["block0"], taps["vp"] = x.clone(), v1
-                taps["caf_plus_a0" if not last else "caf"] = s.clone()
-        for i in range(1, R):
-            last = i == R - 1
-            y0_cur, nxt = y0_next, None
-            if fuse and not last:
-                nxt = (torch.empty(B * TF * H, device=dev), stats[1 + 12 * (i + 1)])
-            tap_i = _TapView(taps, i) if (taps is not None and self.tap_all_blocks) else None
-            fused = self._block(s, x, None if last else a0, bw(i), stats[1 + 12 * i: 13 + 12 * i], B, T, T2, tap=tap_i, y0=y0_cur, next_proj=nxt)
-            y0_next = nxt[0] if fused else None
-            if tap_i is not None:
-                tap_i["block"] = x.clone()
-            s, x = x, s
+        s, x = self._refine(pw, a0, emb, stats, B, T, T2, taps)
         # a11: S3 mask; a12: decoder taps + iSTFT
         masked = x
         self._mm("rtfs_mask_fwd", s, w["mask_slope"], self._wk(w, "mask_w"), w["mask_b"], a_emb, masked, None, B, TF)

@@ -1,8 +1,12 @@
 """Parameter tree of RTFS-Net with the reference's state-dict names and shapes.
 
-The audio branch's modules are PARAMETER HOLDERS: their arithmetic runs in the HIP kernels
-(hip_path.py), so their `forward` raises.  Only the tiny video-branch (VP) block -- 50 tokens,
-~0.05 % of the MACs, SURVEY.md §2 row 9 / §8 a9 -- has a torch `forward` (PyTorch-ROCm glue).
+The audio branch's INNER modules are PARAMETER HOLDERS: their arithmetic runs fused in the HIP
+kernels (hip_path.py), so calling one of them directly raises.  What the reference's module protocol
+offers above them works (models/stage_views.py): the five stage modules of AVNet are callable one by
+one (NCHW in / out), and forward hooks on an RTFS block, its direct children, the VP block and the
+CAF cell fire with the module's inputs and output.  Only the tiny video-branch (VP) block -- 50
+tokens, ~0.05 % of the MACs, SURVEY.md §2 row 9 / §8 a9 -- also has a torch `forward` (PyTorch-ROCm
+glue for one or two video frames).
 
 Naming follows the reference so that checkpoints load unchanged:
   ConvNormAct.full_layer.{0 pre_norm,1 pre_act,2 conv,3 norm,4 act}   src/models/layers/conv_layers.py:121-127
@@ -26,7 +30,9 @@ EPS = 1e-5
 
 
 def _holder_forward(self, *a, **k):
-    raise RuntimeError(f"{type(self).__name__} is executed by the HIP path (rtfs_net_amd.models.hip_path); it has no torch forward")
+    raise RuntimeError(f"{type(self).__name__} is fused into the HIP kernels of the stage module that owns it (rtfs_net_amd.models.hip_path) and has no forward "
+                       "of its own: call encoder / audio_bottleneck / refinement_module / mask_generator / decoder of the AVNet, or observe it with a forward hook "
+                       "(served for RTFS blocks and their direct children, the VP block, the CAF cell: rtfs_net_amd.models.stage_views)")
 
 
 class GlobalLayerNorm(nn.Module):

@@ -52,7 +52,26 @@ def test_parameter_gradients_split_bf16_step_on_ordinary_weights():
     _check_parameter_gradients(*CASES[2], "bf16x3", kind="plain", tol=6e-2, tol_scalar=6e-2, tol_median=5e-3)
 
 
-def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None, tol_scalar=None, tol_median=1e-3):
+def test_parameter_gradients_at_the_config3_shape():
+    """BASELINE configs[2] at its real shape against the REFERENCE: RTFS-Net-6, batch 32 - every large-batch kernel form of the step runs
+    (fast-FIR layer-0 GEMM / ConvTranspose / its input gradient, weight-stationary GEMMs, `rows_ws64`, the >= 2048-sequence SRU forms, the Toeplitz weight
+    gradient at 4000 x 57).  Utterance 0 is the input of the reference's RTFS-Net-6 fixture (float64 autograd of /root/reference, oracle/gen_golden_grads.py),
+    the other 31 are synthetic; the loss weights are the fixture's for utterance 0 and ZERO for the rest.  Every adjoint is linear in d(out) and nothing
+    couples utterances in eval mode (gLN is per utterance, BatchNorm uses running statistics), so all 363 parameter gradients must equal the fixture's."""
+    _check_parameter_gradients(*CASES[-1], "f32", embed_in_batch=32)
+
+
+@pytest.mark.parametrize("training,B,L,R,Tv", SMOOTH_CASES)
+def test_parameter_gradients_fp32_step_in_the_smooth_regime(training, B, L, R, Tv):
+    """the SHARED-block fp32 step where the function is smooth (slopes in [0.97, 1], ReLU inputs positive: no activation kink within
+    round-off of any element), held ten times tighter than on ordinary weights - a 0.5 % operand error in ONE adjoint shows here.  (The ordinary-weight
+    cases above keep 3e-3: their deviations are kink flips)"""
+    # 3e-4 per tensor and per scalar slope, median 1e-5: ten times inside the ordinary-weight bound.  Observed on MI355X: median 1.6e-6; the worst tensor of the
+    # full-length case is a 64 x 4 attention query projection at 1.35e-4 (softmax shift invariance leaves it a cancellation residue), worst slope 1.04e-4
+    _check_parameter_gradients(training, B, L, R, Tv, "f32", kind="smooth", tol=3e-4, tol_scalar=3e-4, tol_median=1e-5)
+
+
+def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None, tol_scalar=None, tol_median=1e-3, embed_in_batch=None):
     model, sd, cfg = make_model(R, "cuda")
     for mod in model.modules():
         if isinstance(getattr(mod, "p", None), float):
@@ -71,8 +90,14 @@ def _check_parameter_gradients(training, B, L, R, Tv, dtype, kind=None, tol=None
     model.train(training)
     model.set_compute_dtype(dtype)
     wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(GRAD_WEIGHT_SEED))
+    if embed_in_batch:  # the fixture's utterances in front of synthetic ones that carry zero loss weight
+        assert not training and embed_in_batch > B
+        mix_all, _, emb_all = synth.synth_inputs(embed_in_batch, L, Tv)
+        mix_all[:B], emb_all[:B] = mix, emb
+        mix, emb, wgt = mix_all, emb_all, torch.cat([wgt, torch.zeros(embed_in_batch - B, 1, L)])
     out = model(mix.cuda(), emb.cuda())
     (out * wgt.cuda()).sum().backward()
+    out = out[:B]
     ref_out = torch.from_numpy(z["out"])
     ref = {k[5:]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith("grad.")}
     ref_stats = {k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("stat.")}
