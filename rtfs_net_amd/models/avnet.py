@@ -166,7 +166,8 @@ class AVNet(nn.Module):
         INFERENCE path: "f32" (default: exact fp32 MFMA), "bf16" (operands rounded to bfloat16, fp32 accumulation: ~4e-3 relative on the
         waveform), "bf16x3" (split-bf16, three bf16 MFMAs per product: ~1e-5 relative, inside the 1e-3 parity bound at 16/3 of the fp32
         MFMA rate) or "bf16x6" (each fp32 operand split into three bfloat16 values = its full 24-bit mantissa, six bf16 MFMAs per product:
-        fp32-level accuracy, not bit-identical, at 8/3 of the fp32 MFMA rate).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
+        fp32-level accuracy, not bit-identical, at 8/3 of the fp32 MFMA rate) or "bf16-attn" (what BASELINE configs[4] names: ONLY the attention core's QK^T and PV
+        on the bf16 MFMA pipe with bfloat16 operands, every other contraction exact fp32; also in the training step's forward, its adjoint stays fp32).  Activations in HBM, norm statistics, the SRU recurrence, softmax and the (i)STFT stay fp32 in every mode.  The
         training step follows the same switch: forward GEMMs, weight-gradient and input-gradient GEMMs of the adjoint chain on the bf16
         pipe with fp32 accumulation (the attention-core adjoint and everything element-wise stay fp32).
         (The reference selects precision through Lightning's `precision` flag; its configs use 32.)"""
@@ -174,10 +175,14 @@ class AVNet(nn.Module):
 
         if name not in COMPUTE_DTYPES:
             raise ValueError(f"compute dtype must be one of {sorted(COMPUTE_DTYPES)}, got {name!r}")
+        from .hip_path import ATTN_TERMS
+
         self._hip.prec = COMPUTE_DTYPES[name]
+        self._hip.attn_terms = ATTN_TERMS.get(name, 0)
         self._compute_prec = COMPUTE_DTYPES[name]
         if getattr(self, "_trainer", None) is not None:
             self._trainer.prec = self._compute_prec
+            self._trainer.attn_terms = self._hip.attn_terms
         return self
 
     def train(self, mode: bool = True):
@@ -283,6 +288,7 @@ class AVNet(nn.Module):
         if getattr(self, "_trainer", None) is None:
             self._trainer = HipTrainer(self)
             self._trainer.prec = getattr(self, "_compute_prec", self._hip.prec)
+            self._trainer.attn_terms = self._hip.attn_terms
         rm = self.refinement_module
         # The video branch runs on a side stream underneath the encoder / first RTFS block of the HIP function, which waits for it right before the
         # CAF cell; autograd runs its backward on that stream as well.  HOST order matters too: each step starts with an idle GPU (the weight

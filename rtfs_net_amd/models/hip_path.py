@@ -31,7 +31,10 @@ def _f32(t):
 
 
 # compute dtype of the dense contractions (every MFMA kernel): name -> `terms` argument of the *_bf16 entry points (0 = the fp32 entry points)
-COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+COMPUTE_DTYPES = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "bf16-attn": 0}
+# "bf16-attn" (BASELINE configs[4]: "bf16 with MFMA attention"; north_star: "MFMA only for the attention QK^T / AV GEMMs"): the two products of the attention
+# core (attention.py:171-173) with operands rounded to bfloat16 on the bf16 MFMA pipe, EVERY other contraction exact fp32 - `prec` stays 0, `attn_terms` is 1
+ATTN_TERMS = {"bf16-attn": 1}
 PACKED_WEIGHT_MODES = (1, 3)  # modes whose *_bf16 entry points take host-packed weights; bf16x6 splits plain fp32 operands in registers
 
 
@@ -258,6 +261,7 @@ class HipForward:
         self.tap_all_blocks = False  # with `taps`: also capture the stages of blocks 1..R-1 (keys suffixed '#i')
         self._vp_stream = None
         self.prec = COMPUTE_DTYPES[os.environ.get("RTFS_COMPUTE_DTYPE", "f32")]  # AVNet.set_compute_dtype
+        self.attn_terms = ATTN_TERMS.get(os.environ.get("RTFS_COMPUTE_DTYPE", "f32"), 0)  # terms of the attention core alone when prec == 0
         # kernel-form choices handed to the C-ABI as explicit `variant` arguments (0 = the library's own choice; include/rtfs_hip.h) - a
         # HOST-side setting for same-box A/B runs and the equivalence tests, the library itself reads no environment
         self.variants = {"resid": int(os.environ.get("RTFS_RESID_VARIANT", "0")), "unfold": int(os.environ.get("RTFS_UNFOLD_VARIANT", "0"))}
@@ -282,6 +286,8 @@ class HipForward:
         """an entry point whose contraction runs on MFMA: the fp32 one, or its *_bf16 sibling with the `terms` argument"""
         if self.prec:
             lib.call(name + "_bf16", *args, self.prec)
+        elif self.attn_terms and name == "rtfs_attn_core_fwd":
+            lib.call(name + "_bf16", *args, self.attn_terms)
         else:
             lib.call(name, *args)
 

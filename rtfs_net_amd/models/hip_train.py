@@ -289,6 +289,7 @@ class HipTrainer:
         self.model = model
         self._prep = None
         self.prec = 0  # AVNet.set_compute_dtype: 0 fp32, 1 bf16, 3 split-bf16 products in every MFMA kernel of the step
+        self.attn_terms = 0  # "bf16-attn": the attention core's forward alone on the bf16 pipe (prec == 0)
 
     def weights(self, defer_scalars=False):
         """defer_scalars (forward_a only): the caller calls `.finish_scalars()` on the result before it reads a scalar slot (PReLU slopes, scale_x, `_scal`)"""
@@ -309,6 +310,8 @@ class HipTrainer:
         """lib.call, routed to the *_bf16 sibling (extra `terms` argument) for the MFMA entry points when a bf16 mode is selected"""
         if self.prec and name in _MFMA_ENTRY_POINTS:
             lib.call(name + "_bf16", *args, self.prec)
+        elif self.attn_terms and name == "rtfs_attn_core_fwd":
+            lib.call(name + "_bf16", *args, self.attn_terms)
         else:
             lib.call(name, *args)
 

@@ -72,3 +72,38 @@ def test_bench_plain_launch_reexecutes_under_torchrun():
         return  # (on a GPU box tests/test_bench_contract.py exercises the real thing)
     assert r.returncode != 0
     assert "bench.py needs an MI355X" in (r.stdout + r.stderr)  # (the elastic agent may stop the second rank as soon as the first has failed)
+
+
+def test_bench_traffic_is_null_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from committed PMC passes (profiles/pmc_traffic.json); the file carries the hashes of the kernel sources it
+    was measured with and bench.py reports null - with the reason - once one of them differs"""
+    import hashlib
+    import json
+    import os
+    import sys
+    from types import SimpleNamespace
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    a = SimpleNamespace(layers=6, batch=32, seconds=2.0, dtype="f32", mode="infer")
+    src = tmp_path / "rtfs_net_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "dualpath.hip").write_text("kernel v1")
+    (tmp_path / "profiles").mkdir()
+    table = {"void rtfs::unfold_ffa_kernel<3, 0>(...)": {"bytes_per_launch": 300e6, "launches": 2},
+             "void rtfs::unfold_ffa_kernel<4, 0>(...)": {"bytes_per_launch": 320e6, "launches": 2},
+             "_source": {"rtfs_net_amd/csrc/dualpath.hip": hashlib.sha256(b"kernel v1").hexdigest()}}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(table))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got, why = bench.pmc_traffic("unfold_ffa_kernel<3, 0>|unfold_ffa_kernel<4, 0>", a)
+    assert got == 310e6 and "committed PMC passes" in why
+    (src / "dualpath.hip").write_text("kernel v2")
+    got, why = bench.pmc_traffic("unfold_ffa_kernel<3, 0>|unfold_ffa_kernel<4, 0>", a)
+    assert got is None and why.startswith("stale: rtfs_net_amd/csrc/dualpath.hip")
+    del table["_source"]
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(table))
+    assert bench.pmc_traffic("unfold_ffa_kernel<3, 0>", a) == (None, "profiles/pmc_traffic.json carries no source hash (measured before round 6): re-run tools/pmc_hbm.sh")
+    a.batch = 16
+    assert bench.pmc_traffic("unfold_ffa_kernel<3, 0>", a)[0] is None

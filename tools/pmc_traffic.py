@@ -43,6 +43,12 @@ def main(fetch_csv, write_csv, out=None):
         import os
 
         js = {k: {"bytes_per_launch": tot, "read_bytes": rd, "write_bytes": wr, "launches": c} for tot, k, c, rd, wr in rows}
+        # what these bytes describe: the kernel sources of the run.  bench.py reports `traffic` only while the roofline kernel's source file still has this hash
+        import hashlib
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        js["_source"] = {rel: hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()
+                         for rel in ("rtfs_net_amd/csrc/dualpath.hip", "rtfs_net_amd/csrc/common.h")}
         json.dump(js, open(os.path.splitext(out)[0] + ".json", "w"), indent=0)  # every kernel; tools/pmc_hbm.sh copies the forward one to pmc_traffic.json
 
 
