@@ -475,6 +475,17 @@ int rtfs_caf_bn_adjoint(const float* R_loc, const float* R_glob, const double* n
                         const float* k_g, const float* k_inv, float* k_d_dw, float* k_d_g, float* k_d_be, const float* v_dw, const float* v_g,
                         const float* v_inv, float* v_d_dw, float* v_d_g, float* v_d_be, float* coef, void* stream);
 
+/* ---- the whole adjoint of up to four stride-1 depth-wise 4x4 convolutions that share one input, in one pass (csrc/bwd_dw.hip, round 6) -----------------
+ * autograd of ConvNormAct(groups = channels) -> gLN (conv_layers.py:65-129; tdanet.py:61-76, layers/fusion.py:25-52).  nconv in {1, 2, 4}; dy[k]: gradient w.r.t.
+ * convolution k's output - or, when x != NULL, w.r.t. its gLN-NORMALISED output, the gLN adjoint  dX = rstd (gamma dN - S1/N - xhat S2/N)  then being applied on load
+ * from x[k] (pre-norm output), x_stats[k] (its forward statistics), red[k] (S1, S2: rtfs_gln_bwd_reduce / rtfs_mix_gln_bwd / rtfs_d0_tail_bwd) and gamma[k];
+ * in: the common input, transformed as the forward saw it (mode 0 raw, 1 gLN, 2 PReLU(gLN)); dIn (=, or += when accumulate) the gradient w.r.t. that TRANSFORMED
+ * input; dW[k] [16][64] += tap gradients, dbias[k] [64] += bias gradients (dbias NULL: none).  Pointer arrays are host arrays of device pointers.
+ * Replaces rtfs_gln_bwd_apply + rtfs_dwconv_bwd_weight + rtfs_dwconv_bwd_input per convolution: dX never reaches HBM. */
+int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
+                    const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
+                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream);
+
 /* ---- module-boundary views (csrc/views.hip): the reference's stage modules called one at a time, forward hooks ------------------------------
  * The reference runs `self.encoder(x)`, `self.audio_bottleneck(...)`, `self.refinement_module(a, v)`, `self.mask_generator(...)`,
  * `self.decoder(...)` as ordinary modules (src/models/tdavnet.py:86-97; base_av_model.py:61-118 calls them one by one) and lets hooks see every

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["gemm.hip", "dualpath.hip", "attention.hip", "tfar.hip", "stft.hip", "bwd_elem.hip", "bwd_gemm.hip", "bwd_seq.hip", "bwd_attn.hip",
-           "bwd_misc.hip", "spread.hip", "loss.hip", "vp.hip", "vp_train.hip", "vp_attn.hip", "lip.hip", "optim.hip", "views.hip"]
+           "bwd_misc.hip", "spread.hip", "loss.hip", "vp.hip", "vp_train.hip", "vp_attn.hip", "lip.hip", "optim.hip", "views.hip", "bwd_dw.hip"]
 LIB = os.path.join(HERE, "librtfs_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 # The video-branch kernels run on a SIDE stream, i.e. next to the main stream's bf16 MFMA kernels on the same CUs in the bf16 / split-bf16

@@ -1,0 +1,272 @@
+// rtfs_dw_adjoint: the WHOLE adjoint of up to four stride-1 depth-wise 4x4 convolutions that share one input, in ONE pass (training step, round 6).
+//
+// Forward (conv_layers.py:65-129 with groups = channels; tdanet.py:61-76, fusion.py:25-52):  y_k = gLN_k(conv_k(in'))  with  in' = in | gLN(in) | PReLU(gLN(in)),
+//     conv_k(in')[t][f] = bias_k + sum_{dt,df} w_k[dt*4+df] * in'[t-1+dt][f-1+df]          ('same' padding of an even kernel: 1 before, 2 after).
+// Until round 6 the adjoint of one such convolution was three launches - rtfs_gln_bwd_apply (dN, X -> dX), rtfs_dwconv_bwd_weight (dX, in -> dW),
+// rtfs_dwconv_bwd_input (dX -> dIn, read-modify-write when several convolutions share the input) - and dX went through HBM three times.  With
+//     W[r][c] = dX[ti-2+r][fi-2+c]   (the 4x4 neighbourhood of dX around an INPUT pixel (ti, fi))
+// both gradients are sums over the same sixteen values:
+//     dIn'[ti][fi]        = sum_{r,c} w[(3-r)*4 + (3-c)] * W[r][c]
+//     dW[(3-r)*4 + (3-c)] += in'[ti][fi] * W[r][c]            (summed over every input pixel; dX = 0 outside the tensor)
+//     dbias               += W[2][2]
+// so one kernel stages the dX tile of convolution k in LDS - the gLN adjoint  dX = rstd (gamma dN - S1/N - xhat S2/N)  applied on the way in, i.e. dX never
+// exists in HBM - walks it once for both sums, moves on to convolution k+1 with the dIn' accumulators still in registers, and stores dIn' once.
+// HBM traffic in tensor units, group of the four global convolutions of the TFAR fusion layers (input G3): 31 -> 10; concat layer's two: 15 -> 6; single
+// convolutions 7 -> 4 (gLN'd) and 4-5 -> 3-4 (direct dOut).
+//
+// Workgroup = 8 input rows x 8 columns per step x 64 channels, 256 threads.  Staging: thread = (pixel, channel quad), 16-byte loads, 11 x 11 pixel tile
+// (two halo rows / columns before, one after).  Window pass: thread = (row, channel PAIR) - with two channels per lane the 16 weight-gradient partials of
+// one convolution are 32 registers, so four convolutions' partials (128) stay resident next to the accumulators; taps are read from LDS (broadcast).
+// Consecutive time tiles of an utterance run on the same XCD (the 1-D grid is re-mapped), so the halo rows a neighbour has just fetched are L2 hits.
+#include "common.h"
+
+namespace rtfs {
+
+constexpr int kAdjMax = 4;
+struct DwAdjArgs {
+    int T, F, B, nt, nseg, fseg;
+    const float* dy[kAdjMax];     // GLN: gradient w.r.t. the NORMALISED output of convolution k; else w.r.t. its output itself
+    const float* x[kAdjMax];      // GLN: the convolution's pre-norm output
+    const double* slot[kAdjMax];  // GLN: forward (sum, sum of squares) of x per utterance
+    const double* red[kAdjMax];   // GLN: adjoint sums (S1, S2) per utterance (rtfs_gln_bwd_reduce / rtfs_mix_gln_bwd / rtfs_d0_tail_bwd)
+    const float* gamma[kAdjMax];  // GLN
+    const float* w[kAdjMax];      // taps [16][64], tap = dt*4 + df
+    const float* in;              // the common input [B][T][F][64]
+    const double* in_slot;        // mode >= 1
+    const float *in_gamma, *in_beta;
+    float in_slope;               // mode 2
+    int mode, accumulate, bias;
+    double inv_n;                 // 1 / (T F 64): every tensor here has the convolution's size
+    float* dIn;
+    float* scr;                   // spread scratch: per convolution [dW 1024 | dbias 64 when bias]
+};
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v ld2v(const float* p) { return *reinterpret_cast<const float2v*>(p); }
+
+template <int NCONV, bool GLN>
+__global__ __launch_bounds__(256, 2) void dw_adjoint_kernel(DwAdjArgs a) {
+    constexpr int TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64;  // tile rows t0-2 .. t0+8, columns fb-2 .. fb+8
+    constexpr int NIT = (R * CB * 16 + 255) / 256;                          // staging items (pixel, quad) per thread
+    __shared__ __attribute__((aligned(16))) float tile[R * RS];
+    __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
+    __shared__ __attribute__((aligned(16))) float coefA[GLN ? NCONV : 1][64];
+    // ---- tile of this workgroup: consecutive time tiles of an utterance on one XCD (workgroups go to XCDs round-robin by linear index) ----
+    const int ntiles = a.nt * a.B * a.nseg, per_xcd = (ntiles + 7) / 8;
+    const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (vid >= ntiles) return;
+    const int tt = vid % a.nt, b = (vid / a.nt) % a.B, seg = vid / (a.nt * a.B);
+    const int T = a.T, F = a.F;
+    const int t0 = tt * TR, f0 = seg * a.fseg, f1 = min(F, f0 + a.fseg);
+    for (int i = threadIdx.x; i < NCONV * 256; i += 256) st4(&ws[i >> 8][(i & 255) * 4], ld4(a.w[i >> 8] + (i & 255) * 4));
+    float Bc[NCONV], Cc[NCONV];
+    if (GLN) {
+#pragma unroll
+        for (int k = 0; k < NCONV; ++k) {
+            float mean, rstd;
+            stats_finalize(a.slot[k], b, a.inv_n, mean, rstd);
+            const float m1 = (float)(a.red[k][kStatStride * b] * a.inv_n), m2 = (float)(a.red[k][kStatStride * b + 1] * a.inv_n);
+            Bc[k] = m2 * rstd * rstd;
+            Cc[k] = Bc[k] * mean - m1 * rstd;
+            if (threadIdx.x < 64) coefA[k][threadIdx.x] = a.gamma[k][threadIdx.x] * rstd;
+        }
+    }
+    // ---- window-pass identity: (row, channel pair) ----
+    const int r = threadIdx.x >> 5, ch = (threadIdx.x & 31) * 2;
+    const int ti = t0 + r;
+    const bool tvalid = ti < T;
+    float2v isc = float2v{1.f, 1.f}, ish = float2v{0.f, 0.f};
+    if (a.mode >= 1) {
+        float mean, rstd;
+        stats_finalize(a.in_slot, b, a.inv_n, mean, rstd);
+        const float2v g = ld2v(a.in_gamma + ch), be = ld2v(a.in_beta + ch);
+        isc = g * rstd;
+        ish = be - isc * mean;
+    }
+    const float am1 = a.in_slope - 1.0f;
+    const size_t ubase = (size_t)b * T * F * kH;
+    const float* inrow = a.in + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
+    float* outrow = a.dIn + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
+    // ---- staging identity: (pixel, channel quad) ----
+    const int q4 = (threadIdx.x & 15) * 4;
+    float2v part[NCONV][16], pb[NCONV];
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        pb[k] = float2v{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[k][i] = float2v{0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int fb = f0; fb < f1; fb += TC) {
+        // the input pixels of this thread's row (transformed as the forward convolution saw them; zero outside the tensor)
+        float2v inv[TC], acc[TC];
+#pragma unroll
+        for (int j = 0; j < TC; ++j) inv[j] = ld2v(inrow + (size_t)min(fb + j, F - 1) * kH);
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            float2v v = inv[j];
+            if (a.mode >= 1) v = v * isc + ish;
+            if (a.mode == 2) v = __builtin_elementwise_min(v, float2v{0.f, 0.f}) * am1 + v;  // prelu(x) = x + (slope - 1) min(x, 0)
+            inv[j] = (tvalid && fb + j < f1) ? v : float2v{0.f, 0.f};
+            acc[j] = float2v{0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < NCONV; ++k) {
+            __syncthreads();  // the previous tile's window reads are done (and ws / coefA are written)
+            // ---- stage dX_k: rows t0-2 .. t0+8, columns fb-2 .. fb+8; the gLN adjoint on the way in; zero outside the tensor ----
+            const float* dyb = a.dy[k] + ubase;
+            const float* xb = GLN ? a.x[k] + ubase : nullptr;
+            float4 A4 = f4(1, 1, 1, 1);
+            if (GLN) A4 = ld4(&coefA[k][q4]);
+            constexpr int NG = NCONV >= 4 ? 2 : 4;  // loads in flight per thread and tensor (four convolutions' partial sums leave room for two)
+#pragma unroll
+            for (int h = 0; h < NIT; h += NG) {
+                float4 vd[NG], vx[NG];
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int item = threadIdx.x + (h + i) * 256, px = min(item >> 4, R * CB - 1), pr = px / CB, pc = px - pr * CB;
+                    const int tq = min(max(t0 - 2 + pr, 0), T - 1), fq = min(max(fb - 2 + pc, 0), F - 1);
+                    const unsigned off = (((unsigned)tq * F + fq) * kH + q4) * 4u;
+                    vd[i] = ld4_off(dyb, off);
+                    if (GLN) vx[i] = ld4_off(xb, off);
+                }
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int item = threadIdx.x + (h + i) * 256, px = item >> 4, pr = px / CB, pc = px - pr * CB;
+                    const int tq = t0 - 2 + pr, fq = fb - 2 + pc;
+                    float4 d = vd[i];
+                    if (GLN)
+                        d = f4(A4.x * d.x - Bc[k] * vx[i].x + Cc[k], A4.y * d.y - Bc[k] * vx[i].y + Cc[k], A4.z * d.z - Bc[k] * vx[i].z + Cc[k],
+                               A4.w * d.w - Bc[k] * vx[i].w + Cc[k]);
+                    if (!(tq >= 0 && tq < T && fq >= 0 && fq < F)) d = f4(0, 0, 0, 0);
+                    if (px < R * CB) st4(tile + px * 64 + q4, d);
+                }
+            }
+            __syncthreads();
+            // ---- window pass: 8 columns in two groups of four; per tap row the 7 window columns and the 4 taps are read once.  The tap-row loop is a REAL loop
+            // (one basic block per row: unrolled, hipcc issues the window and tap reads of all four rows first and spills); the row's four products are summed
+            // in temporaries and added to the register-resident partial sums of that row under a uniform switch, so every register index stays static.
+#pragma unroll
+            for (int jb = 0; jb < TC; jb += 4) {
+#pragma unroll 1
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float* trow = tile + (r + dt) * RS + ch;
+                    float2v wr[7], prod[4];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) wr[c] = ld2v(trow + (jb + c) * 64);
+#pragma unroll
+                    for (int dc = 0; dc < 4; ++dc) {
+                        const float2v w = ld2v(&ws[k][((3 - dt) * 4 + (3 - dc)) * 64 + ch]);
+                        prod[dc] = inv[jb] * wr[dc];
+                        acc[jb] = w * wr[dc] + acc[jb];
+#pragma unroll
+                        for (int jj = 1; jj < 4; ++jj) {
+                            acc[jb + jj] = w * wr[jj + dc] + acc[jb + jj];
+                            prod[dc] = inv[jb + jj] * wr[jj + dc] + prod[dc];
+                        }
+                    }
+#define RTFS_ADD_ROW(ROW)                                                                          \
+    _Pragma("unroll") for (int dc = 0; dc < 4; ++dc) part[k][(ROW) * 4 + (3 - dc)] += prod[dc];
+                    switch (dt) {  // tap row 3 - dt
+                        case 0: RTFS_ADD_ROW(3) break;
+                        case 1: RTFS_ADD_ROW(2) break;
+                        case 2: {
+                            RTFS_ADD_ROW(1)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)  // dX at the thread's own pixels (zero where they lie outside the tensor; columns past f1 are the next segment's)
+                                if (fb + jb + jj < f1) pb[k] += wr[jj + 2];
+                            break;
+                        }
+                        default: RTFS_ADD_ROW(0) break;
+                    }
+#undef RTFS_ADD_ROW
+                }
+            }
+        }
+        if (tvalid) {
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if (fb + j < f1) {
+                    float* o = outrow + (size_t)(fb + j) * kH;
+                    float2v v = acc[j];
+                    if (a.accumulate) v += ld2v(o);
+                    *reinterpret_cast<float2v*>(o) = v;
+                }
+        }
+    }
+    // ---- tap / bias gradients: the two rows of a wave by one xor shuffle, the four waves through LDS, one coalesced atomic per (tap, channel) ----
+    float* mine = spread_copy(a.scr, blockIdx.x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* redl = tile;  // [4 waves][17][64]
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            float2v v = i < 16 ? part[k][i] : pb[k];
+            v.x += __shfl_xor(v.x, 32, 64);
+            v.y += __shfl_xor(v.y, 32, 64);
+            if (lane < 32) *reinterpret_cast<float2v*>(redl + (wave * 17 + i) * 64 + ch) = v;
+        }
+        __syncthreads();
+        const int per = 1024 + (a.bias ? 64 : 0);
+        for (int idx = threadIdx.x; idx < per; idx += 256)
+            atomicAdd(mine + k * per + idx, redl[idx] + redl[17 * 64 + idx] + redl[2 * 17 * 64 + idx] + redl[3 * 17 * 64 + idx]);
+    }
+}
+
+}  // namespace rtfs
+
+using namespace rtfs;
+
+extern "C" {
+
+int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
+                    const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
+                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream) {
+    if (B <= 0 || T <= 0 || F <= 0 || (nconv != 1 && nconv != 2 && nconv != 4) || mode < 0 || mode > 2 || !dy || !w || !dW || !in || !dIn) return RTFS_EINVAL;
+    if (mode >= 1 && (!in_stats || !in_gamma || !in_beta)) return RTFS_EINVAL;
+    if ((size_t)T * F * kH * 4 >= (1ull << 32)) return RTFS_EINVAL;  // 32-bit byte offsets inside an utterance
+    const bool gln = x != nullptr && x[0] != nullptr;
+    const bool bias = dbias != nullptr && dbias[0] != nullptr;
+    DwAdjArgs a{};
+    a.T = T, a.F = F, a.B = B;
+    a.nt = (T + 7) / 8;
+    // f segments: enough workgroups to fill 256 CUs twice over, segments a multiple of the 8-column step
+    a.nseg = 1;
+    while (a.nt * B * a.nseg < 1024 && F / (a.nseg + 1) >= 16) ++a.nseg;
+    a.fseg = (((F + a.nseg - 1) / a.nseg) + 7) / 8 * 8;
+    a.nseg = (F + a.fseg - 1) / a.fseg;
+    SpreadOut so{};
+    for (int k = 0; k < nconv; ++k) {
+        if (!dy[k] || !w[k] || !dW[k]) return RTFS_EINVAL;
+        if (gln && (!x[k] || !x_stats || !x_stats[k] || !red || !red[k] || !gamma || !gamma[k])) return RTFS_EINVAL;
+        if (bias && !dbias[k]) return RTFS_EINVAL;
+        a.dy[k] = dy[k], a.w[k] = w[k];
+        if (gln) a.x[k] = x[k], a.slot[k] = x_stats[k], a.red[k] = red[k], a.gamma[k] = gamma[k];
+        if (bias) {
+            so.dst[2 * k] = dW[k], so.n[2 * k] = 1024, so.dst[2 * k + 1] = dbias[k], so.n[2 * k + 1] = 64;
+        } else {
+            so.dst[k] = dW[k], so.n[k] = 1024;
+        }
+    }
+    a.in = in, a.in_slot = in_stats, a.in_gamma = in_gamma, a.in_beta = in_beta, a.in_slope = in_slope;
+    a.mode = mode, a.accumulate = accumulate ? 1 : 0, a.bias = bias ? 1 : 0;
+    a.inv_n = 1.0 / ((double)T * F * kH);
+    a.dIn = dIn;
+    a.scr = spread_scratch();
+    if (!a.scr) return RTFS_ELAUNCH;
+    const int ntiles = a.nt * B * a.nseg;
+    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8));
+#define DWADJ(N, G) hipLaunchKernelGGL((dw_adjoint_kernel<N, G>), grid, dim3(256), 0, (hipStream_t)stream, a)
+    if (gln) {
+        if (nconv == 1) DWADJ(1, true); else if (nconv == 2) DWADJ(2, true); else DWADJ(4, true);
+    } else {
+        if (nconv == 1) DWADJ(1, false); else if (nconv == 2) DWADJ(2, false); else DWADJ(4, false);
+    }
+#undef DWADJ
+    RTFS_LAUNCH_CHECK();
+    return spread_finish(a.scr, so, (hipStream_t)stream);
+}
+
+}  // extern "C"

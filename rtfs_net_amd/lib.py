@@ -123,6 +123,7 @@ SIGNATURES = {
     "rtfs_adamw_clip_step": [P, P, P, P, P, P, I, P, D, D, D, D, D, D, D, D, P],
     "rtfs_caf_bn_prepare": [P] * 23 + [F, F, P, P, P, P, P],
     "rtfs_caf_bn_adjoint": [P] * 19 + [P],
+    "rtfs_dw_adjoint": [I, P, P, P, P, P, P, P, P, P, P, F, I, P, I, P, P, I, I, I, P],
     "rtfs_gln_stats": [P, P, I, LL, P],
     "rtfs_norm_act_fwd": [P, P, P, P, I, F, P, I, LL, I, P],
     "rtfs_gateway_fwd": [P, P, P, F, P, LL, P],

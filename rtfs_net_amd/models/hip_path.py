@@ -271,7 +271,8 @@ class HipForward:
                      "caf": not off("RTFS_NO_CAF_FUSION"), "gadd": not off("RTFS_NO_GADD_FUSION"),
                      "mixgln": not off("RTFS_NO_MIXGLN_FUSION"), "d0tail": not off("RTFS_NO_D0TAIL_FUSION"),
                      "wgside": not off("RTFS_NO_WGRAD_SIDE"), "wgather": not off("RTFS_NO_WEIGHT_GATHER"), "cafbn": not off("RTFS_NO_CAF_BN_FUSION"),
-                     "decmask": not off("RTFS_NO_DECMASK_FUSION"), "srubwd": not off("RTFS_NO_SRU_BWD_FUSION")}  # (mixgln, d0tail, wgside, srubwd: training step only, models/hip_train.py)
+                     "decmask": not off("RTFS_NO_DECMASK_FUSION"), "srubwd": not off("RTFS_NO_SRU_BWD_FUSION"),
+                     "dwadj": not off("RTFS_NO_DWADJ_FUSION")}  # (mixgln, d0tail, wgside, srubwd: training step only, models/hip_train.py)
         self.vp_ran_as_modules = False
         self.vp_glue = off("RTFS_VP_GLUE")  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
         self.vp_side_stream = not off("RTFS_VP_NO_SIDE")

@@ -619,15 +619,21 @@ class HipTrainer:
         self._call("rtfs_gln_bwd_reduce", dN, X, st, gamma, beta, act, slope, red, dg, db, dslope, B, rows, Cc)
         self._call("rtfs_gln_bwd_apply", dN, X, st, gamma, beta, act, slope, red, dX, 1 if accumulate else 0, B, rows, Cc)
 
-    def _mix_gln_bwd(self, dOut, loc, gate, glob, dLoc, dGate, dGlob, gr, B, T, F, Tg, Fg):
+    def _mix_gln_bwd(self, dOut, loc, gate, glob, dLoc, dGate, dGlob, gr, B, T, F, Tg, Fg, defer_apply=False):
         """adjoint of `n(loc) * sigmoid(n(gate))^ + n(glob)^` (fusion.py:59-67) together with the gLN adjoints of its three embeddings.
         loc / gate / glob: (pre-norm tensor, statistics slot, conv tuple (.., .., gamma, beta), gr key); dLoc / dGate / dGlob: gradients w.r.t.
-        the three convs' OUTPUTS; gamma / beta grads into gr[key]."""
+        the three convs' OUTPUTS; gamma / beta grads into gr[key].
+        defer_apply: the apply pass of the gate / global branches' gLN adjoints is left to the consumer (rtfs_dw_adjoint applies it on load): dGate / dGlob then
+        receive the gradients w.r.t. the NORMALISED outputs and the call returns the two (S1, S2) slots -> (red_gate, red_glob)."""
         dev = dOut.device
         dgb = [_acc(gr, br[3] + sfx, H, dev) for br in (loc, gate, glob) for sfx in (".g", ".b")]
         low_rows = Tg * Fg
         if self.model._hip.fuse["mixgln"]:
             red = gr["_pool"].take(3 * B * lib.STAT_STRIDE, torch.float64).view(3, B, lib.STAT_STRIDE)
+            if defer_apply:
+                self._call("rtfs_mix_gln_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
+                           glob[2][3], dLoc, dGate, dGlob, red, dgb, B, T, F, Tg, Fg)
+                return red[1], red[2]
             dNgate, dNglob = torch.empty_like(dGate), torch.empty_like(dGlob)
             self._call("rtfs_mix_gln_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
                        glob[2][3], dLoc, dNgate, dNglob, red, dgb, B, T, F, Tg, Fg)
@@ -648,6 +654,18 @@ class HipTrainer:
         self._wg("rtfs_dwconv_bwd_weight", dOut, inp, in_st, in_g, in_b, in_slope, mode, stride, dW, dbias, B, Tin, Fin)
         if dIn is not None:
             self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
+
+    def _dw_adjoint(self, convs, inp, in_st, in_g, in_b, in_slope, mode, dIn, accumulate, gr, B, T, F, bias=False):
+        """rtfs_dw_adjoint (csrc/bwd_dw.hip): the whole adjoint of the 1 / 2 / 4 stride-1 depth-wise convolutions `convs` that read `inp` in one launch.
+        convs: list of (dY, conv tuple (taps, bias, gamma, beta), gr key, None | (pre-norm output, statistics slot, (S1, S2) slot)) - with the last entry the
+        gLN adjoint is applied on load and dY is the gradient w.r.t. the normalised output."""
+        dev = dIn.device
+        gln = convs[0][3] is not None
+        dW = [_acc(gr, c[2] + ".w", 16 * 64, dev) for c in convs]
+        db = [_acc(gr, c[2] + ".bias", 64, dev) for c in convs] if bias else None
+        lib.call("rtfs_dw_adjoint", len(convs), [c[0] for c in convs], [c[3][0] for c in convs] if gln else None, [c[3][1] for c in convs] if gln else None,
+                 [c[3][2] for c in convs] if gln else None, [c[1][2] for c in convs] if gln else None, [c[1][0] for c in convs], inp, in_st, in_g, in_b,
+                 float(in_slope), mode, dIn, 1 if accumulate else 0, dW, db, B, T, F)
 
     def _sru_bwd_work(self, S, dev):
         """the workgroups' partial-dW scratch of rtfs_sru_layer_bwd: one buffer per device, reused by every layer of every step (main stream only)"""
@@ -755,26 +773,41 @@ class HipTrainer:
         dN_D0 = dE
         # concat layer: mix + gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
         dcl, dcg, dcgate = full(), low(), low()
-        self._mix_gln_bwd(dE, (k.cl, st[9], cl_, tag + "cl"), (k.cgate, st[11], cgate_, tag + "cgate"), (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr,
-                          B, T, F_BINS, T2, F2)
+        # round 6: the adjoint of every stride-1 depth-wise convolution group in ONE launch (rtfs_dw_adjoint: tap gradients + input gradient from one dX tile in LDS,
+        # the gLN adjoint's apply pass on load - dX never reaches HBM, convolutions that share an input share the launch); `fuse["dwadj"]` off = the round-5 launches
+        dwadj = self.model._hip.fuse["dwadj"] and self.model._hip.fuse["mixgln"]
+        reds = self._mix_gln_bwd(dE, (k.cl, st[9], cl_, tag + "cl"), (k.cgate, st[11], cgate_, tag + "cgate"), (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr,
+                                 B, T, F_BINS, T2, F2, defer_apply=dwadj)
         dF0, dF1 = full(), low()
-        self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, tag + "cl", B, T, F_BINS, False)
-        self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, tag + "cg", B, T2, F2, False)
-        self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, tag + "cgate", B, T2, F2, False)
+        if dwadj:
+            self._dw_adjoint([(dcl, cl_, tag + "cl", None)], k.F0, None, None, None, 0.0, 0, dF0, False, gr, B, T, F_BINS)
+            self._dw_adjoint([(dcg, cg_, tag + "cg", (k.cg, st[10], reds[1])), (dcgate, cgate_, tag + "cgate", (k.cgate, st[11], reds[0]))], k.F1, None, None, None, 0.0, 0,
+                             dF1, False, gr, B, T2, F2)
+        else:
+            self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, tag + "cl", B, T, F_BINS, False)
+            self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, tag + "cg", B, T2, F2, False)
+            self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, tag + "cgate", B, T2, F2, False)
         # fusion layers' mixes
         dl0, dl1 = full(), low()
         dgs = [low() for _ in range(4)]  # gradients w.r.t. the outputs of f0g, f0gate, f1g, f1gate
-        self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, tag + "f0l"), (k.gg0, st[6], f0gate, tag + "f0gate"), (k.g0, st[5], f0g, tag + "f0g"), dl0, dgs[1], dgs[0], gr,
-                          B, T, F_BINS, T2, F2)
-        self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, tag + "f1l"), (k.gg1, st[8], f1gate, tag + "f1gate"), (k.g1, st[7], f1g, tag + "f1g"), dl1, dgs[3], dgs[2], gr,
-                          B, T2, F2, T2, F2)
+        r0 = self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, tag + "f0l"), (k.gg0, st[6], f0gate, tag + "f0gate"), (k.g0, st[5], f0g, tag + "f0g"), dl0, dgs[1], dgs[0], gr,
+                               B, T, F_BINS, T2, F2, defer_apply=dwadj)
+        r1 = self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, tag + "f1l"), (k.gg1, st[8], f1gate, tag + "f1gate"), (k.g1, st[7], f1g, tag + "f1g"), dl1, dgs[3], dgs[2], gr,
+                               B, T2, F2, T2, F2, defer_apply=dwadj)
         # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
         dN_D1 = low()
         self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, tag + "f0l", B, T, F_BINS, False)
         self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, tag + "f1l", B, T2, F2, False)
         dG = low()  # gradient w.r.t. G3 (attention output)
-        for j, (conv, nm) in enumerate(((f0g, "f0g"), (f0gate, "f0gate"), (f1g, "f1g"), (f1gate, "f1gate"))):
-            self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, tag + nm, B, T2, F2, False)
+        if dwadj:
+            # (two launches of two: four convolutions' partial sums do not fit the register file next to the window pass, csrc/bwd_dw.hip)
+            self._dw_adjoint([(dgs[0], f0g, tag + "f0g", (k.g0, st[5], r0[1])), (dgs[1], f0gate, tag + "f0gate", (k.gg0, st[6], r0[0]))], k.G3, None, None, None, 0.0, 0,
+                             dG, False, gr, B, T2, F2)
+            self._dw_adjoint([(dgs[2], f1g, tag + "f1g", (k.g1, st[7], r1[1])), (dgs[3], f1gate, tag + "f1gate", (k.gg1, st[8], r1[0]))], k.G3, None, None, None, 0.0, 0,
+                             dG, True, gr, B, T2, F2)
+        else:
+            for j, (conv, nm) in enumerate(((f0g, "f0g"), (f0gate, "f0gate"), (f1g, "f1g"), (f1gate, "f1gate"))):
+                self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, tag + nm, B, T2, F2, False)
         # attention, dual paths (each updates dG in place to the gradient w.r.t. its input)
         self._attn_bwd(dG, bw["attn"], k, B, T2, gr, tag + "attn")
         self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, tag + "dp1")
@@ -788,13 +821,19 @@ class HipTrainer:
             self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, None, False, gr, tag + "d1", B, T, F_BINS, True)  # (tap / bias gradients only)
             red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
             self._call("rtfs_d0_tail_bwd", dD1, d1w, dG, dN_D0, k.D0, st[1], d0g, d0be, red, _acc(gr, tag + "d0.g", H, dev), _acc(gr, tag + "d0.b", H, dev), B, T, T2)
-            self._call("rtfs_gln_bwd_apply", dN_D0, k.D0, st[1], d0g, d0be, 0, 0.0, red, dD0, 0, B, TF, H)
+            if dwadj:  # D0's gLN apply pass, downsample_layers[0]'s tap / bias gradients and its input gradient in one launch
+                dD0 = None
+                dP = full()
+                self._dw_adjoint([(dN_D0, bw["d0"], tag + "d0", (k.D0, st[1], red))], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, dP, False, gr, B, T, F_BINS, bias=True)
+            else:
+                self._call("rtfs_gln_bwd_apply", dN_D0, k.D0, st[1], d0g, d0be, 0, 0.0, red, dD0, 0, B, TF, H)
         else:
             self._call("rtfs_pool_bwd", dG, dN_D0, B, T, T2)
             self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, dN_D0, True, gr, tag + "d1", B, T, F_BINS, True)
             self._gln_bwd(dN_D0, k.D0, st[1], d0g, d0be, dD0, False, gr, tag + "d0", B, TF)
-        dP = full()
-        self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, tag + "d0", B, T, F_BINS, True)
+        if dD0 is not None:
+            dP = full()
+            self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, tag + "d0", B, T, F_BINS, True)
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
         self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, tag + "p", B, TF, H, 1, bw["pslope"], g("pslope", 1))

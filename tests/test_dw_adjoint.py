@@ -1,0 +1,105 @@
+"""GPU: rtfs_dw_adjoint (csrc/bwd_dw.hip) - the whole adjoint of 1 / 2 / 4 stride-1 depth-wise 4x4 convolutions that share an input, one launch - against float64
+autograd of the forward it is the adjoint of (conv_layers.py:65-129 with groups = channels, 'same' padding of the even kernel; GroupNorm(1, C) behind each
+convolution when the gLN adjoint rides on the load), through the C-ABI, isolated from the rest of the step.  Every output: gradient w.r.t. the transformed
+input (plain and accumulated), tap gradients, bias gradients.  Ragged shapes: rows / columns that are no multiple of the 8 x 8 tile, several f segments."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+H = 64
+
+
+def _cl(x):  # [B, 64, T, F] -> channels-last flat
+    return x.permute(0, 2, 3, 1).contiguous().float()
+
+
+def _case(nconv, gln, mode, accumulate, bias, B, T, Fq, seed):
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    x_in = rnd(B, H, T, Fq)
+    in_g, in_b, slope = 1 + 0.3 * rnd(H), 0.2 * rnd(H), 0.25
+    taps = [0.3 * rnd(16, H) for _ in range(nconv)]
+    biases = [0.1 * rnd(H) for _ in range(nconv)] if bias else [None] * nconv
+    gam, bet = [1 + 0.3 * rnd(H) for _ in range(nconv)], [0.1 * rnd(H) for _ in range(nconv)]
+    dys = [rnd(B, H, T, Fq) for _ in range(nconv)]
+    # float64 reference
+    xin = x_in
+    if mode >= 1:
+        xin = F.group_norm(x_in, 1, in_g, in_b, 1e-5)
+    if mode == 2:
+        xin = F.prelu(xin, torch.tensor([slope], dtype=torch.float64))
+    xin = xin.detach().requires_grad_(True)
+    ws = [t.t().reshape(H, 1, 4, 4).clone().requires_grad_(True) for t in taps]
+    bs = [b.clone().requires_grad_(True) if b is not None else None for b in biases]
+    ys, loss = [], 0
+    for k in range(nconv):
+        y = F.conv2d(F.pad(xin, (1, 2, 1, 2)), ws[k], bs[k], groups=H)
+        ys.append(y.detach())
+        n = F.group_norm(y, 1, gam[k], bet[k], 1e-5) if gln else y
+        loss = loss + (n * dys[k]).sum()
+    loss.backward()
+    # HIP
+    dev = "cuda"
+    N = T * Fq * H
+    slot = lambda t: torch.stack([t.reshape(B, -1).sum(1), (t.reshape(B, -1) ** 2).sum(1)] + [torch.zeros(B, dtype=torch.float64)] * (lib.STAT_STRIDE - 2), 1).contiguous().to(dev)  # noqa: E731
+    x_cl = [_cl(y).to(dev) for y in ys] if gln else None
+    x_st = [slot(y.float().double()) for y in ys] if gln else None
+    red = None
+    if gln:
+        red = []
+        for k in range(nconv):
+            y32 = ys[k].float().double()
+            mean = y32.reshape(B, -1).mean(1).view(B, 1, 1, 1)
+            var = (y32.reshape(B, -1) ** 2).mean(1).view(B, 1, 1, 1) - mean ** 2
+            xh = (y32 - mean) / torch.sqrt(var + 1e-5)
+            a = dys[k] * gam[k].view(1, H, 1, 1)
+            r = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64)
+            r[:, 0], r[:, 1] = a.reshape(B, -1).sum(1), (a * xh).reshape(B, -1).sum(1)
+            red.append(r.to(dev))
+    dIn0 = torch.randn(B * N, generator=torch.Generator().manual_seed(seed + 1)).to(dev) if accumulate else torch.full((B * N,), float("nan"), device=dev)
+    dIn = dIn0.clone()
+    dW = [torch.zeros(16 * H, device=dev) for _ in range(nconv)]
+    db = [torch.zeros(H, device=dev) for _ in range(nconv)] if bias else None
+    f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+    lib.call("rtfs_dw_adjoint", nconv, [_cl(d).to(dev) for d in dys], x_cl, x_st, red, [f32(t) for t in gam] if gln else None, [f32(t) for t in taps],
+             _cl(x_in).to(dev), slot(x_in.float().double()) if mode >= 1 else None, f32(in_g) if mode >= 1 else None, f32(in_b) if mode >= 1 else None,
+             slope, mode, dIn, 1 if accumulate else 0, dW, db, B, T, Fq)
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())  # noqa: E731
+    ref_dIn = _cl(xin.grad).double().reshape(-1) + (dIn0.double().cpu() if accumulate else 0)
+    errs = {"dIn": rel(dIn, ref_dIn)}
+    for k in range(nconv):
+        errs[f"dW{k}"] = rel(dW[k], ws[k].grad.reshape(H, 16).t().reshape(-1))
+        if bias:
+            errs[f"db{k}"] = rel(db[k], bs[k].grad)
+    return errs
+
+
+@pytest.mark.parametrize("nconv,gln,mode,accumulate,bias", [
+    (4, True, 0, False, False),   # the four global convolutions of the TFAR fusion layers (input G3)
+    (2, True, 0, False, False),   # concat layer: global embedding + gate (input F1)
+    (1, False, 1, False, False),  # fusion_layers[1].local_embedding (input gLN(D1))
+    (1, False, 0, False, False),  # concat layer's local embedding (input F0)
+    (1, False, 1, True, False),   # fusion_layers[0].local_embedding, accumulated into d(gLN(D0))
+    (1, True, 2, False, True),    # downsample_layers[0]: gLN adjoint on load, input PReLU(gLN(y0)), bias
+    (2, False, 2, True, True), (4, False, 1, True, False), (1, True, 0, True, False),
+])
+@pytest.mark.parametrize("B,T,Fq", [(2, 21, 19), (3, 8, 64), (1, 125, 64), (2, 33, 129), (1, 9, 8)])
+def test_dw_adjoint_matches_float64_autograd(nconv, gln, mode, accumulate, bias, B, T, Fq):
+    errs = _case(nconv, gln, mode, accumulate, bias, B, T, Fq, seed=7 * nconv + T)
+    worst = max(errs.values())
+    assert worst < 2e-5, errs  # fp32 sums over up to 8000 pixels x B against float64 (observed ~1e-6)
+
+
+def test_dw_adjoint_refuses_unsupported_arguments():
+    from rtfs_net_amd import lib
+
+    t = torch.zeros(64 * 64 * 8, device="cuda")
+    w = torch.zeros(1024, device="cuda")
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_dw_adjoint", 3, [t, t, t], None, None, None, None, [w, w, w], t, None, None, None, 0.0, 0, t.clone(), 0, [w.clone()] * 3, None, 1, 8, 64)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_dw_adjoint", 1, [t], None, None, None, None, [w], t, None, None, None, 0.0, 1, t.clone(), 0, [w.clone()], None, 1, 8, 64)  # mode 1 without statistics
