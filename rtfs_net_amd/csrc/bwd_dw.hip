@@ -45,7 +45,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v ld2v(const float* p) { return *reinterpret_cast<const float2v*>(p); }
 
 template <int NCONV, bool GLN>
-__global__ __launch_bounds__(256, 2) void dw_adjoint_kernel(DwAdjArgs a) {
+__global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(DwAdjArgs a) {
     constexpr int TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64;  // tile rows t0-2 .. t0+8, columns fb-2 .. fb+8
     constexpr int NIT = (R * CB * 16 + 255) / 256;                          // staging items (pixel, quad) per thread
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
@@ -119,12 +119,15 @@ __global__ __launch_bounds__(256, 2) void dw_adjoint_kernel(DwAdjArgs a) {
             float4 A4 = f4(1, 1, 1, 1);
             if (GLN) A4 = ld4(&coefA[k][q4]);
             constexpr int NG = NCONV >= 4 ? 2 : 4;  // loads in flight per thread and tensor (four convolutions' partial sums leave room for two)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));  // opaque per stage: the items' tile coordinates are recomputed here (a dozen integer instructions each) instead of
+                                           // living in ~30 registers across the window passes
 #pragma unroll
             for (int h = 0; h < NIT; h += NG) {
                 float4 vd[NG], vx[NG];
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
-                    const int item = threadIdx.x + (h + i) * 256, px = min(item >> 4, R * CB - 1), pr = px / CB, pc = px - pr * CB;
+                    const int item = tid + (h + i) * 256, px = min(item >> 4, R * CB - 1), pr = px / CB, pc = px - pr * CB;
                     const int tq = min(max(t0 - 2 + pr, 0), T - 1), fq = min(max(fb - 2 + pc, 0), F - 1);
                     const unsigned off = (((unsigned)tq * F + fq) * kH + q4) * 4u;
                     vd[i] = ld4_off(dyb, off);
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void dw_adjoint_kernel(DwAdjArgs a) {
                 }
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
-                    const int item = threadIdx.x + (h + i) * 256, px = item >> 4, pr = px / CB, pc = px - pr * CB;
+                    const int item = tid + (h + i) * 256, px = item >> 4, pr = px / CB, pc = px - pr * CB;
                     const int tq = t0 - 2 + pr, fq = fb - 2 + pc;
                     float4 d = vd[i];
                     if (GLN)
@@ -143,43 +146,36 @@ __global__ __launch_bounds__(256, 2) void dw_adjoint_kernel(DwAdjArgs a) {
                 }
             }
             __syncthreads();
-            // ---- window pass: 8 columns in two groups of four; per tap row the 7 window columns and the 4 taps are read once.  The tap-row loop is a REAL loop
-            // (one basic block per row: unrolled, hipcc issues the window and tap reads of all four rows first and spills); the row's four products are summed
-            // in temporaries and added to the register-resident partial sums of that row under a uniform switch, so every register index stays static.
+            // ---- window pass: 8 columns in two groups of four; per tap row the 7 window columns and the 4 taps are read once.  Every tap row sits in its OWN basic
+            // block (a branch on a scalar the compiler cannot see through, always taken): as one block, hipcc schedules the 88 window / tap reads of a convolution
+            // first and the arithmetic behind them, and spills; a rolled loop would make the partial sums' register indices dynamic.
+            const float* trow0 = tile + r * RS + ch;
+            int always = 1;
+            asm volatile("" : "+s"(always));
 #pragma unroll
             for (int jb = 0; jb < TC; jb += 4) {
-#pragma unroll 1
-                for (int dt = 0; dt < 4; ++dt) {
-                    const float* trow = tile + (r + dt) * RS + ch;
-                    float2v wr[7], prod[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) if (always) {
+                    const float* trow = trow0 + dt * RS;
+                    float2v wr[7];
 #pragma unroll
                     for (int c = 0; c < 7; ++c) wr[c] = ld2v(trow + (jb + c) * 64);
+                    if (dt == 2) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)  // dX at the thread's own pixels (zero where they lie outside the tensor; columns past f1 are the next segment's)
+                            if (fb + jb + jj < f1) pb[k] += wr[jj + 2];
+                    }
 #pragma unroll
                     for (int dc = 0; dc < 4; ++dc) {
-                        const float2v w = ld2v(&ws[k][((3 - dt) * 4 + (3 - dc)) * 64 + ch]);
-                        prod[dc] = inv[jb] * wr[dc];
-                        acc[jb] = w * wr[dc] + acc[jb];
+                        const int tap = (3 - dt) * 4 + (3 - dc);
+                        const float2v w = ld2v(&ws[k][tap * 64 + ch]);
 #pragma unroll
-                        for (int jj = 1; jj < 4; ++jj) {
+                        for (int jj = 0; jj < 4; ++jj) {
                             acc[jb + jj] = w * wr[jj + dc] + acc[jb + jj];
-                            prod[dc] = inv[jb + jj] * wr[jj + dc] + prod[dc];
+                            part[k][tap] = inv[jb + jj] * wr[jj + dc] + part[k][tap];
                         }
                     }
-#define RTFS_ADD_ROW(ROW)                                                                          \
-    _Pragma("unroll") for (int dc = 0; dc < 4; ++dc) part[k][(ROW) * 4 + (3 - dc)] += prod[dc];
-                    switch (dt) {  // tap row 3 - dt
-                        case 0: RTFS_ADD_ROW(3) break;
-                        case 1: RTFS_ADD_ROW(2) break;
-                        case 2: {
-                            RTFS_ADD_ROW(1)
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj)  // dX at the thread's own pixels (zero where they lie outside the tensor; columns past f1 are the next segment's)
-                                if (fb + jb + jj < f1) pb[k] += wr[jj + 2];
-                            break;
-                        }
-                        default: RTFS_ADD_ROW(0) break;
-                    }
-#undef RTFS_ADD_ROW
+                    asm volatile("" : "+s"(always));
                 }
             }
         }

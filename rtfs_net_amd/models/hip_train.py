@@ -796,16 +796,16 @@ class HipTrainer:
                                B, T2, F2, T2, F2, defer_apply=dwadj)
         # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
         dN_D1 = low()
-        self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, tag + "f0l", B, T, F_BINS, False)
-        self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, tag + "f1l", B, T2, F2, False)
         dG = low()  # gradient w.r.t. G3 (attention output)
         if dwadj:
-            # (two launches of two: four convolutions' partial sums do not fit the register file next to the window pass, csrc/bwd_dw.hip)
-            self._dw_adjoint([(dgs[0], f0g, tag + "f0g", (k.g0, st[5], r0[1])), (dgs[1], f0gate, tag + "f0gate", (k.gg0, st[6], r0[0]))], k.G3, None, None, None, 0.0, 0,
+            self._dw_adjoint([(dl0, f0l, tag + "f0l", None)], k.D0, st[1], d0g, d0be, 0.0, 1, dN_D0, True, gr, B, T, F_BINS)
+            self._dw_adjoint([(dl1, f1l, tag + "f1l", None)], k.D1, st[2], d1g, d1be, 0.0, 1, dN_D1, False, gr, B, T2, F2)
+            self._dw_adjoint([(dgs[0], f0g, tag + "f0g", (k.g0, st[5], r0[1])), (dgs[1], f0gate, tag + "f0gate", (k.gg0, st[6], r0[0])),
+                              (dgs[2], f1g, tag + "f1g", (k.g1, st[7], r1[1])), (dgs[3], f1gate, tag + "f1gate", (k.gg1, st[8], r1[0]))], k.G3, None, None, None, 0.0, 0,
                              dG, False, gr, B, T2, F2)
-            self._dw_adjoint([(dgs[2], f1g, tag + "f1g", (k.g1, st[7], r1[1])), (dgs[3], f1gate, tag + "f1gate", (k.gg1, st[8], r1[0]))], k.G3, None, None, None, 0.0, 0,
-                             dG, True, gr, B, T2, F2)
         else:
+            self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, tag + "f0l", B, T, F_BINS, False)
+            self._dw_bwd(dl1, f1l, k.D1, st[2], d1g, d1be, 0.0, 1, 1, dN_D1, False, gr, tag + "f1l", B, T2, F2, False)
             for j, (conv, nm) in enumerate(((f0g, "f0g"), (f0gate, "f0gate"), (f1g, "f1g"), (f1gate, "f1gate"))):
                 self._dw_bwd(dgs[j], conv, k.G3, None, None, None, 0.0, 0, 1, dG, j > 0, gr, tag + nm, B, T2, F2, False)
         # attention, dual paths (each updates dG in place to the gradient w.r.t. its input)
