@@ -486,6 +486,19 @@ int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, co
                     const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
                     float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream);
 
+/* the same for ONE convolution that is the local branch of an InjectionMultiSum (layers/fusion.py:54-69: out = gLN(loc) * sigmoid(gLN(gate))^ + gLN(glob)^): dOut is
+ * the gradient w.r.t. the mix's output; the local branch's mix + gLN adjoint  dX = rstd (gamma dOut s^ - S1/N - xhat S2/N)  is applied on load from loc (pre-norm
+ * output of the convolution), its statistics, loc_red = (S1, S2) and gate_sig = s = sigmoid(gLN(gate)) [B][Tg][Fg][64], both written by rtfs_mix_gln_bwd_sig. */
+int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_stats, const double* loc_red, const float* loc_gamma, const float* gate_sig,
+                        int Tg, int Fg, const float* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta, float in_slope,
+                        int mode, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream);
+/* rtfs_mix_gln_bwd with one more output: sig (or NULL) receives sigmoid(gLN(gate)), which the reduce pass forms anyway; dLoc may then be NULL - the apply pass of the
+ * local branch is left to rtfs_dw_adjoint_mix (dLoc never reaches HBM). */
+int rtfs_mix_gln_bwd_sig(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                         const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats, const float* glob_g,
+                         const float* glob_b, float* dLoc, float* dNgate, float* dNglob, float* sig, double* red, float* const* dgb, int B, int T, int F, int Tg,
+                         int Fg, void* stream);
+
 /* ---- module-boundary views (csrc/views.hip): the reference's stage modules called one at a time, forward hooks ------------------------------
  * The reference runs `self.encoder(x)`, `self.audio_bottleneck(...)`, `self.refinement_module(a, v)`, `self.mask_generator(...)`,
  * `self.decoder(...)` as ordinary modules (src/models/tdavnet.py:86-97; base_av_model.py:61-118 calls them one by one) and lets hooks see every

@@ -39,18 +39,32 @@ struct DwAdjArgs {
     double inv_n;                 // 1 / (T F 64): every tensor here has the convolution's size
     float* dIn;
     float* scr;                   // spread scratch: per convolution [dW 1024 | dbias 64 when bias]
+    // MIX (one convolution, GLN): the convolution is the LOCAL branch of an InjectionMultiSum (fusion.py:54-69: out = gLN(loc) * sigmoid(gLN(gate))^ + gLN(glob)^),
+    // dy[0] is the gradient w.r.t. the mix's OUTPUT and the gradient w.r.t. the normalised local branch, dy * sigmoid(gLN(gate))[nearest(t), nearest(f)], is formed
+    // on load (what rtfs_mix_gln_bwd's apply pass wrote to HBM as dLoc until round 6); the sigmoid itself comes from the reduce pass of rtfs_mix_gln_bwd
+    const float* gate_s;          // [B][Tg][Fg][64]: sigmoid(gLN(gate)), written by rtfs_mix_gln_bwd's reduce pass (which forms it anyway)
+    int Tg, Fg;
+    unsigned mt, mf;              // ceil(2^32 / T), ceil(2^32 / F): nearest source index floor(i * in / out) without a division
 };
+
+// floor(x / d) for x * m < 2^64 with m = ceil(2^32 / d): the estimate is never low and at most one high
+__device__ __forceinline__ int div_magic(unsigned x, unsigned d, unsigned m) {
+    unsigned q = __umulhi(x, m);
+    return (int)(q * d > x ? q - 1 : q);
+}
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v ld2v(const float* p) { return *reinterpret_cast<const float2v*>(p); }
 
-template <int NCONV, bool GLN>
+template <int NCONV, bool GLN, bool MIX = false>
 __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(DwAdjArgs a) {
+    static_assert(!MIX || (NCONV == 1 && GLN), "the mix prologue belongs to one gLN'd convolution");
     constexpr int TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64;  // tile rows t0-2 .. t0+8, columns fb-2 .. fb+8
     constexpr int NIT = (R * CB * 16 + 255) / 256;                          // staging items (pixel, quad) per thread
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
     __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
     __shared__ __attribute__((aligned(16))) float coefA[GLN ? NCONV : 1][64];
+    __shared__ int nearest[MIX ? 2 : 1][R > CB ? R : CB];  // nearest source row / column (in units of 64-float pixels) of the tile's rows / columns
     // ---- tile of this workgroup: consecutive time tiles of an utterance on one XCD (workgroups go to XCDs round-robin by linear index) ----
     const int ntiles = a.nt * a.B * a.nseg, per_xcd = (ntiles + 7) / 8;
     const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -71,6 +85,7 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
             if (threadIdx.x < 64) coefA[k][threadIdx.x] = a.gamma[k][threadIdx.x] * rstd;
         }
     }
+    if (MIX && threadIdx.x < R) nearest[0][threadIdx.x] = div_magic((unsigned)min(max(t0 - 2 + (int)threadIdx.x, 0), T - 1) * a.Tg, T, a.mt) * a.Fg;
     // ---- window-pass identity: (row, channel pair) ----
     const int r = threadIdx.x >> 5, ch = (threadIdx.x & 31) * 2;
     const int ti = t0 + r;
@@ -116,15 +131,21 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
             // ---- stage dX_k: rows t0-2 .. t0+8, columns fb-2 .. fb+8; the gLN adjoint on the way in; zero outside the tensor ----
             const float* dyb = a.dy[k] + ubase;
             const float* xb = GLN ? a.x[k] + ubase : nullptr;
+            const float* gb = MIX ? a.gate_s + (size_t)b * a.Tg * a.Fg * kH : nullptr;
+            if (MIX) {  // (the previous block's staging reads of the column table are behind the barrier above)
+                if (threadIdx.x < CB) nearest[1][threadIdx.x] = div_magic((unsigned)min(max(fb - 2 + (int)threadIdx.x, 0), F - 1) * a.Fg, F, a.mf);
+                __syncthreads();
+            }
             float4 A4 = f4(1, 1, 1, 1);
             if (GLN) A4 = ld4(&coefA[k][q4]);
-            constexpr int NG = NCONV >= 4 ? 2 : 4;  // loads in flight per thread and tensor (four convolutions' partial sums leave room for two)
+            constexpr int NG = (NCONV >= 4 || MIX) ? 2 : 4;  // loads in flight per thread and tensor (four convolutions' partial sums leave room for two; the mix
+                                                            // form reads three tensors and stays at 128 registers = four workgroups per CU with two)
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));  // opaque per stage: the items' tile coordinates are recomputed here (a dozen integer instructions each) instead of
                                            // living in ~30 registers across the window passes
 #pragma unroll
             for (int h = 0; h < NIT; h += NG) {
-                float4 vd[NG], vx[NG];
+                float4 vd[NG], vx[NG], vg[MIX ? NG : 1];
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
                     const int item = tid + (h + i) * 256, px = min(item >> 4, R * CB - 1), pr = px / CB, pc = px - pr * CB;
@@ -132,12 +153,14 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
                     const unsigned off = (((unsigned)tq * F + fq) * kH + q4) * 4u;
                     vd[i] = ld4_off(dyb, off);
                     if (GLN) vx[i] = ld4_off(xb, off);
+                    if (MIX) vg[i] = ld4_off(gb, ((unsigned)(nearest[0][pr] + nearest[1][pc]) * kH + q4) * 4u);
                 }
 #pragma unroll
                 for (int i = 0; i < NG; ++i) {
                     const int item = tid + (h + i) * 256, px = item >> 4, pr = px / CB, pc = px - pr * CB;
                     const int tq = t0 - 2 + pr, fq = fb - 2 + pc;
                     float4 d = vd[i];
+                    if (MIX) d = d * vg[i];
                     if (GLN)
                         d = f4(A4.x * d.x - Bc[k] * vx[i].x + Cc[k], A4.y * d.y - Bc[k] * vx[i].y + Cc[k], A4.z * d.z - Bc[k] * vx[i].z + Cc[k],
                                A4.w * d.w - Bc[k] * vx[i].w + Cc[k]);
@@ -215,11 +238,10 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
 
 using namespace rtfs;
 
-extern "C" {
-
-int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
-                    const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
-                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream) {
+static int dw_adjoint_launch(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
+                             const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma,
+                             const float* in_beta, float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T,
+                             int F, const float* gate_s, int Tg, int Fg, void* stream) {
     if (B <= 0 || T <= 0 || F <= 0 || (nconv != 1 && nconv != 2 && nconv != 4) || mode < 0 || mode > 2 || !dy || !w || !dW || !in || !dIn) return RTFS_EINVAL;
     if (mode >= 1 && (!in_stats || !in_gamma || !in_beta)) return RTFS_EINVAL;
     if ((size_t)T * F * kH * 4 >= (1ull << 32)) return RTFS_EINVAL;  // 32-bit byte offsets inside an utterance
@@ -250,12 +272,20 @@ int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, co
     a.mode = mode, a.accumulate = accumulate ? 1 : 0, a.bias = bias ? 1 : 0;
     a.inv_n = 1.0 / ((double)T * F * kH);
     a.dIn = dIn;
+    const bool mix = gate_s != nullptr;
+    if (mix) {
+        if (nconv != 1 || !gln || Tg <= 0 || Fg <= 0 || Tg > T || Fg > F) return RTFS_EINVAL;
+        a.gate_s = gate_s, a.Tg = Tg, a.Fg = Fg;
+        a.mt = (unsigned)(((1ull << 32) + T - 1) / T), a.mf = (unsigned)(((1ull << 32) + F - 1) / F);
+    }
     a.scr = spread_scratch();
     if (!a.scr) return RTFS_ELAUNCH;
     const int ntiles = a.nt * B * a.nseg;
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8));
 #define DWADJ(N, G) hipLaunchKernelGGL((dw_adjoint_kernel<N, G>), grid, dim3(256), 0, (hipStream_t)stream, a)
-    if (gln) {
+    if (mix) {
+        hipLaunchKernelGGL((dw_adjoint_kernel<1, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (gln) {
         if (nconv == 1) DWADJ(1, true); else if (nconv == 2) DWADJ(2, true); else DWADJ(4, true);
     } else {
         if (nconv == 1) DWADJ(1, false); else if (nconv == 2) DWADJ(2, false); else DWADJ(4, false);
@@ -263,6 +293,30 @@ int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, co
 #undef DWADJ
     RTFS_LAUNCH_CHECK();
     return spread_finish(a.scr, so, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
+                    const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
+                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream) {
+    return dw_adjoint_launch(nconv, dy, x, x_stats, red, gamma, w, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dW, dbias, B, T, F, nullptr,
+                             0, 0, stream);
+}
+
+int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_stats, const double* loc_red, const float* loc_gamma, const float* gate_sig,
+                        int Tg, int Fg, const float* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta, float in_slope,
+                        int mode, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream) {
+    if (!dOut || !loc || !loc_stats || !loc_red || !loc_gamma || !gate_sig || !w || !dW) return RTFS_EINVAL;
+    const float* dy[1] = {dOut};
+    const float* x[1] = {loc};
+    const double* xs[1] = {loc_stats};
+    const double* red[1] = {loc_red};
+    const float* gm[1] = {loc_gamma};
+    const float* ww[1] = {w};
+    float* dw[1] = {dW};
+    return dw_adjoint_launch(1, dy, x, xs, red, gm, ww, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dw, nullptr, B, T, F, gate_sig, Tg, Fg,
+                             stream);
 }
 
 }  // extern "C"

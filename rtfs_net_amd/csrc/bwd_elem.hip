@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restri
 // Epilogue: the 4 position rows of a wave are summed with two xor shuffles, the 4 waves through LDS; 6 x 64 per-channel sums leave as one
 // coalesced atomic each, the 6 per-utterance sums as fp64 atomics.   red: [3][B][kStatStride] (loc, gate, glob)
 __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, NormArg glob,
-                                                                 float* __restrict__ dNgate, float* __restrict__ dNglob, double* __restrict__ red,
+                                                                 float* __restrict__ dNgate, float* __restrict__ dNglob, float* __restrict__ sig, double* __restrict__ red,
                                                                  float* __restrict__ scr, int T, int F, int Tg, int Fg, int B, int qpt) {
     __shared__ __attribute__((aligned(16))) float lds[4][6][64];
     __shared__ float redl[4][6];
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __
         const float4 dNg = f4(A.x * s.x * (1.f - s.x), A.y * s.y * (1.f - s.y), A.z * s.z * (1.f - s.z), A.w * s.w * (1.f - s.w));
         st4(dNgate + o, dNg);
         st4(dNglob + o, Bs);
+        if (sig) st4(sig + o, s);  // (for a consumer that applies the local branch's adjoint on load: rtfs_dw_adjoint_mix)
         const float4 c0 = s * Dx, c1 = s * Bs, c2 = dNg * xg, c4v = Bs * xe;
         ch[0] = ch[0] + c0, ch[1] = ch[1] + c1;
         ch[2] = ch[2] + c2, ch[3] = ch[3] + dNg;
@@ -800,16 +801,24 @@ int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stat
                      const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats, const float* glob_g,
                      const float* glob_b, float* dLoc, float* dNgate, float* dNglob, double* red, float* const* dgb, int B, int T, int F, int Tg, int Fg,
                      void* stream) {
-    if (B <= 0 || !dgb) return RTFS_EINVAL;
+    return rtfs_mix_gln_bwd_sig(dOut, loc, loc_stats, loc_g, loc_b, gate, gate_stats, gate_g, gate_b, glob, glob_stats, glob_g, glob_b, dLoc, dNgate, dNglob, nullptr, red,
+                                dgb, B, T, F, Tg, Fg, stream);
+}
+
+int rtfs_mix_gln_bwd_sig(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,
+                         const double* gate_stats, const float* gate_g, const float* gate_b, const float* glob, const double* glob_stats, const float* glob_g,
+                         const float* glob_b, float* dLoc, float* dNgate, float* dNglob, float* sig, double* red, float* const* dgb, int B, int T, int F, int Tg,
+                         int Fg, void* stream) {
+    if (B <= 0 || !dgb || (!dLoc && !sig)) return RTFS_EINVAL;
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
     NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b},
         e{glob, glob_stats, 1.0 / ((double)Tg * Fg * kH), glob_g, glob_b};
     const int qpt = 8;  // 128 low-resolution positions per workgroup (measured 1 ... 16: the epilogue's 384 atomics stop showing from 4 up)
-    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 16 * qpt - 1) / (16 * qpt), B), dOut, l, g, e, dNgate, dNglob, red, scr, T, F, Tg, Fg, B, qpt);
+    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 16 * qpt - 1) / (16 * qpt), B), dOut, l, g, e, dNgate, dNglob, sig, red, scr, T, F, Tg, Fg, B, qpt);
     const int rc = spread_finish(scr, SpreadOut{{dgb[0], dgb[1], dgb[2], dgb[3], dgb[4], dgb[5]}, {kH, kH, kH, kH, kH, kH}}, (hipStream_t)stream);
     if (rc != RTFS_OK) return rc;
-    LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);
+    if (dLoc) LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);  // (NULL: the consumer applies it on load, rtfs_dw_adjoint_mix, from `sig`)
     return RTFS_OK;
 }
 

@@ -623,17 +623,19 @@ class HipTrainer:
         """adjoint of `n(loc) * sigmoid(n(gate))^ + n(glob)^` (fusion.py:59-67) together with the gLN adjoints of its three embeddings.
         loc / gate / glob: (pre-norm tensor, statistics slot, conv tuple (.., .., gamma, beta), gr key); dLoc / dGate / dGlob: gradients w.r.t.
         the three convs' OUTPUTS; gamma / beta grads into gr[key].
-        defer_apply: the apply pass of the gate / global branches' gLN adjoints is left to the consumer (rtfs_dw_adjoint applies it on load): dGate / dGlob then
-        receive the gradients w.r.t. the NORMALISED outputs and the call returns the two (S1, S2) slots -> (red_gate, red_glob)."""
+        defer_apply: the apply passes of all three branches' gLN adjoints are left to the consumers (rtfs_dw_adjoint / rtfs_dw_adjoint_mix apply them on load):
+        dLoc is not written at all (the local branch's consumer re-forms dOut * sigmoid(n(gate))^ itself), dGate / dGlob receive the gradients w.r.t. the NORMALISED
+        outputs, and the call returns the three (S1, S2) slots -> (red_loc, red_gate, red_glob)."""
         dev = dOut.device
         dgb = [_acc(gr, br[3] + sfx, H, dev) for br in (loc, gate, glob) for sfx in (".g", ".b")]
         low_rows = Tg * Fg
         if self.model._hip.fuse["mixgln"]:
             red = gr["_pool"].take(3 * B * lib.STAT_STRIDE, torch.float64).view(3, B, lib.STAT_STRIDE)
             if defer_apply:
-                self._call("rtfs_mix_gln_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
-                           glob[2][3], dLoc, dGate, dGlob, red, dgb, B, T, F, Tg, Fg)
-                return red[1], red[2]
+                sig = torch.empty_like(dGate)  # sigmoid(gLN(gate)): the reduce pass forms it, rtfs_dw_adjoint_mix multiplies the mix's gradient by it on load
+                self._call("rtfs_mix_gln_bwd_sig", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
+                           glob[2][3], None, dGate, dGlob, sig, red, dgb, B, T, F, Tg, Fg)
+                return (red[0], sig), red[1], red[2]
             dNgate, dNglob = torch.empty_like(dGate), torch.empty_like(dGlob)
             self._call("rtfs_mix_gln_bwd", dOut, loc[0], loc[1], loc[2][2], loc[2][3], gate[0], gate[1], gate[2][2], gate[2][3], glob[0], glob[1], glob[2][2],
                        glob[2][3], dLoc, dNgate, dNglob, red, dgb, B, T, F, Tg, Fg)
@@ -666,6 +668,12 @@ class HipTrainer:
         lib.call("rtfs_dw_adjoint", len(convs), [c[0] for c in convs], [c[3][0] for c in convs] if gln else None, [c[3][1] for c in convs] if gln else None,
                  [c[3][2] for c in convs] if gln else None, [c[1][2] for c in convs] if gln else None, [c[1][0] for c in convs], inp, in_st, in_g, in_b,
                  float(in_slope), mode, dIn, 1 if accumulate else 0, dW, db, B, T, F)
+
+    def _dw_adjoint_mix(self, dOut, loc, gate, red_loc, Tg, Fg, inp, in_st, in_g, in_b, mode, dIn, accumulate, gr, B, T, F):
+        """rtfs_dw_adjoint_mix: the adjoint of an InjectionMultiSum's LOCAL embedding convolution straight from the gradient of the mix's output (the local branch's
+        mix + gLN adjoint on load).  loc / gate: (pre-norm tensor, statistics slot, conv tuple, gr key) as in _mix_gln_bwd."""
+        lib.call("rtfs_dw_adjoint_mix", dOut, loc[0], loc[1], red_loc[0], loc[2][2], red_loc[1], Tg, Fg, loc[2][0], inp, in_st, in_g, in_b,
+                 0.0, mode, dIn, 1 if accumulate else 0, _acc(gr, loc[3] + ".w", 16 * 64, dIn.device), B, T, F)
 
     def _sru_bwd_work(self, S, dev):
         """the workgroups' partial-dW scratch of rtfs_sru_layer_bwd: one buffer per device, reused by every layer of every step (main stream only)"""
@@ -772,36 +780,37 @@ class HipTrainer:
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
         dN_D0 = dE
         # concat layer: mix + gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
-        dcl, dcg, dcgate = full(), low(), low()
+        dcg, dcgate = low(), low()
         # round 6: the adjoint of every stride-1 depth-wise convolution group in ONE launch (rtfs_dw_adjoint: tap gradients + input gradient from one dX tile in LDS,
         # the gLN adjoint's apply pass on load - dX never reaches HBM, convolutions that share an input share the launch); `fuse["dwadj"]` off = the round-5 launches
         dwadj = self.model._hip.fuse["dwadj"] and self.model._hip.fuse["mixgln"]
-        reds = self._mix_gln_bwd(dE, (k.cl, st[9], cl_, tag + "cl"), (k.cgate, st[11], cgate_, tag + "cgate"), (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr,
-                                 B, T, F_BINS, T2, F2, defer_apply=dwadj)
+        c_loc, c_gate = (k.cl, st[9], cl_, tag + "cl"), (k.cgate, st[11], cgate_, tag + "cgate")
+        dcl = None if dwadj else full()
+        reds = self._mix_gln_bwd(dE, c_loc, c_gate, (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr, B, T, F_BINS, T2, F2, defer_apply=dwadj)
         dF0, dF1 = full(), low()
         if dwadj:
-            self._dw_adjoint([(dcl, cl_, tag + "cl", None)], k.F0, None, None, None, 0.0, 0, dF0, False, gr, B, T, F_BINS)
-            self._dw_adjoint([(dcg, cg_, tag + "cg", (k.cg, st[10], reds[1])), (dcgate, cgate_, tag + "cgate", (k.cgate, st[11], reds[0]))], k.F1, None, None, None, 0.0, 0,
+            self._dw_adjoint_mix(dE, c_loc, c_gate, reds[0], T2, F2, k.F0, None, None, None, 0, dF0, False, gr, B, T, F_BINS)
+            self._dw_adjoint([(dcg, cg_, tag + "cg", (k.cg, st[10], reds[2])), (dcgate, cgate_, tag + "cgate", (k.cgate, st[11], reds[1]))], k.F1, None, None, None, 0.0, 0,
                              dF1, False, gr, B, T2, F2)
         else:
             self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, tag + "cl", B, T, F_BINS, False)
             self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, tag + "cg", B, T2, F2, False)
             self._dw_bwd(dcgate, cgate_, k.F1, None, None, None, 0.0, 0, 1, dF1, True, gr, tag + "cgate", B, T2, F2, False)
         # fusion layers' mixes
-        dl0, dl1 = full(), low()
+        dl0, dl1 = (None, None) if dwadj else (full(), low())
         dgs = [low() for _ in range(4)]  # gradients w.r.t. the outputs of f0g, f0gate, f1g, f1gate
-        r0 = self._mix_gln_bwd(dF0, (k.l0, st[3], f0l, tag + "f0l"), (k.gg0, st[6], f0gate, tag + "f0gate"), (k.g0, st[5], f0g, tag + "f0g"), dl0, dgs[1], dgs[0], gr,
-                               B, T, F_BINS, T2, F2, defer_apply=dwadj)
-        r1 = self._mix_gln_bwd(dF1, (k.l1, st[4], f1l, tag + "f1l"), (k.gg1, st[8], f1gate, tag + "f1gate"), (k.g1, st[7], f1g, tag + "f1g"), dl1, dgs[3], dgs[2], gr,
-                               B, T2, F2, T2, F2, defer_apply=dwadj)
+        l0_loc, l0_gate = (k.l0, st[3], f0l, tag + "f0l"), (k.gg0, st[6], f0gate, tag + "f0gate")
+        l1_loc, l1_gate = (k.l1, st[4], f1l, tag + "f1l"), (k.gg1, st[8], f1gate, tag + "f1gate")
+        r0 = self._mix_gln_bwd(dF0, l0_loc, l0_gate, (k.g0, st[5], f0g, tag + "f0g"), dl0, dgs[1], dgs[0], gr, B, T, F_BINS, T2, F2, defer_apply=dwadj)
+        r1 = self._mix_gln_bwd(dF1, l1_loc, l1_gate, (k.g1, st[7], f1g, tag + "f1g"), dl1, dgs[3], dgs[2], gr, B, T2, F2, T2, F2, defer_apply=dwadj)
         # conv adjoints: local embeddings feed D0n / D1n, the four global convs feed G3
         dN_D1 = low()
         dG = low()  # gradient w.r.t. G3 (attention output)
         if dwadj:
-            self._dw_adjoint([(dl0, f0l, tag + "f0l", None)], k.D0, st[1], d0g, d0be, 0.0, 1, dN_D0, True, gr, B, T, F_BINS)
-            self._dw_adjoint([(dl1, f1l, tag + "f1l", None)], k.D1, st[2], d1g, d1be, 0.0, 1, dN_D1, False, gr, B, T2, F2)
-            self._dw_adjoint([(dgs[0], f0g, tag + "f0g", (k.g0, st[5], r0[1])), (dgs[1], f0gate, tag + "f0gate", (k.gg0, st[6], r0[0])),
-                              (dgs[2], f1g, tag + "f1g", (k.g1, st[7], r1[1])), (dgs[3], f1gate, tag + "f1gate", (k.gg1, st[8], r1[0]))], k.G3, None, None, None, 0.0, 0,
+            self._dw_adjoint_mix(dF0, l0_loc, l0_gate, r0[0], T2, F2, k.D0, st[1], d0g, d0be, 1, dN_D0, True, gr, B, T, F_BINS)
+            self._dw_adjoint_mix(dF1, l1_loc, l1_gate, r1[0], T2, F2, k.D1, st[2], d1g, d1be, 1, dN_D1, False, gr, B, T2, F2)
+            self._dw_adjoint([(dgs[0], f0g, tag + "f0g", (k.g0, st[5], r0[2])), (dgs[1], f0gate, tag + "f0gate", (k.gg0, st[6], r0[1])),
+                              (dgs[2], f1g, tag + "f1g", (k.g1, st[7], r1[2])), (dgs[3], f1gate, tag + "f1gate", (k.gg1, st[8], r1[1]))], k.G3, None, None, None, 0.0, 0,
                              dG, False, gr, B, T2, F2)
         else:
             self._dw_bwd(dl0, f0l, k.D0, st[1], d0g, d0be, 0.0, 1, 1, dN_D0, True, gr, tag + "f0l", B, T, F_BINS, False)

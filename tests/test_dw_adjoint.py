@@ -103,3 +103,43 @@ def test_dw_adjoint_refuses_unsupported_arguments():
         lib.call("rtfs_dw_adjoint", 3, [t, t, t], None, None, None, None, [w, w, w], t, None, None, None, 0.0, 0, t.clone(), 0, [w.clone()] * 3, None, 1, 8, 64)
     with pytest.raises(RuntimeError):
         lib.call("rtfs_dw_adjoint", 1, [t], None, None, None, None, [w], t, None, None, None, 0.0, 1, t.clone(), 0, [w.clone()], None, 1, 8, 64)  # mode 1 without statistics
+
+
+@pytest.mark.parametrize("mode,accumulate", [(0, False), (1, True)])
+@pytest.mark.parametrize("B,T,Fq,Tg,Fg", [(2, 21, 19, 10, 9), (1, 33, 129, 16, 64), (2, 16, 64, 16, 64), (1, 251, 129, 125, 64)])
+def test_dw_adjoint_mix_matches_float64_autograd(mode, accumulate, B, T, Fq, Tg, Fg):
+    """rtfs_dw_adjoint_mix: the convolution is the LOCAL branch of an InjectionMultiSum (layers/fusion.py:54-69); the gradient handed over is the one of the
+    mix's OUTPUT, the gate's sigmoid (nearest up-sampling Tg x Fg -> T x F, F.interpolate's floor(i * in / out)) and the local gLN adjoint are applied on load"""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(3 * T + Fq)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    x_in, taps = rnd(B, H, T, Fq), 0.3 * rnd(16, H)
+    in_g, in_b = 1 + 0.3 * rnd(H), 0.2 * rnd(H)
+    lg, lb, gg, gb = 1 + 0.3 * rnd(H), 0.1 * rnd(H), 1 + 0.3 * rnd(H), 0.1 * rnd(H)
+    gate, dout = rnd(B, H, Tg, Fg), rnd(B, H, T, Fq)
+    xin = (F.group_norm(x_in, 1, in_g, in_b, 1e-5) if mode else x_in).detach().requires_grad_(True)
+    w = taps.t().reshape(H, 1, 4, 4).clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xin, (1, 2, 1, 2)), w, None, groups=H)
+    s_up = F.interpolate(torch.sigmoid(F.group_norm(gate, 1, gg, gb, 1e-5)), size=(T, Fq), mode="nearest")
+    (F.group_norm(y, 1, lg, lb, 1e-5) * s_up * dout).sum().backward()
+    dev = "cuda"
+    slot = lambda t: torch.stack([t.reshape(B, -1).sum(1), (t.reshape(B, -1) ** 2).sum(1)] + [torch.zeros(B, dtype=torch.float64)] * (lib.STAT_STRIDE - 2), 1).contiguous().to(dev)  # noqa: E731
+    y32 = y.detach().float().double()
+    mean = y32.reshape(B, -1).mean(1).view(B, 1, 1, 1)
+    xh = (y32 - mean) / torch.sqrt((y32.reshape(B, -1) ** 2).mean(1).view(B, 1, 1, 1) - mean ** 2 + 1e-5)
+    a = dout * s_up * lg.view(1, H, 1, 1)
+    red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64)
+    red[:, 0], red[:, 1] = a.reshape(B, -1).sum(1), (a * xh).reshape(B, -1).sum(1)
+    N = B * T * Fq * H
+    dIn0 = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev) if accumulate else torch.full((N,), float("nan"), device=dev)
+    dIn, dW = dIn0.clone(), torch.zeros(16 * H, device=dev)
+    f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+    sig = _cl(torch.sigmoid(F.group_norm(gate, 1, gg, gb, 1e-5))).to(dev)  # (what rtfs_mix_gln_bwd_sig's reduce pass writes)
+    lib.call("rtfs_dw_adjoint_mix", _cl(dout).to(dev), _cl(y.detach()).to(dev), slot(y32), red.to(dev), f32(lg), sig, Tg, Fg, f32(taps), _cl(x_in).to(dev),
+             slot(x_in.float().double()) if mode else None, f32(in_g) if mode else None, f32(in_b) if mode else None, 0.0, mode, dIn, 1 if accumulate else 0, dW, B, T, Fq)
+    torch.cuda.synchronize()
+    rel = lambda p, q: float((p.double().cpu() - q).norm() / q.norm())  # noqa: E731
+    e_in = rel(dIn, _cl(xin.grad).double().reshape(-1) + (dIn0.double().cpu() if accumulate else 0))
+    e_w = rel(dW, w.grad.reshape(H, 16).t().reshape(-1))
+    assert e_in < 2e-5 and e_w < 2e-5, (e_in, e_w)

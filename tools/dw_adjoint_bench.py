@@ -65,3 +65,28 @@ for name, nconv, gln, mode, acc, bias, T, Fq in GROUPS:
     tot_old, tot_new = tot_old + t_old, tot_new + t_new
     print(f"{name:28s} {t_old:8.1f} us -> {t_new:8.1f} us   ({gb:.2f} GB algorithmic: {gb / t_new * 1e3:.2f} TB/s)", flush=True)
 print(f"per block: {tot_old:.0f} -> {tot_new:.0f} us")
+
+# the local branches of the three mixes: rtfs_mix_gln_bwd's apply pass + the plain adjoint, against rtfs_dw_adjoint_mix
+for name, mode, acc, T, Fq, Tg, Fg in (("cl <- mix", 0, False, 251, 129, 125, 64), ("f0l <- mix +=", 1, True, 251, 129, 125, 64), ("f1l <- mix", 1, False, 125, 64, 125, 64)):
+    N, Ng = B * T * Fq * 64, B * Tg * Fg * 64
+    r = lambda n=N: torch.randn(n, device=dev)  # noqa: E731
+    dOut, loc, xin, dIn, dLoc = r(), r(), r(), r(), r()
+    gate, sig = r(Ng), torch.rand(Ng, device=dev)
+    st = [torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev) for _ in range(3)]
+    for s_ in st:
+        s_[:, 1] = float(T * Fq * 64)
+    red = torch.randn(B, lib.STAT_STRIDE, dtype=torch.float64, device=dev)
+    gam, bet, w, dW = torch.randn(64, device=dev), torch.randn(64, device=dev), torch.randn(1024, device=dev), torch.zeros(1024, device=dev)
+    m = (st[2], gam, bet) if mode else (None, None, None)
+
+    def old():
+        # (the apply pass alone: same traffic as mix_gln_bwd_apply_kernel - dOut, loc, gate in, dLoc out)
+        lib.call("rtfs_gln_bwd_apply", dOut, loc, st[0], gam, bet, 0, 0.0, red, dLoc, 0, B, T * Fq, 64)
+        lib.call("rtfs_dw_adjoint", 1, [dLoc], None, None, None, None, [w], xin, *m, 0.0, mode, dIn, 1 if acc else 0, [dW], None, B, T, Fq)
+
+    def new():
+        lib.call("rtfs_dw_adjoint_mix", dOut, loc, st[0], red, gam, sig, Tg, Fg, w, xin, *m, 0.0, mode, dIn, 1 if acc else 0, dW, B, T, Fq)
+
+    t_old, t_new = timeit(old), timeit(new)
+    gb = (4 + (1 if acc else 0)) * N * 4 / 1e9 + Ng * 4 / 1e9
+    print(f"{name:28s} {t_old:8.1f} us -> {t_new:8.1f} us   ({gb:.2f} GB algorithmic: {gb / t_new * 1e3:.2f} TB/s)", flush=True)
