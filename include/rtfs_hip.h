@@ -479,19 +479,21 @@ int rtfs_caf_bn_adjoint(const float* R_loc, const float* R_glob, const double* n
  * autograd of ConvNormAct(groups = channels) -> gLN (conv_layers.py:65-129; tdanet.py:61-76, layers/fusion.py:25-52).  nconv in {1, 2, 4}; dy[k]: gradient w.r.t.
  * convolution k's output - or, when x != NULL, w.r.t. its gLN-NORMALISED output, the gLN adjoint  dX = rstd (gamma dN - S1/N - xhat S2/N)  then being applied on load
  * from x[k] (pre-norm output), x_stats[k] (its forward statistics), red[k] (S1, S2: rtfs_gln_bwd_reduce / rtfs_mix_gln_bwd / rtfs_d0_tail_bwd) and gamma[k];
- * in: the common input, transformed as the forward saw it (mode 0 raw, 1 gLN, 2 PReLU(gLN)); dIn (=, or += when accumulate) the gradient w.r.t. that TRANSFORMED
- * input; dW[k] [16][64] += tap gradients, dbias[k] [64] += bias gradients (dbias NULL: none).  Pointer arrays are host arrays of device pointers.
+ * in: the common input, transformed as the forward saw it (mode 0 raw, 1 gLN, 2 PReLU(gLN), 3 the TFAR mix gLN(in) * sigmoid(gLN(gate))^ + gLN(glob)^ re-formed per
+ * pixel as rtfs_dwconv_mix_fwd forms it: in_mix = host array {gate, gate_stats, gate_gamma, gate_beta, glob, glob_stats, glob_gamma, glob_beta} at in_Tg x in_Fg, NULL
+ * otherwise); dIn (=, or += when accumulate) the gradient w.r.t. that TRANSFORMED input; dW[k] [16][64] += tap gradients, dbias[k] [64] += bias gradients (dbias NULL: none).  Pointer arrays are host arrays of device pointers.
  * Replaces rtfs_gln_bwd_apply + rtfs_dwconv_bwd_weight + rtfs_dwconv_bwd_input per convolution: dX never reaches HBM. */
 int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                     const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
-                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream);
+                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* const* dW,
+                    float* const* dbias, int B, int T, int F, void* stream);
 
 /* the same for ONE convolution that is the local branch of an InjectionMultiSum (layers/fusion.py:54-69: out = gLN(loc) * sigmoid(gLN(gate))^ + gLN(glob)^): dOut is
  * the gradient w.r.t. the mix's output; the local branch's mix + gLN adjoint  dX = rstd (gamma dOut s^ - S1/N - xhat S2/N)  is applied on load from loc (pre-norm
  * output of the convolution), its statistics, loc_red = (S1, S2) and gate_sig = s = sigmoid(gLN(gate)) [B][Tg][Fg][64], both written by rtfs_mix_gln_bwd_sig. */
 int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_stats, const double* loc_red, const float* loc_gamma, const float* gate_sig,
                         int Tg, int Fg, const float* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta, float in_slope,
-                        int mode, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream);
+                        int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream);
 /* rtfs_mix_gln_bwd with one more output: sig (or NULL) receives sigmoid(gLN(gate)), which the reduce pass forms anyway; dLoc may then be NULL - the apply pass of the
  * local branch is left to rtfs_dw_adjoint_mix (dLoc never reaches HBM). */
 int rtfs_mix_gln_bwd_sig(const float* dOut, const float* loc, const double* loc_stats, const float* loc_g, const float* loc_b, const float* gate,

@@ -44,6 +44,13 @@ struct DwAdjArgs {
     // on load (what rtfs_mix_gln_bwd's apply pass wrote to HBM as dLoc until round 6); the sigmoid itself comes from the reduce pass of rtfs_mix_gln_bwd
     const float* gate_s;          // [B][Tg][Fg][64]: sigmoid(gLN(gate)), written by rtfs_mix_gln_bwd's reduce pass (which forms it anyway)
     int Tg, Fg;
+    // mode 3: the common input is itself a TFAR mix  gLN(in) * sigmoid(gLN(mgate))^ + gLN(mglob)^  of three tensors (the concat layer reads the fusion layers'
+    // outputs F0 / F1): re-formed per pixel as the forward's rtfs_dwconv_mix_fwd does - F0 / F1 are never materialised, not even for the step
+    const float *mgate, *mglob;   // [B][mTg][mFg][64], pre-norm
+    const double *mgate_slot, *mglob_slot;
+    const float *mgate_gamma, *mgate_beta, *mglob_gamma, *mglob_beta;
+    double m_inv_n;
+    int mTg, mFg;
     unsigned mt, mf;              // ceil(2^32 / T), ceil(2^32 / F): nearest source index floor(i * in / out) without a division
 };
 
@@ -65,6 +72,8 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
     __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
     __shared__ __attribute__((aligned(16))) float coefA[GLN ? NCONV : 1][64];
     __shared__ int nearest[MIX ? 2 : 1][R > CB ? R : CB];  // nearest source row / column (in units of 64-float pixels) of the tile's rows / columns
+    __shared__ int mcol[TC];                               // mode 3: nearest source column of the block's 8 input columns
+    __shared__ __attribute__((aligned(16))) float mixc[4][64];  // mode 3: gLN of the mix's gate / global tensors folded (scale, shift)
     // ---- tile of this workgroup: consecutive time tiles of an utterance on one XCD (workgroups go to XCDs round-robin by linear index) ----
     const int ntiles = a.nt * a.B * a.nseg, per_xcd = (ntiles + 7) / 8;
     const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -99,6 +108,19 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
         ish = be - isc * mean;
     }
     const float am1 = a.in_slope - 1.0f;
+    const float *mgrow = nullptr, *merow = nullptr;
+    if (NCONV <= 2 && a.mode == 3) {  // (the four-convolution form has no registers to spare and no caller with a mixed input)
+        float gm, gr, em, er;
+        stats_finalize(a.mgate_slot, b, a.m_inv_n, gm, gr);
+        stats_finalize(a.mglob_slot, b, a.m_inv_n, em, er);
+        if (threadIdx.x < 64) {
+            const float gs = a.mgate_gamma[threadIdx.x] * gr, es = a.mglob_gamma[threadIdx.x] * er;
+            mixc[0][threadIdx.x] = gs, mixc[1][threadIdx.x] = a.mgate_beta[threadIdx.x] - gm * gs;
+            mixc[2][threadIdx.x] = es, mixc[3][threadIdx.x] = a.mglob_beta[threadIdx.x] - em * es;
+        }
+        const size_t lrow = ((size_t)b * a.mTg + div_magic((unsigned)(tvalid ? ti : 0) * a.mTg, T, a.mt)) * a.mFg * kH + ch;
+        mgrow = a.mgate + lrow, merow = a.mglob + lrow;
+    }
     const size_t ubase = (size_t)b * T * F * kH;
     const float* inrow = a.in + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
     float* outrow = a.dIn + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
@@ -117,10 +139,30 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
         float2v inv[TC], acc[TC];
 #pragma unroll
         for (int j = 0; j < TC; ++j) inv[j] = ld2v(inrow + (size_t)min(fb + j, F - 1) * kH);
+        if (NCONV <= 2 && a.mode == 3) {  // (workgroup-uniform)
+            __syncthreads();  // the previous block's readers of mcol are done
+            if (threadIdx.x < TC) mcol[threadIdx.x] = div_magic((unsigned)min(fb + (int)threadIdx.x, F - 1) * a.mFg, F, a.mf) * kH;
+            __syncthreads();
+            int moff = ch;
+            asm volatile("" : "+v"(moff));  // (the six per-channel constants are re-read from LDS per block instead of living in 12 registers)
+            const float2v gs = ld2v(&mixc[0][moff]), gh = ld2v(&mixc[1][moff]), es = ld2v(&mixc[2][moff]), eh = ld2v(&mixc[3][moff]);
+#pragma unroll
+            for (int j0 = 0; j0 < TC; j0 += 4) {
+                float2v vg[4], ve[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vg[j] = ld2v(mgrow + mcol[j0 + j]), ve[j] = ld2v(merow + mcol[j0 + j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2v g = vg[j] * gs + gh;
+                    const float2v sg = float2v{sigmoidf_fast(g.x), sigmoidf_fast(g.y)};
+                    inv[j0 + j] = (inv[j0 + j] * isc + ish) * sg + (ve[j] * es + eh);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
             float2v v = inv[j];
-            if (a.mode >= 1) v = v * isc + ish;
+            if (a.mode == 1 || a.mode == 2) v = v * isc + ish;
             if (a.mode == 2) v = __builtin_elementwise_min(v, float2v{0.f, 0.f}) * am1 + v;  // prelu(x) = x + (slope - 1) min(x, 0)
             inv[j] = (tvalid && fb + j < f1) ? v : float2v{0.f, 0.f};
             acc[j] = float2v{0.f, 0.f};
@@ -241,8 +283,8 @@ using namespace rtfs;
 static int dw_adjoint_launch(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                              const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma,
                              const float* in_beta, float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T,
-                             int F, const float* gate_s, int Tg, int Fg, void* stream) {
-    if (B <= 0 || T <= 0 || F <= 0 || (nconv != 1 && nconv != 2 && nconv != 4) || mode < 0 || mode > 2 || !dy || !w || !dW || !in || !dIn) return RTFS_EINVAL;
+                             int F, const float* gate_s, int Tg, int Fg, const void* const* in_mix, int in_Tg, int in_Fg, void* stream) {
+    if (B <= 0 || T <= 0 || F <= 0 || (nconv != 1 && nconv != 2 && nconv != 4) || mode < 0 || mode > 3 || !dy || !w || !dW || !in || !dIn) return RTFS_EINVAL;
     if (mode >= 1 && (!in_stats || !in_gamma || !in_beta)) return RTFS_EINVAL;
     if ((size_t)T * F * kH * 4 >= (1ull << 32)) return RTFS_EINVAL;  // 32-bit byte offsets inside an utterance
     const bool gln = x != nullptr && x[0] != nullptr;
@@ -272,11 +314,20 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
     a.mode = mode, a.accumulate = accumulate ? 1 : 0, a.bias = bias ? 1 : 0;
     a.inv_n = 1.0 / ((double)T * F * kH);
     a.dIn = dIn;
+    a.mt = (unsigned)(((1ull << 32) + T - 1) / T), a.mf = (unsigned)(((1ull << 32) + F - 1) / F);
+    if (mode == 3) {
+        if (!in_mix || in_Tg <= 0 || in_Fg <= 0 || in_Tg > T || in_Fg > F) return RTFS_EINVAL;
+        for (int i = 0; i < 8; ++i)
+            if (!in_mix[i]) return RTFS_EINVAL;
+        a.mgate = (const float*)in_mix[0], a.mgate_slot = (const double*)in_mix[1], a.mgate_gamma = (const float*)in_mix[2], a.mgate_beta = (const float*)in_mix[3];
+        a.mglob = (const float*)in_mix[4], a.mglob_slot = (const double*)in_mix[5], a.mglob_gamma = (const float*)in_mix[6], a.mglob_beta = (const float*)in_mix[7];
+        a.mTg = in_Tg, a.mFg = in_Fg, a.m_inv_n = 1.0 / ((double)in_Tg * in_Fg * kH);
+    }
+    if (mode == 3 && nconv > 2) return RTFS_EINVAL;
     const bool mix = gate_s != nullptr;
     if (mix) {
         if (nconv != 1 || !gln || Tg <= 0 || Fg <= 0 || Tg > T || Fg > F) return RTFS_EINVAL;
         a.gate_s = gate_s, a.Tg = Tg, a.Fg = Fg;
-        a.mt = (unsigned)(((1ull << 32) + T - 1) / T), a.mf = (unsigned)(((1ull << 32) + F - 1) / F);
     }
     a.scr = spread_scratch();
     if (!a.scr) return RTFS_ELAUNCH;
@@ -299,14 +350,15 @@ extern "C" {
 
 int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                     const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
-                    float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T, int F, void* stream) {
+                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* const* dW,
+                    float* const* dbias, int B, int T, int F, void* stream) {
     return dw_adjoint_launch(nconv, dy, x, x_stats, red, gamma, w, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dW, dbias, B, T, F, nullptr,
-                             0, 0, stream);
+                             0, 0, in_mix, in_Tg, in_Fg, stream);
 }
 
 int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_stats, const double* loc_red, const float* loc_gamma, const float* gate_sig,
                         int Tg, int Fg, const float* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta, float in_slope,
-                        int mode, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream) {
+                        int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* dW, int B, int T, int F, void* stream) {
     if (!dOut || !loc || !loc_stats || !loc_red || !loc_gamma || !gate_sig || !w || !dW) return RTFS_EINVAL;
     const float* dy[1] = {dOut};
     const float* x[1] = {loc};
@@ -316,7 +368,7 @@ int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_s
     const float* ww[1] = {w};
     float* dw[1] = {dW};
     return dw_adjoint_launch(1, dy, x, xs, red, gm, ww, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dw, nullptr, B, T, F, gate_sig, Tg, Fg,
-                             stream);
+                             in_mix, in_Tg, in_Fg, stream);
 }
 
 }  // extern "C"

@@ -450,12 +450,22 @@ class HipTrainer:
         k.g0, k.gg0, k.g1, k.gg1 = low(), low(), low(), low()
         self._call("rtfs_dwconv_fwd", G, None, None, None, 0.0, 0, 1, 4, [f0g[0], f0gate[0], f1g[0], f1gate[0]], [None] * 4, [k.g0, k.gg0, k.g1, k.gg1],
                  [st[5], st[6], st[7], st[8]], B, T2, F2)
-        k.F0, k.F1 = full(), low()
-        self._call("rtfs_tfar_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], k.F0, B, T, F_BINS, T2, F2)
-        self._call("rtfs_tfar_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], k.F1, B, T2, F2, T2, F2)
         k.cl, k.cg, k.cgate = full(), low(), low()
-        self._call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
-        self._call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
+        fz = self.model._hip.fuse
+        if fz["dwadj"] and fz["mixgln"] and fz["mix"]:
+            # round 6: the fusion layers' outputs F0 / F1 are not materialised for the step either - the concat layer's convolutions form them in their staging
+            # as in the inference path, and their adjoint re-forms them per pixel (rtfs_dw_adjoint, input mode 3)
+            k.F0 = k.F1 = None
+            self._call("rtfs_dwconv_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], 1, [cl_[0]], [None],
+                       [k.cl], [st[9]], B, T, F_BINS, T2, F2)
+            self._call("rtfs_dwconv_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], 2, [cg_[0], cgate_[0]],
+                       [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2, T2, F2)
+        else:
+            k.F0, k.F1 = full(), low()
+            self._call("rtfs_tfar_mix_fwd", k.l0, st[3], f0l[2], f0l[3], k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3], k.F0, B, T, F_BINS, T2, F2)
+            self._call("rtfs_tfar_mix_fwd", k.l1, st[4], f1l[2], f1l[3], k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3], k.F1, B, T2, F2, T2, F2)
+            self._call("rtfs_dwconv_fwd", k.F0, None, None, None, 0.0, 0, 1, 1, [cl_[0]], [None], [k.cl], [st[9]], B, T, F_BINS)
+            self._call("rtfs_dwconv_fwd", k.F1, None, None, None, 0.0, 0, 1, 2, [cg_[0], cgate_[0]], [None, None], [k.cg, k.cgate], [st[10], st[11]], B, T2, F2)
         if next_proj is not None and a0_or_none is not None:
             self._call("rtfs_resid_proj_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2],
                        cgate_[3], bw["rw"], bw["rb"], s_in, bw["gw"], bw["gb"], bw["gslope"], a0_or_none, out, bw["pw"], bw["pb"], next_proj[0], next_proj[1],
@@ -657,23 +667,24 @@ class HipTrainer:
         if dIn is not None:
             self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
 
-    def _dw_adjoint(self, convs, inp, in_st, in_g, in_b, in_slope, mode, dIn, accumulate, gr, B, T, F, bias=False):
+    def _dw_adjoint(self, convs, inp, in_st, in_g, in_b, in_slope, mode, dIn, accumulate, gr, B, T, F, bias=False, in_mix=None, in_low=(0, 0)):
         """rtfs_dw_adjoint (csrc/bwd_dw.hip): the whole adjoint of the 1 / 2 / 4 stride-1 depth-wise convolutions `convs` that read `inp` in one launch.
         convs: list of (dY, conv tuple (taps, bias, gamma, beta), gr key, None | (pre-norm output, statistics slot, (S1, S2) slot)) - with the last entry the
-        gLN adjoint is applied on load and dY is the gradient w.r.t. the normalised output."""
+        gLN adjoint is applied on load and dY is the gradient w.r.t. the normalised output.  mode 3: `inp` is the local tensor of a TFAR mix, in_mix = [gate, its
+        statistics, gamma, beta, glob, its statistics, gamma, beta] at resolution in_low."""
         dev = dIn.device
         gln = convs[0][3] is not None
         dW = [_acc(gr, c[2] + ".w", 16 * 64, dev) for c in convs]
         db = [_acc(gr, c[2] + ".bias", 64, dev) for c in convs] if bias else None
         lib.call("rtfs_dw_adjoint", len(convs), [c[0] for c in convs], [c[3][0] for c in convs] if gln else None, [c[3][1] for c in convs] if gln else None,
                  [c[3][2] for c in convs] if gln else None, [c[1][2] for c in convs] if gln else None, [c[1][0] for c in convs], inp, in_st, in_g, in_b,
-                 float(in_slope), mode, dIn, 1 if accumulate else 0, dW, db, B, T, F)
+                 float(in_slope), mode, in_mix, in_low[0], in_low[1], dIn, 1 if accumulate else 0, dW, db, B, T, F)
 
-    def _dw_adjoint_mix(self, dOut, loc, gate, red_loc, Tg, Fg, inp, in_st, in_g, in_b, mode, dIn, accumulate, gr, B, T, F):
+    def _dw_adjoint_mix(self, dOut, loc, gate, red_loc, Tg, Fg, inp, in_st, in_g, in_b, mode, dIn, accumulate, gr, B, T, F, in_mix=None, in_low=(0, 0)):
         """rtfs_dw_adjoint_mix: the adjoint of an InjectionMultiSum's LOCAL embedding convolution straight from the gradient of the mix's output (the local branch's
         mix + gLN adjoint on load).  loc / gate: (pre-norm tensor, statistics slot, conv tuple, gr key) as in _mix_gln_bwd."""
         lib.call("rtfs_dw_adjoint_mix", dOut, loc[0], loc[1], red_loc[0], loc[2][2], red_loc[1], Tg, Fg, loc[2][0], inp, in_st, in_g, in_b,
-                 0.0, mode, dIn, 1 if accumulate else 0, _acc(gr, loc[3] + ".w", 16 * 64, dIn.device), B, T, F)
+                 0.0, mode, in_mix, in_low[0], in_low[1], dIn, 1 if accumulate else 0, _acc(gr, loc[3] + ".w", 16 * 64, dIn.device), B, T, F)
 
     def _sru_bwd_work(self, S, dev):
         """the workgroups' partial-dW scratch of rtfs_sru_layer_bwd: one buffer per device, reused by every layer of every step (main stream only)"""
@@ -789,9 +800,15 @@ class HipTrainer:
         reds = self._mix_gln_bwd(dE, c_loc, c_gate, (k.cg, st[10], cg_, tag + "cg"), dcl, dcgate, dcg, gr, B, T, F_BINS, T2, F2, defer_apply=dwadj)
         dF0, dF1 = full(), low()
         if dwadj:
-            self._dw_adjoint_mix(dE, c_loc, c_gate, reds[0], T2, F2, k.F0, None, None, None, 0, dF0, False, gr, B, T, F_BINS)
-            self._dw_adjoint([(dcg, cg_, tag + "cg", (k.cg, st[10], reds[2])), (dcgate, cgate_, tag + "cgate", (k.cgate, st[11], reds[1]))], k.F1, None, None, None, 0.0, 0,
-                             dF1, False, gr, B, T2, F2)
+            convs_b = [(dcg, cg_, tag + "cg", (k.cg, st[10], reds[2])), (dcgate, cgate_, tag + "cgate", (k.cgate, st[11], reds[1]))]
+            if k.F0 is None:  # the concat layer's inputs re-formed from the fusion layers' three tensors each (input mode 3)
+                self._dw_adjoint_mix(dE, c_loc, c_gate, reds[0], T2, F2, k.l0, st[3], f0l[2], f0l[3], 3, dF0, False, gr, B, T, F_BINS,
+                                     in_mix=[k.gg0, st[6], f0gate[2], f0gate[3], k.g0, st[5], f0g[2], f0g[3]], in_low=(T2, F2))
+                self._dw_adjoint(convs_b, k.l1, st[4], f1l[2], f1l[3], 0.0, 3, dF1, False, gr, B, T2, F2,
+                                 in_mix=[k.gg1, st[8], f1gate[2], f1gate[3], k.g1, st[7], f1g[2], f1g[3]], in_low=(T2, F2))
+            else:
+                self._dw_adjoint_mix(dE, c_loc, c_gate, reds[0], T2, F2, k.F0, None, None, None, 0, dF0, False, gr, B, T, F_BINS)
+                self._dw_adjoint(convs_b, k.F1, None, None, None, 0.0, 0, dF1, False, gr, B, T2, F2)
         else:
             self._dw_bwd(dcl, cl_, k.F0, None, None, None, 0.0, 0, 1, dF0, False, gr, tag + "cl", B, T, F_BINS, False)
             self._dw_bwd(dcg, cg_, k.F1, None, None, None, 0.0, 0, 1, dF1, False, gr, tag + "cg", B, T2, F2, False)

@@ -66,7 +66,7 @@ def _case(nconv, gln, mode, accumulate, bias, B, T, Fq, seed):
     f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
     lib.call("rtfs_dw_adjoint", nconv, [_cl(d).to(dev) for d in dys], x_cl, x_st, red, [f32(t) for t in gam] if gln else None, [f32(t) for t in taps],
              _cl(x_in).to(dev), slot(x_in.float().double()) if mode >= 1 else None, f32(in_g) if mode >= 1 else None, f32(in_b) if mode >= 1 else None,
-             slope, mode, dIn, 1 if accumulate else 0, dW, db, B, T, Fq)
+             slope, mode, None, 0, 0, dIn, 1 if accumulate else 0, dW, db, B, T, Fq)
     torch.cuda.synchronize()
     rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())  # noqa: E731
     ref_dIn = _cl(xin.grad).double().reshape(-1) + (dIn0.double().cpu() if accumulate else 0)
@@ -100,9 +100,9 @@ def test_dw_adjoint_refuses_unsupported_arguments():
     t = torch.zeros(64 * 64 * 8, device="cuda")
     w = torch.zeros(1024, device="cuda")
     with pytest.raises(RuntimeError):
-        lib.call("rtfs_dw_adjoint", 3, [t, t, t], None, None, None, None, [w, w, w], t, None, None, None, 0.0, 0, t.clone(), 0, [w.clone()] * 3, None, 1, 8, 64)
+        lib.call("rtfs_dw_adjoint", 3, [t, t, t], None, None, None, None, [w, w, w], t, None, None, None, 0.0, 0, None, 0, 0, t.clone(), 0, [w.clone()] * 3, None, 1, 8, 64)
     with pytest.raises(RuntimeError):
-        lib.call("rtfs_dw_adjoint", 1, [t], None, None, None, None, [w], t, None, None, None, 0.0, 1, t.clone(), 0, [w.clone()], None, 1, 8, 64)  # mode 1 without statistics
+        lib.call("rtfs_dw_adjoint", 1, [t], None, None, None, None, [w], t, None, None, None, 0.0, 1, None, 0, 0, t.clone(), 0, [w.clone()], None, 1, 8, 64)  # mode 1 without statistics
 
 
 @pytest.mark.parametrize("mode,accumulate", [(0, False), (1, True)])
@@ -137,9 +137,53 @@ def test_dw_adjoint_mix_matches_float64_autograd(mode, accumulate, B, T, Fq, Tg,
     f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
     sig = _cl(torch.sigmoid(F.group_norm(gate, 1, gg, gb, 1e-5))).to(dev)  # (what rtfs_mix_gln_bwd_sig's reduce pass writes)
     lib.call("rtfs_dw_adjoint_mix", _cl(dout).to(dev), _cl(y.detach()).to(dev), slot(y32), red.to(dev), f32(lg), sig, Tg, Fg, f32(taps), _cl(x_in).to(dev),
-             slot(x_in.float().double()) if mode else None, f32(in_g) if mode else None, f32(in_b) if mode else None, 0.0, mode, dIn, 1 if accumulate else 0, dW, B, T, Fq)
+             slot(x_in.float().double()) if mode else None, f32(in_g) if mode else None, f32(in_b) if mode else None, 0.0, mode, None, 0, 0, dIn, 1 if accumulate else 0, dW, B, T, Fq)
     torch.cuda.synchronize()
     rel = lambda p, q: float((p.double().cpu() - q).norm() / q.norm())  # noqa: E731
     e_in = rel(dIn, _cl(xin.grad).double().reshape(-1) + (dIn0.double().cpu() if accumulate else 0))
     e_w = rel(dW, w.grad.reshape(H, 16).t().reshape(-1))
     assert e_in < 2e-5 and e_w < 2e-5, (e_in, e_w)
+
+
+@pytest.mark.parametrize("nconv,B,T,Fq,Tg,Fg", [(1, 2, 21, 19, 10, 9), (2, 1, 125, 64, 125, 64), (2, 2, 16, 64, 16, 64), (1, 1, 251, 129, 125, 64)])
+def test_dw_adjoint_with_a_tfar_mix_as_input(nconv, B, T, Fq, Tg, Fg):
+    """input mode 3: the convolutions read the TFAR mix  gLN(l) * sigmoid(gLN(gate))^ + gLN(glob)^  (the concat layer reading the fusion layers' outputs,
+    tdanet.py:124-129), which the kernel re-forms per pixel from the three tensors as rtfs_dwconv_mix_fwd does in the forward; gLN'd convolutions behind it"""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(11 * T + nconv)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    loc, gate, glob = rnd(B, H, T, Fq), rnd(B, H, Tg, Fg), rnd(B, H, Tg, Fg)
+    aff = [(1 + 0.3 * rnd(H), 0.2 * rnd(H)) for _ in range(3)]
+    up = lambda t: F.interpolate(t, size=(T, Fq), mode="nearest")  # noqa: E731
+    xin = (F.group_norm(loc, 1, *aff[0], 1e-5) * up(torch.sigmoid(F.group_norm(gate, 1, *aff[1], 1e-5))) + up(F.group_norm(glob, 1, *aff[2], 1e-5))).detach().requires_grad_(True)
+    taps = [0.3 * rnd(16, H) for _ in range(nconv)]
+    gam, bet, dns = [1 + 0.3 * rnd(H) for _ in range(nconv)], [0.1 * rnd(H) for _ in range(nconv)], [rnd(B, H, T, Fq) for _ in range(nconv)]
+    ws = [t.t().reshape(H, 1, 4, 4).clone().requires_grad_(True) for t in taps]
+    ys, loss = [], 0
+    for k in range(nconv):
+        y = F.conv2d(F.pad(xin, (1, 2, 1, 2)), ws[k], None, groups=H)
+        ys.append(y.detach())
+        loss = loss + (F.group_norm(y, 1, gam[k], bet[k], 1e-5) * dns[k]).sum()
+    loss.backward()
+    dev = "cuda"
+    slot = lambda t: torch.stack([t.reshape(B, -1).sum(1), (t.reshape(B, -1) ** 2).sum(1)] + [torch.zeros(B, dtype=torch.float64)] * (lib.STAT_STRIDE - 2), 1).contiguous().to(dev)  # noqa: E731
+    f32 = lambda t: t.float().contiguous().to(dev)  # noqa: E731
+    red = []
+    for k in range(nconv):
+        y32 = ys[k].float().double()
+        mean = y32.reshape(B, -1).mean(1).view(B, 1, 1, 1)
+        xh = (y32 - mean) / torch.sqrt((y32.reshape(B, -1) ** 2).mean(1).view(B, 1, 1, 1) - mean ** 2 + 1e-5)
+        a = dns[k] * gam[k].view(1, H, 1, 1)
+        r = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64)
+        r[:, 0], r[:, 1] = a.reshape(B, -1).sum(1), (a * xh).reshape(B, -1).sum(1)
+        red.append(r.to(dev))
+    dIn = torch.full((B * T * Fq * H,), float("nan"), device=dev)
+    dW = [torch.zeros(16 * H, device=dev) for _ in range(nconv)]
+    in_mix = [_cl(gate).to(dev), slot(gate.float().double()), f32(aff[1][0]), f32(aff[1][1]), _cl(glob).to(dev), slot(glob.float().double()), f32(aff[2][0]), f32(aff[2][1])]
+    lib.call("rtfs_dw_adjoint", nconv, [_cl(d).to(dev) for d in dns], [_cl(y).to(dev) for y in ys], [slot(y.float().double()) for y in ys], red, [f32(t) for t in gam],
+             [f32(t) for t in taps], _cl(loc).to(dev), slot(loc.float().double()), f32(aff[0][0]), f32(aff[0][1]), 0.0, 3, in_mix, Tg, Fg, dIn, 0, dW, None, B, T, Fq)
+    torch.cuda.synchronize()
+    rel = lambda p, q: float((p.double().cpu() - q).norm() / q.norm())  # noqa: E731
+    errs = [rel(dIn, _cl(xin.grad).double().reshape(-1))] + [rel(dW[k], ws[k].grad.reshape(H, 16).t().reshape(-1)) for k in range(nconv)]
+    assert max(errs) < 2e-5, errs
