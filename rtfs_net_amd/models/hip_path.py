@@ -264,18 +264,27 @@ class HipForward:
         self.attn_terms = ATTN_TERMS.get(os.environ.get("RTFS_COMPUTE_DTYPE", "f32"), 0)  # terms of the attention core alone when prec == 0
         # kernel-form choices handed to the C-ABI as explicit `variant` arguments (0 = the library's own choice; include/rtfs_hip.h) - a
         # HOST-side setting for same-box A/B runs and the equivalence tests, the library itself reads no environment
-        self.variants = {"resid": int(os.environ.get("RTFS_RESID_VARIANT", "0")), "unfold": int(os.environ.get("RTFS_UNFOLD_VARIANT", "0"))}
-        # A/B switches of the host-side fusion choices, read from the environment ONCE here (not per forward); tests flip the attributes
-        off = lambda name: os.environ.get(name, "0") == "1"  # noqa: E731
-        self.fuse = {"trio": not off("RTFS_NO_TRIO_FUSION"), "mix": not off("RTFS_NO_MIX_FUSION"), "proj": not off("RTFS_NO_PROJ_FUSION"),
-                     "caf": not off("RTFS_NO_CAF_FUSION"), "gadd": not off("RTFS_NO_GADD_FUSION"),
-                     "mixgln": not off("RTFS_NO_MIXGLN_FUSION"), "d0tail": not off("RTFS_NO_D0TAIL_FUSION"),
-                     "wgside": not off("RTFS_NO_WGRAD_SIDE"), "wgather": not off("RTFS_NO_WEIGHT_GATHER"), "cafbn": not off("RTFS_NO_CAF_BN_FUSION"),
-                     "decmask": not off("RTFS_NO_DECMASK_FUSION"), "srubwd": not off("RTFS_NO_SRU_BWD_FUSION"),
-                     "dwadj": not off("RTFS_NO_DWADJ_FUSION")}  # (mixgln, d0tail, wgside, srubwd: training step only, models/hip_train.py)
+        # (RTFS_VARIANTS=resid:2,unfold:3 for bench.py A/B runs; tests set the dictionary)
+        self.variants = {"resid": 0, "unfold": 0}
+        for item in filter(None, (x.strip() for x in os.environ.get("RTFS_VARIANTS", "").split(","))):
+            key, _, val = item.partition(":")
+            if key not in self.variants:
+                raise ValueError(f"RTFS_VARIANTS: unknown kernel family {key!r} (known: resid, unfold)")
+            self.variants[key] = int(val)
+        # A/B switches of the host-side fusion choices.  Every one of them is ON in the product; each has a same-box A/B on record (DESIGN.md / profiles/) and an
+        # equivalence test that flips the attribute.  ONE environment variable, read once here, turns a comma-separated list of them off for same-box A/B runs:
+        #     RTFS_DISABLE=dwadj,wgside python bench.py --mode train          (round 6: this replaced thirteen RTFS_NO_*_FUSION variables)
+        # inference + step: trio, mix, proj, caf, gadd; training step only (models/hip_train.py): mixgln, d0tail, wgside (weight gradients on the side stream),
+        # wgather (weights re-laid by one gather), cafbn, decmask, srubwd, dwadj (depth-wise adjoints in one launch)
+        names = ("trio", "mix", "proj", "caf", "gadd", "mixgln", "d0tail", "wgside", "wgather", "cafbn", "decmask", "srubwd", "dwadj")
+        disabled = {x.strip() for x in os.environ.get("RTFS_DISABLE", "").split(",") if x.strip()}
+        unknown = disabled - set(names) - {"vp_hip", "vp_side"}
+        if unknown:
+            raise ValueError(f"RTFS_DISABLE: unknown switch(es) {sorted(unknown)}; known: {', '.join(names)}, vp_hip, vp_side")
+        self.fuse = {n: n not in disabled for n in names}
         self.vp_ran_as_modules = False
-        self.vp_glue = off("RTFS_VP_GLUE")  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
-        self.vp_side_stream = not off("RTFS_VP_NO_SIDE")
+        self.vp_glue = "vp_hip" in disabled  # the VP block on the PyTorch modules instead of csrc/vp.hip (also read by AVNet's training-step path)
+        self.vp_side_stream = "vp_side" not in disabled
 
     def weights(self) -> PreparedWeights:
         fp = PreparedWeights.fingerprint(self.model)

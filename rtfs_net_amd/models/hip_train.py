@@ -896,7 +896,7 @@ class HipTrainer:
         (an optimizer step on earlier gradients, an EMA swap) -> backward(A) would run A's adjoint on the NEW weights, silently.  Refuse instead."""
         if c.pw.version != c.pw_version:
             raise RuntimeError(f"rtfs_net_amd: the parameters changed and a newer forward re-laid out the kernel weights between this step's forward and its "
-                               f"{stage}; run each step's backward before the next forward after a parameter update (or set RTFS_NO_WEIGHT_GATHER=1: "
+                               f"{stage}; run each step's backward before the next forward after a parameter update (or set RTFS_DISABLE=wgather: "
                                "per-step weight snapshots)")
 
     def backward_b(self, c, dout):

@@ -78,7 +78,7 @@ class BatchCountProbe:
         total = float(self.host[0])
         if total != float(self.B * self.world):
             raise ValueError(f"SyncBatchNorm in the VP block's HIP training step needs equal per-rank batch sizes: this rank holds {self.B} utterances, "
-                             f"the {self.world} ranks together {total:g}: use drop_last / DistributedSampler padding, or RTFS_VP_GLUE=1 for the PyTorch modules")
+                             f"the {self.world} ranks together {total:g}: use drop_last / DistributedSampler padding, or RTFS_DISABLE=vp_hip for the PyTorch modules")
 
 
 class VPTrainer:

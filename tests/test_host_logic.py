@@ -107,3 +107,23 @@ def test_bench_traffic_is_null_when_the_kernel_source_changed(tmp_path, monkeypa
     assert bench.pmc_traffic("unfold_ffa_kernel<3, 0>", a) == (None, "profiles/pmc_traffic.json carries no source hash (measured before round 6): re-run tools/pmc_hbm.sh")
     a.batch = 16
     assert bench.pmc_traffic("unfold_ffa_kernel<3, 0>", a)[0] is None
+
+
+def test_one_environment_variable_for_the_ab_switches(monkeypatch):
+    """round 6: RTFS_DISABLE=<list> (was thirteen RTFS_NO_*_FUSION variables) and RTFS_VARIANTS=<family>:<n>; unknown names raise instead of being ignored"""
+    import pytest
+
+    from util import make_model
+
+    monkeypatch.setenv("RTFS_DISABLE", "dwadj, wgside,vp_hip")
+    monkeypatch.setenv("RTFS_VARIANTS", "resid:2")
+    m, _, _ = make_model(2)
+    assert not m._hip.fuse["dwadj"] and not m._hip.fuse["wgside"] and m._hip.fuse["trio"] and m._hip.vp_glue and m._hip.vp_side_stream
+    assert m._hip.variants == {"resid": 2, "unfold": 0}
+    monkeypatch.setenv("RTFS_DISABLE", "no_such_switch")
+    with pytest.raises(ValueError, match="unknown switch"):
+        make_model(2)
+    monkeypatch.delenv("RTFS_DISABLE")
+    monkeypatch.setenv("RTFS_VARIANTS", "gemm:1")
+    with pytest.raises(ValueError, match="unknown kernel family"):
+        make_model(2)

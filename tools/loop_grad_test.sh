@@ -1,6 +1,6 @@
 cd /root/repo
 for mode in fused three; do
-  if [ $mode = three ]; then export RTFS_NO_SRU_BWD_FUSION=1; else unset RTFS_NO_SRU_BWD_FUSION; fi
+  if [ $mode = three ]; then export RTFS_DISABLE=srubwd; else unset RTFS_DISABLE; fi
   fails=0
   for i in $(seq 1 25); do
     out=$(python -m pytest tests/test_hip_backward.py -q -x -k "test_parameter_gradients and not split" 2>&1 | tail -30)
