@@ -276,6 +276,140 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
     }
 }
 
+
+// The four global convolutions of the TFAR fusion layers (input G3 = the attention's output): four gLN'd convolutions, raw input, fresh dIn - ONE channel per lane.
+// In the two-channels-per-lane kernel above four convolutions' partial sums are 128 registers: 256 registers with spills, two workgroups per CU, 2.6 TB/s of
+// algorithmic bytes against 4.3 for one convolution at four workgroups per CU.  With one channel per lane (a wave = one tile row x 64 channels, 512 threads = 8 rows)
+// they are 64, the kernel fits 128 registers and sixteen waves per CU: the staging latency of one workgroup hides under the window passes of the others again.
+// Scalar v_fma_f32 / ds_read_b32 instead of packed / 64-bit ones: twice the instructions for the same arithmetic, which this HBM-bound kernel has room for.
+__global__ __launch_bounds__(512, 2) void dw_adjoint4_kernel(DwAdjArgs a) {
+    constexpr int NCONV = 4, TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64, NT = 512;
+    constexpr int NIT = (R * CB * 16 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float tile[R * RS];
+    __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
+    __shared__ __attribute__((aligned(16))) float coefA[NCONV][64];
+    const int ntiles = a.nt * a.B * a.nseg, per_xcd = (ntiles + 7) / 8;
+    const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (vid >= ntiles) return;
+    const int tt = vid % a.nt, b = (vid / a.nt) % a.B, seg = vid / (a.nt * a.B);
+    const int T = a.T, F = a.F;
+    const int t0 = tt * TR, f0 = seg * a.fseg, f1 = min(F, f0 + a.fseg);
+    for (int i = threadIdx.x; i < NCONV * 256; i += NT) st4(&ws[i >> 8][(i & 255) * 4], ld4(a.w[i >> 8] + (i & 255) * 4));
+    float Bc[NCONV], Cc[NCONV];
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        float mean, rstd;
+        stats_finalize(a.slot[k], b, a.inv_n, mean, rstd);
+        const float m1 = (float)(a.red[k][kStatStride * b] * a.inv_n), m2 = (float)(a.red[k][kStatStride * b + 1] * a.inv_n);
+        // (workgroup-uniform: kept in scalar registers - the kernel has to fit 128 vector registers)
+        Bc[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m2 * rstd * rstd)));
+        Cc[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Bc[k] * mean - m1 * rstd)));
+        if (threadIdx.x < 64) coefA[k][threadIdx.x] = a.gamma[k][threadIdx.x] * rstd;
+    }
+    const int r = threadIdx.x >> 6, ch = threadIdx.x & 63;  // window pass: wave = tile row, lane = channel
+    const int ti = t0 + r;
+    const bool tvalid = ti < T;
+    const size_t ubase = (size_t)b * T * F * kH;
+    const float* inrow = a.in + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
+    float* outrow = a.dIn + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
+    const int q4 = (threadIdx.x & 15) * 4;  // staging: (pixel, channel quad)
+    float part[NCONV][16];
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[k][i] = 0.f;
+#pragma unroll 1
+    for (int fb = f0; fb < f1; fb += TC) {
+        float inv[TC], acc[TC];
+#pragma unroll
+        for (int j = 0; j < TC; ++j) inv[j] = inrow[(size_t)min(fb + j, F - 1) * kH];
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            inv[j] = (tvalid && fb + j < f1) ? inv[j] : 0.f;
+            acc[j] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NCONV; ++k) {
+            __syncthreads();
+            const float* dyb = a.dy[k] + ubase;
+            const float* xb = a.x[k] + ubase;
+            const float4 A4 = ld4(&coefA[k][q4]);
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));  // (the items' tile coordinates are recomputed per stage, as in the kernel above)
+#pragma unroll
+            for (int h = 0; h < NIT; h += 2) {  // two items (four 16-byte loads) in flight per thread: 128 registers = sixteen waves per CU
+                float4 vd[2], vx[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int item = tid + (h + i) * NT, px = min(item >> 4, R * CB - 1), pr = px / CB, pc = px - pr * CB;
+                    const int tq = min(max(t0 - 2 + pr, 0), T - 1), fq = min(max(fb - 2 + pc, 0), F - 1);
+                    const unsigned off = (((unsigned)tq * F + fq) * kH + q4) * 4u;
+                    vd[i] = ld4_off(dyb, off);
+                    vx[i] = ld4_off(xb, off);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int item = tid + (h + i) * NT, px = item >> 4, pr = px / CB, pc = px - pr * CB;
+                    const int tq = t0 - 2 + pr, fq = fb - 2 + pc;
+                    float4 d = f4(A4.x * vd[i].x - Bc[k] * vx[i].x + Cc[k], A4.y * vd[i].y - Bc[k] * vx[i].y + Cc[k], A4.z * vd[i].z - Bc[k] * vx[i].z + Cc[k],
+                                  A4.w * vd[i].w - Bc[k] * vx[i].w + Cc[k]);
+                    if (!(tq >= 0 && tq < T && fq >= 0 && fq < F)) d = f4(0, 0, 0, 0);
+                    if (px < R * CB) st4(tile + px * 64 + q4, d);
+                }
+            }
+            __syncthreads();
+            const float* trow0 = tile + r * RS + ch;
+            int always = 1;
+            asm volatile("" : "+s"(always));
+#pragma unroll
+            for (int jb = 0; jb < TC; jb += 4) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) if (always) {  // (one basic block per tap row: see the kernel above)
+                    const float* trow = trow0 + dt * RS;
+                    float wr[7];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) wr[c] = trow[(jb + c) * 64];
+#pragma unroll
+                    for (int dc = 0; dc < 4; ++dc) {
+                        const int tap = (3 - dt) * 4 + (3 - dc);
+                        const float w = ws[k][tap * 64 + ch];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            acc[jb + jj] = fmaf(w, wr[jj + dc], acc[jb + jj]);
+                            part[k][tap] = fmaf(inv[jb + jj], wr[jj + dc], part[k][tap]);
+                        }
+                    }
+                    asm volatile("" : "+s"(always));
+                }
+            }
+        }
+        if (tvalid) {
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if (fb + j < f1) outrow[(size_t)(fb + j) * kH] = acc[j];
+        }
+    }
+    // tap gradients: a wave holds one row's partial sums; waves 0-3 park theirs in LDS, waves 4-7 add theirs, one coalesced atomic per (tap, channel)
+    float* mine = spread_copy(a.scr, blockIdx.x);
+    float* redl = tile;  // [4][16][64]
+#pragma unroll
+    for (int k = 0; k < NCONV; ++k) {
+        __syncthreads();
+        if (r < 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) redl[(r * 16 + i) * 64 + ch] = part[k][i];
+        }
+        __syncthreads();
+        if (r >= 4) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) redl[((r - 4) * 16 + i) * 64 + ch] += part[k][i];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 1024; idx += NT)
+            atomicAdd(mine + k * 1024 + idx, redl[idx] + redl[1024 + idx] + redl[2048 + idx] + redl[3072 + idx]);
+    }
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -336,6 +470,8 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
 #define DWADJ(N, G) hipLaunchKernelGGL((dw_adjoint_kernel<N, G>), grid, dim3(256), 0, (hipStream_t)stream, a)
     if (mix) {
         hipLaunchKernelGGL((dw_adjoint_kernel<1, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (gln && nconv == 4 && !bias && mode == 0 && !accumulate) {  // the one caller of the four-convolution form: its own one-channel-per-lane kernel
+        hipLaunchKernelGGL(dw_adjoint4_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
     } else if (gln) {
         if (nconv == 1) DWADJ(1, true); else if (nconv == 2) DWADJ(2, true); else DWADJ(4, true);
     } else {
