@@ -19,6 +19,7 @@
 // one convolution are 32 registers, so four convolutions' partials (128) stay resident next to the accumulators; taps are read from LDS (broadcast).
 // Consecutive time tiles of an utterance run on the same XCD (the 1-D grid is re-mapped), so the halo rows a neighbour has just fetched are L2 hits.
 #include "common.h"
+#include "intdiv.h"
 
 namespace rtfs {
 
@@ -54,11 +55,7 @@ struct DwAdjArgs {
     unsigned mt, mf;              // ceil(2^32 / T), ceil(2^32 / F): nearest source index floor(i * in / out) without a division
 };
 
-// floor(x / d) for x * m < 2^64 with m = ceil(2^32 / d): the estimate is never low and at most one high
-__device__ __forceinline__ int div_magic(unsigned x, unsigned d, unsigned m) {
-    unsigned q = __umulhi(x, m);
-    return (int)(q * d > x ? q - 1 : q);
-}
+
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v ld2v(const float* p) { return *reinterpret_cast<const float2v*>(p); }
@@ -448,7 +445,7 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
     a.mode = mode, a.accumulate = accumulate ? 1 : 0, a.bias = bias ? 1 : 0;
     a.inv_n = 1.0 / ((double)T * F * kH);
     a.dIn = dIn;
-    a.mt = (unsigned)(((1ull << 32) + T - 1) / T), a.mf = (unsigned)(((1ull << 32) + F - 1) / F);
+    a.mt = div_magic_of(T), a.mf = div_magic_of(F);
     if (mode == 3) {
         if (!in_mix || in_Tg <= 0 || in_Fg <= 0 || in_Tg > T || in_Fg > F) return RTFS_EINVAL;
         for (int i = 0; i < 8; ++i)

@@ -14,6 +14,7 @@
 //   rtfs_gateway_bwd          gateway (dw1x1 + PReLU) backward with parameter-gradient reductions
 //   rtfs_axpy                 y += a * x
 #include "common.h"
+#include "intdiv.h"
 
 namespace rtfs {
 
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 // `ppw` groups of 16 positions per workgroup share one reduction epilogue (mix_gln_bwd_reduce_kernel's).
 __global__ __launch_bounds__(256) void d0_tail_bwd_kernel(const float* __restrict__ dD1, const float* __restrict__ w, const float* __restrict__ dG,
                                                           float* __restrict__ dN0, NormArg n, double* __restrict__ red, float* __restrict__ scr, int T,
-                                                          int T2, int ppw) {
+                                                          int T2, int ppw, unsigned mT, unsigned mT2) {
     __shared__ __attribute__((aligned(16))) float ws[16 * 64];
     __shared__ __attribute__((aligned(16))) float lds[4][2][64];
     __shared__ float redl[4][2];
@@ -386,6 +387,8 @@ __global__ __launch_bounds__(256) void d0_tail_bwd_kernel(const float* __restric
         if (p >= T * kF) break;
         const int t = p / kF, f = p - t * kF;
         float4 acc = f4(0, 0, 0, 0);
+        // (round 6: the window arithmetic below divides by the kernel arguments T / T2 eight times per position; as hardware-assisted divisions those were a third
+        // of this kernel's vector instructions - 283 us against 186 us of HBM time; csrc/intdiv.h)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {  // stride-2 transposed convolution (padding 1): to = (t + 1 - dt) / 2 where that is an integer in range
             const int tn = t + 1 - dt;
@@ -401,9 +404,9 @@ __global__ __launch_bounds__(256) void d0_tail_bwd_kernel(const float* __restric
                 acc = fma4(ld4(&ws[(dt * 4 + df) * 64 + c4]), ld4(ob + ((size_t)to * kF2 + fo) * kH), acc);
             }
         }
-        const int tc = (t * T2) / T, fc = (f * kF2) / kF;  // pooling adjoint: the windows that contain (t, f)
+        const int tc = div_magic((unsigned)(t * T2), T, mT), fc = (f * kF2) / kF;  // pooling adjoint: the windows that contain (t, f)
         for (int t2 = max(tc - 1, 0); t2 <= min(tc + 1, T2 - 1); ++t2) {
-            const int ts = (t2 * T) / T2, te = ((t2 + 1) * T + T2 - 1) / T2;
+            const int ts = div_magic((unsigned)(t2 * T), T2, mT2), te = div_magic((unsigned)((t2 + 1) * T + T2 - 1), T2, mT2);
             if (t < ts || t >= te) continue;
             for (int f2 = max(fc - 1, 0); f2 <= min(fc + 1, kF2 - 1); ++f2) {
                 const int fs = (f2 * kF) / kF2, fe = ((f2 + 1) * kF + kF2 - 1) / kF2;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(256) void mix_bwd_glob_kernel(const float* __restri
 // coalesced atomic each, the 6 per-utterance sums as fp64 atomics.   red: [3][B][kStatStride] (loc, gate, glob)
 __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __restrict__ dOut, NormArg loc, NormArg gate, NormArg glob,
                                                                  float* __restrict__ dNgate, float* __restrict__ dNglob, float* __restrict__ sig, double* __restrict__ red,
-                                                                 float* __restrict__ scr, int T, int F, int Tg, int Fg, int B, int qpt) {
+                                                                 float* __restrict__ scr, int T, int F, int Tg, int Fg, int B, int qpt, unsigned mTg, unsigned mFg) {
     __shared__ __attribute__((aligned(16))) float lds[4][6][64];
     __shared__ float redl[4][6];
     const int b = blockIdx.y;
@@ -521,9 +524,10 @@ __global__ __launch_bounds__(256) void mix_gln_bwd_reduce_kernel(const float* __
     for (int it = 0; it < qpt; ++it) {  // qpt groups of 16 low-resolution positions per workgroup: one epilogue for all of them
         const int q = (blockIdx.x * qpt + it) * 16 + (threadIdx.x >> 4);
         if (q >= Tg * Fg) break;
-        const int tg = q / Fg, fg = q - tg * Fg;
-        const int t0 = (tg * T + Tg - 1) / Tg, t1 = min(T, ((tg + 1) * T + Tg - 1) / Tg);
-        const int f0 = (fg * F + Fg - 1) / Fg, f1 = min(F, ((fg + 1) * F + Fg - 1) / Fg);
+        // (round 6: five divisions by the kernel arguments Tg / Fg per position as multiply-high + correction, csrc/intdiv.h)
+        const int tg = div_magic((unsigned)q, Fg, mFg), fg = q - tg * Fg;
+        const int t0 = div_magic((unsigned)(tg * T + Tg - 1), Tg, mTg), t1 = min(T, div_magic((unsigned)((tg + 1) * T + Tg - 1), Tg, mTg));
+        const int f0 = div_magic((unsigned)(fg * F + Fg - 1), Fg, mFg), f1 = min(F, div_magic((unsigned)((fg + 1) * F + Fg - 1), Fg, mFg));
         const size_t o = ((size_t)b * Tg * Fg + q) * kH + c4;
         const float4 xg = sub4(ld4(gate.x + o), gm) * gr, xe = sub4(ld4(glob.x + o), em) * er;
         float4 Dx = f4(0, 0, 0, 0), Bs = f4(0, 0, 0, 0);
@@ -778,7 +782,7 @@ int rtfs_d0_tail_bwd(const float* dD1, const float* w, const float* dG, float* d
     if (!scr) return RTFS_ELAUNCH;
     NormArg n{D0, d0_stats, 1.0 / ((double)T * kF * kH), gamma, beta};
     const int ppw = 8;
-    LAUNCH(d0_tail_bwd_kernel, dim3((T * kF + 16 * ppw - 1) / (16 * ppw), B), dD1, w, dG, dN0, n, red, scr, T, T2, ppw);
+    LAUNCH(d0_tail_bwd_kernel, dim3((T * kF + 16 * ppw - 1) / (16 * ppw), B), dD1, w, dG, dN0, n, red, scr, T, T2, ppw, div_magic_of(T), div_magic_of(T2));
     return spread_finish(scr, SpreadOut{{dgamma, dbeta}, {kH, kH}}, (hipStream_t)stream);
 }
 
@@ -815,7 +819,8 @@ int rtfs_mix_gln_bwd_sig(const float* dOut, const float* loc, const double* loc_
     NormArg l{loc, loc_stats, 1.0 / ((double)T * F * kH), loc_g, loc_b}, g{gate, gate_stats, 1.0 / ((double)Tg * Fg * kH), gate_g, gate_b},
         e{glob, glob_stats, 1.0 / ((double)Tg * Fg * kH), glob_g, glob_b};
     const int qpt = 8;  // 128 low-resolution positions per workgroup (measured 1 ... 16: the epilogue's 384 atomics stop showing from 4 up)
-    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 16 * qpt - 1) / (16 * qpt), B), dOut, l, g, e, dNgate, dNglob, sig, red, scr, T, F, Tg, Fg, B, qpt);
+    LAUNCH(mix_gln_bwd_reduce_kernel, dim3((Tg * Fg + 16 * qpt - 1) / (16 * qpt), B), dOut, l, g, e, dNgate, dNglob, sig, red, scr, T, F, Tg, Fg, B, qpt, div_magic_of(Tg),
+           div_magic_of(Fg));
     const int rc = spread_finish(scr, SpreadOut{{dgb[0], dgb[1], dgb[2], dgb[3], dgb[4], dgb[5]}, {kH, kH, kH, kH, kH, kH}}, (hipStream_t)stream);
     if (rc != RTFS_OK) return rc;
     if (dLoc) LAUNCH(mix_gln_bwd_apply_kernel, dim3((T * F + 15) / 16, B), dOut, l, g, red, dLoc, T, F, Tg, Fg);  // (NULL: the consumer applies it on load, rtfs_dw_adjoint_mix, from `sig`)

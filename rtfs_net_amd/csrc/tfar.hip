@@ -10,6 +10,7 @@
 // Thread mapping for all H=64 tensors: 16 consecutive lanes own the 64 channels of one pixel (float4 each).
 #include <type_traits>
 #include "common.h"
+#include "intdiv.h"
 
 #include <algorithm>
 
@@ -48,6 +49,7 @@ struct DwArgs {
     // ^ = nearest up-sampling from (Tg, Fg)), formed on the way into LDS - the mixed tensor never exists in HBM
     NormRefLite gate, glob;
     int Tg, Fg;
+    unsigned mt, mf;  // ceil(2^32 / Tin), ceil(2^32 / Fin): the nearest source index floor(i * in / out) of the mix without a division (csrc/intdiv.h, round 6)
     // GADD (dwconv_s1_kernel<1, 1, 4, true>): addout[pixel] = addsrc[pixel] + gLN(in)[pixel] rides along (tdanet.py:117-118: G = pooled + gLN(D1))
     const float* addsrc;
     float* addout;
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256, (NCONV <= 2 ? 3 : 2)) void dwconv_s1_kernel(Dw
                 const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
                 vn[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);  // saddr + 32-bit offset
                 if (MODE == 3) {
-                    const unsigned og = (((unsigned)nearest_src(ti, a.Tg, T) * a.Fg + nearest_src(fi, a.Fg, F)) * kH + c4) * 4u;
+                    const unsigned og = (((unsigned)div_magic((unsigned)ti * a.Tg, T, a.mt) * a.Fg + div_magic((unsigned)fi * a.Fg, F, a.mf)) * kH + c4) * 4u;
                     gn[i] = ld4_off(gateb, og), en[i] = ld4_off(globb, og);
                 }
             }
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256, (NCONV <= 2 ? 3 : 2)) void dwconv_s1_kernel(Dw
                 const int ti = min(max(t0 - 1 + r, 0), T - 1), fi = min(max(fb - 1 + c, 0), F - 1);
                 vh[i] = ld4_off(inb, (((unsigned)ti * F + fi) * kH + c4) * 4u);
                 if (MODE == 3) {
-                    const unsigned og = (((unsigned)nearest_src(ti, a.Tg, T) * a.Fg + nearest_src(fi, a.Fg, F)) * kH + c4) * 4u;
+                    const unsigned og = (((unsigned)div_magic((unsigned)ti * a.Tg, T, a.mt) * a.Fg + div_magic((unsigned)fi * a.Fg, F, a.mf)) * kH + c4) * 4u;
                     gh[i] = ld4_off(gateb, og), eh[i] = ld4_off(globb, og);
                 }
             }
@@ -1012,7 +1014,7 @@ int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma,
         a.stats[j] = j < nconv ? stats_out[j] : nullptr;
     }
     a.gate = a.glob = NormRefLite{nullptr, nullptr, 0.0, nullptr, nullptr};
-    a.Tg = a.Fg = 0;
+    a.Tg = a.Fg = 0, a.mt = a.mf = 0;
     a.addsrc = nullptr, a.addout = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
@@ -1046,6 +1048,7 @@ int rtfs_dwconv_mix_fwd(const float* loc, const double* loc_stats, const float* 
     a.gate = NormRefLite{gate, gate_stats, ng, gate_g, gate_b};
     a.glob = NormRefLite{glob, glob_stats, ng, glob_g, glob_b};
     a.Tg = Tg, a.Fg = Fg;
+    a.mt = div_magic_of(T), a.mf = div_magic_of(F);
     a.addsrc = nullptr, a.addout = nullptr;
     return launch_dw<1, 3>(a, B, (hipStream_t)stream);
 }
@@ -1062,7 +1065,7 @@ int rtfs_dwconv_gadd_fwd(const float* in, const double* stats_in, const float* g
     for (int j = 0; j < kMaxConv; ++j) a.w[j] = nullptr, a.bias[j] = nullptr, a.out[j] = nullptr, a.stats[j] = nullptr;
     a.w[0] = w, a.out[0] = out, a.stats[0] = stats_out;
     a.gate = a.glob = NormRefLite{nullptr, nullptr, 0.0, nullptr, nullptr};
-    a.Tg = a.Fg = 0;
+    a.Tg = a.Fg = 0, a.mt = a.mf = 0;
     a.addsrc = pooled, a.addout = G;
     int nseg = F >= 96 ? 4 : 3;
     const long long wg0 = (long long)((T + 15) / 16) * B;

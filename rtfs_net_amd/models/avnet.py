@@ -305,6 +305,13 @@ class AVNet(nn.Module):
         step = StepCtx()
         x0, a0, a_emb = AVNetHipStageA.apply(self._trainer, names, step, x.to(torch.float32), *[params[n] for n in names])
         side.wait_event(inputs_ready)
+        if side is not cur:
+            # The video branch's forward AND backward kernels read the caller's lip-embedding tensor on the side stream, the backward as a tensor saved by
+            # autograd.  It was allocated on the caller's stream: if the caller drops it (`model(mix, emb.cuda())`), the block goes back to that stream's pool the
+            # moment the last side-stream node has been ENQUEUED, and the main stream's next allocation of the running backward can overwrite it before the
+            # side-stream kernel has read it (round 6: seen as a wrong d(video gateway weight) - the product of d(out) with this very tensor - in 27 of 60 fresh
+            # processes once the box was warm, never in the first 20).  The allocator has to know about the second stream.
+            mouth_embedding.record_stream(side)
         with torch.cuda.stream(side):
             vin = self.video_bottleneck(mouth_embedding.to(torch.float32))
             vb = rm.video_net.get_block(0)

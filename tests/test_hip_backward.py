@@ -205,3 +205,32 @@ def test_input_of_caf_video_side_gets_gradient():
     e = emb.cuda().requires_grad_(True)
     model(mix.cuda(), e).square().mean().backward()
     assert e.grad is not None and torch.isfinite(e.grad).all() and float(e.grad.abs().max()) > 0
+
+
+def test_video_branch_backward_after_the_caller_dropped_the_embedding():
+    """Round 6 (found by looping the suite's first test in fresh processes: 27 wrong runs of 60 on a warm box, d(video gateway weight) off by 100 %): the video
+    branch runs on a side stream, forward and backward, and its backward reads the CALLER's lip-embedding tensor (saved by autograd: the gateway's weight gradient
+    is d(out) x that tensor).  A caller that drops the tensor - `model(mix, emb.cuda())` - hands its block back to the main stream's allocator pool as soon as the
+    last side-stream node is enqueued; the running backward's next main-stream allocation can then overwrite it before the side-stream kernel has read it.
+    `AVNet._forward_autograd` now records the side stream on the tensor.  Reproduced deterministically: the side stream is kept busy (`torch.cuda._sleep`) while the
+    backward is enqueued, and the main stream churns through small allocations - without the record, the gradient of the video gateway is garbage."""
+    training, B, L, R, Tv = CASES[0]
+    model, sd, cfg = make_model(R, "cuda")
+    z = load_npz(case_name("plain", training, B, L, R, Tv) + ".npz")
+    mix, _, _ = synth.synth_inputs(B, L, Tv)
+    model.train(training)
+    wgt = torch.randn(B, 1, L, generator=torch.Generator().manual_seed(GRAD_WEIGHT_SEED)).cuda()
+    mix = mix.cuda()
+    model(mix, torch.from_numpy(z["emb"]).cuda()).sum().backward()  # (creates the side stream)
+    model.zero_grad(set_to_none=True)
+    out = model(mix, torch.from_numpy(z["emb"]).cuda())  # the embedding tensor is a temporary: only autograd's saved tensors keep it alive
+    loss = (out * wgt).sum()
+    with torch.cuda.stream(model._glue_stream):
+        torch.cuda._sleep(200_000_000)  # ~0.1 s: the backward's side-stream nodes queue behind it while the host enqueues the rest
+    loss.backward()
+    junk = [torch.full((B * 512 * Tv,), 7.0e3, device="cuda") for _ in range(256)]  # main-stream allocations of the embedding's size class while the side stream sleeps
+    torch.cuda.synchronize()
+    del junk
+    name = "refinement_module.video_net.blocks.gateway.full_layer.2.weight"
+    got, ref = dict(model.named_parameters())[name].grad, torch.from_numpy(z["grad." + name])
+    assert rel(got, ref) < 3e-3, rel(got, ref)
