@@ -387,33 +387,49 @@ __global__ __launch_bounds__(256) void d0_tail_bwd_kernel(const float* __restric
         if (p >= T * kF) break;
         const int t = p / kF, f = p - t * kF;
         float4 acc = f4(0, 0, 0, 0);
-        // (round 6: the window arithmetic below divides by the kernel arguments T / T2 eight times per position; as hardware-assisted divisions those were a third
-        // of this kernel's vector instructions - 283 us against 186 us of HBM time; csrc/intdiv.h)
+        // Round 6: branch-free.  A load under a divergent branch is waited for before the next one issues (DESIGN.md rule 1), and this loop nest was 16 + 9 of
+        // them per position (283 us against 186 us of HBM time).  (a) Stride-2 transposed convolution (padding 1): to = (t + 1 - dt) / 2 is an integer for exactly
+        // two dt (dt = pt, pt + 2 with pt = (t + 1) & 1), likewise df: four candidate taps, loaded from clamped addresses in one batch and masked.  (b) Pooling
+        // adjoint: the windows [floor(i in / out), ceil((i + 1) in / out)) that contain (t, f) are among t2 = tc - 1 .. tc + 1, f2 = fc - 1 .. fc + 1: nine
+        // masked loads of dG (neighbouring positions share them in L1).  The divisions by the kernel arguments T / T2 are multiply-high + correction (intdiv.h).
+        {
+            const int pt = (t + 1) & 1, pf = (f + 1) & 1;
+            float4 tv[4], tw[4];
+            float tm[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {  // stride-2 transposed convolution (padding 1): to = (t + 1 - dt) / 2 where that is an integer in range
-            const int tn = t + 1 - dt;
-            if (tn < 0 || (tn & 1)) continue;
-            const int to = tn >> 1;
-            if (to >= T2) continue;
+            for (int ia = 0; ia < 2; ++ia) {
+                const int dt = pt + 2 * ia, tn = t + 1 - dt, to = tn >> 1;
+                const bool okt = tn >= 0 && to < T2;
 #pragma unroll
-            for (int df = 0; df < 4; ++df) {
-                const int fn = f + 1 - df;
-                if (fn < 0 || (fn & 1)) continue;
-                const int fo = fn >> 1;
-                if (fo >= kF2) continue;
-                acc = fma4(ld4(&ws[(dt * 4 + df) * 64 + c4]), ld4(ob + ((size_t)to * kF2 + fo) * kH), acc);
+                for (int ib = 0; ib < 2; ++ib) {
+                    const int df = pf + 2 * ib, fn = f + 1 - df, fo = fn >> 1;
+                    const bool ok = okt && fn >= 0 && fo < kF2;
+                    tv[ia * 2 + ib] = ld4(ob + ((size_t)min(max(to, 0), T2 - 1) * kF2 + min(max(fo, 0), kF2 - 1)) * kH);
+                    tw[ia * 2 + ib] = ld4(&ws[(dt * 4 + df) * 64 + c4]);
+                    tm[ia * 2 + ib] = ok ? 1.f : 0.f;
+                }
             }
-        }
-        const int tc = div_magic((unsigned)(t * T2), T, mT), fc = (f * kF2) / kF;  // pooling adjoint: the windows that contain (t, f)
-        for (int t2 = max(tc - 1, 0); t2 <= min(tc + 1, T2 - 1); ++t2) {
-            const int ts = div_magic((unsigned)(t2 * T), T2, mT2), te = div_magic((unsigned)((t2 + 1) * T + T2 - 1), T2, mT2);
-            if (t < ts || t >= te) continue;
-            for (int f2 = max(fc - 1, 0); f2 <= min(fc + 1, kF2 - 1); ++f2) {
-                const int fs = (f2 * kF) / kF2, fe = ((f2 + 1) * kF + kF2 - 1) / kF2;
-                if (f < fs || f >= fe) continue;
-                const float inv = 1.0f / (float)((te - ts) * (fe - fs));
-                acc = fma4(ld4(gb + ((size_t)t2 * kF2 + f2) * kH), f4(inv, inv, inv, inv), acc);
+            const int tc = div_magic((unsigned)(t * T2), T, mT), fc = (f * kF2) / kF;
+            float4 pv[9];
+            float pm[9];
+#pragma unroll
+            for (int ia = 0; ia < 3; ++ia) {
+                const int t2 = tc - 1 + ia, t2c = min(max(t2, 0), T2 - 1);
+                const int ts = div_magic((unsigned)(t2c * T), T2, mT2), te = div_magic((unsigned)((t2c + 1) * T + T2 - 1), T2, mT2);
+                const bool okt = t2 >= 0 && t2 < T2 && t >= ts && t < te;
+#pragma unroll
+                for (int ib = 0; ib < 3; ++ib) {
+                    const int f2 = fc - 1 + ib, f2c = min(max(f2, 0), kF2 - 1);
+                    const int fs = (f2c * kF) / kF2, fe = ((f2c + 1) * kF + kF2 - 1) / kF2;
+                    const bool ok = okt && f2 >= 0 && f2 < kF2 && f >= fs && f < fe;
+                    pv[ia * 3 + ib] = ld4(gb + ((size_t)t2c * kF2 + f2c) * kH);
+                    pm[ia * 3 + ib] = ok ? __builtin_amdgcn_rcpf((float)((te - ts) * (fe - fs))) : 0.f;
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma4(tw[k] * tm[k], tv[k], acc);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fma4(pv[k], f4(pm[k], pm[k], pm[k], pm[k]), acc);
         }
         const size_t o = ((size_t)b * T * kF + p) * kH + c4;
         const float4 v = acc + ld4(dN0 + o);
