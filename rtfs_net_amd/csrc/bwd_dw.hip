@@ -274,17 +274,21 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(D
 }
 
 
-// The four global convolutions of the TFAR fusion layers (input G3 = the attention's output): four gLN'd convolutions, raw input, fresh dIn - ONE channel per lane.
-// In the two-channels-per-lane kernel above four convolutions' partial sums are 128 registers: 256 registers with spills, two workgroups per CU, 2.6 TB/s of
-// algorithmic bytes against 4.3 for one convolution at four workgroups per CU.  With one channel per lane (a wave = one tile row x 64 channels, 512 threads = 8 rows)
-// they are 64, the kernel fits 128 registers and sixteen waves per CU: the staging latency of one workgroup hides under the window passes of the others again.
-// Scalar v_fma_f32 / ds_read_b32 instead of packed / 64-bit ones: twice the instructions for the same arithmetic, which this HBM-bound kernel has room for.
-__global__ __launch_bounds__(512, 2) void dw_adjoint4_kernel(DwAdjArgs a) {
-    constexpr int NCONV = 4, TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64, NT = 512;
+// Two or four gLN'd convolutions with a fresh dIn (the concat layer's global embedding + gate, input = the TFAR mix F1; the four global convolutions of the fusion
+// layers, input G3 = the attention's output) - ONE channel per lane.  In the two-channels-per-lane kernel above four convolutions' partial sums are 128 registers:
+// 256 registers with spills, two workgroups per CU, 2.6 TB/s of algorithmic bytes against 4.3 for one convolution at four workgroups per CU.  With one channel per
+// lane (a wave = one tile row x 64 channels, 512 threads = 8 rows) they are 64, the kernel fits 128 registers and sixteen waves per CU: the staging latency of one
+// workgroup hides under the window passes of the others again.  Scalar v_fma_f32 / ds_read_b32 instead of packed / 64-bit ones: twice the instructions for the
+// same arithmetic, which this HBM-bound kernel has room for.  Input raw (mode 0) or re-formed from a TFAR mix (mode 3).
+template <int NCONV, bool MIX3>
+__global__ __launch_bounds__(512, 2) void dw_adjoint1c_kernel(DwAdjArgs a) {
+    constexpr int TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64, NT = 512;
     constexpr int NIT = (R * CB * 16 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
     __shared__ __attribute__((aligned(16))) float ws[NCONV][16 * 64];
     __shared__ __attribute__((aligned(16))) float coefA[NCONV][64];
+    __shared__ int mcol[TC];
+    __shared__ float mixc[6][64];  // mode 3: gLN of the mix's local / gate / global tensors folded (scale, shift each)
     const int ntiles = a.nt * a.B * a.nseg, per_xcd = (ntiles + 7) / 8;
     const int vid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (vid >= ntiles) return;
@@ -309,6 +313,21 @@ __global__ __launch_bounds__(512, 2) void dw_adjoint4_kernel(DwAdjArgs a) {
     const size_t ubase = (size_t)b * T * F * kH;
     const float* inrow = a.in + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
     float* outrow = a.dIn + ubase + (size_t)(tvalid ? ti : 0) * F * kH + ch;
+    const float *mgrow = nullptr, *merow = nullptr;
+    if (MIX3) {
+        float lm, lr, gm, gr, em, er;
+        stats_finalize(a.in_slot, b, a.inv_n, lm, lr);
+        stats_finalize(a.mgate_slot, b, a.m_inv_n, gm, gr);
+        stats_finalize(a.mglob_slot, b, a.m_inv_n, em, er);
+        if (threadIdx.x < 64) {
+            const float ls = a.in_gamma[threadIdx.x] * lr, gs = a.mgate_gamma[threadIdx.x] * gr, es = a.mglob_gamma[threadIdx.x] * er;
+            mixc[0][threadIdx.x] = ls, mixc[1][threadIdx.x] = a.in_beta[threadIdx.x] - lm * ls;
+            mixc[2][threadIdx.x] = gs, mixc[3][threadIdx.x] = a.mgate_beta[threadIdx.x] - gm * gs;
+            mixc[4][threadIdx.x] = es, mixc[5][threadIdx.x] = a.mglob_beta[threadIdx.x] - em * es;
+        }
+        const size_t lrow = ((size_t)b * a.mTg + div_magic((unsigned)(tvalid ? ti : 0) * a.mTg, T, a.mt)) * a.mFg * kH + ch;
+        mgrow = a.mgate + lrow, merow = a.mglob + lrow;
+    }
     const int q4 = (threadIdx.x & 15) * 4;  // staging: (pixel, channel quad)
     float part[NCONV][16];
 #pragma unroll
@@ -320,6 +339,22 @@ __global__ __launch_bounds__(512, 2) void dw_adjoint4_kernel(DwAdjArgs a) {
         float inv[TC], acc[TC];
 #pragma unroll
         for (int j = 0; j < TC; ++j) inv[j] = inrow[(size_t)min(fb + j, F - 1) * kH];
+        if (MIX3) {  // the input pixel = gLN(l) * sigmoid(gLN(gate))^ + gLN(glob)^, as rtfs_dwconv_mix_fwd forms it
+            __syncthreads();
+            if (threadIdx.x < TC) mcol[threadIdx.x] = div_magic((unsigned)min(fb + (int)threadIdx.x, F - 1) * a.mFg, F, a.mf) * kH;
+            __syncthreads();
+            int moff = ch;
+            asm volatile("" : "+v"(moff));
+            const float ls = mixc[0][moff], lh = mixc[1][moff], gs = mixc[2][moff], gh = mixc[3][moff], es = mixc[4][moff], eh = mixc[5][moff];
+#pragma unroll
+            for (int j0 = 0; j0 < TC; j0 += 4) {
+                float vg[4], ve[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vg[j] = mgrow[mcol[j0 + j]], ve[j] = merow[mcol[j0 + j]];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) inv[j0 + j] = fmaf(fmaf(inv[j0 + j], ls, lh), sigmoidf_fast(fmaf(vg[j], gs, gh)), fmaf(ve[j], es, eh));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
             inv[j] = (tvalid && fb + j < f1) ? inv[j] : 0.f;
@@ -454,7 +489,7 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
         a.mglob = (const float*)in_mix[4], a.mglob_slot = (const double*)in_mix[5], a.mglob_gamma = (const float*)in_mix[6], a.mglob_beta = (const float*)in_mix[7];
         a.mTg = in_Tg, a.mFg = in_Fg, a.m_inv_n = 1.0 / ((double)in_Tg * in_Fg * kH);
     }
-    if (mode == 3 && nconv > 2) return RTFS_EINVAL;
+    if (mode == 3 && nconv > 2 && !(x != nullptr && !accumulate)) return RTFS_EINVAL;  // (four convolutions with a mixed input: the one-channel-per-lane kernel only)
     const bool mix = gate_s != nullptr;
     if (mix) {
         if (nconv != 1 || !gln || Tg <= 0 || Fg <= 0 || Tg > T || Fg > F) return RTFS_EINVAL;
@@ -467,8 +502,11 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
 #define DWADJ(N, G) hipLaunchKernelGGL((dw_adjoint_kernel<N, G>), grid, dim3(256), 0, (hipStream_t)stream, a)
     if (mix) {
         hipLaunchKernelGGL((dw_adjoint_kernel<1, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    } else if (gln && nconv == 4 && !bias && mode == 0 && !accumulate) {  // the one caller of the four-convolution form: its own one-channel-per-lane kernel
-        hipLaunchKernelGGL(dw_adjoint4_kernel, grid, dim3(512), 0, (hipStream_t)stream, a);
+    } else if (gln && nconv >= 2 && !bias && (mode == 0 || mode == 3) && !accumulate) {  // the step's two- and four-convolution groups: one channel per lane
+        if (nconv == 2 && mode == 3) hipLaunchKernelGGL((dw_adjoint1c_kernel<2, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        else if (nconv == 2) hipLaunchKernelGGL((dw_adjoint1c_kernel<2, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        else if (mode == 3) hipLaunchKernelGGL((dw_adjoint1c_kernel<4, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((dw_adjoint1c_kernel<4, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
     } else if (gln) {
         if (nconv == 1) DWADJ(1, true); else if (nconv == 2) DWADJ(2, true); else DWADJ(4, true);
     } else {
