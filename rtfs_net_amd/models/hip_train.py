@@ -784,7 +784,8 @@ class HipTrainer:
         cl_, cg_, cgate_ = bw["concat_layers.0.local_embedding"], bw["concat_layers.0.global_embedding"], bw["concat_layers.0.global_gate"]
         # residual_conv: bias, weight (needs `expanded`), input gradient
         E = full()
-        self._call("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
+        # (round 6: `expanded` is re-formed ON THE SIDE STREAM - its only reader is the weight-gradient launch behind it there, the adjoint chain does not wait for it)
+        self._wg("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
         self._wg("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
         dE = full()
         self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
