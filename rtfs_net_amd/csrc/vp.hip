@@ -119,11 +119,14 @@ __global__ __launch_bounds__(256) void vp_block_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 1; i < 4; ++i) T[i] = (T[i - 1] - 1) / 2 + 1;
     const int Tg = T[3], sumT = T[0] + T[1] + T[2] + T[3];
+    // The GlobalAttention stage re-uses the W1..W3 span for 576 Tg floats of temporaries: that fits 3 x 64 x T0 from three frames on; with one or two frames
+    // (T0 < 3 Tg) the buffers are spaced for 3 Tg columns instead (round 6: until then the stage overran the span and 1 - 2 frames went to the PyTorch modules)
+    const int Tw = max(T[0], 3 * Tg);
     float* DS = lds;                       // ds0..ds3, [64][Ti] each
-    float* W1 = DS + VH * sumT;            // three [64][T0] work buffers
-    float* W2 = W1 + VH * T[0];
-    float* W3 = W2 + VH * T[0];
-    float* SM = W3 + VH * T[0];            // VSM floats: pooled g + attention / IMS temporaries
+    float* W1 = DS + VH * sumT;            // three [64][T0] work buffers (capacity [64][Tw])
+    float* W2 = W1 + VH * Tw;
+    float* W3 = W2 + VH * Tw;
+    float* SM = W3 + VH * Tw;              // VSM floats: pooled g + attention / IMS temporaries
     float* dsp[4] = {DS, DS + VH * T[0], DS + VH * (T[0] + T[1]), DS + VH * (T[0] + T[1] + T[2])};
     const float* xb = x + (size_t)b * VIN * Tv;
     const float gslope = P[VpOff::gslope], pslope = P[VpOff::pslope];
@@ -349,13 +352,14 @@ extern "C" {
 int rtfs_vp_param_count(void) { return VpOff::total; }
 
 // x, out: [B][512][Tv] (the reference's NCT layout of the lip embedding); params: rtfs_vp_param_count() floats; pe: [>= Tg][64] rows
-// of the positional-encoding buffer.  3 <= Tv <= 100 (25 fps x 4 s).
+// of the positional-encoding buffer.  1 <= Tv <= 100 (25 fps x 4 s).
 int rtfs_vp_block_fwd(const float* x, const float* params, const float* pe, float* out, int B, int Tv, void* stream) {
-    if (B <= 0 || Tv < 3 || Tv > VMAXT) return RTFS_EINVAL;  // (1 and 2 frames - 40 / 80 ms of video - do not match the modules: PyTorch glue, hip_path.py)
+    if (B <= 0 || Tv < 1 || Tv > VMAXT) return RTFS_EINVAL;
     int T = Tv, sumT = Tv;
     for (int i = 1; i < 4; ++i) T = (T - 1) / 2 + 1, sumT += T;
     if (T > 16) return RTFS_EINVAL;
-    const size_t bytes = ((size_t)VH * (sumT + 3 * Tv) + VSM) * sizeof(float);
+    const int Tw = Tv > 3 * T ? Tv : 3 * T;  // (the kernel's work-buffer spacing)
+    const size_t bytes = ((size_t)VH * (sumT + 3 * Tw) + VSM) * sizeof(float);
     static bool attr_set[16] = {};  // the attribute is per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return RTFS_ELAUNCH;

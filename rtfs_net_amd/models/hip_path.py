@@ -451,7 +451,7 @@ class HipForward:
             vin = (m.video_bottleneck(emb.to(torch.float32)) if bottleneck else emb.to(torch.float32)).contiguous()  # identity for RTFS-Net (kernel_size -1)
             vblock = m.refinement_module.video_net.get_block(0)
             use_hip = w["vp"] is not None and not self.vp_glue
-            if use_hip and 3 <= Tv <= 100:  # (round 5: the kernel matches the modules from 3 frames on; it was only tested from 8)
+            if use_hip and 1 <= Tv <= 100:  # (round 6: from ONE frame on - the attention stage's temporaries overran their LDS span below three)
                 v1 = torch.empty_like(vin)
                 lib.call("rtfs_vp_block_fwd", vin, w["vp"], w["vp_pe"], v1, B, Tv)  # whole VP block, one workgroup per utterance
             elif use_hip and 100 < Tv <= 4096:
@@ -461,9 +461,9 @@ class HipForward:
 
                 v1 = vp_block_eval(vblock, vin, (pw._scal["refinement_module.video_net.blocks.gateway.full_layer.4.weight"],
                                                  pw._scal["refinement_module.video_net.blocks.projection.full_layer.4.weight"]))
-            else:  # other video_params / one or two frames: PyTorch-ROCm glue (models/modules.py)
+            else:  # other video_params (or RTFS_DISABLE=vp_hip): PyTorch-ROCm glue (models/modules.py)
                 v1 = vblock(vin).contiguous()
-            self.vp_ran_as_modules = not (use_hip and 3 <= Tv <= 4096)  # (forward hooks: torch fires the modules' own, models/stage_views.py the kernels')
+            self.vp_ran_as_modules = not (use_hip and 1 <= Tv <= 4096)  # (forward hooks: torch fires the modules' own, models/stage_views.py the kernels')
             # the CAF cell's video side (one workgroup per utterance, 64 us) rides on the side stream as well
             lib.call("rtfs_caf_video_fwd", v1, w["caf_att_w"], w["caf_att_b"], w["caf_att_g"], w["caf_att_be"], w["caf_rs_w"], w["caf_rs_b"],
                      w["caf_rs_g"], w["caf_rs_be"], att, rsz, B, Tv)

@@ -6,7 +6,7 @@ offers above them works (models/stage_views.py): the five stage modules of AVNet
 one (NCHW in / out), and forward hooks on an RTFS block, its direct children, the VP block and the
 CAF cell fire with the module's inputs and output.  Only the tiny video-branch (VP) block -- 50
 tokens, ~0.05 % of the MACs, SURVEY.md §2 row 9 / §8 a9 -- also has a torch `forward` (PyTorch-ROCm
-glue for one or two video frames).
+glue: the training step on fewer than 8 video frames, `RTFS_DISABLE=vp_hip`).
 
 Naming follows the reference so that checkpoints load unchanged:
   ConvNormAct.full_layer.{0 pre_norm,1 pre_act,2 conv,3 norm,4 act}   src/models/layers/conv_layers.py:121-127

@@ -293,7 +293,7 @@ def fire_refinement_hooks(hip, pw, taps, stats, a0_cl, audio_nchw, video, B, T, 
             vb = rm.video_net.get_block(0)
             fusion = rm.crossmodal_fusion.get_fusion_block(0)
             need_caf = _has_hooks(fusion) or _has_hooks(fusion.audio_lstm)
-            if _has_hooks(vb) and not hip.vp_ran_as_modules:  # (as PyTorch modules - one or two video frames - torch has fired them already)
+            if _has_hooks(vb) and not hip.vp_ran_as_modules:  # (as PyTorch modules - RTFS_DISABLE=vp_hip - torch has fired them already)
                 _fire(vb, (video,), taps["vp"])
             if need_caf:
                 caf_cl = taps["caf"] if last_only else minus(taps["caf_plus_a0"], a0_cl)

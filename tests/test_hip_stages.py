@@ -108,7 +108,7 @@ def test_vp_block(run):
     assert rel(run["taps"]["vp"], run["otaps"]["vp"]) < 5e-5
 
 
-@pytest.mark.parametrize("Tv", [3, 4, 5, 7, 8, 9, 25, 50, 63, 64, 65, 100])
+@pytest.mark.parametrize("Tv", [1, 2, 3, 4, 5, 7, 8, 9, 25, 50, 63, 64, 65, 100])
 def test_vp_block_lengths_match_glue(Tv):
     """every supported length (ragged down-sampling chains, two-pass lane = t loops) against the PyTorch-glue modules"""
     import copy
