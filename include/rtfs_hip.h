@@ -481,14 +481,12 @@ int rtfs_caf_bn_adjoint(const float* R_loc, const float* R_glob, const double* n
  * from x[k] (pre-norm output), x_stats[k] (its forward statistics), red[k] (S1, S2: rtfs_gln_bwd_reduce / rtfs_mix_gln_bwd / rtfs_d0_tail_bwd) and gamma[k];
  * in: the common input, transformed as the forward saw it (mode 0 raw, 1 gLN, 2 PReLU(gLN), 3 the TFAR mix gLN(in) * sigmoid(gLN(gate))^ + gLN(glob)^ re-formed per
  * pixel as rtfs_dwconv_mix_fwd forms it: in_mix = host array {gate, gate_stats, gate_gamma, gate_beta, glob, glob_stats, glob_gamma, glob_beta} at in_Tg x in_Fg, NULL
- * otherwise); in_adj (one convolution, mode 2, fresh dIn; NULL otherwise) = host array {double* red, float* dgamma, float* dbeta, float* dslope}: the REDUCE pass
- * of the input's own PReLU + gLN adjoint (rtfs_gln_bwd_reduce with act 1 on dIn) rides in the store of dIn - red[b] += (S1, S2), the three accumulators are added into;
- * dIn (=, or += when accumulate) the gradient w.r.t. that TRANSFORMED input; dW[k] [16][64] += tap gradients, dbias[k] [64] += bias gradients (dbias NULL: none).  Pointer arrays are host arrays of device pointers.
+ * otherwise); dIn (=, or += when accumulate) the gradient w.r.t. that TRANSFORMED input; dW[k] [16][64] += tap gradients, dbias[k] [64] += bias gradients (dbias NULL: none).  Pointer arrays are host arrays of device pointers.
  * Replaces rtfs_gln_bwd_apply + rtfs_dwconv_bwd_weight + rtfs_dwconv_bwd_input per convolution: dX never reaches HBM. */
 int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                     const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
-                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, void* const* in_adj, float* dIn, int accumulate,
-                    float* const* dW, float* const* dbias, int B, int T, int F, void* stream);
+                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* const* dW,
+                    float* const* dbias, int B, int T, int F, void* stream);
 
 /* the same for ONE convolution that is the local branch of an InjectionMultiSum (layers/fusion.py:54-69: out = gLN(loc) * sigmoid(gLN(gate))^ + gLN(glob)^): dOut is
  * the gradient w.r.t. the mix's output; the local branch's mix + gLN adjoint  dX = rstd (gamma dOut s^ - S1/N - xhat S2/N)  is applied on load from loc (pre-norm

@@ -53,10 +53,6 @@ struct DwAdjArgs {
     double m_inv_n;
     int mTg, mFg;
     unsigned mt, mf;              // ceil(2^32 / T), ceil(2^32 / F): nearest source index floor(i * in / out) without a division
-    // INRED (one convolution, input mode 2, fresh dIn): the REDUCE pass of the input's own PReLU + gLN adjoint rides in the store of dIn - the thread holds dP = dIn at
-    // its pixel and re-reads the raw input (an L1 / L2 hit): dslope += [y <= 0] dP y, g = dP prelu'(y), dbeta += g, dgamma += g xhat, S1 += g gamma, S2 += g gamma xhat
-    // (what rtfs_gln_bwd_reduce(act = 1) computes from a second pass over dP and the input: 0.53 GB and a launch per RTFS block)
-    double* in_red;               // [B][kStatStride]: (S1, S2) of the input's gLN adjoint, added with fp64 atomics; scr then ends with [dgamma 64 | dbeta 64 | dslope 1]
 };
 
 
@@ -64,10 +60,9 @@ struct DwAdjArgs {
 typedef float float2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2v ld2v(const float* p) { return *reinterpret_cast<const float2v*>(p); }
 
-template <int NCONV, bool GLN, bool MIX = false, bool INRED = false>
-__global__ __launch_bounds__(256, (NCONV == 1 ? (INRED ? 3 : 4) : 2)) void dw_adjoint_kernel(DwAdjArgs a) {
+template <int NCONV, bool GLN, bool MIX = false>
+__global__ __launch_bounds__(256, (NCONV == 1 ? 4 : 2)) void dw_adjoint_kernel(DwAdjArgs a) {
     static_assert(!MIX || (NCONV == 1 && GLN), "the mix prologue belongs to one gLN'd convolution");
-    static_assert(!INRED || (NCONV == 1 && !MIX), "the input's reduce pass rides with one convolution");
     constexpr int TR = 8, TC = 8, R = TR + 3, CB = TC + 3, RS = CB * 64;  // tile rows t0-2 .. t0+8, columns fb-2 .. fb+8
     constexpr int NIT = (R * CB * 16 + 255) / 256;                          // staging items (pixel, quad) per thread
     __shared__ __attribute__((aligned(16))) float tile[R * RS];
@@ -102,15 +97,13 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? (INRED ? 3 : 4) : 2)) void dw_ad
     const int ti = t0 + r;
     const bool tvalid = ti < T;
     float2v isc = float2v{1.f, 1.f}, ish = float2v{0.f, 0.f};
-    float imean = 0.f, irstd = 1.f;
     if (a.mode >= 1) {
-        stats_finalize(a.in_slot, b, a.inv_n, imean, irstd);
+        float mean, rstd;
+        stats_finalize(a.in_slot, b, a.inv_n, mean, rstd);
         const float2v g = ld2v(a.in_gamma + ch), be = ld2v(a.in_beta + ch);
-        isc = g * irstd;
-        ish = be - isc * imean;
+        isc = g * rstd;
+        ish = be - isc * mean;
     }
-    float2v rdg = float2v{0.f, 0.f}, rdb = float2v{0.f, 0.f};  // INRED: dgamma, dbeta partials of the input's gLN
-    float rsl = 0.f, rs1 = 0.f, rs2 = 0.f;                       //        dslope, S1, S2
     const float am1 = a.in_slope - 1.0f;
     const float *mgrow = nullptr, *merow = nullptr;
     if (NCONV <= 2 && a.mode == 3) {  // (the four-convolution form has no registers to spare and no caller with a mixed input)
@@ -256,17 +249,6 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? (INRED ? 3 : 4) : 2)) void dw_ad
                     float2v v = acc[j];
                     if (a.accumulate) v += ld2v(o);
                     *reinterpret_cast<float2v*>(o) = v;
-                    if (INRED) {
-                        const float2v raw = ld2v(inrow + (size_t)(fb + j) * kH);
-                        const float2v y = raw * isc + ish, xh = (raw - imean) * irstd;
-                        const float2v gq = float2v{y.x > 0.f ? v.x : v.x * a.in_slope, y.y > 0.f ? v.y : v.y * a.in_slope};
-                        rsl += (y.x > 0.f ? 0.f : v.x * y.x) + (y.y > 0.f ? 0.f : v.y * y.y);
-                        rdb += gq;
-                        rdg += gq * xh;
-                        const float2v ag = gq * isc;  // g gamma rstd: the rstd is divided out once at the end
-                        rs1 += ag.x + ag.y;
-                        rs2 += ag.x * xh.x + ag.y * xh.y;
-                    }
                 }
         }
     }
@@ -288,29 +270,6 @@ __global__ __launch_bounds__(256, (NCONV == 1 ? (INRED ? 3 : 4) : 2)) void dw_ad
         const int per = 1024 + (a.bias ? 64 : 0);
         for (int idx = threadIdx.x; idx < per; idx += 256)
             atomicAdd(mine + k * per + idx, redl[idx] + redl[17 * 64 + idx] + redl[2 * 17 * 64 + idx] + redl[3 * 17 * 64 + idx]);
-    }
-    if (INRED) {  // [dgamma 64 | dbeta 64 | dslope] behind the convolution's region; (S1, S2) as fp64 atomics like every gLN reduce pass
-        __syncthreads();
-        const float irs = 1.0f / irstd;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float2v v = i ? rdb : rdg;
-            v.x += __shfl_xor(v.x, 32, 64);
-            v.y += __shfl_xor(v.y, 32, 64);
-            if (lane < 32) *reinterpret_cast<float2v*>(redl + (wave * 2 + i) * 64 + ch) = v;
-        }
-        const float t0s = wave_sum(rsl), t1s = wave_sum(rs1) * irs, t2s = wave_sum(rs2) * irs;
-        if (lane == 0) redl[512 + wave * 4] = t0s, redl[512 + wave * 4 + 1] = t1s, redl[512 + wave * 4 + 2] = t2s;
-        __syncthreads();
-        float* tail = mine + (1024 + (a.bias ? 64 : 0));
-        if (threadIdx.x < 128) {
-            const int i = threadIdx.x >> 6, c = threadIdx.x & 63;
-            atomicAdd(tail + threadIdx.x, redl[i * 64 + c] + redl[(2 + i) * 64 + c] + redl[(4 + i) * 64 + c] + redl[(6 + i) * 64 + c]);
-        }
-        if (threadIdx.x == 0) atomicAdd(tail + 128, redl[512] + redl[516] + redl[520] + redl[524]);
-        if (threadIdx.x == 1 || threadIdx.x == 2)
-            atomicAdd(a.in_red + kStatStride * b + (threadIdx.x - 1), (double)redl[512 + threadIdx.x] + (double)redl[516 + threadIdx.x] + (double)redl[520 + threadIdx.x] +
-                                                                        (double)redl[524 + threadIdx.x]);
     }
 }
 
@@ -490,7 +449,7 @@ using namespace rtfs;
 static int dw_adjoint_launch(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                              const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma,
                              const float* in_beta, float in_slope, int mode, float* dIn, int accumulate, float* const* dW, float* const* dbias, int B, int T,
-                             int F, const float* gate_s, int Tg, int Fg, const void* const* in_mix, int in_Tg, int in_Fg, void* const* in_adj, void* stream) {
+                             int F, const float* gate_s, int Tg, int Fg, const void* const* in_mix, int in_Tg, int in_Fg, void* stream) {
     if (B <= 0 || T <= 0 || F <= 0 || (nconv != 1 && nconv != 2 && nconv != 4) || mode < 0 || mode > 3 || !dy || !w || !dW || !in || !dIn) return RTFS_EINVAL;
     if (mode >= 1 && (!in_stats || !in_gamma || !in_beta)) return RTFS_EINVAL;
     if ((size_t)T * F * kH * 4 >= (1ull << 32)) return RTFS_EINVAL;  // 32-bit byte offsets inside an utterance
@@ -531,13 +490,6 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
         a.mTg = in_Tg, a.mFg = in_Fg, a.m_inv_n = 1.0 / ((double)in_Tg * in_Fg * kH);
     }
     if (mode == 3 && nconv > 2 && !(x != nullptr && !accumulate)) return RTFS_EINVAL;  // (four convolutions with a mixed input: the one-channel-per-lane kernel only)
-    const bool inred = in_adj != nullptr;
-    if (inred) {  // {double* red, float* dgamma, float* dbeta, float* dslope}
-        if (nconv != 1 || !gln || gate_s || mode != 2 || accumulate || !in_adj[0] || !in_adj[1] || !in_adj[2] || !in_adj[3]) return RTFS_EINVAL;
-        a.in_red = (double*)in_adj[0];
-        const int j = bias ? 2 : 1;
-        so.dst[j] = (float*)in_adj[1], so.n[j] = 64, so.dst[j + 1] = (float*)in_adj[2], so.n[j + 1] = 64, so.dst[j + 2] = (float*)in_adj[3], so.n[j + 2] = 1;
-    }
     const bool mix = gate_s != nullptr;
     if (mix) {
         if (nconv != 1 || !gln || Tg <= 0 || Fg <= 0 || Tg > T || Fg > F) return RTFS_EINVAL;
@@ -548,9 +500,7 @@ static int dw_adjoint_launch(int nconv, const float* const* dy, const float* con
     const int ntiles = a.nt * B * a.nseg;
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8));
 #define DWADJ(N, G) hipLaunchKernelGGL((dw_adjoint_kernel<N, G>), grid, dim3(256), 0, (hipStream_t)stream, a)
-    if (inred) {
-        hipLaunchKernelGGL((dw_adjoint_kernel<1, true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    } else if (mix) {
+    if (mix) {
         hipLaunchKernelGGL((dw_adjoint_kernel<1, true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
     } else if (gln && nconv >= 2 && !bias && (mode == 0 || mode == 3) && !accumulate) {  // the step's two- and four-convolution groups: one channel per lane
         if (nconv == 2 && mode == 3) hipLaunchKernelGGL((dw_adjoint1c_kernel<2, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
@@ -571,10 +521,10 @@ extern "C" {
 
 int rtfs_dw_adjoint(int nconv, const float* const* dy, const float* const* x, const double* const* x_stats, const double* const* red,
                     const float* const* gamma, const float* const* w, const float* in, const double* in_stats, const float* in_gamma, const float* in_beta,
-                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, void* const* in_adj, float* dIn, int accumulate,
-                    float* const* dW, float* const* dbias, int B, int T, int F, void* stream) {
+                    float in_slope, int mode, const void* const* in_mix, int in_Tg, int in_Fg, float* dIn, int accumulate, float* const* dW,
+                    float* const* dbias, int B, int T, int F, void* stream) {
     return dw_adjoint_launch(nconv, dy, x, x_stats, red, gamma, w, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dW, dbias, B, T, F, nullptr,
-                             0, 0, in_mix, in_Tg, in_Fg, in_adj, stream);
+                             0, 0, in_mix, in_Tg, in_Fg, stream);
 }
 
 int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_stats, const double* loc_red, const float* loc_gamma, const float* gate_sig,
@@ -589,7 +539,7 @@ int rtfs_dw_adjoint_mix(const float* dOut, const float* loc, const double* loc_s
     const float* ww[1] = {w};
     float* dw[1] = {dW};
     return dw_adjoint_launch(1, dy, x, xs, red, gm, ww, in, in_stats, in_gamma, in_beta, in_slope, mode, dIn, accumulate, dw, nullptr, B, T, F, gate_sig, Tg, Fg,
-                             in_mix, in_Tg, in_Fg, nullptr, stream);
+                             in_mix, in_Tg, in_Fg, stream);
 }
 
 }  // extern "C"

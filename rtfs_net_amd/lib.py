@@ -123,7 +123,7 @@ SIGNATURES = {
     "rtfs_adamw_clip_step": [P, P, P, P, P, P, I, P, D, D, D, D, D, D, D, D, P],
     "rtfs_caf_bn_prepare": [P] * 23 + [F, F, P, P, P, P, P],
     "rtfs_caf_bn_adjoint": [P] * 19 + [P],
-    "rtfs_dw_adjoint": [I, P, P, P, P, P, P, P, P, P, P, F, I, P, I, I, P, P, I, P, P, I, I, I, P],
+    "rtfs_dw_adjoint": [I, P, P, P, P, P, P, P, P, P, P, F, I, P, I, I, P, I, P, P, I, I, I, P],
     "rtfs_dw_adjoint_mix": [P] * 6 + [I, I, P, P, P, P, P, F, I, P, I, I, P, I, P, I, I, I, P],
     "rtfs_mix_gln_bwd_sig": [P] * 19 + [I, I, I, I, I, P],
     "rtfs_gln_stats": [P, P, I, LL, P],

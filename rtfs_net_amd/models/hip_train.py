@@ -667,7 +667,7 @@ class HipTrainer:
         if dIn is not None:
             self._call("rtfs_dwconv_bwd_input", dOut, conv[0], dIn, 1 if accumulate else 0, stride, B, Tin, Fin)
 
-    def _dw_adjoint(self, convs, inp, in_st, in_g, in_b, in_slope, mode, dIn, accumulate, gr, B, T, F, bias=False, in_mix=None, in_low=(0, 0), in_adj=None):
+    def _dw_adjoint(self, convs, inp, in_st, in_g, in_b, in_slope, mode, dIn, accumulate, gr, B, T, F, bias=False, in_mix=None, in_low=(0, 0)):
         """rtfs_dw_adjoint (csrc/bwd_dw.hip): the whole adjoint of the 1 / 2 / 4 stride-1 depth-wise convolutions `convs` that read `inp` in one launch.
         convs: list of (dY, conv tuple (taps, bias, gamma, beta), gr key, None | (pre-norm output, statistics slot, (S1, S2) slot)) - with the last entry the
         gLN adjoint is applied on load and dY is the gradient w.r.t. the normalised output.  mode 3: `inp` is the local tensor of a TFAR mix, in_mix = [gate, its
@@ -678,7 +678,7 @@ class HipTrainer:
         db = [_acc(gr, c[2] + ".bias", 64, dev) for c in convs] if bias else None
         lib.call("rtfs_dw_adjoint", len(convs), [c[0] for c in convs], [c[3][0] for c in convs] if gln else None, [c[3][1] for c in convs] if gln else None,
                  [c[3][2] for c in convs] if gln else None, [c[1][2] for c in convs] if gln else None, [c[1][0] for c in convs], inp, in_st, in_g, in_b,
-                 float(in_slope), mode, in_mix, in_low[0], in_low[1], in_adj, dIn, 1 if accumulate else 0, dW, db, B, T, F)
+                 float(in_slope), mode, in_mix, in_low[0], in_low[1], dIn, 1 if accumulate else 0, dW, db, B, T, F)
 
     def _dw_adjoint_mix(self, dOut, loc, gate, red_loc, Tg, Fg, inp, in_st, in_g, in_b, mode, dIn, accumulate, gr, B, T, F, in_mix=None, in_low=(0, 0)):
         """rtfs_dw_adjoint_mix: the adjoint of an InjectionMultiSum's LOCAL embedding convolution straight from the gradient of the mix's output (the local branch's
@@ -848,13 +848,10 @@ class HipTrainer:
             self._dw_bwd(dD1, bw["d1"], k.D0, st[1], d0g, d0be, 0.0, 1, 2, None, False, gr, tag + "d1", B, T, F_BINS, True)  # (tap / bias gradients only)
             red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
             self._call("rtfs_d0_tail_bwd", dD1, d1w, dG, dN_D0, k.D0, st[1], d0g, d0be, red, _acc(gr, tag + "d0.g", H, dev), _acc(gr, tag + "d0.b", H, dev), B, T, T2)
-            if dwadj:  # D0's gLN apply pass, downsample_layers[0]'s tap / bias gradients and its input gradient in one launch - and, in the store of that
-                # input gradient dP, the REDUCE pass of the projection's PReLU + gLN adjoint (what rtfs_gln_bwd_reduce(act = 1) made of a second pass over dP and y0)
+            if dwadj:  # D0's gLN apply pass, downsample_layers[0]'s tap / bias gradients and its input gradient in one launch
                 dD0 = None
                 dP = full()
-                red_p = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
-                self._dw_adjoint([(dN_D0, bw["d0"], tag + "d0", (k.D0, st[1], red))], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, dP, False, gr, B, T, F_BINS, bias=True,
-                                 in_adj=[red_p, _acc(gr, tag + "p.g", H, dev), _acc(gr, tag + "p.b", H, dev), g("pslope", 1)])
+                self._dw_adjoint([(dN_D0, bw["d0"], tag + "d0", (k.D0, st[1], red))], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, dP, False, gr, B, T, F_BINS, bias=True)
             else:
                 self._call("rtfs_gln_bwd_apply", dN_D0, k.D0, st[1], d0g, d0be, 0, 0.0, red, dD0, 0, B, TF, H)
         else:
@@ -866,10 +863,7 @@ class HipTrainer:
             self._dw_bwd(dD0, bw["d0"], k.y0, st[0], bw["pg"], bw["pbe"], bw["pslope"], 2, 1, dP, False, gr, tag + "d0", B, T, F_BINS, True)
         # projection: PReLU + gLN adjoint, then the 1x1 conv
         dy0 = full()
-        if dD0 is None:  # (the reduce pass rode in rtfs_dw_adjoint above)
-            self._call("rtfs_gln_bwd_apply", dP, k.y0, st[0], bw["pg"], bw["pbe"], 1, bw["pslope"], red_p, dy0, 0, B, TF, H)
-        else:
-            self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, tag + "p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
+        self._gln_bwd(dP, k.y0, st[0], bw["pg"], bw["pbe"], dy0, False, gr, tag + "p", B, TF, H, 1, bw["pslope"], g("pslope", 1))
         self._wg("rtfs_wgrad", dy0, H, k.s_in, C, g("pw", H * C), C, g("pb", H), B * TF, 0, 0, 0, 1, H, C, 1, bw["gw"], bw["gb"], bw["gslope"], None, 0)
         # d(gateway out) = dx (residual path) + dy0 . Wp, formed inside the gateway adjoint
         if a0_mode >= 3:

@@ -57,7 +57,7 @@ for name, nconv, gln, mode, acc, bias, T, Fq in GROUPS:
 
     def new():
         lib.call("rtfs_dw_adjoint", nconv, dy, x if gln else None, st[:nconv] if gln else None, red if gln else None, gam[:nconv] if gln else None, w, xin,
-                 st[nconv] if mode else None, gam[nconv] if mode else None, bet[nconv] if mode else None, 0.25, mode, None, 0, 0, None, dIn, 1 if acc else 0, dW, db if bias else None, B, T, Fq)
+                 st[nconv] if mode else None, gam[nconv] if mode else None, bet[nconv] if mode else None, 0.25, mode, None, 0, 0, dIn, 1 if acc else 0, dW, db if bias else None, B, T, Fq)
 
     t_old, t_new = timeit(old), timeit(new)
     units_new = nconv * (2 if gln else 1) + 1 + 1 + (1 if acc else 0)
@@ -82,7 +82,7 @@ for name, mode, acc, T, Fq, Tg, Fg in (("cl <- mix", 0, False, 251, 129, 125, 64
     def old():
         # (the apply pass alone: same traffic as mix_gln_bwd_apply_kernel - dOut, loc, gate in, dLoc out)
         lib.call("rtfs_gln_bwd_apply", dOut, loc, st[0], gam, bet, 0, 0.0, red, dLoc, 0, B, T * Fq, 64)
-        lib.call("rtfs_dw_adjoint", 1, [dLoc], None, None, None, None, [w], xin, *m, 0.0, mode, None, 0, 0, None, dIn, 1 if acc else 0, [dW], None, B, T, Fq)
+        lib.call("rtfs_dw_adjoint", 1, [dLoc], None, None, None, None, [w], xin, *m, 0.0, mode, None, 0, 0, dIn, 1 if acc else 0, [dW], None, B, T, Fq)
 
     def new():
         lib.call("rtfs_dw_adjoint_mix", dOut, loc, st[0], red, gam, sig, Tg, Fg, w, xin, *m, 0.0, mode, None, 0, 0, dIn, 1 if acc else 0, dW, B, T, Fq)
