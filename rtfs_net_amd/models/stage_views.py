@@ -37,6 +37,14 @@ def _cl(x_nchw):
     return out
 
 
+def _check_map(x, what, chan=C):
+    """the stage modules take the reference's [B, chan, T, 129] feature maps on the HIP device (the kernels are specialised to 129 frequency bins)"""
+    if x.ndim != 4 or x.shape[1] != chan or x.shape[3] != F_BINS:
+        raise ValueError(f"{what}: expected a [B, {chan}, T, {F_BINS}] tensor, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        raise RuntimeError("AVNet's stage modules run on an MI355X HIP device only (no CPU fallback)")
+
+
 def _check_inference(hip, what):
     if hip.model.training or (torch.is_grad_enabled() and any(p.requires_grad for p in hip.model.parameters())):
         raise NotImplementedError(f"{what}: the stage modules of rtfs_net_amd.AVNet are callable one by one on the inference path only (model.eval() under "
@@ -72,6 +80,7 @@ class StageViews:
     # ---- audio_bottleneck = ConvNormAct(gLN -> ReLU -> 1x1) (tdavnet.py:59; conv_layers.py:65-129) ----
     def bottleneck(self, a_emb):
         _check_inference(self.hip, "audio_bottleneck")
+        _check_map(a_emb, "audio_bottleneck")
         with torch.no_grad(), torch.cuda.device(a_emb.device):
             hip, pw = self.hip, self.hip.weights()
             w = pw.w
@@ -86,6 +95,9 @@ class StageViews:
     # ---- RefinementModule.forward (TDAVNet/refinement_module.py:45-62) ----
     def refinement(self, audio, video):
         _check_inference(self.hip, "refinement_module")
+        _check_map(audio, "refinement_module")
+        if video.ndim != 3 or video.shape[0] != audio.shape[0] or video.shape[1] != 512:
+            raise ValueError(f"refinement_module: expected lip features [B, 512, Tv], got {tuple(video.shape)}")
         with torch.no_grad(), torch.cuda.device(audio.device):
             hip, pw = self.hip, self.hip.weights()
             B, _, T, Fq = audio.shape
@@ -110,6 +122,9 @@ class StageViews:
     # ---- MaskGenerator.forward + __apply_masks (TDAVNet/mask_generator.py:67-99): -> [B, n_src = 1, 256, T, F] ----
     def mask(self, refined, a_emb):
         _check_inference(self.hip, "mask_generator")
+        _check_map(refined, "mask_generator"), _check_map(a_emb, "mask_generator")
+        if refined.shape != a_emb.shape:
+            raise ValueError(f"mask_generator: refined features {tuple(refined.shape)} and the mixture embedding {tuple(a_emb.shape)} differ in shape")
         with torch.no_grad(), torch.cuda.device(refined.device):
             hip, pw = self.hip, self.hip.weights()
             w = pw.w
@@ -122,6 +137,8 @@ class StageViews:
     # ---- STFTDecoder.forward (TDAVNet/decoder.py:110-132): [B, 1, 256, T, F], input shape -> [B, 1, L] ----
     def decoder(self, x, input_shape):
         _check_inference(self.hip, "decoder")
+        if x.ndim != 5 or x.shape[1] != 1 or x.shape[2] != C or not x.is_cuda:
+            raise ValueError(f"decoder: expected the mask generator's [B, 1, {C}, T, {F_BINS}] device tensor, got {tuple(x.shape)}")
         with torch.no_grad(), torch.cuda.device(x.device):
             hip, pw = self.hip, self.hip.weights()
             w = pw.w

@@ -105,6 +105,10 @@ def test_stage_modules_called_one_by_one_like_get_macs():
             model.refinement_module.audio_net.blocks.globalatt[0](torch.zeros(1, 64, 62, 64, device="cuda"))
         with pytest.raises(ValueError):
             model.decoder(sep, (2, 12000))
+        with pytest.raises(ValueError):
+            model.audio_bottleneck(a_emb[:, :, :, :64])  # not 129 bins
+        with pytest.raises(ValueError):
+            model.mask_generator(refined, a_emb[:1])
     with pytest.raises(NotImplementedError):  # under autograd the stage modules refuse (the training step is one chain behind AVNet.forward)
         model.encoder(mix)
 
@@ -132,3 +136,37 @@ def test_hooks_observe_only_and_unserved_hooks_are_refused():
     with torch.no_grad(), pytest.raises(NotImplementedError, match="cannot be served"):
         model(mix, emb)
     inner.remove(), served.remove()
+
+
+def test_hooked_route_in_a_split_bf16_mode_and_with_non_shared_blocks():
+    """the module-by-module route runs the SAME kernels as the fused one: in the bf16x3 mode the hooked forward equals the fused forward of that mode, and with
+    `audio_params.shared = False` (tdanet.py:170-181) every block's own modules fire once, in order"""
+    import copy
+
+    from rtfs_net_amd import AVNet
+
+    model, _, _ = make_model(3, "cuda")
+    mix, _, emb = synth.synth_inputs(2, 16000, 25)
+    mix, emb = mix.cuda(), emb.cuda()
+    model.set_compute_dtype("bf16x3")
+    with torch.no_grad():
+        fused = model(mix, emb)
+        seen = []
+        h = model.refinement_module.audio_net.blocks.register_forward_hook(lambda m, i, o: seen.append(o.shape))
+        hooked = model(mix, emb)
+        h.remove()
+    model.set_compute_dtype("f32")
+    assert len(seen) == 3 and rel(hooked, fused) < 1e-5
+    cfg = synth.rtfs_audionet(2)
+    cfg["audio_params"]["shared"] = False
+    ns = AVNet(print_macs=False, **copy.deepcopy(cfg)).eval()
+    ns.load_state_dict(synth.synth_state_dict(ns.state_dict()))
+    ns = ns.cuda()
+    order = []
+    hooks = [ns.refinement_module.audio_net.blocks[i].residual_conv.register_forward_hook(lambda m, inp, o, i=i: order.append((i, tuple(o.shape)))) for i in (0, 1)]
+    with torch.no_grad():
+        plain = ns._hip(mix, emb)  # (the fused route, hooks ignored)
+        out = ns(mix, emb)
+    for hk in hooks:
+        hk.remove()
+    assert order == [(0, (2, 256, 126, 129)), (1, (2, 256, 126, 129))] and rel(out, plain) < 1e-5
