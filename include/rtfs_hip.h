@@ -185,6 +185,8 @@ int rtfs_istft_fwd(const float* taps, float* frames, float* out, int B, int L, v
  * ====================================================================================================================== */
 int rtfs_colsum_add(const float* X, float* out, long long M, int N, void* stream);
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream);
+/* out = xs[0] + ... + xs[n-1] (n <= 8, count % 4 == 0; xs: host array of device pointers): the running d(a0) sum of the step, formed once */
+int rtfs_sum_n(const float* const* xs, int n, float* out, long long count, void* stream);
 /* Deferred mode of the parameter-gradient reducers (every *_bwd / rtfs_wgrad-style entry point that adds per-workgroup partial sums into dgamma / dbeta / dW /
  * dslope ... through the spread scratch): between rtfs_spread_defer(1) and rtfs_spread_defer(0) their small finish launches (219 per training step) are
  * recorded and applied by one launch per ~20 producers, with fp32 atomic adds (two producers may name the same destination: the RTFS blocks share their

@@ -243,6 +243,26 @@ __global__ __launch_bounds__(256) void spec_patches_kernel(const float* __restri
     patches[((size_t)b * T * kF + p) * 32 + col] = v;
 }
 
+
+// out = x[0] + ... + x[n-1] (n <= 8): the running d(a0) sum of the training step formed ONCE from the input gradients of blocks R-1 .. 1 (each kept as the next
+// block's dx anyway) instead of a read-modify-write of a [B][T][F][256] tensor inside every block's last kernel (round 6)
+struct SumArgs {
+    const float* x[8];
+    int n;
+};
+__global__ __launch_bounds__(256) void sum_n_kernel(SumArgs a, float* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ld4(a.x[k < a.n ? k : 0] + i * 4);  // (all loads in flight; slots past n re-read x[0]: an L1 hit)
+    float4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < a.n) s = s + v[k];
+    st4(out + i * 4, s);
+}
+
 }  // namespace rtfs
 
 using namespace rtfs;
@@ -307,6 +327,18 @@ int rtfs_istft_bwd(const float* dout, float* dspec, float* dtaps, int B, int L, 
 int rtfs_spec_patches(const float* spec, float* patches, int B, int T, void* stream) {
     if (B <= 0 || T <= 0) return RTFS_EINVAL;
     LAUNCH(spec_patches_kernel, dim3((T * kF + 7) / 8, B), spec, patches, T);
+    return RTFS_OK;
+}
+
+int rtfs_sum_n(const float* const* xs, int n, float* out, long long count, void* stream) {
+    if (!xs || n < 1 || n > 8 || count <= 0 || (count & 3)) return RTFS_EINVAL;
+    SumArgs a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) {
+        if (!xs[k]) return RTFS_EINVAL;
+        a.x[k] = xs[k];
+    }
+    LAUNCH(sum_n_kernel, dim3((unsigned)((count / 4 + 255) / 256)), a, out, count / 4);
     return RTFS_OK;
 }
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rtfs_gemm_rows": [P, P, P, P, I, I, I, I, P],
     "rtfs_colsum_add": [P, P, LL, I, P],
     "rtfs_axpy": [P, F, P, LL, P],
+    "rtfs_sum_n": [P, I, P, LL, P],
     "rtfs_gln_bwd_reduce": [P, P, P, P, P, I, F, P, P, P, P, I, I, I, P],
     "rtfs_gln_bwd_apply": [P, P, P, P, P, I, F, P, P, I, I, I, I, P],
     "rtfs_dwconv_bwd_input": [P, P, P, I, I, I, I, I, P],

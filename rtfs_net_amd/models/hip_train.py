@@ -769,7 +769,7 @@ class HipTrainer:
     def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode, tag="blk."):
         """dx: gradient w.r.t. the block output [B,TF,256] (overwritten).  Returns ds (gradient w.r.t. the block input).
         tag: prefix of this block's gradient accumulators in `gr` ("blk." for the shared block, "blk<i>." for block i of a non-shared stack).
-        a0_mode: how ds also enters the running d(a0) sum `da0` -- 1: da0 = ds, 2: da0 += ds (blocks whose input was
+        a0_mode: how ds also enters the running d(a0) sum `da0` -- 0: not at all (the caller sums the blocks' ds itself), 1: da0 = ds, 2: da0 += ds (blocks whose input was
         `previous + a0`), 3: block 0, whose input IS a0: ds is accumulated straight into da0, 4: same but da0 is empty (R = 1)."""
         dev = dx.device
         TF, lo = T * F_BINS, T2 * F2
@@ -944,8 +944,26 @@ class HipTrainer:
         da0 = torch.empty(B * TF * C, device=dev)  # running sum of the gradients of every block input (each is `... + a0`)
         blocks = pw.blocks
         bw = lambda i: blocks[0] if len(blocks) == 1 else blocks[i]  # noqa: E731
+        # d(a0) = the sum of the input gradients of blocks R-1 .. 1 (each input was `previous output + a0`).  Until round 6 every block's last kernel kept a running
+        # sum (a 2.1 GB read-modify-write per block at 32 utterances); every one of those gradients is the next block's dx and alive anyway, so they are summed
+        # ONCE, by one n-ary launch on the weight-gradient side stream - its result is not read before block 0's adjoint in the other backward stage
+        sum_once = m._hip.fuse["da0sum"] and 2 <= R - 1 <= 8
+        parts = []
         for i in range(R - 1, 0, -1):
-            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, da0, 1 if i == R - 1 else 2, tag=self._tag(len(blocks), i))
+            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, None if sum_once else da0, 0 if sum_once else (1 if i == R - 1 else 2),
+                                 tag=self._tag(len(blocks), i))
+            parts.append(dx)
+        if sum_once:
+            side = self._side(dev)
+            if side is None:
+                lib.call("rtfs_sum_n", parts, len(parts), da0, B * TF * C)
+            else:
+                side.wait_stream(torch.cuda.current_stream(dev))
+                for t in parts + [da0]:
+                    t.record_stream(side)
+                with torch.cuda.stream(side):
+                    lib.call("rtfs_sum_n", parts, len(parts), da0, B * TF * C)
+        del parts
         # CAF: out = key*rsz^ + att^*val (+ a0)
         datt, drsz = _zeros(B * Tv * C, dev), _zeros(B * Tv * C, dev)
         Rr = _zeros(4 * C, dev)

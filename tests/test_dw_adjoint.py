@@ -187,3 +187,25 @@ def test_dw_adjoint_with_a_tfar_mix_as_input(nconv, B, T, Fq, Tg, Fg):
     rel = lambda p, q: float((p.double().cpu() - q).norm() / q.norm())  # noqa: E731
     errs = [rel(dIn, _cl(xin.grad).double().reshape(-1))] + [rel(dW[k], ws[k].grad.reshape(H, 16).t().reshape(-1)) for k in range(nconv)]
     assert max(errs) < 2e-5, errs
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 8])
+def test_sum_n_is_the_left_to_right_fp32_sum(n):
+    """rtfs_sum_n (csrc/bwd_misc.hip): out = x[0] + x[1] + ... in one launch - the gradient of the audio embedding a0, which every RTFS block after the
+    first adds to its input (TDAVNet.py:109-113's residual), summed once instead of read-modify-written by each block's last kernel.  Bit-exact against the
+    same left-to-right fp32 sum; refuses more than 8 terms, a count that is no multiple of 4, and a null term."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(n)
+    count = 4 * 70001
+    xs = [torch.randn(count, generator=g).cuda() for _ in range(n)]
+    out = torch.full((count,), float("nan"), device="cuda")
+    lib.call("rtfs_sum_n", xs, n, out, count)
+    want = xs[0].clone()
+    for x in xs[1:]:
+        want += x
+    assert torch.equal(out, want)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_sum_n", xs, 9, out, count)
+    with pytest.raises(RuntimeError):
+        lib.call("rtfs_sum_n", xs, n, out, count - 1)
