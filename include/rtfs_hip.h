@@ -282,6 +282,17 @@ int rtfs_mask_bwd_elem(const float* dmasked, const float* a_emb, const float* m,
 int rtfs_decoder_mask_bwd(const float* dtaps, const float* dec_wT, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,
                           void* stream);
 int rtfs_prelu_bwd(const float* dy, const float* x, float slope, float* dx, int accumulate, float* dslope, long long n, void* stream);
+/* Round 6: the two 256 -> 256 input-gradient GEMMs of the step whose consumer is an activation's adjoint, with that adjoint in the GEMM's epilogue
+ * (weight-stationary kernel at large maps; the launches they replace, in order, at small ones - same results).  Wt: [256][256] as rtfs_gemm_rows takes it
+ * (Y = X . Wt^T), utterance layout [B][rows][256].
+ *   rtfs_gemm_prelu_bwd            dx = prelu'(x) * (dz . Wt^T), dslope[0] += sum (dz . Wt^T) x [x <= 0]: the adjoint of Conv2d(PReLU(x)) w.r.t. x
+ *                                  (mask_generator.py:47-48; = rtfs_gemm_rows + rtfs_prelu_bwd, dx may not alias dz or x)
+ *   rtfs_gemm_gln_relu_bwd_reduce  dR = dy . Wt^T and the REDUCE pass of relu(gLN(x))'s adjoint on it (red: double[B][16] zeroed by the caller, dgamma /
+ *                                  dbeta [256] accumulated; tdavnet.py:59,89's pre-norm + pre-act; = rtfs_gemm_rows + rtfs_gln_bwd_reduce(act 2));
+ *                                  rtfs_gln_bwd_apply(dR, x, ..., act 2, red, ...) finishes the adjoint as before. */
+int rtfs_gemm_prelu_bwd(const float* dz, const float* Wt, const float* x, float slope, float* dx, float* dslope, int B, int rows, void* stream);
+int rtfs_gemm_gln_relu_bwd_reduce(const float* dy, const float* Wt, const float* x, const double* stats, const float* gamma, const float* beta, float* dR,
+                                  double* red, float* dgamma, float* dbeta, int B, int rows, void* stream);
 int rtfs_chan_stats(const float* x, double* sum, double* sumsq, long long rows, void* stream);
 int rtfs_caf_bwd_reduce(const float* dOut, const float* x, const float* ks, const float* kb, const float* vs, const float* vb, const float* att,
                         const float* rsz, float* datt, float* drsz, float* R, int B, int T, int Tv, void* stream);

@@ -25,10 +25,6 @@ struct NormArg {
     const float *gamma, *beta;
 };
 
-__device__ __forceinline__ float4 sub4(float4 a, float s) { return f4(a.x - s, a.y - s, a.z - s, a.w - s); }
-__device__ __forceinline__ float hsum4(float4 a) { return a.x + a.y + a.z + a.w; }
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
 // Reduce per-thread float4 partials that share a channel quad (thread = (row = tid / QUADS, quad = tid % QUADS)) and add
 // the workgroup total to out[0 .. 4*QUADS) with ONE coalesced atomic request per 128-byte line.  lds: 1024 floats.
 template <int QUADS>

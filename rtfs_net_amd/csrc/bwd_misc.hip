@@ -33,8 +33,8 @@ __global__ __launch_bounds__(256) void mask_bwd_elem_kernel(const float* __restr
 }
 
 template <bool ACCUM>
-__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float slope, float* __restrict__ dx,
-                                                        float* __restrict__ scr, long long n4) {
+// (dy and dx may be the same buffer - rtfs_gemm_prelu_bwd's small-map form runs this in place: every element is read once, by the thread that writes it)
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* dy, const float* __restrict__ x, float slope, float* dx, float* __restrict__ scr, long long n4) {
     __shared__ float red[4];
     float acc = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {

@@ -167,6 +167,9 @@ __device__ __forceinline__ float4 f4(float a, float b, float c, float d) { retur
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return f4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return f4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 operator*(float4 a, float s) { return f4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 sub4(float4 a, float s) { return f4(a.x - s, a.y - s, a.z - s, a.w - s); }
+__device__ __forceinline__ float hsum4(float4 a) { return a.x + a.y + a.z + a.w; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
     return f4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }

@@ -102,6 +102,7 @@ struct ProExpanded {
 template <bool HAS_BIAS, bool ACCUM = false>
 struct EpiBias {  // y (= or +=) acc (+ bias)
     static constexpr bool kAccum = ACCUM;
+    static constexpr int kSide = 0;
     float* __restrict__ y;
     const float* __restrict__ bias;
     int N;
@@ -147,6 +148,7 @@ struct EpiResidual {
 // S3 complex mask (mask_generator.py:70-82): m = relu(acc + bias); channels [0,128) real, [128,256) imaginary
 struct EpiMask {
     static constexpr bool kAccum = false;
+    static constexpr int kSide = 0;
     float* __restrict__ y;
     const float* __restrict__ bias;
     const float* __restrict__ emb;
@@ -176,6 +178,7 @@ struct EpiMask {
 // Same arithmetic as mask_bwd_elem_kernel (bwd_misc.hip); d(masked) itself never exists in HBM.
 struct EpiMaskBwd {
     static constexpr bool kAccum = false;
+    static constexpr int kSide = 0;
     const float* __restrict__ emb;  // a_emb [rows][256]
     const float* __restrict__ m;    // post-ReLU mask [rows][256]
     float* __restrict__ dz;
@@ -195,6 +198,26 @@ struct EpiMaskBwd {
         st4(de + o, f4(dor.x * mr.x + doi.x * mi.x, dor.y * mr.y + doi.y * mi.y, dor.z * mr.z + doi.z * mi.z, dor.w * mr.w + doi.w * mi.w));
         st4(de + o + 128, f4(doi.x * mr.x - dor.x * mi.x, doi.y * mr.y - dor.y * mi.y, doi.z * mr.z - dor.z * mi.z, doi.w * mr.w - dor.w * mi.w));
     }
+};
+
+// Input-gradient GEMMs of the training step whose consumer is an activation's adjoint (ws256_kernel only, round 6): the rows of the activation's INPUT x are
+// fetched next to the output rows and the element-wise adjoint runs in the epilogue registers, so the GEMM's output is not written and re-read for it.
+//   SIDE 1  y = prelu'(x) * acc,  dslope += sum acc * x * [x <= 0]                     (mask_generator.py:47-48: PReLU -> Conv2d; prelu_bwd_kernel's arithmetic)
+//   SIDE 2  y = acc (unchanged) and the REDUCE pass of relu(gLN(x))'s adjoint with g = acc * [gLN(x) > 0]: S1 = sum g gamma, S2 = sum g gamma xhat per
+//           utterance, dgamma_c += sum g xhat, dbeta_c += sum g    (tdavnet.py:59,89: audio_bottleneck's pre-norm + pre-act; gln_bwd_reduce_kernel<256, 2>'s arithmetic)
+template <int SIDE>
+struct EpiAdjoint {
+    static constexpr bool kAccum = false;
+    static constexpr int kSide = SIDE;
+    float* __restrict__ y;
+    const float* __restrict__ x;  // the activation's input [B][Mb][256]
+    float slope;                  // SIDE 1
+    const double* slot;           // SIDE 2: gLN statistics of x
+    double inv_n;
+    const float *__restrict__ gamma, *__restrict__ beta;
+    double* red;  // SIDE 2: [B][kStatStride] (S1, S2)
+    float* scr;   // spread scratch: SIDE 1 [dslope], SIDE 2 [dgamma 256 | dbeta 256]
+    __device__ float4 colconst(int) const { return f4(0, 0, 0, 0); }
 };
 
 // sum and sum of squares of a float4 in scalar VALU instructions.  Left to hipcc, the SLP vectoriser turned the gLN partial sums of the MFMA waves of
@@ -1045,6 +1068,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int b = blockIdx.y;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, kh = lane >> 5;
     pro.init(b, ptab);
+    if constexpr (Epi::kSide == 2) ptab[threadIdx.x] = epi.gamma[threadIdx.x], ptab[kC + threadIdx.x] = epi.beta[threadIdx.x];
 
     float4 wf[2][32];  // W fragments: rows n = 64 w + 32 nt + i, k = 8 q + 4 kh .. +3
 #pragma unroll
@@ -1131,8 +1155,32 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             }
         }
     };
+    // activation adjoint in the epilogue (EpiAdjoint): the activation's input rows of the tile whose epilogue runs next, fetched with the plain epilogue's
+    // thread map (whole 1 KB rows, channel quad cq fixed per thread => the per-channel sums stay in registers for the workgroup's whole life)
+    constexpr int SIDE = Epi::kSide;
+    __shared__ float redl[8];
+    float4 xs[8];
+    __amdgpu_buffer_rsrc_t rs = ry;
+    float4 dgam = f4(0, 0, 0, 0), dbet = f4(0, 0, 0, 0);
+    float smean = 0.f, srstd = 0.f, sum1 = 0.f;  // SIDE 1: sum1 = dslope
+    if constexpr (SIDE != 0) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.x) + uoff, 0, (int)slab, 0x00020000);
+    if constexpr (SIDE == 2) {  // (gamma | beta wait in ptab - ProPlain leaves it free; mean / rstd are wave-uniform: scalar registers)
+        stats_finalize(epi.slot, b, epi.inv_n, smean, srstd);
+        smean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, smean)));
+        srstd = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, srstd)));
+    }
+    auto load_side = [&](unsigned base) {
+        if constexpr (SIDE != 0) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) xs[it] = bld(rs, voff + (base + it * 4u * kC * 4u));
+        }
+    };
     float4 hold[8];  // previous tile's accumulators [nt][g]
     float4 orow[8];  // previous tile's output rows on their way out
+    if constexpr (SIDE != 0) {  // (the first tile's hand-over runs a dropped epilogue over these: its sums must see zeros, not whatever the registers held)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) hold[it] = f4(0, 0, 0, 0);
+    }
     auto ot_write = [&](int it) { st4(Ot + i * LD + 64 * w + 32 * (it >> 2) + 8 * (it & 3) + 4 * kh, hold[it]); };
     auto ot_read = [&]() {
 #pragma unroll
@@ -1154,6 +1202,20 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 bst(ry, o, f4(xr.x * mr.x - xi.x * mi.x, xr.y * mr.y - xi.y * mi.y, xr.z * mr.z - xi.z * mi.z, xr.w * mr.w - xi.w * mi.w));
                 bst(ry, o + 512u, f4(fmaf(xr.x, mi.x, xi.x * mr.x), fmaf(xr.y, mi.y, xi.y * mr.y), fmaf(xr.z, mi.z, xi.z * mr.z), fmaf(xr.w, mi.w, xi.w * mr.w)));
             }
+        } else if constexpr (SIDE == 1) {  // prelu_bwd_kernel's arithmetic (bwd_misc.hip); rows past the end: x reads as 0, the accumulator is 0
+            const float4 g = orow[it], v = xs[it];
+            sum1 += (v.x > 0.f ? 0.f : g.x * v.x) + (v.y > 0.f ? 0.f : g.y * v.y) + (v.z > 0.f ? 0.f : g.z * v.z) + (v.w > 0.f ? 0.f : g.w * v.w);
+            bst(ry, voff + (base + it * 4u * kC * 4u),
+                f4(v.x > 0.f ? g.x : g.x * epi.slope, v.y > 0.f ? g.y : g.y * epi.slope, v.z > 0.f ? g.z : g.z * epi.slope, v.w > 0.f ? g.w : g.w * epi.slope));
+        } else if constexpr (SIDE == 2) {  // gln_bwd_reduce_kernel<256, 2>'s arithmetic (bwd_elem.hip)
+            // (S1 = sum g gamma and S2 = sum g gamma xhat of this utterance are sum_c gamma_c dbeta_c and sum_c gamma_c dgamma_c: formed once, at the end)
+            const float4 xh = sub4(xs[it], smean) * srstd;
+            const float4 yy = fma4(xh, ld4(ptab + cq), ld4(ptab + kC + cq));
+            float4 g = orow[it];
+            bst(ry, voff + (base + it * 4u * kC * 4u), g);
+            g = f4(yy.x > 0.f ? g.x : 0.f, yy.y > 0.f ? g.y : 0.f, yy.z > 0.f ? g.z : 0.f, yy.w > 0.f ? g.w : 0.f);
+            dbet = dbet + g;
+            dgam = fma4(g, xh, dgam);
         } else {  // EpiBias<HAS_BIAS, false>::store
             bst(ry, voff + (base + it * 4u * kC * 4u), orow[it] + cc);
         }
@@ -1163,6 +1225,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
     for (int it = 0; it < 8; ++it) store_a1(As[0], it);
     load_emb(kNowhere);  // (not used: the same sequence of memory operations as at the end of a tile)
+    load_side(kNowhere);
     load_a(tile0 + 1);
     __syncthreads();
     unsigned prev_base = kNowhere;  // no previous tile yet: every store of its epilogue is dropped
@@ -1190,6 +1253,7 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             if (q == 9) ot_read();
             if (q >= 10 && q < 18) epi_out(q - 10, prev_base);
             if (q == 14) load_emb(tile_base);  // this tile's embedding rows: its epilogue runs inside the next tile
+            if (q == 18) load_side(tile_base);  // after the epilogue's last store; consumed by this tile's epilogue inside the next tile
             if (q >= 18 && q < 26) store_a1(An, q - 18);
             if (q == 26) load_a(tile + 2);
         };
@@ -1264,6 +1328,24 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     ot_read();
 #pragma unroll
     for (int it = 0; it < 8; ++it) epi_out(it, prev_base);
+    if constexpr (SIDE == 1) {
+        sum1 = wave_sum(sum1);
+        if (lane == 0) redl[w] = sum1;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(spread_copy(epi.scr, blockIdx.x + blockIdx.y), redl[0] + redl[1] + redl[2] + redl[3]);
+    }
+    if constexpr (SIDE == 2) {
+        __syncthreads();  // Ot: every wave has read the last tile's rows
+        st4(Ot + w * 512 + cq, dgam);
+        st4(Ot + w * 512 + 256 + cq, dbet);
+        __syncthreads();
+        float* mine = spread_copy(epi.scr, blockIdx.x + blockIdx.y);  // [dgamma 256 | dbeta 256]; thread = channel: one coalesced atomic request per line
+        const int c = threadIdx.x;
+        atomicAdd(mine + c, Ot[c] + Ot[512 + c] + Ot[1024 + c] + Ot[1536 + c]);
+        atomicAdd(mine + 256 + c, Ot[256 + c] + Ot[768 + c] + Ot[1280 + c] + Ot[1792 + c]);
+        const float4 sg4 = ld4(ptab + cq);
+        block_stats_commit(dot4(dbet, sg4), dot4(dgam, sg4), redl, epi.red, b);
+    }
 }
 
 // the weight-stationary form pays one 256 KB weight read per workgroup: worth it from ~32 tiles per workgroup on
@@ -1663,6 +1745,41 @@ int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, f
     RG(96, 64, 128, 2, 1)
 #undef RG
     return RTFS_EINVAL;
+}
+
+// ---- input-gradient GEMMs of the training step with the consumer activation's adjoint in the epilogue (round 6) ----------------------------------
+// Large maps (the weight-stationary kernel applies): one launch, the GEMM's output rows meet the activation's input rows in the epilogue registers.
+// Small maps: the launches they replace, in order (same results; the PReLU adjoint then runs in place on dx).
+int rtfs_gemm_prelu_bwd(const float* dz, const float* Wt, const float* x, float slope, float* dx, float* dslope, int B, int rows, void* stream) {
+    if (!dz || !Wt || !x || !dx || !dslope || B <= 0 || rows <= 0 || (long long)B * rows > 0x7fffffffLL) return RTFS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ws256_applies(B, rows)) {
+        const int rc = rtfs_gemm_rows(dz, Wt, nullptr, dx, B * rows, kC, kC, 0, stream);
+        if (rc != RTFS_OK) return rc;
+        return rtfs_prelu_bwd(dx, x, slope, dx, 0, dslope, (long long)B * rows * kC, stream);
+    }
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int rc = launch_ws256<false, 0>(ProPlain{dz, kC}, EpiAdjoint<1>{dx, x, slope, nullptr, 0.0, nullptr, nullptr, nullptr, scr}, Wt, B, rows, st);
+    if (rc != RTFS_OK) return rc;
+    return spread_finish(scr, SpreadOut{{dslope}, {1}}, st);
+}
+
+int rtfs_gemm_gln_relu_bwd_reduce(const float* dy, const float* Wt, const float* x, const double* stats, const float* gamma, const float* beta, float* dR,
+                                  double* red, float* dgamma, float* dbeta, int B, int rows, void* stream) {
+    if (!dy || !Wt || !x || !stats || !gamma || !beta || !dR || !red || !dgamma || !dbeta || B <= 0 || rows <= 0 || (long long)B * rows > 0x7fffffffLL)
+        return RTFS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ws256_applies(B, rows)) {
+        const int rc = rtfs_gemm_rows(dy, Wt, nullptr, dR, B * rows, kC, kC, 0, stream);
+        if (rc != RTFS_OK) return rc;
+        return rtfs_gln_bwd_reduce(dR, x, stats, gamma, beta, 2, 0.f, red, dgamma, dbeta, nullptr, B, rows, kC, stream);
+    }
+    float* scr = spread_scratch();
+    if (!scr) return RTFS_ELAUNCH;
+    const int rc = launch_ws256<false, 0>(ProPlain{dy, kC}, EpiAdjoint<2>{dR, x, 0.f, stats, 1.0 / ((double)rows * kC), gamma, beta, red, scr}, Wt, B, rows, st);
+    if (rc != RTFS_OK) return rc;
+    return spread_finish(scr, SpreadOut{{dgamma, dbeta}, {kC, kC}}, st);
 }
 
 int rtfs_decoder_mask_bwd(const float* dtaps, const float* dec_wT, const float* a_emb, const float* m, float* dz, float* da_emb, long long rows,

@@ -98,6 +98,8 @@ SIGNATURES = {
     "rtfs_transpose_tok": [P, P, I, P],
     "rtfs_mask_bwd_elem": [P, P, P, P, P, LL, P],
     "rtfs_prelu_bwd": [P, P, F, P, I, P, LL, P],
+    "rtfs_gemm_prelu_bwd": [P, P, P, F, P, P, I, I, P],
+    "rtfs_gemm_gln_relu_bwd_reduce": [P] * 10 + [I, I, P],
     "rtfs_chan_stats": [P, P, P, LL, P],
     "rtfs_caf_bwd_reduce": [P] * 11 + [I, I, I, P],
     "rtfs_caf_bwd_apply": [P] * 8 + [I, I, I, I, P],

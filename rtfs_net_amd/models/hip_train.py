@@ -11,6 +11,8 @@ kernel layout and mapped back to the reference parameter shapes at the end (`_gr
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 try:
@@ -936,10 +938,14 @@ class HipTrainer:
             self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
             del dmasked
         self._wg("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
-        dpre = torch.empty(B * TF * C, device=dev)
-        self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
-        self._call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
+        if m._hip.fuse["actepi"] and not self.prec:  # the PReLU's adjoint in the input-gradient GEMM's epilogue (round 6; fp32 contraction only)
+            lib.call("rtfs_gemm_prelu_bwd", dz, w["mask_wT"], c.refined, w["mask_slope"], dx, g("mask_slope", 1), B, TF)
+        else:
+            dpre = torch.empty(B * TF * C, device=dev)
+            self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
+            self._call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
+            del dpre
         # RTFS blocks R-1 .. 1, CAF, block 0
         da0 = torch.empty(B * TF * C, device=dev)  # running sum of the gradients of every block input (each is `... + a0`)
         blocks = pw.blocks
@@ -992,8 +998,14 @@ class HipTrainer:
         # bottleneck: a0 = Wb . relu(gLN(a_emb)) + bb
         self._wg("rtfs_wgrad", da0, C, c.a_emb, C, g("bn_w", C * C), C, g("bn_bias", C), B * TF, 0, 0, 0, 1, C, C, 3, w["bn_g"], w["bn_b"], 0.0, c.stats[0], TF)
         dR = torch.empty(B * TF * C, device=dev)
-        self._call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
-        self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
+        if self.model._hip.fuse["actepi"] and not self.prec:  # the reduce pass of relu(gLN(a_emb))'s adjoint in the GEMM's epilogue (round 6)
+            red = gr["_pool"].take(B * lib.STAT_STRIDE, torch.float64).view(B, lib.STAT_STRIDE)
+            lib.call("rtfs_gemm_gln_relu_bwd_reduce", da0, w["bn_wT"], c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], dR, red, _acc(gr, "bn.g", C, dev), _acc(gr, "bn.b", C, dev),
+                     B, TF)
+            self._call("rtfs_gln_bwd_apply", dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], 2, 0.0, red, da_emb, 1, B, TF, C)
+        else:
+            self._call("rtfs_gemm_rows", da0, w["bn_wT"], None, dR, B * TF, C, C, 0)
+            self._gln_bwd(dR, c.a_emb, c.stats[0], w["bn_g"], w["bn_b"], da_emb, True, gr, "bn", B, TF, C, 2)
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
         self._call("rtfs_spec_patches", c.spec, patches, B, T)

@@ -209,3 +209,72 @@ def test_sum_n_is_the_left_to_right_fp32_sum(n):
         lib.call("rtfs_sum_n", xs, 9, out, count)
     with pytest.raises(RuntimeError):
         lib.call("rtfs_sum_n", xs, n, out, count - 1)
+
+
+def _gemm_adjoint_inputs(B, rows, seed):
+    g = torch.Generator().manual_seed(seed)
+    dz = torch.randn(B, rows, 256, generator=g).cuda()
+    x = torch.randn(B, rows, 256, generator=g).cuda()
+    Wt = (torch.randn(256, 256, generator=g) / 16).cuda()  # [out of the adjoint = in of the forward][k]: Y = X . Wt^T as rtfs_gemm_rows takes it
+    return dz, x, Wt
+
+
+@pytest.mark.parametrize("B,rows", [(2, 777), (32, 8200)])
+def test_gemm_prelu_bwd_against_the_two_launches_and_float64(B, rows):
+    """rtfs_gemm_prelu_bwd: dx = prelu'(x) * (dz . Wt^T) and dslope in one launch (csrc/gemm.hip: ws256_kernel<ProPlain, EpiAdjoint<1>>, the weight-stationary
+    form, at the large map; rtfs_gemm_rows + rtfs_prelu_bwd in place at the small one) - the adjoint of mask_generator.py:47-48's PReLU -> Conv2d w.r.t. the
+    PReLU's input.  dx bit-identical to the two launches it replaces (same products in the same order), dslope against float64."""
+    from rtfs_net_amd import lib
+
+    dz, x, Wt = _gemm_adjoint_inputs(B, rows, 5)
+    slope = 0.25
+    dx, dsl = torch.full_like(x, float("nan")), torch.zeros(1, device="cuda")
+    lib.call("rtfs_gemm_prelu_bwd", dz, Wt, x, slope, dx, dsl, B, rows)
+    dpre, dx2, dsl2 = torch.empty_like(x), torch.empty_like(x), torch.zeros(1, device="cuda")
+    lib.call("rtfs_gemm_rows", dz, Wt, None, dpre, B * rows, 256, 256, 0)
+    lib.call("rtfs_prelu_bwd", dpre, x, slope, dx2, 0, dsl2, B * rows * 256)
+    assert torch.equal(dx, dx2)
+    pre64 = dz.double() @ Wt.double().t()
+    want = float((pre64 * x.double() * (x <= 0)).sum())
+    scale = float((pre64 * x.double() * (x <= 0)).abs().sum()) ** 0.5 + 1.0
+    assert abs(float(dsl) - want) <= 2e-3 * scale, (float(dsl), want)
+    assert abs(float(dsl2) - want) <= 2e-3 * scale
+    # accumulates into dslope
+    lib.call("rtfs_gemm_prelu_bwd", dz, Wt, x, slope, dx, dsl, B, rows)
+    assert abs(float(dsl) - 2 * want) <= 4e-3 * scale
+
+
+@pytest.mark.parametrize("B,rows", [(2, 777), (32, 8200)])
+def test_gemm_gln_relu_bwd_reduce_against_the_two_launches(B, rows):
+    """rtfs_gemm_gln_relu_bwd_reduce: dR = dy . Wt^T with the reduce pass of relu(gLN(x))'s adjoint (S1, S2 per utterance, dgamma, dbeta) in the GEMM's epilogue
+    (tdavnet.py:59,89: audio_bottleneck = pre-norm gLN + pre-act ReLU + Conv2d) against rtfs_gemm_rows + rtfs_gln_bwd_reduce(act 2): dR bit-identical, the sums to
+    fp32 summation-order tolerance, and against float64."""
+    from rtfs_net_amd import lib
+
+    dy, x, Wt = _gemm_adjoint_inputs(B, rows, 9)
+    g = torch.Generator().manual_seed(1)
+    gamma, beta = (1 + 0.3 * torch.randn(256, generator=g)).cuda(), (0.2 * torch.randn(256, generator=g)).cuda()
+    st = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device="cuda")
+    st[:, 0], st[:, 1] = x.double().sum((1, 2)), (x.double() ** 2).sum((1, 2))
+    out = []
+    for fused in (True, False):
+        dR = torch.full_like(x, float("nan"))
+        red = torch.zeros(B, lib.STAT_STRIDE, dtype=torch.float64, device="cuda")
+        dg, db = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda")
+        if fused:
+            lib.call("rtfs_gemm_gln_relu_bwd_reduce", dy, Wt, x, st, gamma, beta, dR, red, dg, db, B, rows)
+        else:
+            lib.call("rtfs_gemm_rows", dy, Wt, None, dR, B * rows, 256, 256, 0)
+            lib.call("rtfs_gln_bwd_reduce", dR, x, st, gamma, beta, 2, 0.0, red, dg, db, None, B, rows, 256)
+        out.append((dR, red[:, :2].clone(), dg, db))
+    assert torch.equal(out[0][0], out[1][0])
+    # float64 restatement
+    n = rows * 256
+    mean = (st[:, 0] / n).view(B, 1, 1)
+    rstd = 1.0 / torch.sqrt((st[:, 1] / n).view(B, 1, 1) - mean ** 2 + 1e-5)
+    xh = (x.double() - mean) * rstd
+    gg = (dy.double() @ Wt.double().t()) * ((xh * gamma.double() + beta.double()) > 0)
+    want = (torch.stack([(gg * gamma.double()).sum((1, 2)), (gg * gamma.double() * xh).sum((1, 2))], 1), (gg * xh).sum((0, 1)), gg.sum((0, 1)))
+    for got in out:
+        for a, b_ in zip(got[1:], want):
+            assert float((a.double() - b_).abs().max()) <= 2e-4 * float(b_.abs().max()) + 1e-3 * (rows * B) ** 0.5, (a, b_)
