@@ -1009,7 +1009,9 @@ class HipTrainer:
         # encoder conv weight
         patches = torch.empty(B * TF * 32, device=dev)
         self._call("rtfs_spec_patches", c.spec, patches, B, T)
-        self._wg("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
+        # (the step's LAST weight gradient, in line: on the side stream it queued behind the bottleneck's - 1.5 ms, issued when da0 was final - and the stage end
+        # waited ~0.4 ms for it with an idle chain; in line it runs while the side stream finishes)
+        (self._call if self.model._hip.fuse["enctail"] else self._wg)("rtfs_wgrad", da_emb, C, patches, 32, g("enc", C * 32), 32, None, B * TF, 0, 0, 0, 1, C, 32, 0, None, None, 0.0, None, 0)
         return gr
 
     def _caf_bwd_coeffs(self, cf, w, Rr, gr, m):
