@@ -351,8 +351,24 @@ class HipTrainer:
         finally:
             lib.spread_lane(0)
 
+    # The MFMA-bound weight gradients of a dual-path stage (two Toeplitz launches, ~360 us each alone) become ready in the middle of the chain's own
+    # MFMA-bound stretch (SRU layer adjoints, rtfs_fold_gemm_bwd): launched there, they and the chain's GEMMs slow each other down by what the overlap
+    # was meant to save.  _wg_later parks such a launch (its operands stay referenced); _wg_flush issues the parked ones where the chain turns
+    # bandwidth-bound (the depth-wise / gateway adjoints behind the dual paths) - a side-stream launch waits for the chain's position AT ISSUE.
+    def _wg_later(self, name, *args):
+        if self.model._hip.fuse["wgdefer"] and self.model._hip.fuse["wgside"]:
+            self.__dict__.setdefault("_parked", []).append((name, args))
+        else:
+            self._wg(name, *args)
+
+    def _wg_flush(self):
+        parked, self._parked = self.__dict__.get("_parked", []), []
+        for name, args in parked:
+            self._wg(name, *args)
+
     def begin_stage(self, dev):
         """deferred finish of the parameter-gradient reducers (csrc/spread.hip) on both lanes for one backward stage"""
+        self._parked = []  # (a stage that raised may have left launches parked: they belong to a dead step)
         lib.spread_defer(True, dev)
         side = self._side(dev)
         if side is not None:
@@ -365,6 +381,7 @@ class HipTrainer:
 
     def end_stage(self, dev):
         """flush both lanes; the main stream then waits for the side stream: every parameter gradient of the stage is complete, stream-ordered"""
+        self._wg_flush()
         side = self._side(dev)
         try:
             if side is not None:
@@ -707,7 +724,7 @@ class HipTrainer:
         dG_seq = torch.empty(S * npos * 64, device=dev)
         self._call("rtfs_seq_gather", dG, None, None, 0, dG_seq, B, T2, dim)
         dct = g("ct_w", 64 * 512)
-        self._wg("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
+        self._wg_later("rtfs_wgrad", dG_seq, 64, sv.h[3], 64, dct, 512, g("ct_b", 64), S * npos, npos, L, -7, 8, 64, 64, 0, None, None, 0.0, None, 0)
         dh = torch.empty(S * L * 64, device=dev)
         self._call("rtfs_convt_bwd_input", dG, d["ctbi_w"], dh, B, T2, dim)
         # SRU layers 3..1.  fp32 (and the six-term mode, whose backward GEMMs are the fp32 kernels): one launch per layer - recurrence adjoint, weight
@@ -739,7 +756,7 @@ class HipTrainer:
         xn_seq = torch.empty(S * npos * 64, device=dev)
         self._call("rtfs_seq_gather", sv.G_in, d["g"], d["b"], 1, xn_seq, B, T2, dim)
         dw0 = g("w0", 256 * 512)
-        self._wg("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
+        self._wg_later("rtfs_wgrad", dU0, 256, xn_seq, 64, dw0, 512, None, S * L, L, npos, 0, 8, 256, 64, 0, None, None, 0.0, None, 0)
         dxn = torch.empty(B * T2 * F2 * 64, device=dev)
         self._call("rtfs_fold_gemm_bwd", dU0, d["fold_w"], dxn, B, T2, dim)
         self._call("rtfs_ln4d_c_bwd", dxn, sv.G_in, d["g"], dG, g("g", 64), g("b", 64), B * T2 * F2)  # dG += LN adjoint (residual already in dG)
@@ -841,6 +858,9 @@ class HipTrainer:
         self._attn_bwd(dG, bw["attn"], k, B, T2, gr, tag + "attn")
         self._dual_path_bwd(dG, bw["dp1"], k.dp[1], B, T2, 3, gr, tag + "dp1")
         self._dual_path_bwd(dG, bw["dp0"], k.dp[0], B, T2, 4, gr, tag + "dp0")
+        # (the chain is bandwidth-bound from here to the next block's attention adjoint.  Same-box sweep of the issue point, ms per step: here 88.1-88.3, behind the
+        # D0 adjoints 88.2, half here / half there 88.2, at the next block's start 89.4, half here / half at the next block's start 90.1; not parked at all 88.9)
+        self._wg_flush()
         # pooled = avgpool(D0n) + D1n; downsample[1] (stride 2, input D0n) and downsample[0] (stride 1, input P = prelu(n0(y0)))
         self._call("rtfs_axpy", dG, 1.0, dN_D1, B * lo * H)
         dD1, dD0 = low(), full()
@@ -937,7 +957,8 @@ class HipTrainer:
             self._call("rtfs_gemm_rows", dtaps, w["dec_wT"], None, dmasked, B * TF, 32, C, 0)
             self._call("rtfs_mask_bwd_elem", dmasked, c.a_emb, c.m, dz, da_emb, B * TF)
             del dmasked
-        self._wg("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
+        # (parked: the input-gradient GEMM below is MFMA-bound as well; issued behind it, this one runs under the last block's bandwidth-bound adjoints)
+        self._wg_later("rtfs_wgrad", dz, C, c.refined, C, g("mask_w", C * C), C, g("mask_b", C), B * TF, 0, 0, 0, 1, C, C, 2, None, None, w["mask_slope"], None, 0)
         dx = torch.empty(B * TF * C, device=dev)  # gradient w.r.t. the refined features
         if m._hip.fuse["actepi"] and not self.prec:  # the PReLU's adjoint in the input-gradient GEMM's epilogue (round 6; fp32 contraction only)
             lib.call("rtfs_gemm_prelu_bwd", dz, w["mask_wT"], c.refined, w["mask_slope"], dx, g("mask_slope", 1), B, TF)
@@ -946,6 +967,7 @@ class HipTrainer:
             self._call("rtfs_gemm_rows", dz, w["mask_wT"], None, dpre, B * TF, C, C, 0)
             self._call("rtfs_prelu_bwd", dpre, c.refined, w["mask_slope"], dx, 0, g("mask_slope", 1), B * TF * C)
             del dpre
+        self._wg_flush()
         # RTFS blocks R-1 .. 1, CAF, block 0
         da0 = torch.empty(B * TF * C, device=dev)  # running sum of the gradients of every block input (each is `... + a0`)
         blocks = pw.blocks
