@@ -51,7 +51,7 @@ int rtfs_proj_fwd(const float* s, const float* gw, const float* gb, float gslope
                   double* stats_out, int B, int TF, void* stream);
 
 /* ---- a5.3, a5.6: depth-wise 4x4 convolutions, tdanet.py:61-76,112-114; layers/fusion.py:25-52 ---------------- */
-/* nconv in {1,2,4} convolutions of one input; mode 0 raw, 1 gLN(in), 2 PReLU(gLN(in)); stride 1 ('same') or 2 (pad 1) */
+/* nconv in {1,2,4} convolutions of one input (stride 2: nconv = 1); mode 0 raw, 1 gLN(in), 2 PReLU(gLN(in)); stride 1 ('same') or 2 (pad 1) */
 int rtfs_dwconv_fwd(const float* in, const double* stats_in, const float* gamma, const float* beta, float slope, int mode, int stride, int nconv,
                     const float* const* w /*[16][64]*/, const float* const* bias, float* const* out, double* const* stats_out, int B, int Tin,
                     int Fin, void* stream);
@@ -87,7 +87,9 @@ int rtfs_sru_layer_fwd(const float* Hprev, const float* Wt, const float* weight_
 int rtfs_sru_layer_fwd_form(const float* Hprev, const float* Wt, const float* weight_c, const float* bias, float scale_x, float* Hout, float* Cout_or_null,
                             float* Uout_or_null, int S, int L, int form, void* stream);
 int rtfs_gemm_rows_fwd(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, void* stream);
-/* generic row GEMM Y (= or +=) X . Wt^T (+bias): also every input-gradient GEMM of the backward pass (Wt = transposed weight) */
+/* row GEMM Y (= or +=) X . Wt^T for the (K, N) pairs of the path: SRU input projections, decoder taps, every input-gradient GEMM of the backward pass (Wt = transposed
+ * weight).  Round 6: bias_or_null must be NULL (no row GEMM of the path carries a bias) and `accumulate` exists for (K, N) = (192, 64) and (96, 64) only - the two input
+ * gradients that add to a residual gradient; other requests return RTFS_EINVAL (their kernels were instantiated and never launched). */
 int rtfs_gemm_rows(const float* X, const float* Wt, const float* bias_or_null, float* Y, int M, int K, int N, int accumulate, void* stream);
 int rtfs_dp_convt_fwd(const float* H3, const float* Wt /*[64][512]*/, const float* bias, float* G /*in place*/, int B, int T2, int dim, void* stream);
 /* the same with the kernel form named: 0 = the library's choice (fp32 at >= 1024 tiles of 63 pair rows: the fast-FIR kernel of rtfs_dp_unfold_gemm_fwd in its
@@ -238,7 +240,9 @@ int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const flo
 int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
                           int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream);
 /* weight gradient of any 1x1 conv / linear map; rows may be segmented and nshift > 1 computes the taps of a Toeplitz map
- * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k] */
+ * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k].  pro: X as stored (0), or re-derived on load - the gateway
+ * (1: p0 / p1 = gw / gb, slope; NOUT = 64, KIN = 256 - the projection's map), PReLU (2) or ReLU(gLN) (3: p0 / p1 = gamma / beta, stats, rows_per_b) with
+ * NOUT a multiple of 128; other prologue / shape pairs return RTFS_EINVAL */
 int rtfs_wgrad(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, float* dbias_or_null, long long M, int seg_len, int x_seg, int x_off, int nshift,
                int NOUT, int KIN, int pro, const float* p0, const float* p1, float slope, const double* stats, int rows_per_b, void* stream);
 /* adjoints of rtfs_dp_unfold_gemm_fwd (input side) and rtfs_dp_convt_fwd */

@@ -506,8 +506,14 @@ __global__ __launch_bounds__(256, 2) void toeplitz_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Prologue x tile forms that exist (round 6: the others were instantiated and never launched - tools/kernel_coverage.py): the gateway prologue (pro 1) feeds the
+// projection's weight gradient (64 x 256: <2, 4>), PReLU (2) and ReLU(gLN) (3) the 256 x 256 maps (<4, 2>); everything else runs the plain prologue.
+template <int NT, int KT>
+static constexpr bool wgrad_has(int pro) { return pro == 0 || (NT == 2 && KT == 4 && pro == 1) || (NT == 4 && KT == 2 && (pro == 2 || pro == 3)); }
+
 template <int NT, int KT, int P = 0>
-static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
+static int wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
+    if (!wgrad_has<NT, KT>(pro)) return RTFS_EINVAL;
     WgradArgs a = a0;
     const int nblk = ((a.NOUT + NT * 32 - 1) / (NT * 32)) * ((a.KIN + KT * 32 - 1) / (KT * 32)) * a.nshift;
     // ~2048 workgroups, but at least 1024 rows each: every workgroup ends with a cross-wave LDS sum and one atomic request per
@@ -519,12 +525,11 @@ static void wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     a.rows_per_wg = (int)(rpw < 1024 ? 1024 : rpw);
     a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
     const dim3 grid((unsigned)((a.ngroups + 7) / 8 * 8 * nblk));
-    switch (pro) {
-        case 0: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 0, P>), grid, dim3(256), 0, st, a); break;
-        case 1: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 1, P>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 2, P>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((wgrad_kernel<NT, KT, 3, P>), grid, dim3(256), 0, st, a); break;
-    }
+    if (pro == 0) hipLaunchKernelGGL((wgrad_kernel<NT, KT, 0, P>), grid, dim3(256), 0, st, a);
+    if constexpr (wgrad_has<NT, KT>(1)) { if (pro == 1) hipLaunchKernelGGL((wgrad_kernel<NT, KT, 1, P>), grid, dim3(256), 0, st, a); }
+    if constexpr (wgrad_has<NT, KT>(2)) { if (pro == 2) hipLaunchKernelGGL((wgrad_kernel<NT, KT, 2, P>), grid, dim3(256), 0, st, a); }
+    if constexpr (wgrad_has<NT, KT>(3)) { if (pro == 3) hipLaunchKernelGGL((wgrad_kernel<NT, KT, 3, P>), grid, dim3(256), 0, st, a); }
+    return RTFS_OK;
 }
 
 // ---- projection input gradient + gateway adjoint, fused ------------------------------------------------------------------------
@@ -818,9 +823,11 @@ static int wgrad_impl(const float* dY, int ldy, const float* X, int ldx, float* 
     // the plain-shape kernel reads its operands as scalars from LDS and would split each of them in registers for the six-term mode: measured
     // slower than the fp32 MFMAs it replaces (825 vs 480 us on the projection weight gradient) - bf16x6 keeps it on the fp32 pipe
     constexpr int PP = P == 6 ? 0 : P;
-    if (NOUT >= 128 && NOUT % 128 == 0) wgrad_launch<4, 2, PP>(a, pro, st);
-    else if (KIN >= 128) wgrad_launch<2, 4, PP>(a, pro, st);
-    else wgrad_launch<2, 2, PP>(a, pro, st);
+    int rc;
+    if (NOUT >= 128 && NOUT % 128 == 0) rc = wgrad_launch<4, 2, PP>(a, pro, st);
+    else if (KIN >= 128) rc = wgrad_launch<2, 4, PP>(a, pro, st);
+    else rc = wgrad_launch<2, 2, PP>(a, pro, st);
+    if (rc != RTFS_OK) return rc;
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }

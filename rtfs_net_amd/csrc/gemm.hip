@@ -1458,8 +1458,11 @@ static int rows_ws64(const float* X, const float* Wt, float* Y, int M, int accum
     const int ntiles = (M + 31) / 32;
     const int per = (ntiles + 767) / 768 < 4 ? 4 : (ntiles + 767) / 768;  // ~768 workgroups (three per CU), at least 4 tiles each to pay for the weight read
     const dim3 grid((ntiles + per - 1) / per);
-    if (accumulate) hipLaunchKernelGGL((rows_ws64_kernel<K, true>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
-    else hipLaunchKernelGGL((rows_ws64_kernel<K, false>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
+    if constexpr (K == 192 || K == 96) {  // (`Y +=` exists for the two residual-gradient maps only, see rows_gemm)
+        if (accumulate) hipLaunchKernelGGL((rows_ws64_kernel<K, true>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
+    }
+    if (accumulate && !(K == 192 || K == 96)) return RTFS_EINVAL;
+    if (!accumulate) hipLaunchKernelGGL((rows_ws64_kernel<K, false>), grid, dim3(256), 0, st, X, Wt, Y, M, per);
     RTFS_LAUNCH_CHECK();
     return RTFS_OK;
 }
@@ -1470,12 +1473,15 @@ using namespace rtfs;
 
 template <int K, int N, int BM, int WM, int WN, int NT = 0>
 static int rows_gemm(const float* X, const float* Wt, const float* bias, float* Y, int M, int accumulate, hipStream_t st) {
+    // Forms that exist (round 6: 112 of the 160 bias x accumulate x precision instantiations of this launcher were never launched - tools/kernel_coverage.py): no row
+    // GEMM of the path carries a bias, and `Y +=` is the input-gradient form of the two maps onto 64 columns that add to a residual gradient (dx += dU . W of the SRU
+    // layers, K = 192; dG += dY96 . Wqkv of the attention, K = 96)
     ProPlain pro{X, K};
-    if (bias) {
-        if (accumulate) return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<true, true>{Y, bias, N}, Wt, 1, M, st);
-        return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<true, false>{Y, bias, N}, Wt, 1, M, st);
+    if (bias) return RTFS_EINVAL;
+    if constexpr (N == 64 && (K == 192 || K == 96)) {
+        if (accumulate) return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<false, true>{Y, nullptr, N}, Wt, 1, M, st);
     }
-    if (accumulate) return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<false, true>{Y, nullptr, N}, Wt, 1, M, st);
+    if (accumulate) return RTFS_EINVAL;
     return launch<K, N, BM, WM, WN, false, 32, NT>(pro, EpiBias<false, false>{Y, nullptr, N}, Wt, 1, M, st);
 }
 

@@ -960,7 +960,7 @@ static int caf_set_lds(const void* fn, bool* flags) {  // dynamic LDS beyond 64 
 
 template <int STRIDE, int MODE>
 static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
-    if (STRIDE == 1) {  // LDS-staged kernel, f segments in multiples of its 8-column block
+    if constexpr (STRIDE == 1) {  // LDS-staged kernel, f segments in multiples of its 8-column block
         // f segments per row tile: 4 at full resolution (2048 workgroups, 2.7 rounds of the 768 resident ones); at the compressed resolution 3 for the
         // 4-column kernels (8 x 32 x 3 = 768 workgroups = one full round of three per CU; 2 left a third of the slots empty: 79 -> 71 us, 35 -> 31 us)
         int nseg = a.Fout >= 96 ? 4 : (a.nconv <= 2 ? 3 : 2);
@@ -978,18 +978,15 @@ static int launch_dw(const DwArgs& a, int B, hipStream_t st) {
         }
         RTFS_LAUNCH_CHECK();
         return RTFS_OK;
+    } else {  // stride 2: downsample_layers[1] alone (tdanet.py:112-114) - one convolution per launch
+        if (a.nconv != 1) return RTFS_EINVAL;
+        const int nseg = a.Fout >= 96 ? 4 : 2;
+        const int fseg = (((a.Fout + nseg - 1) / nseg) + 3) / 4 * 4;
+        dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
+        hipLaunchKernelGGL((dwconv_kernel<STRIDE, 1, MODE>), grid, dim3(256), 0, st, a, fseg);
+        RTFS_LAUNCH_CHECK();
+        return RTFS_OK;
     }
-    const int nseg = a.Fout >= 96 ? 4 : 2;
-    const int fseg = (((a.Fout + nseg - 1) / nseg) + 3) / 4 * 4;
-    dim3 grid((a.Tout + 15) / 16, B, (a.Fout + fseg - 1) / fseg);
-    switch (a.nconv) {
-        case 1: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 1, MODE>), grid, dim3(256), 0, st, a, fseg); break;
-        case 2: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 2, MODE>), grid, dim3(256), 0, st, a, fseg); break;
-        case 4: hipLaunchKernelGGL((dwconv_kernel<STRIDE, 4, MODE>), grid, dim3(256), 0, st, a, fseg); break;
-        default: return RTFS_EINVAL;
-    }
-    RTFS_LAUNCH_CHECK();
-    return RTFS_OK;
 }
 
 extern "C" {
