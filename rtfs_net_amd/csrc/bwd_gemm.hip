@@ -520,7 +520,7 @@ static int wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
     // line of its tile, and requests to one line are served serially (~27 ns) - a few hundred row groups keep that tail short
     // (round 4: ~512 workgroups = one resident round for the full-resolution maps - a workgroup's prologue + cross-wave sum + atomics cost as much as
     // ~9 of its 32-row stages, s_memtime build - the short SRU maps keep ~2048)
-    const long long wg_target = a.M >= 500000 ? 512 : 2048;
+    const long long wg_target = a.M >= 500000 ? 512 : 2048;  // (round 6, in the step: 256 / 384 / 768 for the large maps measured the same within 0.2 ms)
     long long rpw = ((long long)a.M * nblk / wg_target + 31) / 32 * 32;
     a.rows_per_wg = (int)(rpw < 1024 ? 1024 : rpw);
     a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
@@ -813,7 +813,10 @@ static int wgrad_impl(const float* dY, int ldy, const float* X, int ldx, float* 
     hipStream_t st = (hipStream_t)stream;
     if (nshift == 8 && KIN == 64 && NOUT % 64 == 0 && pro == 0 && a.seg_len >= 32 && a.seg_len) {  // unfold / conv-transpose weights
         const int nblk = NOUT / 64;
-        long long rpw = ((long long)a.M * nblk / 512 + 31) / 32 * 32;  // ~512 workgroups = one resident round (round 4: 1024 -> 512, -3 %)
+        // ~384 workgroups (round 4: 1024 -> 512, -3 % alone).  Round 6: these launches run on the weight-gradient side stream under the bandwidth-bound stretch of the
+        // adjoint chain, two 42 KB / 112-register workgroups per CU at 512; at 384 half the CUs carry one and the chain's kernels keep more of their waves - training step,
+        // same box: 88.04 / 88.24 ms at 512, 87.39 / 87.41 at 384, 87.8-87.9 at 256 / 352, 88.0-88.2 at 416 / 448, 88.9 at 320
+        long long rpw = ((long long)a.M * nblk / 384 + 31) / 32 * 32;
         a.rows_per_wg = (int)(rpw < 512 ? 512 : rpw);
         a.ngroups = (a.M + a.rows_per_wg - 1) / a.rows_per_wg;
         hipLaunchKernelGGL(toeplitz_wgrad_kernel<P>, dim3((unsigned)((a.ngroups + 7) / 8 * 8 * nblk)), dim3(256), 0, st, a);
