@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rtfs_net_amd import lib
 g = torch.Generator().manual_seed(5)
-for M, K, acc in ((4000 * 57, 192, 1), (2048 * 118, 192, 1), (32 * 251 * 129, 256, 0), (32 * 251 * 129, 256, 1), (40000, 192, 1), (256000, 96, 1), (256000, 64, 0)):
+for M, K, acc in ((4000 * 57, 192, 1), (2048 * 118, 192, 1), (32 * 251 * 129, 256, 0), (40000, 192, 1), (256000, 96, 1), (256000, 64, 0)):
     X = torch.randn(M, K, generator=g).cuda()
     W = (torch.randn(64, K, generator=g) * 0.1).cuda()
     Y0 = torch.randn(M, 64, generator=g).cuda()
