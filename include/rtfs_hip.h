@@ -239,6 +239,10 @@ int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const flo
 /* the same adjoint applied to dG = dx + dy0 . Wp, formed on the fly (WpT [256][64]): replaces rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd */
 int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
                           int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream);
+/* round 6: the same (plain form) + the residual conv's input gradient of the block whose output gradient ds is - the next block of the backward pass, tdanet.py:127-131 -
+ * from the finished ds rows while they are in LDS: next_dE [rows][64] = ds . next_WrT^T (next_WrT [64][256], the weight rtfs_gemm_rows(.., 256, 64) takes; same bits) */
+int rtfs_proj_gateway_bwd_next(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                               float* dgw, float* dgb, float* dslope, const float* next_WrT, float* next_dE, long long rows, void* stream);
 /* weight gradient of any 1x1 conv / linear map; rows may be segmented and nshift > 1 computes the taps of a Toeplitz map
  * (unfold / ConvTranspose1d) in one launch: dW[n][z*KIN+k] += sum dY[seq,l][n] * X[seq, l+x_off+z][k].  pro: X as stored (0), or re-derived on load - the gateway
  * (1: p0 / p1 = gw / gb, slope; NOUT = 64, KIN = 256 - the projection's map), PReLU (2) or ReLU(gLN) (3: p0 / p1 = gamma / beta, stats, rows_per_b) with

@@ -539,11 +539,17 @@ static int wgrad_launch(const WgradArgs& a0, int pro, hipStream_t st) {
 // applies the gateway adjoint on the way out:  ds (= or +=) dG*prelu'(u)*gw, the running d(a0) sum, and the three parameter
 // reductions.  dG never exists in HBM: 2 GB less traffic per block than rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd.
 // ACCM: 0 none, 1 acc = ds, 2 acc += ds.   Wt: [256][64] (output channel major, k contiguous).
-template <bool ACCUM, int ACCM, int P = 0>  // P != 0: Wt host-PACKED (common.h)
+// NEXT (round 6, fp32): ds is the gradient of the PREVIOUS block's output, and the first thing that block's adjoint does with it is the residual conv's input
+// gradient dE = ds . Wr^T (256 -> 64: rows_ws64_kernel<256>, a 1.06 GB read of ds at the start of every block's backward).  Here the finished ds rows of a 32-pixel
+// half go back into the LDS tile they came through, and the four waves form dE for those rows - wave w its 16 output columns, the weight WrT [64][256] in 64 registers
+// per lane, v_mfma_f32_16x16x4_f32 with the products in rows_ws64_kernel's order (same bits) - before the next half overwrites the tile: ds is not read again.
+template <bool ACCUM, int ACCM, int P = 0, bool NEXT = false>  // P != 0: Wt host-PACKED (common.h)
 __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* __restrict__ dy0, const float* __restrict__ Wt, const float* __restrict__ dx,
                                                                   const float* __restrict__ s_in, const float* __restrict__ gw,
                                                                   const float* __restrict__ gb, float slope, float* __restrict__ ds,
-                                                                  float* __restrict__ acc_out, float* __restrict__ scr, int M, int tiles_per_wg) {
+                                                                  float* __restrict__ acc_out, float* __restrict__ scr, int M, int tiles_per_wg,
+                                                                  const float* __restrict__ WrT = nullptr, float* __restrict__ dE = nullptr) {
+    static_assert(!NEXT || (P == 0 && !ACCUM && ACCM == 0), "the next block's input-gradient GEMM rides in the plain fp32 form only");
     constexpr int LDE = 68, LDO = 260;
     __shared__ __attribute__((aligned(16))) float Es[64 * LDE];
     __shared__ __attribute__((aligned(16))) float Ot[32 * LDO];
@@ -557,6 +563,13 @@ __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* _
         for (int q = 0; q < 8; ++q) wf[nt][q] = ld4(Wt + (size_t)(64 * w + 32 * nt + i) * 64 + 8 * q + 4 * kh);
     float4 aw = f4(0, 0, 0, 0), ab = f4(0, 0, 0, 0);
     float asl = 0.f;
+    // NEXT: lane (j, kg) of wave w holds WrT[16 w + j][16 q + 4 kg .. + 3] (rows_ws64_kernel's weight layout)
+    const int nj = lane & 15, nkg = lane >> 4;
+    float4 wn[NEXT ? 16 : 1];
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wn[q] = ld4(WrT + (size_t)(16 * w + nj) * kC + 16 * q + 4 * nkg);
+    }
     const int tile0 = blockIdx.x * tiles_per_wg;
 #pragma unroll 1
     for (int tl = 0; tl < tiles_per_wg; ++tl) {
@@ -640,7 +653,30 @@ __global__ __launch_bounds__(256, 2) void proj_gateway_bwd_kernel(const float* _
                         if (ACCM == 2) st4_off(acc_out, o, d + ao[k]);
                         if (ACCUM) d = d + old[k];
                         st4_off(ds, o, d);
+                        if constexpr (NEXT) st4(Ot + r * LDO + cq, d);  // (this thread's own slot of the tile: it read g from there above)
                     }
+                }
+            }
+            if constexpr (NEXT) {
+                __syncthreads();  // the half's 32 ds rows are in Ot (rows past M keep stale values: their outputs are not stored)
+                const float* xp = Ot + nj * LDO + 4 * nkg;
+                floatx4 na[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 e0 = ld4(xp + 16 * q), e1 = ld4(xp + 16 * LDO + 16 * q);
+                    na[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].x, e0.x, na[0], 0, 0, 0);
+                    na[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].x, e1.x, na[1], 0, 0, 0);
+                    na[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].y, e0.y, na[0], 0, 0, 0);
+                    na[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].y, e1.y, na[1], 0, 0, 0);
+                    na[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].z, e0.z, na[0], 0, 0, 0);
+                    na[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].z, e1.z, na[1], 0, 0, 0);
+                    na[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].w, e0.w, na[0], 0, 0, 0);
+                    na[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wn[q].w, e1.w, na[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int row = m0 + pt * 32 + rt * 16 + nj;
+                    if (row < M) st4(dE + (size_t)row * kH + 16 * w + 4 * nkg, f4(na[rt][0], na[rt][1], na[rt][2], na[rt][3]));
                 }
             }
         }
@@ -837,14 +873,23 @@ static int wgrad_impl(const float* dY, int ldy, const float* X, int ldx, float* 
 
 template <int P>
 static int proj_gateway_bwd_impl(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
-                                 int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
+                                 int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream,
+                                 const float* next_WrT = nullptr, float* next_dE = nullptr) {
     if (rows <= 0 || rows * 1024 >= (1ll << 32) || acc_mode < 0 || acc_mode > 2 || (acc_mode && (!acc || accumulate))) return RTFS_EINVAL;
     float* scr = spread_scratch();
     if (!scr) return RTFS_ELAUNCH;
     const int M = (int)rows, tiles = (M + 63) / 64, per = 16;
     const dim3 grid((tiles + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
-#define PGB(A, MODE) hipLaunchKernelGGL((proj_gateway_bwd_kernel<A, MODE, P>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per)
+#define PGB(A, MODE) hipLaunchKernelGGL((proj_gateway_bwd_kernel<A, MODE, P>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per, nullptr, nullptr)
+    if constexpr (P == 0) {
+        if (next_WrT) {
+            if (accumulate || acc_mode || !next_dE) return RTFS_EINVAL;
+            hipLaunchKernelGGL((proj_gateway_bwd_kernel<false, 0, 0, true>), grid, dim3(256), 0, st, dy0, WpT, dx, s, gw, gb, slope, ds, acc, scr, M, per, next_WrT, next_dE);
+            RTFS_LAUNCH_CHECK();
+            return spread_finish(scr, SpreadOut{{dgw, dgb, dslope}, {kC, kC, 1}}, st);
+        }
+    }
     if (accumulate) PGB(true, 0);
     else if (acc_mode == 0) PGB(false, 0);
     else if (acc_mode == 1) PGB(false, 1);
@@ -917,6 +962,13 @@ int rtfs_wgrad_bf16(const float* dY, int ldy, const float* X, int ldx, float* dW
 int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
                           int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
     return proj_gateway_bwd_impl<0>(dy0, WpT, dx, s, gw, gb, slope, ds, accumulate, acc, acc_mode, dgw, dgb, dslope, rows, stream);
+}
+// ... and the residual conv's input gradient of the block whose output gradient ds is (the next block of the backward pass): dE = ds . WrT^T, [rows][64]
+// (= rtfs_gemm_rows(ds, WrT, .., 256, 64) on the stored ds, same bits); plain form only (no accumulate, no acc)
+int rtfs_proj_gateway_bwd_next(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
+                               float* dgw, float* dgb, float* dslope, const float* next_WrT, float* next_dE, long long rows, void* stream) {
+    if (!next_WrT || !next_dE) return RTFS_EINVAL;
+    return proj_gateway_bwd_impl<0>(dy0, WpT, dx, s, gw, gb, slope, ds, 0, nullptr, 0, dgw, dgb, dslope, rows, stream, next_WrT, next_dE);
 }
 int rtfs_proj_gateway_bwd_bf16(const float* dy0, const void* WpT_pk, const float* dx, const float* s, const float* gw, const float* gb, float slope,
                                float* ds, int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, int terms,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],
     "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
     "rtfs_proj_gateway_bwd": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
+    "rtfs_proj_gateway_bwd_next": [P, P, P, P, P, P, F, P, P, P, P, P, P, LL, P],
     "rtfs_wgrad": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, P],
     "rtfs_fold_gemm_bwd": [P, P, P, I, I, I, P],
     "rtfs_convt_bwd_input": [P, P, P, I, I, I, P],

@@ -277,8 +277,9 @@ class HipForward:
         # inference + step: trio, mix, proj, caf, gadd; training step only (models/hip_train.py): mixgln, d0tail, wgside (weight gradients on the side stream),
         # wgather (weights re-laid by one gather), cafbn, decmask, srubwd, dwadj (depth-wise adjoints in one launch), da0sum (d(a0) summed once on the side stream),
         # actepi (PReLU / ReLU(gLN) adjoints in the epilogue of the 256 -> 256 input-gradient GEMMs), enctail (the step's last weight gradient in line),
-        # wgdefer (the dual paths' Toeplitz weight gradients issued where the adjoint chain turns bandwidth-bound)
-        names = ("trio", "mix", "proj", "caf", "gadd", "mixgln", "d0tail", "wgside", "wgather", "cafbn", "decmask", "srubwd", "dwadj", "da0sum", "actepi", "enctail", "wgdefer")
+        # wgdefer (the dual paths' Toeplitz weight gradients issued where the adjoint chain turns bandwidth-bound), nextde (the next block's residual-conv input
+        # gradient formed by the previous block's gateway adjoint kernel)
+        names = ("trio", "mix", "proj", "caf", "gadd", "mixgln", "d0tail", "wgside", "wgather", "cafbn", "decmask", "srubwd", "dwadj", "da0sum", "actepi", "enctail", "wgdefer", "nextde")
         disabled = {x.strip() for x in os.environ.get("RTFS_DISABLE", "").split(",") if x.strip()}
         unknown = disabled - set(names) - {"vp_hip", "vp_side"}
         if unknown:

@@ -785,7 +785,7 @@ class HipTrainer:
         self._wg("rtfs_wgrad", dY96, 96, k.G2, 64, g("w", 96 * 64), 64, g("bias", 96), rows, 0, 0, 0, 1, 96, 64, 0, None, None, 0.0, None, 0)
         self._call("rtfs_gemm_rows", dY96, a["wT"], None, dG, rows, 96, 64, 1)  # dG (residual) += dY96 . Wqkv
 
-    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode, tag="blk."):
+    def _block_bwd(self, dx, k, bw, B, T, T2, gr, da0, a0_mode, tag="blk.", dE_in=None, next_rwT=None):
         """dx: gradient w.r.t. the block output [B,TF,256] (overwritten).  Returns ds (gradient w.r.t. the block input).
         tag: prefix of this block's gradient accumulators in `gr` ("blk." for the shared block, "blk<i>." for block i of a non-shared stack).
         a0_mode: how ds also enters the running d(a0) sum `da0` -- 0: not at all (the caller sums the blocks' ds itself), 1: da0 = ds, 2: da0 += ds (blocks whose input was
@@ -806,8 +806,11 @@ class HipTrainer:
         # (round 6: `expanded` is re-formed ON THE SIDE STREAM - its only reader is the weight-gradient launch behind it there, the adjoint chain does not wait for it)
         self._wg("rtfs_expand_fwd", k.cl, st[9], cl_[2], cl_[3], k.D0, st[1], d0g, d0be, k.cg, st[10], cg_[2], cg_[3], k.cgate, st[11], cgate_[2], cgate_[3], E, B, T, T2)
         self._wg("rtfs_wgrad", dx, C, E, H, g("rw", C * H), H, g("rb", C), B * TF, 0, 0, 0, 1, C, H, 0, None, None, 0.0, None, 0)
-        dE = full()
-        self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
+        if dE_in is not None:  # formed by the previous block's last kernel from its ds rows (rtfs_proj_gateway_bwd_next)
+            dE = dE_in
+        else:
+            dE = full()
+            self._call("rtfs_gemm_rows", dx, bw["rwT"], None, dE, B * TF, C, H, 0)
         # expanded = n(cl)*sigmoid(n(cgate))^ + n(cg)^ + n(D0):  dN_D0 starts as dE itself (dE has no reader after rtfs_mix_bwd: no copy)
         dN_D0 = dE
         # concat layer: mix + gLN adjoints, then conv adjoints (inputs F0 / F1 are raw tensors)
@@ -893,9 +896,15 @@ class HipTrainer:
                      g("gw", C), g("gb", C), g("gslope", 1), B * TF)
             return da0
         ds = torch.empty(B * TF * C, device=dev)
+        if next_rwT is not None and a0_mode == 0 and not self.prec:
+            # ... and the NEXT block's residual-conv input gradient dE = ds . Wr^T from the ds rows while they are in LDS (round 6): that block does not read ds for it
+            dE_next = full()
+            lib.call("rtfs_proj_gateway_bwd_next", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, g("gw", C), g("gb", C), g("gslope", 1), next_rwT,
+                     dE_next, B * TF)
+            return ds, dE_next
         self._call("rtfs_proj_gateway_bwd", dy0, bw["pwT"], dx, k.s_in, bw["gw"], bw["gb"], bw["gslope"], ds, 0, da0, a0_mode, g("gw", C), g("gb", C),
                  g("gslope", 1), B * TF)
-        return ds
+        return (ds, None) if next_rwT is not None else ds
 
     @staticmethod
     def _tag(n_blocks, i):
@@ -977,9 +986,14 @@ class HipTrainer:
         # ONCE, by one n-ary launch on the weight-gradient side stream - its result is not read before block 0's adjoint in the other backward stage
         sum_once = m._hip.fuse["da0sum"] and 2 <= R - 1 <= 8
         parts = []
+        dE = None
         for i in range(R - 1, 0, -1):
-            dx = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, None if sum_once else da0, 0 if sum_once else (1 if i == R - 1 else 2),
-                                 tag=self._tag(len(blocks), i))
+            # (block i's last kernel also forms the residual-conv input gradient of block i - 1, whose output gradient its ds is: not for block 1 - the CAF adjoint sits
+            # between it and block 0 - and only in the plain form of that kernel, i.e. with d(a0) summed once)
+            nxt = bw(i - 1)["rwT"] if (m._hip.fuse["nextde"] and sum_once and i >= 2) else None
+            res = self._block_bwd(dx, c.blk[i], bw(i), B, T, T2, gr, None if sum_once else da0, 0 if sum_once else (1 if i == R - 1 else 2),
+                                  tag=self._tag(len(blocks), i), dE_in=dE, next_rwT=nxt)
+            dx, dE = res if nxt is not None else (res, None)
             parts.append(dx)
         if sum_once:
             side = self._side(dev)

@@ -278,3 +278,33 @@ def test_gemm_gln_relu_bwd_reduce_against_the_two_launches(B, rows):
     for got in out:
         for a, b_ in zip(got[1:], want):
             assert float((a.double() - b_).abs().max()) <= 2e-4 * float(b_.abs().max()) + 1e-3 * (rows * B) ** 0.5, (a, b_)
+
+
+@pytest.mark.parametrize("rows", [64 * 16 * 3 + 37, 100003])
+def test_proj_gateway_bwd_next_equals_the_two_launches(rows):
+    """rtfs_proj_gateway_bwd_next: the gateway / projection adjoint (tdanet.py:108-109) + the NEXT block's residual-conv input gradient dE = ds . Wr^T (tdanet.py:127-131)
+    from the ds rows while they are in LDS, against rtfs_proj_gateway_bwd followed by rtfs_gemm_rows(ds, WrT, 256 -> 64) on the stored ds: ds bit-identical, dE the same
+    products (observed bit-identical; held to 1e-6), parameter sums to fp32 atomics' order; ragged last tile, guard rows behind dE."""
+    from rtfs_net_amd import lib
+
+    g = torch.Generator().manual_seed(rows)
+    dy0, dx, s = torch.randn(rows, 64, generator=g).cuda(), torch.randn(rows, 256, generator=g).cuda(), torch.randn(rows, 256, generator=g).cuda()
+    WpT, WrT = (torch.randn(256, 64, generator=g) / 8).cuda(), (torch.randn(64, 256, generator=g) / 16).cuda()
+    gw, gb = (1 + 0.3 * torch.randn(256, generator=g)).cuda(), (0.2 * torch.randn(256, generator=g)).cuda()
+    out = []
+    for fused in (True, False):
+        ds = torch.full((rows, 256), float("nan"), device="cuda")
+        dE = torch.cat([torch.full((rows, 64), float("nan")), torch.full((64, 64), 7.0)]).cuda()
+        dgw, dgb, dsl = torch.zeros(256, device="cuda"), torch.zeros(256, device="cuda"), torch.zeros(1, device="cuda")
+        if fused:
+            lib.call("rtfs_proj_gateway_bwd_next", dy0, WpT, dx, s, gw, gb, 0.25, ds, dgw, dgb, dsl, WrT, dE, rows)
+        else:
+            lib.call("rtfs_proj_gateway_bwd", dy0, WpT, dx, s, gw, gb, 0.25, ds, 0, None, 0, dgw, dgb, dsl, rows)
+            lib.call("rtfs_gemm_rows", ds, WrT, None, dE, rows, 256, 64, 0)
+        out.append((ds, dE, dgw, dgb, dsl))
+    a, b = out
+    assert torch.equal(a[0], b[0])
+    assert bool((a[1][rows:] == 7.0).all()) and bool(torch.isfinite(a[1][:rows]).all())
+    assert float((a[1][:rows] - b[1][:rows]).norm()) <= 1e-6 * float(b[1][:rows].norm())
+    for x, y in zip(a[2:], b[2:]):
+        assert float((x - y).norm()) <= 1e-4 * float(y.norm()) + 1e-6

@@ -1121,7 +1121,7 @@ def test_d0_tail_bwd_matches_separate_calls(B, T):
     assert float((res[True][0] - dN0).abs().max()) > 0.1  # (something was added)
 
 
-@pytest.mark.parametrize("switch", ["mixgln", "d0tail", "wgside", "decmask", "srubwd", "dwadj", "da0sum", "actepi", "enctail", "wgdefer"])
+@pytest.mark.parametrize("switch", ["mixgln", "d0tail", "wgside", "decmask", "srubwd", "dwadj", "da0sum", "actepi", "enctail", "wgdefer", "nextde"])
 def test_training_step_fusion_switches_leave_the_gradients_alone(switch):
     """The backward chain's host-side choices (models/hip_train.py: rtfs_mix_gln_bwd, rtfs_d0_tail_bwd, the weight-gradient launches on a side
     stream with their own scratch lane, the SRU layers' adjoint in one launch - rtfs_sru_layer_bwd - against rtfs_sru_scan_bwd2 + rtfs_wgrad + rtfs_gemm_rows, rtfs_dw_adjoint / rtfs_dw_adjoint_mix against the per-convolution launches, d(a0) summed once by rtfs_sum_n against the per-block read-modify-write) against the separate / in-line launches they replace, on a whole training step of RTFS-Net-3 (eval mode under autograd = the training-step path without dropout masks)."""
