@@ -233,10 +233,8 @@ int rtfs_mix_gln_bwd(const float* dOut, const float* loc, const double* loc_stat
 int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, const float* cl_b, const float* d0, const double* d0_stats,
                     const float* d0_g, const float* d0_b, const float* cg, const double* cg_stats, const float* cg_g, const float* cg_b, const float* cgate,
                     const double* cgate_stats, const float* cgate_g, const float* cgate_b, float* E, int B, int T, int T2, void* stream);
-int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* acc,
-                     int acc_mode /* 0 none, 1 acc = ds, 2 acc += ds (running d(a0)) */, float* dgw, float* dgb, float* dslope, long long rows,
-                     void* stream);
-/* the same adjoint applied to dG = dx + dy0 . Wp, formed on the fly (WpT [256][64]): replaces rtfs_gemm_rows(accumulate) + rtfs_gateway_bwd */
+/* gateway adjoint (dw1x1 + PReLU, tdanet.py:34-49) with its parameter reductions, applied to dG = dx + dy0 . Wp formed on the fly (WpT [256][64]); ds (= or +=),
+ * acc_mode 0 none, 1 acc = ds, 2 acc += ds (a running d(a0)).  (Until round 6 there was also the un-fused rtfs_gateway_bwd on a materialised dG: no caller, deleted.) */
 int rtfs_proj_gateway_bwd(const float* dy0, const float* WpT, const float* dx, const float* s, const float* gw, const float* gb, float slope, float* ds,
                           int accumulate, float* acc, int acc_mode, float* dgw, float* dgb, float* dslope, long long rows, void* stream);
 /* round 6: the same (plain form) + the residual conv's input gradient of the block whose output gradient ds is - the next block of the backward pass, tdanet.py:127-131 -

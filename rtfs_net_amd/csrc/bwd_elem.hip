@@ -11,7 +11,6 @@
 //   rtfs_mix_bwd              adjoint of InjectionMultiSum's gate/upsample mix (fusion.py:59-67)
 //   rtfs_mix_gln_bwd          the same fused with the gLN adjoint of the local branch (no dNloc tensor) and the gate / global branches' reduce passes
 //   rtfs_expand_fwd           materialise `expanded` (TFAR tail) for the residual_conv weight gradient
-//   rtfs_gateway_bwd          gateway (dw1x1 + PReLU) backward with parameter-gradient reductions
 //   rtfs_axpy                 y += a * x
 #include "common.h"
 #include "intdiv.h"
@@ -625,53 +624,6 @@ __global__ __launch_bounds__(256) void expand_kernel(NormArg cl, NormArg d0, Nor
     st4(E + hi, fma4(nrm(cl, hi), sigmoid4(nrm(cgate, lo)), nrm(cg, lo)) + nrm(d0, hi));
 }
 
-// ---- gateway backward -------------------------------------------------------------------------------------------------
-// forward: G = prelu(u), u = s*gw + gb (per channel).  dG -> ds (= or +=), dgw += sum du*s, dgb += sum du, dslope += sum dG*u*[u<=0].
-// ACCM: the same gradient also feeds the running d(a0) sum (block input = previous output + a0): 1 store it, 2 add it.
-template <bool ACCUM, int ACCM>
-__global__ __launch_bounds__(256) void gateway_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ s, const float* __restrict__ gw,
-                                                          const float* __restrict__ gb, float slope, float* __restrict__ ds, float* __restrict__ acc,
-                                                          float* __restrict__ scr, long long rows, int rows_per_wg) {
-    __shared__ __attribute__((aligned(16))) float lds[1024];
-    const int c4 = (threadIdx.x & 63) * 4, rsub = threadIdx.x >> 6;
-    const float4 w4 = ld4(gw + c4), b4 = ld4(gb + c4);
-    const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
-    float4 aw = f4(0, 0, 0, 0), ab = f4(0, 0, 0, 0);
-    float asl = 0.f;
-    constexpr int U = 4;  // rows in flight per thread
-    for (long long rb = r0 + rsub; rb < r1; rb += 4 * U) {
-        float4 sv[U], g[U], old[U], ao[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const long long r = rb + 4 * j < r1 ? rb + 4 * j : r1 - 1;  // clamped: loads stay unconditional
-            const size_t o = (size_t)r * kC + c4;
-            sv[j] = ld4(s + o), g[j] = ld4(dG + o);
-            if (ACCUM) old[j] = ld4(ds + o);
-            if (ACCM == 2) ao[j] = ld4(acc + o);
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (rb + 4 * j >= r1) break;
-            const size_t o = (size_t)(rb + 4 * j) * kC + c4;
-            const float4 u = fma4(sv[j], w4, b4), gj = g[j];
-            asl += (u.x > 0.f ? 0.f : gj.x * u.x) + (u.y > 0.f ? 0.f : gj.y * u.y) + (u.z > 0.f ? 0.f : gj.z * u.z) + (u.w > 0.f ? 0.f : gj.w * u.w);
-            const float4 du = f4(u.x > 0.f ? gj.x : gj.x * slope, u.y > 0.f ? gj.y : gj.y * slope, u.z > 0.f ? gj.z : gj.z * slope,
-                                 u.w > 0.f ? gj.w : gj.w * slope);
-            aw = fma4(du, sv[j], aw);
-            ab = ab + du;
-            float4 d = du * w4;
-            if (ACCM == 1) st4(acc + o, d);
-            if (ACCM == 2) st4(acc + o, d + ao[j]);
-            if (ACCUM) d = d + old[j];
-            st4(ds + o, d);
-        }
-    }
-    float* mine = spread_copy(scr, blockIdx.x);  // [dgw 256 | dgb 256 | dslope]
-    quad_reduce_atomic<64>(aw, lds, mine);
-    quad_reduce_atomic<64>(ab, lds, mine + kC);
-    scalar_reduce_atomic(asl, lds, mine + 2 * kC);
-}
-
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long n4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) st4(y + i * 4, fma4(ld4(x + i * 4), f4(a, a, a, a), ld4(y + i * 4)));
@@ -847,22 +799,6 @@ int rtfs_expand_fwd(const float* cl, const double* cl_stats, const float* cl_g, 
     NormArg a{cl, cl_stats, nf, cl_g, cl_b}, d{d0, d0_stats, nf, d0_g, d0_b}, g{cg, cg_stats, nl, cg_g, cg_b}, s{cgate, cgate_stats, nl, cgate_g, cgate_b};
     LAUNCH(expand_kernel, dim3((T * kF + 15) / 16, B), a, d, g, s, E, T, T2);
     return RTFS_OK;
-}
-
-int rtfs_gateway_bwd(const float* dG, const float* s, const float* gw, const float* gb, float slope, float* ds, int accumulate, float* acc, int acc_mode,
-                     float* dgw, float* dgb, float* dslope, long long rows, void* stream) {
-    if (rows <= 0 || acc_mode < 0 || acc_mode > 2 || (acc_mode && (!acc || accumulate))) return RTFS_EINVAL;
-    const int per = 256;
-    dim3 grid((unsigned)((rows + per - 1) / per));
-    float* scr = spread_scratch();
-    if (!scr) return RTFS_ELAUNCH;
-#define GWB(A, M) LAUNCH((gateway_bwd_kernel<A, M>), grid, dG, s, gw, gb, slope, ds, acc, scr, rows, per)
-    if (accumulate) { GWB(true, 0); }
-    else if (acc_mode == 0) { GWB(false, 0); }
-    else if (acc_mode == 1) { GWB(false, 1); }
-    else { GWB(false, 2); }
-#undef GWB
-    return spread_finish(scr, SpreadOut{{dgw, dgb, dslope}, {kC, kC, 1}}, (hipStream_t)stream);
 }
 
 int rtfs_axpy(const float* x, float a, float* y, long long n, void* stream) {

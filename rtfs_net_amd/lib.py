@@ -79,7 +79,6 @@ SIGNATURES = {
     "rtfs_mix_bwd": [P] * 12 + [I, I, I, I, I, P],
     "rtfs_mix_gln_bwd": [P] * 18 + [I, I, I, I, I, P],
     "rtfs_expand_fwd": [P] * 17 + [I, I, I, P],
-    "rtfs_gateway_bwd": [P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
     "rtfs_proj_gateway_bwd": [P, P, P, P, P, P, F, P, I, P, I, P, P, P, LL, P],
     "rtfs_proj_gateway_bwd_next": [P, P, P, P, P, P, F, P, P, P, P, P, P, LL, P],
     "rtfs_wgrad": [P, I, P, I, P, I, P, LL, I, I, I, I, I, I, I, P, P, F, P, I, P],
